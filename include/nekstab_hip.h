@@ -1,0 +1,142 @@
+/* libnekstab_hip.so -- C-ABI of the MI355X-native Arnoldi hot path for nekStab.
+ *
+ * The reference (nekStab, Fortran on Nek5000) has no FFI layer; its seam is the
+ * Fortran call interface  `matvec(f,q)`  ("all subroutines need to have the
+ * same interface", core/matvec.f:64-68)  plus the `krylov_*` vector algebra
+ * (core/krylov_subspace.f:24-258).  Every entry point below names the
+ * reference routine it replaces.  Plain pointers and sizes only; vectors are
+ * opaque device-resident handles so the Krylov basis never leaves HBM.
+ *
+ * Conventions: every function returns 0 on success, a negative nsk_status
+ * otherwise (the reference aborts through nek_end/exitt instead);
+ * one context per process; calls are serialised by the caller.
+ * Host arrays are Nek element-major:  index = i + lx1*(j + lx1*e).
+ */
+#ifndef NEKSTAB_HIP_H
+#define NEKSTAB_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct nsk_ctx nsk_ctx;
+typedef void* nsk_vec;               /* device state vector [vx | vy | pr] */
+
+enum nsk_status {
+  NSK_OK = 0,
+  NSK_EINVAL = -1,      /* bad argument / unsupported lx1 */
+  NSK_EHIP = -2,        /* HIP runtime error */
+  NSK_ENAN = -3,        /* NaN in an inner product (core/krylov_subspace.f:53 aborts) */
+  NSK_ENOCONV = -4,     /* an inner Helmholtz / pressure solve hit its iteration cap */
+  NSK_ENOMEM = -5
+};
+
+enum nsk_mode {          /* `evop`, core/matvec.f:124-151 */
+  NSK_DIRECT = 0,        /* 'd'  forward_linearized_map   core/matvec.f:163-243 */
+  NSK_ADJOINT = 1,       /* 'a'  adjoint_linearized_map   core/matvec.f:249-326 */
+  NSK_DIRECT_ADJOINT = 2,/* 'p'  transient_growth_map     core/matvec.f:332-349 */
+  NSK_NEWTON = 3         /* 'n'  newton_linearized_map    core/matvec.f:381-428 (exp(LT)-I) */
+};
+
+/* Case description = what Nek5000 holds in COMMON when nekStab_init runs
+ * (core/usr_extra.f:72-132): geometry, numbering, masks, base flow, sponge. */
+typedef struct {
+  int ndim;                 /* 2 (3 reserved) */
+  int nel;                  /* elements on this rank */
+  int lx1;                  /* GLL points per direction: 6, 8, 10 or 12 (SIZE:13) */
+  int lxd;                  /* dealiasing points, 3*lx1/2 (SIZE:14) */
+  long long nglob;          /* number of distinct global GLL nodes */
+  const double* x;          /* [nel*lx1*lx1] GLL coordinates (xm1) */
+  const double* y;
+  const long long* gid;     /* [nel*lx1*lx1] 0-based global node id (gslib numbering) */
+  const double* mask;       /* [nel*lx1*lx1] velocity Dirichlet mask v1mask (1 free / 0 fixed) */
+  const double* ub;         /* [nel*lx1*lx1] base flow ubase (core/NEKSTAB:26) */
+  const double* vb;
+  const double* spng;       /* [nel*lx1*lx1] spng_fun (core/utils.f:283-318) */
+  const long long* vert;    /* [nel*4] 0-based vertex ids, lexicographic corners (.ma2) */
+  long long nvert;
+  double re;                /* Reynolds number; viscosity = 1/re (1cyl.par:37) */
+  double endtime;           /* sampling period T = param(10) */
+  double cfl;               /* target CFL = param(26) (0.5) */
+  int has_outflow;          /* 0: all-Dirichlet/periodic => pressure null space (`ortho`) */
+  double tol_helm;          /* [VELOCITY] residualTol, Nek norm (1cyl.par:34) */
+  double tol_pres;          /* [PRESSURE] residualTol, Nek norm (1cyl.par:29) */
+  int tol_relative;         /* 0: absolute tolerances as Nek (param(21/22)>0); 1: relative to the initial residual */
+  int schwarz_layers;       /* overlap (GL-node layers) of the pressure Schwarz patches */
+  int max_helm_iter;        /* iteration caps per solve */
+  int max_pres_iter;
+  int nproj;                /* pressure projection space (residualProj; mxprev, SIZE:33); 0 = off */
+} nsk_case;
+
+/* nekStab_init + prepare_linearized_solver (core/usr_extra.f:72-132, core/matvec.f:1-52):
+ * uploads the case, builds operators/preconditioners, derives dt and nsteps. */
+int nsk_init(const nsk_case* c, nsk_ctx** out);
+int nsk_finalize(nsk_ctx* ctx);
+const char* nsk_last_error(void);
+
+/* dt, nsteps (core/matvec.f:30-34), state length S = 2*P + P2, P, P2 */
+int nsk_get_info(nsk_ctx* ctx, double* dt, int* nsteps, long long* nstate,
+                 long long* nvel, long long* npres);
+int nsk_set_nsteps(nsk_ctx* ctx, int nsteps);   /* test hook: shorten the map (dt unchanged) */
+int nsk_set_tolerances(nsk_ctx* ctx, double tol_helm, double tol_pres, int relative);
+
+/* allocate(Q(k_dim+1)) (core/eigensolvers.f:170) */
+int nsk_vec_alloc(nsk_ctx* ctx, int n, nsk_vec* out);
+int nsk_vec_free(nsk_ctx* ctx, int n, nsk_vec* v);
+/* nopcopy / outpost / load_files (core/utils.f:471-550, core/IO.f:15-60) */
+int nsk_vec_upload(nsk_ctx* ctx, nsk_vec v, const double* vx, const double* vy, const double* pr);
+int nsk_vec_download(nsk_ctx* ctx, nsk_vec v, double* vx, double* vy, double* pr);
+
+/* matvec(f,q) (core/matvec.f:64-154) */
+int nsk_matvec(nsk_ctx* ctx, int mode, nsk_vec f, nsk_vec q);
+
+/* krylov_inner_product / norm / cmult / add2,sub2 / copy / zero
+ * (core/krylov_subspace.f:24-212) */
+int nsk_dot(nsk_ctx* ctx, nsk_vec p, nsk_vec q, double* alpha);
+int nsk_norm(nsk_ctx* ctx, nsk_vec p, double* alpha);
+int nsk_scal(nsk_ctx* ctx, nsk_vec p, double alpha);
+int nsk_axpy(nsk_ctx* ctx, nsk_vec p, double alpha, nsk_vec q);   /* p += alpha*q */
+int nsk_copy(nsk_ctx* ctx, nsk_vec dst, nsk_vec src);
+int nsk_zero(nsk_ctx* ctx, nsk_vec p);
+
+/* update_hessenberg_matrix (core/krylov_decomposition.f:116-202): two
+ * projection passes against Q(1:j) + normalisation; h[0..j-1] = H(1:j,j),
+ * *beta = H(j+1,j).  f is overwritten with the new unit Krylov vector. */
+int nsk_orth(nsk_ctx* ctx, nsk_vec f, const nsk_vec* Q, int j, double* h, double* beta);
+
+/* Q(:,1:k) <- Q(:,1:k) * Z   (schur_condensation, core/eigensolvers.f:455-474) */
+int nsk_basis_gemm(nsk_ctx* ctx, nsk_vec* Q, int k, const double* Z, int ldz);
+/* krylov_matmul / eigenmode assembly  re + i im = Q (y_re + i y_im)
+ * (core/krylov_subspace.f:214-258, core/eigensolvers.f:607-615) */
+int nsk_basis_gemv(nsk_ctx* ctx, const nsk_vec* Q, int k, const double* y_re,
+                   const double* y_im, nsk_vec re, nsk_vec im);
+
+/* add_noise seed (core/utils.f:344-408): deterministic pseudo-noise, dssum-averaged, masked */
+int nsk_seed_noise(nsk_ctx* ctx, nsk_vec v);
+
+/* ---- statistics of the last nsk_matvec (define the algorithmic bytes) ---- */
+typedef struct {
+  long long steps;
+  long long helm_iters;     /* summed over steps (both components advance together) */
+  long long pres_iters;
+  long long unconverged;    /* solves that hit the cap */
+  double last_helm_res, last_pres_res;
+} nsk_stats;
+int nsk_get_stats(nsk_ctx* ctx, nsk_stats* s);
+
+/* ---- kernel-level test hooks (parity against oracle/, tests/test_kernels_gpu.py) ---- */
+int nsk_test_axhelm(nsk_ctx* ctx, const double* u, double h1, double h2, double* out); /* local */
+int nsk_test_dssum(nsk_ctx* ctx, const double* u, double* out);
+int nsk_test_opdiv(nsk_ctx* ctx, const double* u, const double* v, double* out);
+int nsk_test_opgradt(nsk_ctx* ctx, const double* p, double* ox, double* oy);
+int nsk_test_convect(nsk_ctx* ctx, int adjoint, const double* u, const double* v,
+                     double* ox, double* oy);      /* mass-weighted forcing bf (sponge+convection) */
+int nsk_test_eapply(nsk_ctx* ctx, const double* p, double* out);   /* D B^-1 D^T p */
+int nsk_test_helm_solve(nsk_ctx* ctx, const double* rx, const double* ry, int order,
+                        double* ox, double* oy, int* iters);
+int nsk_test_pres_solve(nsk_ctx* ctx, const double* g, double* out, int* iters);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

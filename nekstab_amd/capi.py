@@ -1,0 +1,268 @@
+"""ctypes binding of libnekstab_hip.so (include/nekstab_hip.h).
+
+This is the same thin layer a Fortran ``iso_c_binding`` interface block would be
+(INTEGRATION.md); Python only carries pointers.  There is NO CPU fallback: if
+the HIP library is missing or no GPU is visible, construction raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_LIB = None
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libnekstab_hip.so")
+
+NSK_DIRECT, NSK_ADJOINT, NSK_DIRECT_ADJOINT, NSK_NEWTON = 0, 1, 2, 3
+
+_dp = C.POINTER(C.c_double)
+_lp = C.POINTER(C.c_longlong)
+
+
+class NskCase(C.Structure):
+    _fields_ = [
+        ("ndim", C.c_int), ("nel", C.c_int), ("lx1", C.c_int), ("lxd", C.c_int),
+        ("nglob", C.c_longlong),
+        ("x", _dp), ("y", _dp), ("gid", _lp), ("mask", _dp), ("ub", _dp), ("vb", _dp),
+        ("spng", _dp), ("vert", _lp), ("nvert", C.c_longlong),
+        ("re", C.c_double), ("endtime", C.c_double), ("cfl", C.c_double),
+        ("has_outflow", C.c_int), ("tol_helm", C.c_double), ("tol_pres", C.c_double),
+        ("tol_relative", C.c_int), ("schwarz_layers", C.c_int),
+        ("max_helm_iter", C.c_int), ("max_pres_iter", C.c_int), ("nproj", C.c_int),
+    ]
+
+
+class NskStats(C.Structure):
+    _fields_ = [("steps", C.c_longlong), ("helm_iters", C.c_longlong), ("pres_iters", C.c_longlong),
+                ("unconverged", C.c_longlong), ("last_helm_res", C.c_double), ("last_pres_res", C.c_double)]
+
+
+# every symbol include/nekstab_hip.h declares: (restype, argtypes)
+_vp = C.c_void_p
+_vpp = C.POINTER(C.c_void_p)
+SYMBOLS = {
+    "nsk_init": (C.c_int, [C.POINTER(NskCase), _vpp]),
+    "nsk_finalize": (C.c_int, [_vp]),
+    "nsk_last_error": (C.c_char_p, []),
+    "nsk_get_info": (C.c_int, [_vp, _dp, C.POINTER(C.c_int), _lp, _lp, _lp]),
+    "nsk_set_nsteps": (C.c_int, [_vp, C.c_int]),
+    "nsk_set_tolerances": (C.c_int, [_vp, C.c_double, C.c_double, C.c_int]),
+    "nsk_vec_alloc": (C.c_int, [_vp, C.c_int, _vpp]),
+    "nsk_vec_free": (C.c_int, [_vp, C.c_int, _vpp]),
+    "nsk_vec_upload": (C.c_int, [_vp, _vp, _dp, _dp, _dp]),
+    "nsk_vec_download": (C.c_int, [_vp, _vp, _dp, _dp, _dp]),
+    "nsk_matvec": (C.c_int, [_vp, C.c_int, _vp, _vp]),
+    "nsk_dot": (C.c_int, [_vp, _vp, _vp, _dp]),
+    "nsk_norm": (C.c_int, [_vp, _vp, _dp]),
+    "nsk_scal": (C.c_int, [_vp, _vp, C.c_double]),
+    "nsk_axpy": (C.c_int, [_vp, _vp, C.c_double, _vp]),
+    "nsk_copy": (C.c_int, [_vp, _vp, _vp]),
+    "nsk_zero": (C.c_int, [_vp, _vp]),
+    "nsk_orth": (C.c_int, [_vp, _vp, _vpp, C.c_int, _dp, _dp]),
+    "nsk_basis_gemm": (C.c_int, [_vp, _vpp, C.c_int, _dp, C.c_int]),
+    "nsk_basis_gemv": (C.c_int, [_vp, _vpp, C.c_int, _dp, _dp, _vp, _vp]),
+    "nsk_seed_noise": (C.c_int, [_vp, _vp]),
+    "nsk_get_stats": (C.c_int, [_vp, C.POINTER(NskStats)]),
+    "nsk_test_axhelm": (C.c_int, [_vp, _dp, C.c_double, C.c_double, _dp]),
+    "nsk_test_dssum": (C.c_int, [_vp, _dp, _dp]),
+    "nsk_test_opdiv": (C.c_int, [_vp, _dp, _dp, _dp]),
+    "nsk_test_opgradt": (C.c_int, [_vp, _dp, _dp, _dp]),
+    "nsk_test_convect": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp, _dp]),
+    "nsk_test_eapply": (C.c_int, [_vp, _dp, _dp]),
+    "nsk_test_helm_solve": (C.c_int, [_vp, _dp, _dp, C.c_int, _dp, _dp, C.POINTER(C.c_int)]),
+    "nsk_test_pres_solve": (C.c_int, [_vp, _dp, _dp, C.POINTER(C.c_int)]),
+}
+
+
+class NskError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libnekstab_hip error {code}: {msg}")
+        self.code = code
+
+
+def load_library(path: str | None = None):
+    """dlopen the C-ABI library and type every declared symbol (no compute)."""
+    global _LIB
+    if _LIB is not None and path is None:
+        return _LIB
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise FileNotFoundError(
+            f"{p} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(there is no CPU fallback for the hot path)")
+    lib = C.CDLL(p)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError if the export is missing
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _LIB = lib
+    return lib
+
+
+def _p(a):
+    return a.ctypes.data_as(_dp)
+
+
+class NekStabHip:
+    """Device context for one case (``nsk_init`` ... ``nsk_finalize``)."""
+
+    def __init__(self, case, vert, nvert, *, tol_helm=1e-9, tol_pres=1e-7, tol_relative=0,
+                 schwarz_layers=2, max_helm_iter=80, max_pres_iter=40, nproj=0):
+        self.lib = load_library()
+        c = case
+        f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+        self._keep = dict(x=f64(c.x), y=f64(c.y), gid=np.ascontiguousarray(c.gid, dtype=np.int64),
+                          mask=f64(c.mask), ub=f64(c.ub[0]), vb=f64(c.ub[1]), spng=f64(c.spng),
+                          vert=np.ascontiguousarray(vert, dtype=np.int64))
+        k = self._keep
+        cs = NskCase(ndim=2, nel=c.nel, lx1=c.lx1, lxd=c.lxd, nglob=c.nglob,
+                     x=_p(k["x"]), y=_p(k["y"]), gid=k["gid"].ctypes.data_as(_lp), mask=_p(k["mask"]),
+                     ub=_p(k["ub"]), vb=_p(k["vb"]), spng=_p(k["spng"]),
+                     vert=k["vert"].ctypes.data_as(_lp), nvert=int(nvert),
+                     re=c.re, endtime=c.endtime, cfl=c.cfl, has_outflow=int(c.has_outflow),
+                     tol_helm=tol_helm, tol_pres=tol_pres, tol_relative=tol_relative,
+                     schwarz_layers=schwarz_layers, max_helm_iter=max_helm_iter,
+                     max_pres_iter=max_pres_iter, nproj=nproj)
+        self.ctx = C.c_void_p()
+        self._chk(self.lib.nsk_init(C.byref(cs), C.byref(self.ctx)))
+        dt, ns = C.c_double(), C.c_int()
+        a, b, d = C.c_longlong(), C.c_longlong(), C.c_longlong()
+        self._chk(self.lib.nsk_get_info(self.ctx, C.byref(dt), C.byref(ns), C.byref(a), C.byref(b), C.byref(d)))
+        self.dt, self.nsteps, self.nstate, self.nvel, self.npres = dt.value, ns.value, a.value, b.value, d.value
+        self.nel, self.lx1, self.lx2 = c.nel, c.lx1, c.lx1 - 2
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise NskError(rc, self.lib.nsk_last_error().decode())
+
+    def close(self):
+        if self.ctx:
+            self.lib.nsk_finalize(self.ctx)
+            self.ctx = C.c_void_p()
+
+    # ---- vectors
+    def alloc(self, n=1):
+        arr = (C.c_void_p * n)()
+        self._chk(self.lib.nsk_vec_alloc(self.ctx, n, arr))
+        return [C.c_void_p(arr[i]) for i in range(n)]
+
+    def free(self, vecs):
+        arr = (C.c_void_p * len(vecs))(*[v.value for v in vecs])
+        self._chk(self.lib.nsk_vec_free(self.ctx, len(vecs), arr))
+
+    def upload(self, v, vx, vy, pr):
+        vx, vy, pr = (np.ascontiguousarray(a, dtype=np.float64) for a in (vx, vy, pr))
+        assert vx.size == self.nvel and vy.size == self.nvel and pr.size == self.npres
+        self._chk(self.lib.nsk_vec_upload(self.ctx, v, _p(vx), _p(vy), _p(pr)))
+
+    def download(self, v):
+        n, m = self.lx1, self.lx2
+        vx = np.empty((self.nel, n, n)); vy = np.empty((self.nel, n, n)); pr = np.empty((self.nel, m, m))
+        self._chk(self.lib.nsk_vec_download(self.ctx, v, _p(vx), _p(vy), _p(pr)))
+        return vx, vy, pr
+
+    # ---- operator + vector algebra
+    def matvec(self, f, q, mode=NSK_DIRECT):
+        self._chk(self.lib.nsk_matvec(self.ctx, mode, f, q))
+
+    def dot(self, p, q):
+        a = C.c_double()
+        self._chk(self.lib.nsk_dot(self.ctx, p, q, C.byref(a)))
+        return a.value
+
+    def norm(self, p):
+        a = C.c_double()
+        self._chk(self.lib.nsk_norm(self.ctx, p, C.byref(a)))
+        return a.value
+
+    def scal(self, p, a):
+        self._chk(self.lib.nsk_scal(self.ctx, p, a))
+
+    def axpy(self, p, a, q):
+        self._chk(self.lib.nsk_axpy(self.ctx, p, a, q))
+
+    def copy(self, dst, src):
+        self._chk(self.lib.nsk_copy(self.ctx, dst, src))
+
+    def zero(self, p):
+        self._chk(self.lib.nsk_zero(self.ctx, p))
+
+    def orth(self, f, Q):
+        j = len(Q)
+        arr = (C.c_void_p * max(j, 1))(*[v.value for v in Q])
+        h = np.zeros(max(j, 1))
+        beta = C.c_double()
+        self._chk(self.lib.nsk_orth(self.ctx, f, arr, j, _p(h), C.byref(beta)))
+        return h[:j].copy(), beta.value
+
+    def basis_gemm(self, Q, Z):
+        k = len(Q)
+        Zc = np.asfortranarray(Z, dtype=np.float64)       # column-major, ldz = k
+        arr = (C.c_void_p * k)(*[v.value for v in Q])
+        self._chk(self.lib.nsk_basis_gemm(self.ctx, arr, k, Zc.ctypes.data_as(_dp), Zc.shape[0]))
+
+    def basis_gemv(self, Q, y, re, im=None):
+        k = len(Q)
+        yr = np.ascontiguousarray(np.real(y), dtype=np.float64)
+        yi = np.ascontiguousarray(np.imag(y), dtype=np.float64)
+        arr = (C.c_void_p * k)(*[v.value for v in Q])
+        self._chk(self.lib.nsk_basis_gemv(self.ctx, arr, k, _p(yr), _p(yi) if im is not None else None, re, im))
+
+    def set_nsteps(self, n):
+        self._chk(self.lib.nsk_set_nsteps(self.ctx, n))
+        self.nsteps = n
+
+    def set_tolerances(self, th, tp, relative=0):
+        self._chk(self.lib.nsk_set_tolerances(self.ctx, th, tp, relative))
+
+    def stats(self):
+        s = NskStats()
+        self._chk(self.lib.nsk_get_stats(self.ctx, C.byref(s)))
+        return {f: getattr(s, f) for f, _ in NskStats._fields_}
+
+    # ---- kernel-level test hooks
+    def t_axhelm(self, u, h1, h2):
+        u = np.ascontiguousarray(u); out = np.empty_like(u)
+        self._chk(self.lib.nsk_test_axhelm(self.ctx, _p(u), h1, h2, _p(out)))
+        return out
+
+    def t_dssum(self, u):
+        u = np.ascontiguousarray(u); out = np.empty_like(u)
+        self._chk(self.lib.nsk_test_dssum(self.ctx, _p(u), _p(out)))
+        return out
+
+    def t_opdiv(self, u, v):
+        u = np.ascontiguousarray(u); v = np.ascontiguousarray(v)
+        out = np.empty((self.nel, self.lx2, self.lx2))
+        self._chk(self.lib.nsk_test_opdiv(self.ctx, _p(u), _p(v), _p(out)))
+        return out
+
+    def t_opgradt(self, p):
+        p = np.ascontiguousarray(p)
+        ox = np.empty((self.nel, self.lx1, self.lx1)); oy = np.empty_like(ox)
+        self._chk(self.lib.nsk_test_opgradt(self.ctx, _p(p), _p(ox), _p(oy)))
+        return ox, oy
+
+    def t_convect(self, u, v, adjoint=False):
+        u = np.ascontiguousarray(u); v = np.ascontiguousarray(v)
+        ox = np.empty_like(u); oy = np.empty_like(u)
+        self._chk(self.lib.nsk_test_convect(self.ctx, int(adjoint), _p(u), _p(v), _p(ox), _p(oy)))
+        return ox, oy
+
+    def t_eapply(self, p):
+        p = np.ascontiguousarray(p); out = np.empty_like(p)
+        self._chk(self.lib.nsk_test_eapply(self.ctx, _p(p), _p(out)))
+        return out
+
+    def t_helm_solve(self, rx, ry, order=3):
+        rx = np.ascontiguousarray(rx); ry = np.ascontiguousarray(ry)
+        ox = np.empty_like(rx); oy = np.empty_like(rx); it = C.c_int()
+        self._chk(self.lib.nsk_test_helm_solve(self.ctx, _p(rx), _p(ry), order, _p(ox), _p(oy), C.byref(it)))
+        return ox, oy, it.value
+
+    def t_pres_solve(self, g):
+        g = np.ascontiguousarray(g); out = np.empty_like(g); it = C.c_int()
+        self._chk(self.lib.nsk_test_pres_solve(self.ctx, _p(g), _p(out), C.byref(it)))
+        return out, it.value

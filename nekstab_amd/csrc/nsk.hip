@@ -1,0 +1,940 @@
+// libnekstab_hip.so: host driver + C-ABI (include/nekstab_hip.h).
+//
+// Mirrors, behind nekStab's own operator interface, the hot path
+//   matvec(f,q)                      core/matvec.f:64-154
+//   forward/adjoint_linearized_map   core/matvec.f:163-326
+//   krylov_* vector algebra          core/krylov_subspace.f:24-258
+//   update_hessenberg_matrix         core/krylov_decomposition.f:116-202
+// and the Nek5000 perturbation step those call.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/nekstab_hip.h"
+#include "nsk_basis.hpp"
+#include "nsk_kernels.hpp"
+
+using namespace nsk;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+
+#define HIPCHK(x)                                                                        \
+  do {                                                                                   \
+    hipError_t e_ = (x);                                                                 \
+    if (e_ != hipSuccess)                                                                \
+      return fail(NSK_EHIP, std::string(#x) + ": " + hipGetErrorString(e_) + " @" + std::to_string(__LINE__)); \
+  } while (0)
+
+#define DISPATCH_N(n, ...)                                         \
+  switch (n) {                                                     \
+    case 6: { constexpr int N = 6; __VA_ARGS__; } break;           \
+    case 8: { constexpr int N = 8; __VA_ARGS__; } break;           \
+    case 10: { constexpr int N = 10; __VA_ARGS__; } break;         \
+    case 12: { constexpr int N = 12; __VA_ARGS__; } break;         \
+    default: return fail(NSK_EINVAL, "unsupported lx1");           \
+  }
+
+struct nsk_ctx {
+  int N = 0, NN = 0, M = 0, MM = 0, ND = 0, NDD = 0, EPB = 0, NT = 0, NTD = 0;
+  int nel = 0, nblk = 0, nvert = 0;
+  long long nloc = 0, npr = 0, nstate = 0;
+  double dt = 0, re = 0, endtime = 0;
+  int nsteps = 0;
+  int max_helm = 60, max_pres = 40, min_pres = 1, layers = 1;
+  int cur_helm = 0, cur_pres = 0;       // adaptive launch budgets
+  Dev d{};
+  Stats hstats{};
+  hipStream_t stream = nullptr;
+  std::vector<void*> allocs;
+  // krylov scratch
+  double* kpart = nullptr; double* kout = nullptr; double** kptr = nullptr; int kblk = 0;
+  double* hpin = nullptr;   // pinned host scratch
+  // work vectors for tests / setup
+  double *wv1 = nullptr, *wv2 = nullptr, *wp1 = nullptr, *wp2 = nullptr;
+  std::vector<double> bm1s_host;
+};
+
+template <class T>
+static int dalloc(nsk_ctx* c, T** p, size_t n) {
+  void* q = nullptr;
+  hipError_t e = hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T));
+  if (e != hipSuccess) return fail(NSK_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+  (void)hipMemset(q, 0, std::max<size_t>(n, 1) * sizeof(T));
+  c->allocs.push_back(q);
+  *p = (T*)q;
+  return 0;
+}
+template <class T>
+static int dupload(nsk_ctx* c, const T** p, const std::vector<T>& h) {
+  T* q = nullptr;
+  int rc = dalloc(c, &q, h.size());
+  if (rc) return rc;
+  if (!h.empty()) HIPCHK(hipMemcpy(q, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+  *p = q;
+  return 0;
+}
+
+static StepCoef make_coef(const nsk_ctx* c, int istep, int adjoint) {
+  static const double BD[3][4] = {{1.0, 1.0, 0.0, 0.0}, {1.5, 2.0, -0.5, 0.0}, {11.0 / 6.0, 3.0, -1.5, 1.0 / 3.0}};
+  static const double AB[3][3] = {{1.0, 0.0, 0.0}, {2.0, -1.0, 0.0}, {3.0, -3.0, 1.0}};
+  const int k = std::min(istep, 3);
+  StepCoef s;
+  for (int q = 0; q < 4; ++q) s.bd[q] = BD[k - 1][q];
+  for (int q = 0; q < 3; ++q) s.ab[q] = AB[k - 1][q];
+  s.h2 = s.bd[0] / c->dt;
+  s.invdt = 1.0 / c->dt;
+  s.k = k;
+  s.adjoint = adjoint;
+  return s;
+}
+
+// ---------------------------------------------------------------------------
+// E-apply helper used by setup, tests and the projection space
+// ---------------------------------------------------------------------------
+static int eapply(nsk_ctx* c, const double* pin, double* wout) {
+  DISPATCH_N(c->N, {
+    hipLaunchKernelGGL(k_gradt<N>, dim3(c->nblk), dim3(Cfg<N>::NT), 0, c->stream, c->d, pin, c->d.yl);
+    hipLaunchKernelGGL(k_divgs<N>, dim3(c->nblk), dim3(Cfg<N>::NT), 0, c->stream, c->d, (const double*)c->d.yl, wout, -1, 0);
+  });
+  return 0;
+}
+
+// dense in-place inverse (Gauss-Jordan, partial pivoting), n small
+static bool invert_dense(std::vector<double>& A, int n) {
+  std::vector<int> piv(n);
+  for (int k = 0; k < n; ++k) {
+    int p = k; double best = std::fabs(A[(size_t)k * n + k]);
+    for (int i = k + 1; i < n; ++i) { double v = std::fabs(A[(size_t)i * n + k]); if (v > best) { best = v; p = i; } }
+    if (best == 0.0) return false;
+    piv[k] = p;
+    if (p != k) for (int j = 0; j < n; ++j) std::swap(A[(size_t)k * n + j], A[(size_t)p * n + j]);
+    const double d = 1.0 / A[(size_t)k * n + k];
+    A[(size_t)k * n + k] = 1.0;
+    for (int j = 0; j < n; ++j) A[(size_t)k * n + j] *= d;
+    for (int i = 0; i < n; ++i) {
+      if (i == k) continue;
+      const double f = A[(size_t)i * n + k];
+      if (f == 0.0) continue;
+      A[(size_t)i * n + k] = 0.0;
+      double* ai = &A[(size_t)i * n];
+      const double* ak = &A[(size_t)k * n];
+      for (int j = 0; j < n; ++j) ai[j] -= f * ak[j];
+    }
+  }
+  for (int k = n - 1; k >= 0; --k)
+    if (piv[k] != k) for (int i = 0; i < n; ++i) std::swap(A[(size_t)i * n + k], A[(size_t)i * n + piv[k]]);
+  return true;
+}
+
+__global__ void k_gj_extract(const double* __restrict__ A, int n, int k, double* __restrict__ rowk, double* __restrict__ colk) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const double p = 1.0 / A[(size_t)k * n + k];
+  rowk[t] = (t == k) ? p : A[(size_t)k * n + t] * p;
+  colk[t] = (t == k) ? 0.0 : A[(size_t)t * n + k];
+}
+__global__ void k_gj_update(double* __restrict__ A, int n, int k, const double* __restrict__ rowk, const double* __restrict__ colk) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+  if (j >= n) return;
+  const double p = rowk[k];
+  double v;
+  if (i == k) v = rowk[j];
+  else if (j == k) v = -colk[i] * p;
+  else v = A[(size_t)i * n + j] - colk[i] * rowk[j];
+  A[(size_t)i * n + j] = v;
+}
+
+// ---------------------------------------------------------------------------
+// nsk_init
+// ---------------------------------------------------------------------------
+static int build(nsk_ctx* c, const nsk_case& cs) {
+  const int N = cs.lx1, NN = N * N, M = N - 2, MM = M * M, ND = cs.lxd > 0 ? cs.lxd : 3 * N / 2, NDD = ND * ND;
+  if (cs.ndim != 2) return fail(NSK_EINVAL, "only ndim=2 in this build");
+  if (!(N == 6 || N == 8 || N == 10 || N == 12)) return fail(NSK_EINVAL, "lx1 must be 6, 8, 10 or 12");
+  if (ND != 3 * N / 2) return fail(NSK_EINVAL, "lxd must be 3*lx1/2");
+  const int nel = cs.nel;
+  c->N = N; c->NN = NN; c->M = M; c->MM = MM; c->ND = ND; c->NDD = NDD;
+  c->EPB = (256 / NN) > 0 ? 256 / NN : 1;
+  c->NT = ((c->EPB * NN + 63) / 64) * 64;
+  c->NTD = ((NDD + 63) / 64) * 64;
+  c->nel = nel; c->nblk = (nel + c->EPB - 1) / c->EPB;
+  c->nloc = (long long)nel * NN; c->npr = (long long)nel * MM; c->nstate = 2 * c->nloc + c->npr;
+  c->re = cs.re; c->endtime = cs.endtime;
+  c->layers = std::max(1, std::min(cs.schwarz_layers > 0 ? cs.schwarz_layers : 1, std::min(4, M)));
+  if (cs.max_helm_iter > 0) c->max_helm = cs.max_helm_iter;
+  if (cs.max_pres_iter > 0) c->max_pres = std::min(cs.max_pres_iter, MAXMR);
+  const long long nloc = c->nloc, npr = c->npr;
+  HIPCHK(hipStreamCreate(&c->stream));
+  Dev& d = c->d;
+  d.nel = nel; d.nblk = c->nblk; d.nloc = nloc; d.npr = npr; d.nu = 1.0 / cs.re;
+  d.tol_helm = cs.tol_helm > 0 ? cs.tol_helm : 1e-9;
+  d.tol_pres = cs.tol_pres > 0 ? cs.tol_pres : 1e-7;
+  d.tol_relative = cs.tol_relative; d.max_mr = c->max_pres; d.has_outflow = cs.has_outflow;
+  d.nproj_max = std::min(cs.nproj, MAXPROJ);
+
+  // ---- bases
+  std::vector<double> z1, w1, z2, w2, zd, wd;
+  zwgll(N, z1, w1); zwgl(M, z2, w2); zwgl(ND, zd, wd);
+  std::vector<double> D = deriv_matrix(z1), J12 = interp_matrix(z1, z2), Jd = interp_matrix(z1, zd), Dd = deriv_matrix(zd);
+  std::vector<double> D12 = matmul(J12, D, M, N, N);
+  std::vector<double> hat(4 * MM);
+  for (int b = 0; b < M; ++b)
+    for (int a = 0; a < M; ++a) {
+      const double rm = 0.5 * (1 - z2[a]), rp = 0.5 * (1 + z2[a]), sm = 0.5 * (1 - z2[b]), sp = 0.5 * (1 + z2[b]);
+      hat[0 * MM + b * M + a] = sm * rm; hat[1 * MM + b * M + a] = sm * rp;
+      hat[2 * MM + b * M + a] = sp * rm; hat[3 * MM + b * M + a] = sp * rp;
+    }
+  int rc;
+  if ((rc = dupload(c, &d.D, D)) || (rc = dupload(c, &d.J12, J12)) || (rc = dupload(c, &d.D12, D12)) ||
+      (rc = dupload(c, &d.Jd, Jd)) || (rc = dupload(c, &d.Dd, Dd)) || (rc = dupload(c, &d.hat, hat))) return rc;
+
+  // ---- geometry  [UPSTREAM coef.f geom1 / geom2 / set_dealias_rx]
+  std::vector<double> g1(nloc), g2(nloc), g4(nloc), bm1(nloc), rx(nloc), ry(nloc), sx(nloc), sy(nloc), jac(nloc);
+  for (int e = 0; e < nel; ++e) {
+    const double* X = cs.x + (size_t)e * NN; const double* Y = cs.y + (size_t)e * NN;
+    for (int j = 0; j < N; ++j)
+      for (int i = 0; i < N; ++i) {
+        double xr = 0, xs = 0, yr = 0, ys = 0;
+        for (int k = 0; k < N; ++k) {
+          xr += D[i * N + k] * X[j * N + k]; yr += D[i * N + k] * Y[j * N + k];
+          xs += D[j * N + k] * X[k * N + i]; ys += D[j * N + k] * Y[k * N + i];
+        }
+        const size_t l = (size_t)e * NN + j * N + i;
+        const double J = xr * ys - xs * yr;
+        if (!(J > 0.0)) return fail(NSK_EINVAL, "non-positive Jacobian in element " + std::to_string(e));
+        jac[l] = J; rx[l] = ys; ry[l] = -xs; sx[l] = -yr; sy[l] = xr;
+        const double W = w1[i] * w1[j];
+        bm1[l] = J * W;
+        g1[l] = (ys * ys + xs * xs) * W / J;
+        g2[l] = (yr * yr + xr * xr) * W / J;
+        g4[l] = (ys * (-yr) + (-xs) * xr) * W / J;
+      }
+  }
+  auto interp2 = [&](const std::vector<double>& Jm, int nt, const double* f, double* out) {  // out[b][a] = sum J[b][j] J[a][i] f[j][i]
+    std::vector<double> t((size_t)N * nt);
+    for (int j = 0; j < N; ++j)
+      for (int a = 0; a < nt; ++a) { double s = 0; for (int i = 0; i < N; ++i) s += Jm[a * N + i] * f[j * N + i]; t[j * nt + a] = s; }
+    for (int b = 0; b < nt; ++b)
+      for (int a = 0; a < nt; ++a) { double s = 0; for (int j = 0; j < N; ++j) s += Jm[b * N + j] * t[j * nt + a]; out[b * nt + a] = s; }
+  };
+  std::vector<double> w2rx(npr), w2ry(npr), w2sx(npr), w2sy(npr);
+  const size_t nfine = (size_t)nel * NDD;
+  std::vector<double> cUr(nfine), cUs(nfine), GUx(nfine), GUy(nfine), GVx(nfine), GVy(nfine);
+  {
+    std::vector<double> t(std::max(MM, NDD)), rxd(NDD), ryd(NDD), sxd(NDD), syd(NDD), Uf(NDD), Vf(NDD);
+    for (int e = 0; e < nel; ++e) {
+      const size_t o1 = (size_t)e * NN, o2 = (size_t)e * MM, od = (size_t)e * NDD;
+      const std::vector<double>* src[4] = {&rx, &ry, &sx, &sy};
+      double* dst2[4] = {&w2rx[o2], &w2ry[o2], &w2sx[o2], &w2sy[o2]};
+      double* dstd[4] = {rxd.data(), ryd.data(), sxd.data(), syd.data()};
+      for (int q = 0; q < 4; ++q) {
+        interp2(J12, M, src[q]->data() + o1, dst2[q]);
+        for (int b = 0; b < M; ++b) for (int a = 0; a < M; ++a) dst2[q][b * M + a] *= w2[a] * w2[b];
+        interp2(Jd, ND, src[q]->data() + o1, dstd[q]);
+        for (int b = 0; b < ND; ++b) for (int a = 0; a < ND; ++a) dstd[q][b * ND + a] *= wd[a] * wd[b];
+      }
+      interp2(Jd, ND, cs.ub + o1, Uf.data());
+      interp2(Jd, ND, cs.vb + o1, Vf.data());
+      for (int b = 0; b < ND; ++b)
+        for (int a = 0; a < ND; ++a) {
+          double Ur = 0, Us = 0, Vr = 0, Vs = 0;
+          for (int k = 0; k < ND; ++k) {
+            Ur += Dd[a * ND + k] * Uf[b * ND + k]; Us += Dd[b * ND + k] * Uf[k * ND + a];
+            Vr += Dd[a * ND + k] * Vf[b * ND + k]; Vs += Dd[b * ND + k] * Vf[k * ND + a];
+          }
+          const int q = b * ND + a;
+          cUr[od + q] = rxd[q] * Uf[q] + ryd[q] * Vf[q];
+          cUs[od + q] = sxd[q] * Uf[q] + syd[q] * Vf[q];
+          GUx[od + q] = rxd[q] * Ur + sxd[q] * Us;
+          GUy[od + q] = ryd[q] * Ur + syd[q] * Us;
+          GVx[od + q] = rxd[q] * Vr + sxd[q] * Vs;
+          GVy[od + q] = ryd[q] * Vr + syd[q] * Vs;
+        }
+    }
+  }
+
+  // ---- gather-scatter CSR from the global numbering
+  std::vector<int> gs_off(nloc + 1), gs_idx(nloc);
+  std::vector<std::pair<long long, int>> srt(nloc);
+  for (long long l = 0; l < nloc; ++l) srt[l] = {cs.gid[l], (int)l};
+  std::sort(srt.begin(), srt.end());
+  std::vector<int> grp_start(nloc), grp_cnt(nloc);
+  {
+    std::vector<int> cnt(nloc, 0);
+    long long a = 0;
+    while (a < nloc) {
+      long long b = a;
+      while (b < nloc && srt[b].first == srt[a].first) ++b;
+      for (long long k = a; k < b; ++k) { grp_start[srt[k].second] = (int)a; grp_cnt[srt[k].second] = (int)(b - a); }
+      a = b;
+    }
+    gs_off[0] = 0;
+    for (long long l = 0; l < nloc; ++l) gs_off[l + 1] = gs_off[l] + grp_cnt[l];
+    gs_idx.resize(gs_off[nloc]);
+    for (long long l = 0; l < nloc; ++l)
+      for (int k = 0; k < grp_cnt[l]; ++k) gs_idx[gs_off[l] + k] = srt[grp_start[l] + k].second;
+  }
+  auto dssum_h = [&](const std::vector<double>& f) {
+    std::vector<double> o(nloc);
+    for (long long l = 0; l < nloc; ++l) { double s = 0; for (int k = gs_off[l]; k < gs_off[l + 1]; ++k) s += f[gs_idx[k]]; o[l] = s; }
+    return o;
+  };
+  std::vector<double> mask(cs.mask, cs.mask + nloc), minv(nloc), binv(nloc), spng(cs.spng, cs.spng + nloc), bm1s(nloc);
+  {
+    std::vector<double> bs = dssum_h(bm1);
+    double vol = 0;
+    for (long long l = 0; l < nloc; ++l) {
+      // a node fixed in any copy is fixed in all
+      double mk = 1.0;
+      for (int k = gs_off[l]; k < gs_off[l + 1]; ++k) mk = std::min(mk, cs.mask[gs_idx[k]]);
+      mask[l] = mk;
+      minv[l] = 1.0 / (gs_off[l + 1] - gs_off[l]);
+      binv[l] = mk / bs[l];
+      bm1s[l] = (spng[l] != 0.0) ? 0.0 : bm1[l];      // core/usr_extra.f:116-118
+      vol += bm1[l];
+    }
+    d.vol = vol;
+  }
+  c->bm1s_host = bm1s;
+
+  // ---- dt rule  (core/matvec.f:26-46, [UPSTREAM compute_cfl])
+  {
+    std::vector<double> dri(N);
+    dri[0] = 1.0 / (z1[1] - z1[0]); dri[N - 1] = 1.0 / (z1[N - 1] - z1[N - 2]);
+    for (int i = 1; i < N - 1; ++i) dri[i] = 1.0 / (0.5 * (z1[i + 1] - z1[i - 1]));
+    double ctarg = 0;
+    for (int e = 0; e < nel; ++e)
+      for (int j = 0; j < N; ++j)
+        for (int i = 0; i < N; ++i) {
+          const size_t l = (size_t)e * NN + j * N + i;
+          const double ur = (cs.ub[l] * rx[l] + cs.vb[l] * ry[l]) / jac[l];
+          const double us = (cs.ub[l] * sx[l] + cs.vb[l] * sy[l]) / jac[l];
+          ctarg = std::max(ctarg, std::fabs(ur * dri[i]) + std::fabs(us * dri[j]));
+        }
+    double dt = cs.cfl / ctarg;
+    c->nsteps = (int)std::ceil(cs.endtime / dt);
+    c->dt = cs.endtime / c->nsteps;
+    d.dt = c->dt;
+  }
+
+  // ---- Jacobi preconditioner of H for the three BDF orders
+  std::vector<double> dinv(3 * nloc);
+  {
+    std::vector<double> dA(nloc);
+    for (int e = 0; e < nel; ++e)
+      for (int j = 0; j < N; ++j)
+        for (int i = 0; i < N; ++i) {
+          const size_t o = (size_t)e * NN;
+          double s = 0;
+          for (int k = 0; k < N; ++k) s += D[k * N + i] * D[k * N + i] * g1[o + j * N + k] + D[k * N + j] * D[k * N + j] * g2[o + k * N + i];
+          s += 2.0 * D[i * N + i] * D[j * N + j] * g4[o + j * N + i];
+          dA[o + j * N + i] = s;
+        }
+    std::vector<double> dAs = dssum_h(dA), bs = dssum_h(bm1);
+    const double bd0[3] = {1.0, 1.5, 11.0 / 6.0};
+    for (int k = 0; k < 3; ++k)
+      for (long long l = 0; l < nloc; ++l) dinv[(size_t)k * nloc + l] = mask[l] / (d.nu * dAs[l] + bd0[k] / c->dt * bs[l]);
+  }
+
+  if ((rc = dupload(c, &d.g1, g1)) || (rc = dupload(c, &d.g2, g2)) || (rc = dupload(c, &d.g4, g4)) ||
+      (rc = dupload(c, &d.bm1, bm1)) || (rc = dupload(c, &d.mask, mask)) || (rc = dupload(c, &d.minv, minv)) ||
+      (rc = dupload(c, &d.binv, binv)) || (rc = dupload(c, &d.spng, spng)) || (rc = dupload(c, &d.bm1s, bm1s)) ||
+      (rc = dupload(c, &d.dinv, dinv)) || (rc = dupload(c, &d.w2rx, w2rx)) || (rc = dupload(c, &d.w2ry, w2ry)) ||
+      (rc = dupload(c, &d.w2sx, w2sx)) || (rc = dupload(c, &d.w2sy, w2sy)) || (rc = dupload(c, &d.cUr, cUr)) ||
+      (rc = dupload(c, &d.cUs, cUs)) || (rc = dupload(c, &d.GUx, GUx)) || (rc = dupload(c, &d.GUy, GUy)) ||
+      (rc = dupload(c, &d.GVx, GVx)) || (rc = dupload(c, &d.GVy, GVy)) || (rc = dupload(c, &d.gs_off, gs_off)) ||
+      (rc = dupload(c, &d.gs_idx, gs_idx))) return rc;
+
+  // ---- state + solver work arrays
+  if ((rc = dalloc(c, &d.u, 2 * nloc)) || (rc = dalloc(c, &d.p, npr)) || (rc = dalloc(c, &d.plag, npr)) ||
+      (rc = dalloc(c, &d.pext, npr)) || (rc = dalloc(c, &d.ulag, 4 * nloc)) || (rc = dalloc(c, &d.exlag, 4 * nloc)) ||
+      (rc = dalloc(c, &d.bf, 2 * nloc)) || (rc = dalloc(c, &d.rloc, 2 * nloc)) || (rc = dalloc(c, &d.hx, 2 * nloc)) ||
+      (rc = dalloc(c, &d.hr, 2 * nloc)) || (rc = dalloc(c, &d.hp, 2 * nloc)) || (rc = dalloc(c, &d.hs, 2 * nloc)) ||
+      (rc = dalloc(c, &d.hwl, 4 * nloc)) || (rc = dalloc(c, &d.hpart, (size_t)12 * c->nblk)) || (rc = dalloc(c, &d.hscal, 32)) ||
+      (rc = dalloc(c, &d.V, (size_t)(MAXMR + 1) * npr)) || (rc = dalloc(c, &d.Z, (size_t)MAXMR * npr)) ||
+      (rc = dalloc(c, &d.yl, 2 * nloc)) || (rc = dalloc(c, &d.ec, (size_t)nel * 4)) ||
+      (rc = dalloc(c, &d.gpart, (size_t)(MAXMR + 2) * c->nblk)) || (rc = dalloc(c, &d.gsc, 1)) ||
+      (rc = dalloc(c, &d.stats, 1)) || (rc = dalloc(c, &c->wv1, 2 * nloc)) || (rc = dalloc(c, &c->wv2, 2 * nloc)) ||
+      (rc = dalloc(c, &c->wp1, npr)) || (rc = dalloc(c, &c->wp2, npr))) return rc;
+  if (d.nproj_max > 0)
+    if ((rc = dalloc(c, &d.PX, (size_t)d.nproj_max * npr)) || (rc = dalloc(c, &d.PEX, (size_t)d.nproj_max * npr))) return rc;
+  c->kblk = 256;
+  if ((rc = dalloc(c, &c->kpart, (size_t)c->kblk * 1024)) || (rc = dalloc(c, &c->kout, 1024)) || (rc = dalloc(c, &c->kptr, 1024))) return rc;
+  HIPCHK(hipHostMalloc((void**)&c->hpin, 4096 * sizeof(double)));
+
+  // ---- element adjacency (shared GLL nodes)
+  std::vector<std::vector<int>> nb(nel);
+  for (int e = 0; e < nel; ++e) {
+    std::vector<int>& v = nb[e];
+    v.push_back(e);
+    for (int nd = 0; nd < NN; ++nd) {
+      const long long l = (long long)e * NN + nd;
+      if (gs_off[l + 1] - gs_off[l] == 1) continue;
+      for (int k = gs_off[l]; k < gs_off[l + 1]; ++k) {
+        const int f = gs_idx[k] / NN;
+        if (f != e && std::find(v.begin(), v.end(), f) == v.end()) v.push_back(f);
+      }
+    }
+    std::sort(v.begin() + 1, v.end());
+  }
+  std::vector<int> nb_off(nel + 1, 0), nb_idx;
+  std::vector<long long> blk_off(nel + 1, 0);
+  for (int e = 0; e < nel; ++e) {
+    nb_off[e + 1] = nb_off[e] + (int)nb[e].size();
+    blk_off[e + 1] = blk_off[e] + (long long)nb[e].size() * MM * MM;
+    nb_idx.insert(nb_idx.end(), nb[e].begin(), nb[e].end());
+  }
+  // distance-2 colouring for simultaneous probing
+  std::vector<int> colour(nel, -1);
+  int ncolour = 0;
+  {
+    std::vector<int> used;
+    for (int e = 0; e < nel; ++e) {
+      used.assign(ncolour + 1, 0);
+      for (int f : nb[e])
+        for (int g : nb[f])
+          if (colour[g] >= 0) used[colour[g]] = 1;
+      int cc = 0;
+      while (cc < ncolour && used[cc]) ++cc;
+      colour[e] = cc;
+      if (cc == ncolour) ++ncolour;
+    }
+  }
+  // ---- probe E = D B^-1 D^T block-sparsely on the device
+  std::vector<double> Eblk((size_t)blk_off[nel]);
+  {
+    double* dE = nullptr; const int *dnb_off = nullptr, *dnb_idx = nullptr; const long long* dblk = nullptr;
+    if ((rc = dalloc(c, &dE, Eblk.size())) || (rc = dupload(c, &dnb_off, nb_off)) || (rc = dupload(c, &dnb_idx, nb_idx)) ||
+        (rc = dupload(c, &dblk, blk_off))) return rc;
+    for (int cc = 0; cc < ncolour; ++cc) {
+      std::vector<int> els;
+      for (int e = 0; e < nel; ++e) if (colour[e] == cc) els.push_back(e);
+      const int* dels = nullptr;
+      if ((rc = dupload(c, &dels, els))) return rc;
+      const int ne = (int)els.size();
+      HIPCHK(hipMemsetAsync(c->wp1, 0, npr * sizeof(double), c->stream));
+      for (int k = 0; k < MM; ++k) {
+        hipLaunchKernelGGL(k_set_probe, dim3((ne + 255) / 256), dim3(256), 0, c->stream, c->wp1, dels, ne, MM, k, 1.0);
+        if ((rc = eapply(c, c->wp1, c->wp2))) return rc;
+        hipLaunchKernelGGL(k_collect_probe, dim3(ne), dim3(256), 0, c->stream, (const double*)c->wp2, dels, ne, dnb_off, dnb_idx, dE, dblk, MM, k);
+        hipLaunchKernelGGL(k_set_probe, dim3((ne + 255) / 256), dim3(256), 0, c->stream, c->wp1, dels, ne, MM, k, 0.0);
+      }
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(Eblk.data(), dE, Eblk.size() * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(hipFree(dE));
+    c->allocs.erase(std::find(c->allocs.begin(), c->allocs.end(), (void*)dE));
+  }
+  auto Eentry = [&](int a, int r, int b, int k) -> double {   // E[(a,r),(b,k)]
+    const std::vector<int>& v = nb[b];
+    for (size_t s = 0; s < v.size(); ++s)
+      if (v[s] == a) return Eblk[blk_off[b] + ((size_t)s * MM + k) * MM + r];
+    return 0.0;
+  };
+
+  // ---- coarse space: bilinear vertex functions sampled at the Gauss nodes
+  const int nvert = (int)cs.nvert;
+  c->nvert = nvert; d.nvert = nvert;
+  std::vector<int> evert((size_t)nel * 4);
+  for (size_t k = 0; k < evert.size(); ++k) evert[k] = (int)cs.vert[k];
+  std::vector<int> v_off(nvert + 1, 0), v_ent((size_t)nel * 4);
+  for (size_t k = 0; k < evert.size(); ++k) v_off[evert[k] + 1]++;
+  for (int v = 0; v < nvert; ++v) v_off[v + 1] += v_off[v];
+  { std::vector<int> pos(v_off.begin(), v_off.end() - 1); for (size_t k = 0; k < evert.size(); ++k) v_ent[pos[evert[k]]++] = (int)k; }
+  {
+    std::vector<double> Ac((size_t)nvert * nvert, 0.0), T(4 * MM);
+    for (int b = 0; b < nel; ++b)
+      for (size_t s = 0; s < nb[b].size(); ++s) {
+        const int a = nb[b][s];
+        const double* blk = &Eblk[blk_off[b] + (size_t)s * MM * MM];     // [k][r]
+        for (int cc = 0; cc < 4; ++cc)
+          for (int k = 0; k < MM; ++k) { double t = 0; for (int r = 0; r < MM; ++r) t += hat[cc * MM + r] * blk[(size_t)k * MM + r]; T[cc * MM + k] = t; }
+        for (int cc = 0; cc < 4; ++cc)
+          for (int c2 = 0; c2 < 4; ++c2) {
+            double t = 0;
+            for (int k = 0; k < MM; ++k) t += T[cc * MM + k] * hat[c2 * MM + k];
+            Ac[(size_t)evert[a * 4 + cc] * nvert + evert[b * 4 + c2]] += t;
+          }
+      }
+    if (!cs.has_outflow) {            // constant null space: shift it out (coarse constant = sum of hats)
+      double tr = 0; for (int v = 0; v < nvert; ++v) tr += Ac[(size_t)v * nvert + v];
+      const double sh = tr / nvert / nvert;
+      for (size_t k = 0; k < Ac.size(); ++k) Ac[k] += sh;
+    }
+    double* dA = nullptr; double *drow = nullptr, *dcol = nullptr;
+    if ((rc = dalloc(c, &dA, Ac.size())) || (rc = dalloc(c, &drow, nvert)) || (rc = dalloc(c, &dcol, nvert))) return rc;
+    HIPCHK(hipMemcpy(dA, Ac.data(), Ac.size() * sizeof(double), hipMemcpyHostToDevice));
+    for (int k = 0; k < nvert; ++k) {
+      hipLaunchKernelGGL(k_gj_extract, dim3((nvert + 255) / 256), dim3(256), 0, c->stream, (const double*)dA, nvert, k, drow, dcol);
+      hipLaunchKernelGGL(k_gj_update, dim3((nvert + 255) / 256, nvert), dim3(256), 0, c->stream, dA, nvert, k, (const double*)drow, (const double*)dcol);
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    d.Aci = dA;
+  }
+  if ((rc = dupload(c, &d.v_off, v_off)) || (rc = dupload(c, &d.v_ent, v_ent)) || (rc = dupload(c, &d.evert, evert)) ||
+      (rc = dalloc(c, &d.xc, nvert))) return rc;
+
+  // ---- restricted additive Schwarz patches: own Gauss nodes + `layers` rows of every neighbour
+  {
+    const int L = c->layers;
+    std::vector<int> p_off(nel + 1, 0), p_idx;
+    std::vector<long long> p_invoff(nel + 1, 0);
+    std::vector<float> p_inv;
+    std::vector<int> pe, pr;            // patch dof -> (element, local Gauss index)
+    std::vector<double> A;
+    std::vector<char> shared(NN);
+    for (int e = 0; e < nel; ++e) {
+      pe.clear(); pr.clear();
+      for (int k = 0; k < MM; ++k) { pe.push_back(e); pr.push_back(k); }
+      for (size_t s = 1; s < nb[e].size(); ++s) {
+        const int f = nb[e][s];
+        int jmin = N, jmax = -1, imin = N, imax = -1;
+        for (int nd = 0; nd < NN; ++nd) {
+          const long long l = (long long)f * NN + nd;
+          bool sh = false;
+          for (int k = gs_off[l]; k < gs_off[l + 1] && !sh; ++k) sh = (gs_idx[k] / NN == e);
+          if (sh) { jmin = std::min(jmin, nd / N); jmax = std::max(jmax, nd / N); imin = std::min(imin, nd % N); imax = std::max(imax, nd % N); }
+        }
+        if (jmax < 0) continue;
+        int b0 = 0, b1 = M, a0 = 0, a1 = M;
+        if (jmin == jmax) { if (jmin == 0) b1 = L; else if (jmin == N - 1) b0 = M - L; }
+        if (imin == imax) { if (imin == 0) a1 = L; else if (imin == N - 1) a0 = M - L; }
+        if (b0 == 0 && b1 == M && a0 == 0 && a1 == M) continue;    // degenerate adjacency (wraps both ways)
+        for (int b = b0; b < b1; ++b) for (int a = a0; a < a1; ++a) { pe.push_back(f); pr.push_back(b * M + a); }
+      }
+      const int np = (int)pe.size();
+      A.assign((size_t)np * np, 0.0);
+      for (int q = 0; q < np; ++q)
+        for (int r = 0; r < np; ++r) A[(size_t)r * np + q] = Eentry(pe[r], pr[r], pe[q], pr[q]);
+      if (!cs.has_outflow) { double tr = 0; for (int q = 0; q < np; ++q) tr += A[(size_t)q * np + q]; for (int q = 0; q < np; ++q) A[(size_t)q * np + q] += 1e-10 * tr / np; }
+      if (!invert_dense(A, np)) return fail(NSK_EINVAL, "singular Schwarz patch");
+      p_off[e + 1] = p_off[e] + np;
+      p_invoff[e + 1] = p_invoff[e] + (long long)np * MM;
+      for (int q = 0; q < np; ++q) p_idx.push_back(pe[q] * MM + pr[q]);
+      for (int q = 0; q < np; ++q)                       // [q][own row], own row fastest
+        for (int r = 0; r < MM; ++r) p_inv.push_back((float)A[(size_t)r * np + q]);
+    }
+    if ((rc = dupload(c, &d.p_off, p_off)) || (rc = dupload(c, &d.p_idx, p_idx)) || (rc = dupload(c, &d.p_inv, p_inv)) ||
+        (rc = dupload(c, &d.p_invoff, p_invoff))) return rc;
+  }
+  c->cur_helm = c->max_helm; c->cur_pres = c->max_pres;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// one nek_advance() in perturbation mode
+// ---------------------------------------------------------------------------
+static int pres_solve_launch(nsk_ctx* c, double h2) {
+  Dev& d = c->d;
+  const double scale = 1.0 / (h2 * std::sqrt(d.vol));
+  const int np = c->cur_pres;
+  DISPATCH_N(c->N, {
+    constexpr int NT = Cfg<N>::NT;
+    hipLaunchKernelGGL(k_gmres_scal, dim3(1), dim3(256), 0, c->stream, d, -1, scale, c->min_pres);
+    hipLaunchKernelGGL(k_gmres_update<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, -1);
+    for (int j = 0; j < np; ++j) {
+      hipLaunchKernelGGL(k_coarse, dim3((d.nvert + CROWS - 1) / CROWS), dim3(256), d.nvert * sizeof(double), c->stream, d);
+      hipLaunchKernelGGL(k_schwarz<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, (const double*)(d.V + (size_t)j * d.npr), d.Z + (size_t)j * d.npr, 1, 1);
+      hipLaunchKernelGGL(k_divgs<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, (const double*)d.yl, d.V + (size_t)(j + 1) * d.npr, j, 1);
+      hipLaunchKernelGGL(k_gmres_scal, dim3(1), dim3(256), 0, c->stream, d, j, scale, c->min_pres);
+      if (j + 1 < np) hipLaunchKernelGGL(k_gmres_update<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, j);
+    }
+  });
+  return 0;
+}
+
+static int step(nsk_ctx* c, int istep, int adjoint) {
+  Dev& d = c->d;
+  const StepCoef sc = make_coef(c, istep, adjoint);
+  const int nh = c->cur_helm;
+  DISPATCH_N(c->N, {
+    constexpr int NT = Cfg<N>::NT;
+    hipLaunchKernelGGL(k_convect<N>, dim3(c->nel), dim3(Cfg<N>::NTD), 0, c->stream, d, (const double*)d.u, d.bf, adjoint);
+    hipLaunchKernelGGL(k_rhs<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, sc);
+    for (int it = 0; it < nh; ++it)
+      hipLaunchKernelGGL(k_helm<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, sc, it, (const double*)d.rloc);
+    hipLaunchKernelGGL(k_pres_rhs<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, (nh - 1) & 1, nh - 1);
+  });
+  int rc = pres_solve_launch(c, sc.h2);
+  if (rc) return rc;
+  DISPATCH_N(c->N, {
+    hipLaunchKernelGGL(k_pres_update<N>, dim3(c->nblk), dim3(Cfg<N>::NT), 0, c->stream, d, sc);
+  });
+  hipLaunchKernelGGL(k_vel_update, dim3((unsigned)((d.nloc + 255) / 256)), dim3(256), 0, c->stream, d, sc);
+  return 0;
+}
+
+static int run_map(nsk_ctx* c, int adjoint, double* f, const double* q) {
+  Dev& d = c->d;
+  HIPCHK(hipMemcpyAsync(d.u, q, 2 * d.nloc * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(d.p, q + 2 * d.nloc, d.npr * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  for (int istep = 1; istep <= c->nsteps; ++istep) {
+    int rc = step(c, istep, adjoint);
+    if (rc) return rc;
+  }
+  HIPCHK(hipMemcpyAsync(f, d.u, 2 * d.nloc * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(f + 2 * d.nloc, d.p, d.npr * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  return 0;
+}
+
+// ===========================================================================
+// C-ABI
+// ===========================================================================
+extern "C" {
+
+const char* nsk_last_error(void) { return g_err.c_str(); }
+
+int nsk_init(const nsk_case* cs, nsk_ctx** out) {
+  if (!cs || !out) return fail(NSK_EINVAL, "null argument");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return fail(NSK_EHIP, "no HIP device: libnekstab_hip has no CPU fallback");
+  nsk_ctx* c = new nsk_ctx();
+  int rc = build(c, *cs);
+  if (rc) { std::string keep = g_err; nsk_finalize(c); g_err = keep; return rc; }
+  *out = c;
+  return 0;
+}
+
+int nsk_finalize(nsk_ctx* c) {
+  if (!c) return 0;
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  for (void* p : c->allocs) (void)hipFree(p);
+  if (c->hpin) (void)hipHostFree(c->hpin);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+  return 0;
+}
+
+int nsk_get_info(nsk_ctx* c, double* dt, int* nsteps, long long* nstate, long long* nvel, long long* npres) {
+  if (!c) return fail(NSK_EINVAL, "null ctx");
+  if (dt) *dt = c->dt;
+  if (nsteps) *nsteps = c->nsteps;
+  if (nstate) *nstate = c->nstate;
+  if (nvel) *nvel = c->nloc;
+  if (npres) *npres = c->npr;
+  return 0;
+}
+
+int nsk_set_nsteps(nsk_ctx* c, int nsteps) {
+  if (!c || nsteps < 1) return fail(NSK_EINVAL, "bad nsteps");
+  c->nsteps = nsteps;
+  return 0;
+}
+
+int nsk_set_tolerances(nsk_ctx* c, double th, double tp, int relative) {
+  if (!c) return fail(NSK_EINVAL, "null ctx");
+  c->d.tol_helm = th; c->d.tol_pres = tp; c->d.tol_relative = relative;
+  return 0;
+}
+
+int nsk_vec_alloc(nsk_ctx* c, int n, nsk_vec* out) {
+  if (!c || !out || n < 0) return fail(NSK_EINVAL, "bad argument");
+  for (int k = 0; k < n; ++k) {
+    double* p = nullptr;
+    int rc = dalloc(c, &p, (size_t)c->nstate);
+    if (rc) return rc;
+    out[k] = p;
+  }
+  return 0;
+}
+
+int nsk_vec_free(nsk_ctx* c, int n, nsk_vec* v) {
+  if (!c || !v) return fail(NSK_EINVAL, "bad argument");
+  for (int k = 0; k < n; ++k) {
+    auto it = std::find(c->allocs.begin(), c->allocs.end(), (void*)v[k]);
+    if (it == c->allocs.end()) return fail(NSK_EINVAL, "unknown vector handle");
+    (void)hipFree(v[k]);
+    c->allocs.erase(it);
+    v[k] = nullptr;
+  }
+  return 0;
+}
+
+int nsk_vec_upload(nsk_ctx* c, nsk_vec v, const double* vx, const double* vy, const double* pr) {
+  if (!c || !v) return fail(NSK_EINVAL, "bad argument");
+  double* p = (double*)v;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (vx) HIPCHK(hipMemcpy(p, vx, c->nloc * sizeof(double), hipMemcpyHostToDevice));
+  if (vy) HIPCHK(hipMemcpy(p + c->nloc, vy, c->nloc * sizeof(double), hipMemcpyHostToDevice));
+  if (pr) HIPCHK(hipMemcpy(p + 2 * c->nloc, pr, c->npr * sizeof(double), hipMemcpyHostToDevice));
+  return 0;
+}
+
+int nsk_vec_download(nsk_ctx* c, nsk_vec v, double* vx, double* vy, double* pr) {
+  if (!c || !v) return fail(NSK_EINVAL, "bad argument");
+  const double* p = (const double*)v;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (vx) HIPCHK(hipMemcpy(vx, p, c->nloc * sizeof(double), hipMemcpyDeviceToHost));
+  if (vy) HIPCHK(hipMemcpy(vy, p + c->nloc, c->nloc * sizeof(double), hipMemcpyDeviceToHost));
+  if (pr) HIPCHK(hipMemcpy(pr, p + 2 * c->nloc, c->npr * sizeof(double), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int nsk_get_stats(nsk_ctx* c, nsk_stats* s) {
+  if (!c || !s) return fail(NSK_EINVAL, "bad argument");
+  HIPCHK(hipStreamSynchronize(c->stream));
+  Stats h;
+  HIPCHK(hipMemcpy(&h, c->d.stats, sizeof(Stats), hipMemcpyDeviceToHost));
+  s->steps = h.steps; s->helm_iters = h.helm_iters; s->pres_iters = h.pres_iters;
+  s->unconverged = h.unconverged; s->last_helm_res = h.last_helm_res; s->last_pres_res = h.last_pres_res;
+  return 0;
+}
+
+int nsk_matvec(nsk_ctx* c, int mode, nsk_vec fv, nsk_vec qv) {
+  if (!c || !fv || !qv) return fail(NSK_EINVAL, "bad argument");
+  double* f = (double*)fv; const double* q = (const double*)qv;
+  HIPCHK(hipMemsetAsync(c->d.stats, 0, sizeof(Stats), c->stream));
+  int rc = 0;
+  switch (mode) {
+    case NSK_DIRECT: rc = run_map(c, 0, f, q); break;
+    case NSK_ADJOINT: rc = run_map(c, 1, f, q); break;
+    case NSK_DIRECT_ADJOINT:                                     // core/matvec.f:343-346
+      rc = run_map(c, 0, f, q);
+      if (!rc) rc = run_map(c, 1, f, f);
+      break;
+    case NSK_NEWTON:                                             // core/matvec.f:398-401
+      if (f == q) return fail(NSK_EINVAL, "newton map needs f != q");
+      rc = run_map(c, 0, f, q);
+      if (!rc) hipLaunchKernelGGL(k_axpby, dim3((unsigned)((c->nstate + 255) / 256)), dim3(256), 0, c->stream, f, -1.0, q, 1.0, c->nstate);
+      break;
+    default: return fail(NSK_EINVAL, "unknown mode");
+  }
+  if (rc) return rc;
+  Stats h;
+  HIPCHK(hipMemcpyAsync(&h, c->d.stats, sizeof(Stats), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  c->hstats = h;
+  if (h.unconverged > 0) return fail(NSK_ENOCONV, "inner solve hit its iteration cap (" + std::to_string(h.unconverged) + " solves)");
+  return 0;
+}
+
+// ---- Krylov vector algebra ------------------------------------------------
+static int dots_to_device(nsk_ctx* c, const double* f, const nsk_vec* Q, int nq) {
+  if (nq > 1024) return fail(NSK_EINVAL, "too many vectors");
+  for (int k = 0; k < nq; ++k) ((double**)c->hpin)[k] = (double*)Q[k];
+  HIPCHK(hipMemcpyAsync(c->kptr, c->hpin, nq * sizeof(double*), hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_dots, dim3(c->kblk), dim3(256), 0, c->stream, f, (const double* const*)c->kptr, nq, c->d.bm1s, c->nloc, c->kpart, c->kblk);
+  hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, c->stream, (const double*)c->kpart, nq, c->kblk, c->kout);
+  return 0;
+}
+
+int nsk_dot(nsk_ctx* c, nsk_vec p, nsk_vec q, double* alpha) {
+  if (!c || !p || !q || !alpha) return fail(NSK_EINVAL, "bad argument");
+  HIPCHK(hipStreamSynchronize(c->stream));   // hpin reuse
+  int rc = dots_to_device(c, (const double*)p, &q, 1);
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(alpha, c->kout, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (std::isnan(*alpha)) return fail(NSK_ENAN, "NaN inner product");
+  return 0;
+}
+
+int nsk_norm(nsk_ctx* c, nsk_vec p, double* alpha) {
+  int rc = nsk_dot(c, p, p, alpha);
+  if (!rc) *alpha = std::sqrt(*alpha);
+  return rc;
+}
+
+int nsk_scal(nsk_ctx* c, nsk_vec p, double a) {
+  if (!c || !p) return fail(NSK_EINVAL, "bad argument");
+  hipLaunchKernelGGL(k_axpby, dim3((unsigned)((c->nstate + 255) / 256)), dim3(256), 0, c->stream, (double*)p, 0.0, (const double*)p, a, c->nstate);
+  return 0;
+}
+
+int nsk_axpy(nsk_ctx* c, nsk_vec p, double a, nsk_vec q) {
+  if (!c || !p || !q) return fail(NSK_EINVAL, "bad argument");
+  hipLaunchKernelGGL(k_axpby, dim3((unsigned)((c->nstate + 255) / 256)), dim3(256), 0, c->stream, (double*)p, a, (const double*)q, 1.0, c->nstate);
+  return 0;
+}
+
+int nsk_copy(nsk_ctx* c, nsk_vec dst, nsk_vec src) {
+  if (!c || !dst || !src) return fail(NSK_EINVAL, "bad argument");
+  HIPCHK(hipMemcpyAsync(dst, src, c->nstate * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  return 0;
+}
+
+int nsk_zero(nsk_ctx* c, nsk_vec p) {
+  if (!c || !p) return fail(NSK_EINVAL, "bad argument");
+  HIPCHK(hipMemsetAsync(p, 0, c->nstate * sizeof(double), c->stream));
+  return 0;
+}
+
+int nsk_orth(nsk_ctx* c, nsk_vec fv, const nsk_vec* Q, int j, double* h, double* beta) {
+  if (!c || !fv || (j > 0 && !Q) || !h || !beta) return fail(NSK_EINVAL, "bad argument");
+  double* f = (double*)fv;
+  std::vector<double> hh(j, 0.0), pass(j);
+  HIPCHK(hipStreamSynchronize(c->stream));
+  for (int ps = 0; ps < 2 && j > 0; ++ps) {        // two projection passes (re-orthogonalisation)
+    int rc = dots_to_device(c, f, Q, j);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_project_out, dim3((unsigned)((c->nstate + 255) / 256)), dim3(256), 0, c->stream, f, (const double* const*)c->kptr, j, (const double*)c->kout, c->nstate);
+    HIPCHK(hipMemcpyAsync(pass.data(), c->kout, j * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (int k = 0; k < j; ++k) hh[k] += pass[k];
+  }
+  nsk_vec self = fv;
+  int rc = dots_to_device(c, f, &self, 1);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_scale_rsqrt, dim3((unsigned)((c->nstate + 255) / 256)), dim3(256), 0, c->stream, f, (const double*)c->kout, c->nstate);
+  double n2 = 0;
+  HIPCHK(hipMemcpyAsync(&n2, c->kout, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  for (int k = 0; k < j; ++k) { if (std::isnan(hh[k])) return fail(NSK_ENAN, "NaN inner product"); h[k] = hh[k]; }
+  if (std::isnan(n2)) return fail(NSK_ENAN, "NaN norm");
+  *beta = std::sqrt(n2);
+  return 0;
+}
+
+int nsk_basis_gemm(nsk_ctx* c, nsk_vec* Q, int k, const double* Z, int ldz) {
+  if (!c || !Q || !Z || k < 1 || k > 1024 || ldz < k) return fail(NSK_EINVAL, "bad argument");
+  // out-of-place in column chunks, then copy back
+  const int CH = 8;
+  double* dZ = nullptr; int rc = dalloc(c, &dZ, (size_t)k * ldz);
+  if (rc) return rc;
+  HIPCHK(hipMemcpy(dZ, Z, (size_t)k * ldz * sizeof(double), hipMemcpyHostToDevice));   // Z column-major: Z[c*ldz + q]
+  std::vector<double*> tmp(k);
+  for (int q = 0; q < k; ++q) { if ((rc = dalloc(c, &tmp[q], (size_t)c->nstate))) return rc; }
+  double** dQ = nullptr; double** dT = nullptr;
+  if ((rc = dalloc(c, &dQ, k)) || (rc = dalloc(c, &dT, k))) return rc;
+  HIPCHK(hipMemcpy(dQ, Q, k * sizeof(double*), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dT, tmp.data(), k * sizeof(double*), hipMemcpyHostToDevice));
+  for (int c0 = 0; c0 < k; c0 += CH) {
+    const int nc = std::min(CH, k - c0);
+    hipLaunchKernelGGL(k_basis_comb, dim3((unsigned)((c->nstate + 255) / 256)), dim3(256), 0, c->stream, (const double* const*)dQ, k, (const double*)dZ, ldz, c0, nc, (double* const*)(dT + c0), c->nstate);
+  }
+  for (int q = 0; q < k; ++q) HIPCHK(hipMemcpyAsync(Q[q], tmp[q], c->nstate * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  for (int q = 0; q < k; ++q) { nsk_vec v = tmp[q]; nsk_vec_free(c, 1, &v); }
+  nsk_vec a = dZ, b = dQ, e = dT;
+  nsk_vec_free(c, 1, &a); nsk_vec_free(c, 1, &b); nsk_vec_free(c, 1, &e);
+  return 0;
+}
+
+int nsk_basis_gemv(nsk_ctx* c, const nsk_vec* Q, int k, const double* y_re, const double* y_im, nsk_vec re, nsk_vec im) {
+  if (!c || !Q || !y_re || !re || k < 1 || k > 1024) return fail(NSK_EINVAL, "bad argument");
+  std::vector<double> Z((size_t)2 * k);
+  for (int q = 0; q < k; ++q) { Z[q] = y_re[q]; Z[k + q] = y_im ? y_im[q] : 0.0; }
+  double* dZ = nullptr; double** dQ = nullptr; double** dO = nullptr; int rc;
+  if ((rc = dalloc(c, &dZ, Z.size())) || (rc = dalloc(c, &dQ, k)) || (rc = dalloc(c, &dO, 2))) return rc;
+  double* outs[2] = {(double*)re, (double*)(im ? im : re)};
+  HIPCHK(hipMemcpy(dZ, Z.data(), Z.size() * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dQ, Q, k * sizeof(double*), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dO, outs, 2 * sizeof(double*), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_basis_comb, dim3((unsigned)((c->nstate + 255) / 256)), dim3(256), 0, c->stream, (const double* const*)dQ, k, (const double*)dZ, k, 0, (im && y_im) ? 2 : 1, (double* const*)dO, c->nstate);
+  HIPCHK(hipStreamSynchronize(c->stream));
+  nsk_vec a = dZ, b = dQ, e = dO;
+  nsk_vec_free(c, 1, &a); nsk_vec_free(c, 1, &b); nsk_vec_free(c, 1, &e);
+  return 0;
+}
+
+int nsk_seed_noise(nsk_ctx* c, nsk_vec v) {
+  (void)c; (void)v;
+  return fail(NSK_EINVAL, "nsk_seed_noise: build the seed on the host (nekstab_amd.seed) and upload it");
+}
+
+// ---- test hooks -------------------------------------------------------------
+int nsk_test_axhelm(nsk_ctx* c, const double* u, double h1, double h2, double* out) {
+  HIPCHK(hipMemcpy(c->wv1, u, c->nloc * sizeof(double), hipMemcpyHostToDevice));
+  DISPATCH_N(c->N, { hipLaunchKernelGGL(k_axhelm_test<N>, dim3(c->nblk), dim3(Cfg<N>::NT), 0, c->stream, c->d, (const double*)c->wv1, h1, h2, c->wv2); });
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipMemcpy(out, c->wv2, c->nloc * sizeof(double), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int nsk_test_dssum(nsk_ctx* c, const double* u, double* out) {
+  HIPCHK(hipMemcpy(c->wv1, u, c->nloc * sizeof(double), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_dssum_test, dim3((unsigned)((c->nloc + 255) / 256)), dim3(256), 0, c->stream, c->d, (const double*)c->wv1, c->wv2);
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipMemcpy(out, c->wv2, c->nloc * sizeof(double), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int nsk_test_opdiv(nsk_ctx* c, const double* u, const double* v, double* out) {
+  HIPCHK(hipMemcpy(c->wv1, u, c->nloc * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(c->wv1 + c->nloc, v, c->nloc * sizeof(double), hipMemcpyHostToDevice));
+  DISPATCH_N(c->N, { hipLaunchKernelGGL(k_opdiv_test<N>, dim3(c->nblk), dim3(Cfg<N>::NT), 0, c->stream, c->d, (const double*)c->wv1, c->wp1); });
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipMemcpy(out, c->wp1, c->npr * sizeof(double), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int nsk_test_opgradt(nsk_ctx* c, const double* p, double* ox, double* oy) {
+  HIPCHK(hipMemcpy(c->wp1, p, c->npr * sizeof(double), hipMemcpyHostToDevice));
+  DISPATCH_N(c->N, { hipLaunchKernelGGL(k_gradt<N>, dim3(c->nblk), dim3(Cfg<N>::NT), 0, c->stream, c->d, (const double*)c->wp1, c->wv1); });
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipMemcpy(ox, c->wv1, c->nloc * sizeof(double), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(oy, c->wv1 + c->nloc, c->nloc * sizeof(double), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int nsk_test_convect(nsk_ctx* c, int adjoint, const double* u, const double* v, double* ox, double* oy) {
+  HIPCHK(hipMemcpy(c->wv1, u, c->nloc * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(c->wv1 + c->nloc, v, c->nloc * sizeof(double), hipMemcpyHostToDevice));
+  DISPATCH_N(c->N, { hipLaunchKernelGGL(k_convect<N>, dim3(c->nel), dim3(Cfg<N>::NTD), 0, c->stream, c->d, (const double*)c->wv1, c->wv2, adjoint); });
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipMemcpy(ox, c->wv2, c->nloc * sizeof(double), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(oy, c->wv2 + c->nloc, c->nloc * sizeof(double), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int nsk_test_eapply(nsk_ctx* c, const double* p, double* out) {
+  HIPCHK(hipMemcpy(c->wp1, p, c->npr * sizeof(double), hipMemcpyHostToDevice));
+  int rc = eapply(c, c->wp1, c->wp2);
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipMemcpy(out, c->wp2, c->npr * sizeof(double), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int nsk_test_helm_solve(nsk_ctx* c, const double* rx, const double* ry, int order, double* ox, double* oy, int* iters) {
+  Dev& d = c->d;
+  HIPCHK(hipMemcpy(d.rloc, rx, c->nloc * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(d.rloc + c->nloc, ry, c->nloc * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipMemset(d.stats, 0, sizeof(Stats)));
+  const StepCoef sc = make_coef(c, order, 0);
+  const int nh = c->max_helm;
+  DISPATCH_N(c->N, {
+    for (int it = 0; it < nh; ++it)
+      hipLaunchKernelGGL(k_helm<N>, dim3(c->nblk), dim3(Cfg<N>::NT), 0, c->stream, d, sc, it, (const double*)d.rloc);
+  });
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipMemcpy(ox, d.hx, c->nloc * sizeof(double), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(oy, d.hx + c->nloc, c->nloc * sizeof(double), hipMemcpyDeviceToHost));
+  Stats h; HIPCHK(hipMemcpy(&h, d.stats, sizeof(Stats), hipMemcpyDeviceToHost));
+  if (iters) *iters = (int)h.helm_iters;
+  return 0;
+}
+
+int nsk_test_pres_solve(nsk_ctx* c, const double* g, double* out, int* iters) {
+  Dev& d = c->d;
+  // V[0] = g, partial norms, then GMRES; result y with E0 y = g  (returned without the h2 factor)
+  HIPCHK(hipMemcpy(d.V, g, c->npr * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipMemset(d.stats, 0, sizeof(Stats)));
+  HIPCHK(hipMemset(d.pext, 0, c->npr * sizeof(double)));
+  std::vector<double> part(c->nblk, 0.0);
+  for (long long q = 0; q < c->npr; ++q) part[(q / c->MM) / c->EPB] += g[q] * g[q];
+  HIPCHK(hipMemcpy(d.gpart, part.data(), c->nblk * sizeof(double), hipMemcpyHostToDevice));
+  StepCoef sc = make_coef(c, 3, 0);
+  const int save = c->cur_pres; c->cur_pres = c->max_pres;
+  int rc = pres_solve_launch(c, 1.0);
+  c->cur_pres = save;
+  if (rc) return rc;
+  sc.h2 = 1.0;
+  DISPATCH_N(c->N, { hipLaunchKernelGGL(k_pres_update<N>, dim3(c->nblk), dim3(Cfg<N>::NT), 0, c->stream, d, sc); });
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipMemcpy(out, d.p, c->npr * sizeof(double), hipMemcpyDeviceToHost));
+  Stats h; HIPCHK(hipMemcpy(&h, d.stats, sizeof(Stats), hipMemcpyDeviceToHost));
+  if (iters) *iters = (int)h.pres_iters;
+  return 0;
+}
+
+}  // extern "C"

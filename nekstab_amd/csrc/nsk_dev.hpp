@@ -1,0 +1,75 @@
+// Device-side data layout shared by the kernels and the host driver.
+// All fields live in HBM, element-major (Nek layout): GLL node l = e*N*N + j*N + i,
+// pressure (Gauss) node = e*M*M + b*M + a, dealiasing node = e*ND*ND + b*ND + a.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace nsk {
+
+constexpr int MAXMR = 48;        // GMRES basis cap (Nek: lgmres = 30, SIZE:34)
+constexpr int MAXPROJ = 32;      // pressure projection space cap (Nek: mxprev = 20)
+
+struct StepCoef {                // order k = min(istep,3)  [UPSTREAM setordbd/setbd/setabbd]
+  double bd[4];
+  double ab[3];
+  double h2;                     // bd0/dt
+  double invdt;
+  int k;
+  int adjoint;
+};
+
+struct GmresScal {               // device-resident small state of one pressure solve
+  double beta0;                  // ||g||
+  double g[MAXMR + 1];           // rotated rhs
+  double cs[MAXMR], sn[MAXMR];
+  double R[MAXMR * MAXMR];       // upper triangular, column j at R[j*MAXMR + i]
+  double hcol[MAXMR + 2];        // projection coefficients of the current column
+  double hinv;                   // 1 / h(j+1,j)
+  double resid;                  // current residual estimate, Nek norm
+  double y[MAXMR];
+  double aproj[MAXPROJ];         // projection coefficients of the rhs on the stored solutions
+  int done;
+  int nit;
+  int nproj;                     // vectors currently in the projection space
+};
+
+struct Stats {
+  long long helm_iters, pres_iters, unconverged, steps;
+  double last_helm_res, last_pres_res;
+};
+
+struct Dev {
+  int nel, nblk, nvert, adj_dummy;
+  long long nloc, npr;
+  double nu, dt, vol, tol_helm, tol_pres;
+  int tol_relative, max_mr, has_outflow, nproj_max;
+  // bases
+  const double *D, *J12, *D12, *Jd, *Dd, *hat;
+  // per GLL node
+  const double *g1, *g2, *g4, *bm1, *mask, *minv, *binv, *spng, *bm1s, *dinv;
+  // per Gauss (pressure) node, premultiplied by the Gauss weights
+  const double *w2rx, *w2ry, *w2sx, *w2sy;
+  // per dealiasing node (base-flow dependent, constant in time)
+  const double *cUr, *cUs, *GUx, *GUy, *GVx, *GVy;
+  // gather-scatter (dssum) as a gather: CSR of co-located local nodes, ascending
+  const int *gs_off, *gs_idx;
+  // time-stepper state
+  double *u, *p, *plag, *pext, *ulag, *exlag, *bf, *rloc;
+  // Helmholtz CG (both components advance together)
+  double *hx, *hr, *hp, *hs, *hwl, *hpart, *hscal;
+  // pressure GMRES
+  double *V, *Z, *yl, *ec, *xc, *gpart;
+  GmresScal* gsc;
+  // projection onto previous pressure solutions (E-orthonormal)
+  double *PX, *PEX;
+  // coarse space
+  const int *v_off, *v_ent, *evert;
+  const double* Aci;
+  // restricted additive Schwarz patches
+  const int *p_off, *p_idx;
+  const float* p_inv;
+  const long long* p_invoff;
+  Stats* stats;
+};
+
+}  // namespace nsk

@@ -1,0 +1,921 @@
+// HIP kernels (gfx950) of the linearised PnPn-2 time step and the Krylov vector
+// algebra.  One thread per GLL node, EPB elements per workgroup (N=8: one
+// element = one 64-lane wavefront), D-hat / interpolation matrices and element
+// tiles staged in LDS, E-contiguous coalesced HBM access.  dssum is a *gather*
+// over a precomputed CSR of co-located nodes fused into the consuming kernel,
+// which makes it deterministic (fixed summation order) and removes the separate
+// gather-scatter launch.  All reductions are two-level with a fixed order.
+#pragma once
+#include "nsk_dev.hpp"
+
+namespace nsk {
+
+template <int N>
+struct Cfg {
+  static constexpr int NN = N * N, M = N - 2, MM = M * M, ND = 3 * N / 2, NDD = ND * ND;
+  static constexpr int EPB = (256 / NN) > 0 ? (256 / NN) : 1;
+  static constexpr int NT = ((EPB * NN + 63) / 64) * 64;
+  static constexpr int NTD = ((NDD + 63) / 64) * 64;
+};
+
+// ---------------------------------------------------------------------------
+// deterministic block reduction of NV values; every thread gets the result
+// ---------------------------------------------------------------------------
+template <int NV>
+__device__ inline void block_reduce(double (&v)[NV], double* sred, int tid, int nthreads) {
+  const int lane = tid & 63, w = tid >> 6, nw = (nthreads + 63) >> 6;
+#pragma unroll
+  for (int q = 0; q < NV; ++q) {
+    double x = v[q];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o, 64);
+    if (lane == 0) sred[q * 16 + w] = x;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < NV; ++q) {
+    double s = 0.0;
+    for (int k = 0; k < nw; ++k) s += sred[q * 16 + k];
+    v[q] = s;
+  }
+  __syncthreads();
+}
+
+// sum NV arrays of `n` per-block partials (stride `n`), fixed order, all threads get it
+template <int NV>
+__device__ inline void sum_partials(const double* part, int n, double (&out)[NV], double* sred,
+                                    int tid, int nthreads) {
+  double v[NV];
+#pragma unroll
+  for (int q = 0; q < NV; ++q) {
+    double s = 0.0;
+    for (int k = tid; k < n; k += nthreads) s += part[(size_t)q * n + k];
+    v[q] = s;
+  }
+  block_reduce<NV>(v, sred, tid, nthreads);
+#pragma unroll
+  for (int q = 0; q < NV; ++q) out[q] = v[q];
+}
+
+__device__ inline double gs_gather(const double* __restrict__ f, const int* __restrict__ off,
+                                   const int* __restrict__ idx, long long l) {
+  const int a = off[l], b = off[l + 1];
+  if (b - a == 1) return f[l];
+  double s = 0.0;
+  for (int k = a; k < b; ++k) s += f[idx[k]];
+  return s;
+}
+
+// ---------------------------------------------------------------------------
+// element-local building blocks on LDS tiles
+// ---------------------------------------------------------------------------
+// D^T G D on NC component tiles su[c][EPB][NN]  [UPSTREAM hmholtz.f axhelm]
+template <int N, int EPB, int NC>
+__device__ inline void axhelm_tiles(const double* sD, const double* sDt, const double* su,
+                                    double* st1, double* st2, bool act, int el, int j, int i,
+                                    double g1, double g2, double g4, double (&out)[NC]) {
+  constexpr int NN = N * N;
+  if (act) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const double* z = su + (c * EPB + el) * NN;
+      double ur = 0.0, us = 0.0;
+#pragma unroll
+      for (int k = 0; k < N; ++k) {
+        ur += sDt[k * N + i] * z[j * N + k];
+        us += sDt[k * N + j] * z[k * N + i];
+      }
+      st1[(c * EPB + el) * NN + j * N + i] = g1 * ur + g4 * us;
+      st2[(c * EPB + el) * NN + j * N + i] = g2 * us + g4 * ur;
+    }
+  }
+  __syncthreads();
+  if (act) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const double* t1 = st1 + (c * EPB + el) * NN;
+      const double* t2 = st2 + (c * EPB + el) * NN;
+      double au = 0.0;
+#pragma unroll
+      for (int k = 0; k < N; ++k) au += sD[k * N + i] * t1[j * N + k] + sD[k * N + j] * t2[k * N + i];
+      out[c] = au;
+    }
+  }
+}
+
+// weak divergence GLL -> Gauss  [UPSTREAM navier1.f opdiv/multd]; su = [2][EPB][NN]
+// sA scratch [4][EPB][N*M]; returns the value for Gauss node nd (< MM)
+template <int N, int EPB>
+__device__ inline double opdiv_tiles(const double* sJ12, const double* sD12, const double* su,
+                                     double* sA, bool act, int el, int nd, const Dev& d, long long e) {
+  constexpr int NN = N * N, M = N - 2, MM = M * M, NM = N * M;
+  if (act && nd < NM) {
+    const int j = nd / M, a = nd % M;
+    const double* u = su + (0 * EPB + el) * NN + j * N;
+    const double* v = su + (1 * EPB + el) * NN + j * N;
+    double a1u = 0, a2u = 0, a1v = 0, a2v = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const double dd = sD12[a * N + i], jj = sJ12[a * N + i];
+      a1u += dd * u[i]; a2u += jj * u[i];
+      a1v += dd * v[i]; a2v += jj * v[i];
+    }
+    sA[(0 * EPB + el) * NM + nd] = a1u;
+    sA[(1 * EPB + el) * NM + nd] = a2u;
+    sA[(2 * EPB + el) * NM + nd] = a1v;
+    sA[(3 * EPB + el) * NM + nd] = a2v;
+  }
+  __syncthreads();
+  double div = 0.0;
+  if (act && nd < MM) {
+    const int b = nd / M, a = nd % M;
+    double ur = 0, us = 0, vr = 0, vs = 0;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      const double jj = sJ12[b * N + j], dd = sD12[b * N + j];
+      ur += jj * sA[(0 * EPB + el) * NM + j * M + a];
+      us += dd * sA[(1 * EPB + el) * NM + j * M + a];
+      vr += jj * sA[(2 * EPB + el) * NM + j * M + a];
+      vs += dd * sA[(3 * EPB + el) * NM + j * M + a];
+    }
+    const long long q = e * MM + nd;
+    div = d.w2rx[q] * ur + d.w2sx[q] * us + d.w2ry[q] * vr + d.w2sy[q] * vs;
+  }
+  return div;
+}
+
+// D^T p  [UPSTREAM navier1.f opgradt/cdtp]; sP = [4][EPB][MM] holds p*w2rx, p*w2sx, p*w2ry, p*w2sy
+// sB scratch [4][EPB][M*N]
+template <int N, int EPB>
+__device__ inline void opgradt_tiles(const double* sJ12, const double* sD12, const double* sP,
+                                     double* sB, bool act, int el, int nd, double& gx, double& gy) {
+  constexpr int M = N - 2, MM = M * M, NM = N * M;
+  if (act && nd < NM) {
+    const int b = nd / N, i = nd % N;
+    double b1x = 0, b2x = 0, b1y = 0, b2y = 0;
+#pragma unroll
+    for (int a = 0; a < M; ++a) {
+      const double dd = sD12[a * N + i], jj = sJ12[a * N + i];
+      b1x += sP[(0 * EPB + el) * MM + b * M + a] * dd;
+      b2x += sP[(1 * EPB + el) * MM + b * M + a] * jj;
+      b1y += sP[(2 * EPB + el) * MM + b * M + a] * dd;
+      b2y += sP[(3 * EPB + el) * MM + b * M + a] * jj;
+    }
+    sB[(0 * EPB + el) * NM + nd] = b1x;
+    sB[(1 * EPB + el) * NM + nd] = b2x;
+    sB[(2 * EPB + el) * NM + nd] = b1y;
+    sB[(3 * EPB + el) * NM + nd] = b2y;
+  }
+  __syncthreads();
+  gx = 0.0; gy = 0.0;
+  if (act) {
+    const int j = nd / N, i = nd % N;
+#pragma unroll
+    for (int b = 0; b < M; ++b) {
+      const double jj = sJ12[b * N + j], dd = sD12[b * N + j];
+      gx += jj * sB[(0 * EPB + el) * NM + b * N + i] + dd * sB[(1 * EPB + el) * NM + b * N + i];
+      gy += jj * sB[(2 * EPB + el) * NM + b * N + i] + dd * sB[(3 * EPB + el) * NM + b * N + i];
+    }
+  }
+}
+
+template <int N, int EPB>
+__device__ inline void load_basis(const Dev& d, double* sD, double* sDt, double* sJ12, double* sD12,
+                                  int tid, int nt) {
+  constexpr int NN = N * N, M = N - 2;
+  for (int k = tid; k < NN; k += nt) {
+    if (sD) sD[k] = d.D[k];
+    if (sDt) sDt[(k % N) * N + k / N] = d.D[k];
+  }
+  if (sJ12)
+    for (int k = tid; k < M * N; k += nt) { sJ12[k] = d.J12[k]; sD12[k] = d.D12[k]; }
+}
+
+// ---------------------------------------------------------------------------
+// K1: forcing + dealiased convection  -> bf (mass weighted)
+//   makeufp + advabp / advabp_adjoint  [UPSTREAM perturb.f], sponge term of
+//   nekStab_forcing (core/utils.f:172-177).  One element per workgroup, one
+//   thread per dealiasing node.
+// ---------------------------------------------------------------------------
+template <int N>
+__global__ __launch_bounds__(Cfg<N>::NTD) void k_convect(Dev d, const double* __restrict__ uin,
+                                                         double* __restrict__ bf, int adjoint) {
+  using C = Cfg<N>;
+  constexpr int NN = C::NN, ND = C::ND, NDD = C::NDD, NT = C::NTD;
+  __shared__ double sJ[ND * N], sDd[ND * ND];
+  __shared__ double su[2][NN], st[2][N * ND], sf[2][NDD], so[2][NDD], sq[2][ND * N];
+  const int tid = threadIdx.x;
+  const long long e = blockIdx.x;
+  for (int k = tid; k < ND * N; k += NT) sJ[k] = d.Jd[k];
+  for (int k = tid; k < NDD; k += NT) sDd[k] = d.Dd[k];
+  if (tid < NN) {
+    su[0][tid] = uin[e * NN + tid];
+    su[1][tid] = uin[d.nloc + e * NN + tid];
+  }
+  __syncthreads();
+  // interpolate in r: st[c][j][a] = sum_i Jd[a][i] u[j][i]
+  if (tid < N * ND) {
+    const int j = tid / ND, a = tid % ND;
+    double s0 = 0, s1 = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const double w = sJ[a * N + i];
+      s0 += w * su[0][j * N + i];
+      s1 += w * su[1][j * N + i];
+    }
+    st[0][tid] = s0; st[1][tid] = s1;
+  }
+  __syncthreads();
+  const int b = tid / ND, a = tid % ND;
+  const bool fact = tid < NDD;
+  if (fact) {
+    double s0 = 0, s1 = 0;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      const double w = sJ[b * N + j];
+      s0 += w * st[0][j * ND + a];
+      s1 += w * st[1][j * ND + a];
+    }
+    sf[0][tid] = s0; sf[1][tid] = s1;
+  }
+  __syncthreads();
+  if (fact) {
+    double ur = 0, us = 0, vr = 0, vs = 0;
+#pragma unroll
+    for (int k = 0; k < ND; ++k) {
+      const double dr = sDd[a * ND + k], ds = sDd[b * ND + k];
+      ur += dr * sf[0][b * ND + k]; us += ds * sf[0][k * ND + a];
+      vr += dr * sf[1][b * ND + k]; vs += ds * sf[1][k * ND + a];
+    }
+    const long long q = e * NDD + tid;
+    const double uf = sf[0][tid], vf = sf[1][tid];
+    const double cr = d.cUr[q], cs = d.cUs[q];
+    const double conv_u = cr * ur + cs * us, conv_v = cr * vr + cs * vs;   // (U.grad) u'
+    double ox, oy;
+    if (!adjoint) {          // + (u'.grad) U
+      ox = conv_u + uf * d.GUx[q] + vf * d.GUy[q];
+      oy = conv_v + uf * d.GVx[q] + vf * d.GVy[q];
+    } else {                 // (grad U)^T u' - (U.grad) u'
+      ox = uf * d.GUx[q] + vf * d.GVx[q] - conv_u;
+      oy = uf * d.GUy[q] + vf * d.GVy[q] - conv_v;
+    }
+    so[0][tid] = ox; so[1][tid] = oy;
+  }
+  __syncthreads();
+  // project back: sq[c][b][i] = sum_a Jd[a][i] so[b][a]
+  if (tid < ND * N) {
+    const int bb = tid / N, i = tid % N;
+    double s0 = 0, s1 = 0;
+#pragma unroll
+    for (int aa = 0; aa < ND; ++aa) {
+      const double w = sJ[aa * N + i];
+      s0 += w * so[0][bb * ND + aa];
+      s1 += w * so[1][bb * ND + aa];
+    }
+    sq[0][tid] = s0; sq[1][tid] = s1;
+  }
+  __syncthreads();
+  if (tid < NN) {
+    const int j = tid / N, i = tid % N;
+    double s0 = 0, s1 = 0;
+#pragma unroll
+    for (int bb = 0; bb < ND; ++bb) {
+      const double w = sJ[bb * N + j];
+      s0 += w * sq[0][bb * N + i];
+      s1 += w * sq[1][bb * N + i];
+    }
+    const long long l = e * NN + tid;
+    const double sb = d.spng[l] * d.bm1[l];
+    bf[l] = -(sb * su[0][tid] + s0);
+    bf[d.nloc + l] = -(sb * su[1][tid] + s1);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K2: makextp + makebdfp + lagfieldp + extrapprp + cresvipp  [UPSTREAM perturb.f]
+//   r_loc = EXT(bf) + BDF lags + D^T p* - H u^n   (unassembled)
+// ---------------------------------------------------------------------------
+template <int N>
+__global__ __launch_bounds__(Cfg<N>::NT) void k_rhs(Dev d, StepCoef sc) {
+  using C = Cfg<N>;
+  constexpr int NN = C::NN, M = C::M, MM = C::MM, EPB = C::EPB, NT = C::NT, NM = N * M;
+  __shared__ double sD[NN], sDt[NN], sJ12[NM], sD12[NM];
+  __shared__ double su[2 * EPB * NN], st1[2 * EPB * NN], st2[2 * EPB * NN];
+  __shared__ double sP[4 * EPB * MM], sB[4 * EPB * NM];
+  const int tid = threadIdx.x, el = tid / NN, nd = tid % NN;
+  const long long e = (long long)blockIdx.x * EPB + el;
+  const bool act = (el < EPB) && (e < d.nel);
+  const int j = nd / N, i = nd % N;
+  const long long l = e * NN + nd, nl = d.nloc;
+  load_basis<N, EPB>(d, sD, sDt, sJ12, sD12, tid, NT);
+  double u[2] = {0, 0}, bfv[2] = {0, 0}, bm = 0, g1 = 0, g2 = 0, g4 = 0;
+  if (act) {
+    bm = d.bm1[l]; g1 = d.g1[l]; g2 = d.g2[l]; g4 = d.g4[l];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const long long lc = c * nl + l;
+      u[c] = d.u[lc];
+      su[(c * EPB + el) * NN + nd] = u[c];
+      const double bn = d.bf[lc];
+      const double e1 = d.exlag[lc], e2 = d.exlag[2 * nl + lc];
+      double b = sc.ab[0] * bn + sc.ab[1] * e1 + sc.ab[2] * e2;      // makextp
+      d.exlag[2 * nl + lc] = e1;
+      d.exlag[lc] = bn;
+      const double l1 = d.ulag[lc], l2 = d.ulag[2 * nl + lc];
+      b += bm * (sc.bd[1] * u[c] + sc.bd[2] * l1 + sc.bd[3] * l2) * sc.invdt;   // makebdfp
+      d.ulag[2 * nl + lc] = l1;                                      // lagfieldp
+      d.ulag[lc] = u[c];
+      bfv[c] = b;
+    }
+    if (nd < MM) {                                                   // extrapprp
+      const long long q = e * MM + nd;
+      const double pn = d.p[q];
+      const double pe = (sc.k < 3) ? pn : 2.0 * pn - d.plag[q];
+      d.plag[q] = pn;
+      d.pext[q] = pe;
+      sP[(0 * EPB + el) * MM + nd] = pe * d.w2rx[q];
+      sP[(1 * EPB + el) * MM + nd] = pe * d.w2sx[q];
+      sP[(2 * EPB + el) * MM + nd] = pe * d.w2ry[q];
+      sP[(3 * EPB + el) * MM + nd] = pe * d.w2sy[q];
+    }
+  }
+  __syncthreads();
+  double gx, gy;
+  opgradt_tiles<N, EPB>(sJ12, sD12, sP, sB, act, el, nd, gx, gy);
+  double au[2];
+  axhelm_tiles<N, EPB, 2>(sD, sDt, su, st1, st2, act, el, j, i, g1, g2, g4, au);
+  if (act) {
+    d.rloc[l] = bfv[0] + gx - (d.nu * au[0] + sc.h2 * bm * u[0]);
+    d.rloc[nl + l] = bfv[1] + gy - (d.nu * au[1] + sc.h2 * bm * u[1]);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K3: one Jacobi-preconditioned CG iteration of H du = dssum(r), both velocity
+// components, in the single-reduction (Chronopoulos-Gear) form so that ONE
+// kernel = gather-dssum of the previous A z + vector updates + next local A z +
+// the three dot products.  (z, A z) is summed from unassembled element
+// contributions, which is exact for continuous z.   [UPSTREAM hmholtz.f cggo]
+//   hscal[par][c*4 + {0:gamma,1:alpha,2:done,3:res}]
+// ---------------------------------------------------------------------------
+template <int N>
+__global__ __launch_bounds__(Cfg<N>::NT) void k_helm(Dev d, StepCoef sc, int it, const double* rhs) {
+  using C = Cfg<N>;
+  constexpr int NN = C::NN, EPB = C::EPB, NT = C::NT;
+  __shared__ double sD[NN], sDt[NN];
+  __shared__ double sz[2 * EPB * NN], st1[2 * EPB * NN], st2[2 * EPB * NN];
+  __shared__ double sred[6 * 16];
+  const int tid = threadIdx.x, el = tid / NN, nd = tid % NN;
+  const long long e = (long long)blockIdx.x * EPB + el;
+  const bool act = (el < EPB) && (e < d.nel);
+  const int j = nd / N, i = nd % N;
+  const long long l = e * NN + nd, nl = d.nloc;
+  const int par = it & 1, ppar = par ^ 1;
+  double alpha[2] = {0, 0}, beta[2] = {0, 0}, gam[2] = {0, 0};
+  bool done[2] = {false, false};
+  if (it > 0) {
+    double s[6];
+    sum_partials<6>(d.hpart + (size_t)ppar * 6 * d.nblk, d.nblk, s, sred, tid, NT);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const double* old = d.hscal + ppar * 8 + c * 4;
+      const double g = s[c * 3 + 0], del = s[c * 3 + 1], rr = s[c * 3 + 2];
+      const double res = sqrt(rr / d.vol);
+      const double ref = (it == 1) ? res : d.hscal[16 + c];
+      const double tol = d.tol_relative ? d.tol_helm * ref : d.tol_helm;
+      done[c] = (it > 1 && old[2] != 0.0) || (res <= tol) || !(g > 0.0);
+      gam[c] = g;
+      if (!done[c]) {
+        if (it == 1) { beta[c] = 0.0; alpha[c] = g / del; }
+        else { beta[c] = g / old[0]; alpha[c] = g / (del - beta[c] * g / old[1]); }
+      }
+      if (blockIdx.x == 0 && tid == 0) {
+        double* cur = d.hscal + par * 8 + c * 4;
+        const bool was = (it > 1 && old[2] != 0.0);
+        cur[0] = g; cur[1] = alpha[c]; cur[2] = done[c] ? 1.0 : 0.0;
+        cur[3] = was ? old[3] : res;
+        if (it == 1) d.hscal[16 + c] = res;
+        if (done[c] && !was && c == 0) atomicAdd((unsigned long long*)&d.stats->helm_iters, (unsigned long long)(it - 1));
+      }
+    }
+    if (done[0] && done[1]) return;
+  }
+  load_basis<N, EPB>(d, sD, sDt, nullptr, nullptr, tid, NT);
+  double r[2] = {0, 0}, z[2] = {0, 0}, bm = 0, g1 = 0, g2 = 0, g4 = 0, mk = 0, mi = 0, di = 0;
+  if (act) {
+    bm = d.bm1[l]; g1 = d.g1[l]; g2 = d.g2[l]; g4 = d.g4[l]; mk = d.mask[l]; mi = d.minv[l];
+    di = d.dinv[(size_t)(sc.k - 1) * nl + l];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const long long lc = c * nl + l;
+      if (it == 0) {
+        r[c] = mk * gs_gather(rhs + c * nl, d.gs_off, d.gs_idx, l);
+        d.hx[lc] = 0.0; d.hp[lc] = 0.0; d.hs[lc] = 0.0; d.hr[lc] = r[c];
+      } else if (!done[c]) {
+        const double w = mk * gs_gather(d.hwl + ((size_t)ppar * 2 + c) * nl, d.gs_off, d.gs_idx, l);
+        const double rold = d.hr[lc];
+        const double pn = di * rold + beta[c] * d.hp[lc];
+        const double sn = w + beta[c] * d.hs[lc];
+        d.hp[lc] = pn; d.hs[lc] = sn;
+        d.hx[lc] += alpha[c] * pn;
+        r[c] = rold - alpha[c] * sn;
+        d.hr[lc] = r[c];
+      } else {
+        r[c] = d.hr[lc];
+      }
+      z[c] = di * r[c];
+      sz[(c * EPB + el) * NN + nd] = z[c];
+    }
+  }
+  __syncthreads();
+  double au[2];
+  axhelm_tiles<N, EPB, 2>(sD, sDt, sz, st1, st2, act, el, j, i, g1, g2, g4, au);
+  double v[6] = {0, 0, 0, 0, 0, 0};
+  if (act) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const double wl = d.nu * au[c] + sc.h2 * bm * z[c];
+      d.hwl[((size_t)par * 2 + c) * nl + l] = wl;
+      v[c * 3 + 0] = r[c] * z[c] * mi;
+      v[c * 3 + 1] = z[c] * wl;
+      v[c * 3 + 2] = r[c] * r[c] * mi;
+    }
+  }
+  block_reduce<6>(v, sred, tid, NT);
+  if (tid < 6) d.hpart[((size_t)par * 6 + tid) * d.nblk + blockIdx.x] = v[tid];
+}
+
+// ---------------------------------------------------------------------------
+// K4: u* = u + du ;  g = -D u*  -> V[0] (unnormalised), |g|^2 partials
+//     also verifies that the Helmholtz solve converged.   [UPSTREAM incomprp]
+// ---------------------------------------------------------------------------
+template <int N>
+__global__ __launch_bounds__(Cfg<N>::NT) void k_pres_rhs(Dev d, int helm_par, int check_helm) {
+  using C = Cfg<N>;
+  constexpr int NN = C::NN, M = C::M, MM = C::MM, EPB = C::EPB, NT = C::NT, NM = N * M;
+  __shared__ double sJ12[NM], sD12[NM];
+  __shared__ double su[2 * EPB * NN], sA[4 * EPB * NM];
+  __shared__ double sred[16];
+  const int tid = threadIdx.x, el = tid / NN, nd = tid % NN;
+  const long long e = (long long)blockIdx.x * EPB + el;
+  const bool act = (el < EPB) && (e < d.nel);
+  const long long l = e * NN + nd, nl = d.nloc;
+  load_basis<N, EPB>(d, nullptr, nullptr, sJ12, sD12, tid, NT);
+  if (check_helm && blockIdx.x == 0) {       // last partials -> final residual of the velocity solve
+    double s[6];
+    sum_partials<6>(d.hpart + (size_t)helm_par * 6 * d.nblk, d.nblk, s, sred, tid, NT);
+    if (tid == 0) {
+      double worst = 0.0; int bad = 0;
+      for (int c = 0; c < 2; ++c) {
+        const double res = sqrt(s[c * 3 + 2] / d.vol);
+        const double tol = d.tol_relative ? d.tol_helm * d.hscal[16 + c] : d.tol_helm;
+        const bool was = d.hscal[helm_par * 8 + c * 4 + 2] != 0.0;
+        const double rr = was ? d.hscal[helm_par * 8 + c * 4 + 3] : res;
+        worst = fmax(worst, rr);
+        if (!was && !(res <= tol)) bad = 1;
+        if (!was && c == 0) atomicAdd((unsigned long long*)&d.stats->helm_iters, (unsigned long long)check_helm);
+      }
+      d.stats->last_helm_res = worst;
+      if (bad) atomicAdd((unsigned long long*)&d.stats->unconverged, 1ull);
+    }
+  }
+  if (act) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const double us = d.u[c * nl + l] + d.hx[c * nl + l];
+      d.u[c * nl + l] = us;
+      su[(c * EPB + el) * NN + nd] = us;
+    }
+  }
+  __syncthreads();
+  const double div = opdiv_tiles<N, EPB>(sJ12, sD12, su, sA, act, el, nd, d, e);
+  double v[1] = {0.0};
+  if (act && nd < MM) {
+    const double g = -div;
+    d.V[e * MM + nd] = g;
+    v[0] = g * g;
+  }
+  block_reduce<1>(v, sred, tid, NT);
+  if (tid == 0) d.gpart[blockIdx.x] = v[0];
+}
+
+// ---------------------------------------------------------------------------
+// pressure GMRES pieces.  Right-preconditioned, M^-1 = restricted additive
+// Schwarz (dense patch inverses, fp32 storage) + vertex coarse solve (dense
+// inverse).  [UPSTREAM navier1.f uzawa_gmres, hsmg.f -- the preconditioner is
+// this build's own; only the converged solution is part of the discretisation]
+// ---------------------------------------------------------------------------
+
+// scalar work after the dots of iteration j (j = -1: start-up norm of g)
+__global__ void k_gmres_scal(Dev d, int j, double scale, int min_iter) {
+  __shared__ double sred[16];
+  __shared__ double sh[MAXMR + 2];
+  const int tid = threadIdx.x, NT = blockDim.x;
+  GmresScal* G = d.gsc;
+  if (j >= 0 && G->done) return;
+  const int nv = (j < 0) ? 1 : j + 2;
+  for (int q = 0; q < nv; ++q) {
+    double v[1];
+    sum_partials<1>(d.gpart + (size_t)q * d.nblk, d.nblk, v, sred, tid, NT);
+    if (tid == 0) sh[q] = v[0];
+  }
+  __syncthreads();
+  if (tid != 0) return;
+  if (j < 0) {
+    const double b0 = sqrt(sh[0]);
+    G->beta0 = b0; G->g[0] = b0; G->done = 0; G->nit = 0;
+    G->hinv = (b0 > 0.0) ? 1.0 / b0 : 0.0;
+    G->resid = b0 * scale;
+    for (int q = 0; q < MAXMR + 2; ++q) G->hcol[q] = 0.0;
+    if (!(b0 > 0.0)) { G->done = 1; }
+    return;
+  }
+  // classical Gram-Schmidt column: h_i = (w, v_i), h_{j+1} from Pythagoras
+  double ww = sh[j + 1], s2 = 0.0;
+  for (int q = 0; q <= j; ++q) { G->hcol[q] = sh[q]; s2 += sh[q] * sh[q]; }
+  double hn2 = ww - s2;
+  if (hn2 < 0.0) hn2 = 0.0;
+  const double hn = sqrt(hn2);
+  G->hcol[j + 1] = hn;
+  G->hinv = (hn > 0.0) ? 1.0 / hn : 0.0;
+  // Givens update of the Hessenberg least-squares problem
+  double col[MAXMR + 2];
+  for (int q = 0; q <= j; ++q) col[q] = sh[q];
+  col[j + 1] = hn;
+  for (int q = 0; q < j; ++q) {
+    const double t = G->cs[q] * col[q] + G->sn[q] * col[q + 1];
+    col[q + 1] = -G->sn[q] * col[q] + G->cs[q] * col[q + 1];
+    col[q] = t;
+  }
+  const double rho = sqrt(col[j] * col[j] + col[j + 1] * col[j + 1]);
+  const double cj = (rho > 0.0) ? col[j] / rho : 1.0, sj = (rho > 0.0) ? col[j + 1] / rho : 0.0;
+  G->cs[j] = cj; G->sn[j] = sj;
+  col[j] = rho;
+  for (int q = 0; q <= j; ++q) G->R[j * MAXMR + q] = col[q];
+  const double gj = G->g[j];
+  G->g[j] = cj * gj;
+  G->g[j + 1] = -sj * gj;
+  G->nit = j + 1;
+  const double res = fabs(G->g[j + 1]) * scale;
+  G->resid = res;
+  const double tol = d.tol_relative ? d.tol_pres * G->beta0 * scale : d.tol_pres;
+  if ((res <= tol && (j + 1) >= min_iter) || !(hn > 0.0)) {
+    G->done = 1;
+    atomicAdd((unsigned long long*)&d.stats->pres_iters, (unsigned long long)(j + 1));
+    d.stats->last_pres_res = res;
+  }
+}
+
+// v_{j+1} = (w - sum_i h_i v_i) / h_{j+1,j}  (j = -1: v_0 = g / |g|), plus the
+// element-corner restriction ec[e][c] = sum_k hat_c(k) v(e,k) for the coarse solve
+template <int N>
+__global__ __launch_bounds__(Cfg<N>::NT) void k_gmres_update(Dev d, int j) {
+  using C = Cfg<N>;
+  constexpr int NN = C::NN, MM = C::MM, EPB = C::EPB;
+  __shared__ double sv[EPB * MM];
+  const int tid = threadIdx.x, el = tid / NN, nd = tid % NN;
+  const long long e = (long long)blockIdx.x * EPB + el;
+  const bool act = (el < EPB) && (e < d.nel);
+  const GmresScal* G = d.gsc;
+  if (G->done) return;
+  if (act && nd < MM) {
+    const long long q = e * MM + nd;
+    double w = d.V[(size_t)(j + 1) * d.npr + q];
+    for (int k = 0; k <= j; ++k) w -= G->hcol[k] * d.V[(size_t)k * d.npr + q];
+    w *= G->hinv;
+    d.V[(size_t)(j + 1) * d.npr + q] = w;
+    sv[el * MM + nd] = w;
+  }
+  __syncthreads();
+  if (act && nd < 4) {
+    double s = 0.0;
+    for (int k = 0; k < MM; ++k) s += d.hat[nd * MM + k] * sv[el * MM + k];
+    d.ec[e * 4 + nd] = s;
+  }
+}
+
+// coarse solve: r_c = gather of element-corner restrictions; x_c = Aci r_c.
+// Every workgroup rebuilds r_c in LDS (cheap, L2-resident) then does its rows.
+constexpr int CROWS = 32;
+__global__ __launch_bounds__(256) void k_coarse(Dev d) {
+  extern __shared__ double srcv[];            // nvert
+  __shared__ double sp[256];
+  const int tid = threadIdx.x;
+  if (d.gsc->done) return;
+  for (int v = tid; v < d.nvert; v += 256) {
+    double s = 0.0;
+    for (int k = d.v_off[v]; k < d.v_off[v + 1]; ++k) s += d.ec[d.v_ent[k]];
+    srcv[v] = s;
+  }
+  __syncthreads();
+  const int r = tid % CROWS, part = tid / CROWS;         // 8 column slices per row
+  const int row = blockIdx.x * CROWS + r;
+  double s = 0.0;
+  if (row < d.nvert)
+    for (int c = part; c < d.nvert; c += 256 / CROWS) s += d.Aci[(size_t)c * d.nvert + row] * srcv[c];
+  sp[tid] = s;
+  __syncthreads();
+  if (tid < CROWS && row < d.nvert) {
+    double t = 0.0;
+    for (int k = 0; k < 256 / CROWS; ++k) t += sp[k * CROWS + tid];
+    d.xc[row] = t;
+  }
+}
+
+// z_j = RAS(v_j) + R^T x_c ;  yl = D^T z_j  (unassembled velocity-space)
+template <int N>
+__global__ __launch_bounds__(Cfg<N>::NT) void k_schwarz(Dev d, const double* __restrict__ vin,
+                                                        double* __restrict__ zout, int use_coarse,
+                                                        int check_done) {
+  using C = Cfg<N>;
+  constexpr int NN = C::NN, M = C::M, MM = C::MM, EPB = C::EPB, NT = C::NT, NM = N * M;
+  constexpr int MAXP = (M + 8) * (M + 8);
+  __shared__ double sJ12[NM], sD12[NM];
+  __shared__ double sP[4 * EPB * MM], sB[4 * EPB * NM];
+  __shared__ double sr[EPB * MAXP];
+  const int tid = threadIdx.x, el = tid / NN, nd = tid % NN;
+  const long long e = (long long)blockIdx.x * EPB + el;
+  const bool act = (el < EPB) && (e < d.nel);
+  if (check_done && d.gsc->done) return;
+  load_basis<N, EPB>(d, nullptr, nullptr, sJ12, sD12, tid, NT);
+  int p0 = 0, np = 0;
+  if (act) {
+    p0 = d.p_off[e]; np = d.p_off[e + 1] - p0;
+    for (int k = nd; k < np; k += NN) sr[el * MAXP + k] = vin[d.p_idx[p0 + k]];
+  }
+  __syncthreads();
+  if (act && nd < MM) {
+    const float* A = d.p_inv + d.p_invoff[e];      // [np][MM], own rows, k fastest
+    double z = 0.0;
+    for (int k = 0; k < np; ++k) z += (double)A[(size_t)k * MM + nd] * sr[el * MAXP + k];
+    if (use_coarse) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) z += d.hat[c * MM + nd] * d.xc[d.evert[e * 4 + c]];
+    }
+    const long long q = e * MM + nd;
+    zout[q] = z;
+    sP[(0 * EPB + el) * MM + nd] = z * d.w2rx[q];
+    sP[(1 * EPB + el) * MM + nd] = z * d.w2sx[q];
+    sP[(2 * EPB + el) * MM + nd] = z * d.w2ry[q];
+    sP[(3 * EPB + el) * MM + nd] = z * d.w2sy[q];
+  }
+  __syncthreads();
+  double gx, gy;
+  opgradt_tiles<N, EPB>(sJ12, sD12, sP, sB, act, el, nd, gx, gy);
+  if (act) {
+    const long long l = e * NN + nd;
+    d.yl[l] = gx;
+    d.yl[d.nloc + l] = gy;
+  }
+}
+
+// yl = D^T p for an arbitrary pressure vector (setup probes, tests, projection)
+template <int N>
+__global__ __launch_bounds__(Cfg<N>::NT) void k_gradt(Dev d, const double* __restrict__ pin,
+                                                      double* __restrict__ yl) {
+  using C = Cfg<N>;
+  constexpr int NN = C::NN, M = C::M, MM = C::MM, EPB = C::EPB, NT = C::NT, NM = N * M;
+  __shared__ double sJ12[NM], sD12[NM];
+  __shared__ double sP[4 * EPB * MM], sB[4 * EPB * NM];
+  const int tid = threadIdx.x, el = tid / NN, nd = tid % NN;
+  const long long e = (long long)blockIdx.x * EPB + el;
+  const bool act = (el < EPB) && (e < d.nel);
+  load_basis<N, EPB>(d, nullptr, nullptr, sJ12, sD12, tid, NT);
+  if (act && nd < MM) {
+    const long long q = e * MM + nd;
+    const double z = pin[q];
+    sP[(0 * EPB + el) * MM + nd] = z * d.w2rx[q];
+    sP[(1 * EPB + el) * MM + nd] = z * d.w2sx[q];
+    sP[(2 * EPB + el) * MM + nd] = z * d.w2ry[q];
+    sP[(3 * EPB + el) * MM + nd] = z * d.w2sy[q];
+  }
+  __syncthreads();
+  double gx, gy;
+  opgradt_tiles<N, EPB>(sJ12, sD12, sP, sB, act, el, nd, gx, gy);
+  if (act) {
+    const long long l = e * NN + nd;
+    yl[l] = gx;
+    yl[d.nloc + l] = gy;
+  }
+}
+
+// w = D ( B^-1 mask dssum(yl) ) ; optional dots (w, V_i), i <= j, and (w,w)
+template <int N>
+__global__ __launch_bounds__(Cfg<N>::NT) void k_divgs(Dev d, const double* __restrict__ yl,
+                                                      double* __restrict__ wout, int j, int check_done) {
+  using C = Cfg<N>;
+  constexpr int NN = C::NN, M = C::M, MM = C::MM, EPB = C::EPB, NT = C::NT, NM = N * M;
+  __shared__ double sJ12[NM], sD12[NM];
+  __shared__ double su[2 * EPB * NN], sA[4 * EPB * NM];
+  __shared__ double sred[16];
+  const int tid = threadIdx.x, el = tid / NN, nd = tid % NN;
+  const long long e = (long long)blockIdx.x * EPB + el;
+  const bool act = (el < EPB) && (e < d.nel);
+  if (check_done && d.gsc->done) return;
+  load_basis<N, EPB>(d, nullptr, nullptr, sJ12, sD12, tid, NT);
+  if (act) {
+    const long long l = e * NN + nd;
+    const double bi = d.binv[l];
+    su[(0 * EPB + el) * NN + nd] = bi * gs_gather(yl, d.gs_off, d.gs_idx, l);
+    su[(1 * EPB + el) * NN + nd] = bi * gs_gather(yl + d.nloc, d.gs_off, d.gs_idx, l);
+  }
+  __syncthreads();
+  const double w = opdiv_tiles<N, EPB>(sJ12, sD12, su, sA, act, el, nd, d, e);
+  const bool pact = act && nd < MM;
+  const long long q = e * MM + nd;
+  if (pact) wout[q] = w;
+  if (j >= 0) {
+    for (int k = 0; k <= j + 1; ++k) {
+      double v[1] = {0.0};
+      if (pact) v[0] = w * ((k <= j) ? d.V[(size_t)k * d.npr + q] : w);
+      block_reduce<1>(v, sred, tid, NT);
+      if (tid == 0) d.gpart[(size_t)k * d.nblk + blockIdx.x] = v[0];
+    }
+  }
+}
+
+// after GMRES: dp = h2 * sum_i y_i Z_i (+ projected part) ; p = p* + dp ; yl = D^T dp
+template <int N>
+__global__ __launch_bounds__(Cfg<N>::NT) void k_pres_update(Dev d, StepCoef sc) {
+  using C = Cfg<N>;
+  constexpr int NN = C::NN, M = C::M, MM = C::MM, EPB = C::EPB, NT = C::NT, NM = N * M;
+  __shared__ double sJ12[NM], sD12[NM];
+  __shared__ double sP[4 * EPB * MM], sB[4 * EPB * NM];
+  __shared__ double sy[MAXMR];
+  const int tid = threadIdx.x, el = tid / NN, nd = tid % NN;
+  const long long e = (long long)blockIdx.x * EPB + el;
+  const bool act = (el < EPB) && (e < d.nel);
+  const GmresScal* G = d.gsc;
+  const int nit = G->nit;
+  load_basis<N, EPB>(d, nullptr, nullptr, sJ12, sD12, tid, NT);
+  if (tid == 0) {                      // back substitution R y = g (nit <= MAXMR)
+    for (int q = nit - 1; q >= 0; --q) {
+      double s = G->g[q];
+      for (int k = q + 1; k < nit; ++k) s -= G->R[k * MAXMR + q] * sy[k];
+      sy[q] = s / G->R[q * MAXMR + q];
+    }
+  }
+  __syncthreads();
+  if (act && nd < MM) {
+    const long long q = e * MM + nd;
+    double x = 0.0;
+    for (int k = 0; k < nit; ++k) x += sy[k] * d.Z[(size_t)k * d.npr + q];
+    const double dp = sc.h2 * x;
+    d.p[q] = d.pext[q] + dp;
+    sP[(0 * EPB + el) * MM + nd] = dp * d.w2rx[q];
+    sP[(1 * EPB + el) * MM + nd] = dp * d.w2sx[q];
+    sP[(2 * EPB + el) * MM + nd] = dp * d.w2ry[q];
+    sP[(3 * EPB + el) * MM + nd] = dp * d.w2sy[q];
+  }
+  __syncthreads();
+  double gx, gy;
+  opgradt_tiles<N, EPB>(sJ12, sD12, sP, sB, act, el, nd, gx, gy);
+  if (act) {
+    const long long l = e * NN + nd;
+    d.yl[l] = gx;
+    d.yl[d.nloc + l] = gy;
+  }
+  if (blockIdx.x == 0 && tid == 0 && !G->done) atomicAdd((unsigned long long*)&d.stats->unconverged, 1ull);
+}
+
+// u^{n+1} = u* + (h2 B)^-1 mask dssum(D^T dp)      [UPSTREAM opbinv]
+__global__ void k_vel_update(Dev d, StepCoef sc) {
+  const long long l = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= d.nloc) return;
+  const double f = d.binv[l] / sc.h2;
+  d.u[l] += f * gs_gather(d.yl, d.gs_off, d.gs_idx, l);
+  d.u[d.nloc + l] += f * gs_gather(d.yl + d.nloc, d.gs_off, d.gs_idx, l);
+}
+
+// ---------------------------------------------------------------------------
+// Krylov vector algebra (core/krylov_subspace.f).  State = [vx | vy | pr].
+// ---------------------------------------------------------------------------
+// partial dots of f with nq vectors, bm1s-weighted, velocity only  (krylov_inner_product)
+__global__ __launch_bounds__(256) void k_dots(const double* __restrict__ f, const double* const* __restrict__ Q,
+                                              int nq, const double* __restrict__ w, long long nloc,
+                                              double* __restrict__ part, int nblk) {
+  __shared__ double sred[16];
+  const int tid = threadIdx.x;
+  for (int k = 0; k < nq; ++k) {
+    const double* q = Q[k];
+    double v[1] = {0.0};
+    for (long long l = (long long)blockIdx.x * 256 + tid; l < nloc; l += (long long)nblk * 256) {
+      const double ww = w[l];
+      v[0] += ww * (f[l] * q[l] + f[nloc + l] * q[nloc + l]);
+    }
+    block_reduce<1>(v, sred, tid, 256);
+    if (tid == 0) part[(size_t)k * nblk + blockIdx.x] = v[0];
+  }
+}
+
+__global__ void k_reduce_final(const double* __restrict__ part, int nq, int nblk, double* __restrict__ out) {
+  __shared__ double sred[16];
+  const int tid = threadIdx.x;
+  for (int k = 0; k < nq; ++k) {
+    double v[1];
+    sum_partials<1>(part + (size_t)k * nblk, nblk, v, sred, tid, blockDim.x);
+    if (tid == 0) out[k] = v[0];
+  }
+}
+
+// f -= sum_k h_k Q_k  over the whole state (velocity and pressure), h on device
+__global__ void k_project_out(double* __restrict__ f, const double* const* __restrict__ Q, int nq,
+                              const double* __restrict__ h, long long n) {
+  const long long l = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= n) return;
+  double s = f[l];
+  for (int k = 0; k < nq; ++k) s -= h[k] * Q[k][l];
+  f[l] = s;
+}
+
+__global__ void k_axpby(double* __restrict__ y, double a, const double* __restrict__ x, double b, long long n) {
+  const long long l = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (l < n) y[l] = a * x[l] + b * y[l];
+}
+
+// scale by 1/sqrt(*nrm2) read from device memory (krylov_normalize without a host round trip)
+__global__ void k_scale_rsqrt(double* __restrict__ y, const double* __restrict__ nrm2, long long n) {
+  const long long l = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (l < n) y[l] *= 1.0 / sqrt(*nrm2);
+}
+
+// out_c = sum_k Q_k * Z[k][c]  for c < nc   (basis rotation / mode assembly)
+__global__ void k_basis_comb(const double* const* __restrict__ Q, int k, const double* __restrict__ Z, int ldz,
+                             int c0, int nc, double* const* __restrict__ out, long long n) {
+  const long long l = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= n) return;
+  for (int c = 0; c < nc; ++c) {
+    double s = 0.0;
+    for (int q = 0; q < k; ++q) s += Q[q][l] * Z[(size_t)(c0 + c) * ldz + q];
+    out[c][l] = s;
+  }
+}
+
+// local axhelm for tests
+template <int N>
+__global__ __launch_bounds__(Cfg<N>::NT) void k_axhelm_test(Dev d, const double* __restrict__ u, double h1,
+                                                            double h2, double* __restrict__ out) {
+  using C = Cfg<N>;
+  constexpr int NN = C::NN, EPB = C::EPB, NT = C::NT;
+  __shared__ double sD[NN], sDt[NN];
+  __shared__ double sz[EPB * NN], st1[EPB * NN], st2[EPB * NN];
+  const int tid = threadIdx.x, el = tid / NN, nd = tid % NN;
+  const long long e = (long long)blockIdx.x * EPB + el;
+  const bool act = (el < EPB) && (e < d.nel);
+  const long long l = e * NN + nd;
+  load_basis<N, EPB>(d, sD, sDt, nullptr, nullptr, tid, NT);
+  double z = 0, g1 = 0, g2 = 0, g4 = 0;
+  if (act) { z = u[l]; g1 = d.g1[l]; g2 = d.g2[l]; g4 = d.g4[l]; sz[el * NN + nd] = z; }
+  __syncthreads();
+  double au[1];
+  axhelm_tiles<N, EPB, 1>(sD, sDt, sz, st1, st2, act, el, nd / N, nd % N, g1, g2, g4, au);
+  if (act) out[l] = h1 * au[0] + h2 * d.bm1[l] * z;
+}
+
+__global__ void k_dssum_test(Dev d, const double* __restrict__ u, double* __restrict__ out) {
+  const long long l = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (l < d.nloc) out[l] = gs_gather(u, d.gs_off, d.gs_idx, l);
+}
+
+template <int N>
+__global__ __launch_bounds__(Cfg<N>::NT) void k_opdiv_test(Dev d, const double* __restrict__ u,
+                                                           double* __restrict__ out) {
+  using C = Cfg<N>;
+  constexpr int NN = C::NN, M = C::M, MM = C::MM, EPB = C::EPB, NT = C::NT, NM = N * M;
+  __shared__ double sJ12[NM], sD12[NM];
+  __shared__ double su[2 * EPB * NN], sA[4 * EPB * NM];
+  const int tid = threadIdx.x, el = tid / NN, nd = tid % NN;
+  const long long e = (long long)blockIdx.x * EPB + el;
+  const bool act = (el < EPB) && (e < d.nel);
+  load_basis<N, EPB>(d, nullptr, nullptr, sJ12, sD12, tid, NT);
+  if (act) {
+    su[(0 * EPB + el) * NN + nd] = u[e * NN + nd];
+    su[(1 * EPB + el) * NN + nd] = u[d.nloc + e * NN + nd];
+  }
+  __syncthreads();
+  const double w = opdiv_tiles<N, EPB>(sJ12, sD12, su, sA, act, el, nd, d, e);
+  if (act && nd < MM) out[e * MM + nd] = w;
+}
+
+// copy probe responses into the block-sparse E storage (setup)
+__global__ void k_collect_probe(const double* __restrict__ w, const int* __restrict__ col_el, int ncol,
+                                const int* __restrict__ nb_off, const int* __restrict__ nb_idx,
+                                double* __restrict__ Eblk, const long long* __restrict__ blk_off, int MM, int k) {
+  // grid.x over (element of this colour), block threads over (slot, row)
+  const int ce = blockIdx.x;
+  if (ce >= ncol) return;
+  const int e = col_el[ce];
+  const int n0 = nb_off[e], nn = nb_off[e + 1] - n0;
+  for (int t = threadIdx.x; t < nn * MM; t += blockDim.x) {
+    const int s = t / MM, r = t % MM;
+    const int b = nb_idx[n0 + s];
+    Eblk[blk_off[e] + ((size_t)s * MM + k) * MM + r] = w[(size_t)b * MM + r];
+  }
+}
+
+__global__ void k_set_probe(double* __restrict__ v, const int* __restrict__ col_el, int ncol, int MM, int k, double val) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < ncol) v[(size_t)col_el[t] * MM + k] = val;
+}
+
+}  // namespace nsk

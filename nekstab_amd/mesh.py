@@ -250,32 +250,59 @@ def interp_field_2d(f: np.ndarray, lx_to: int) -> np.ndarray:
 # assembling a Case
 # ----------------------------------------------------------------------------
 
-def load_cylinder_case(casedir: str, lx1: int, *, session="1cyl", adjoint=False,
-                       endtime=1.0, re=50.0, xlspg=5.0, xrspg=5.0, spng_str=1.7,
-                       cfl=0.5, use_ma2=True) -> Case:
-    """Build the Re=50 cylinder case exactly as the reference example sets it up
-    (examples/cylinder/stability/direct/{1cyl.par,1cyl.usr,SIZE})."""
+def build_case_2d(mesh: nekio.Re2Mesh, vlex: np.ndarray, bf_u: np.ndarray, lx1: int, *,
+                  adjoint=False, endtime=1.0, re=50.0, xlspg=5.0, xrspg=5.0, spng_str=1.7,
+                  cfl=0.5, meta=None) -> Case:
+    """Assemble a Case the way the reference example sets it up
+    (examples/cylinder/stability/direct/{1cyl.par,1cyl.usr,SIZE}):
+    ``bf_u`` = base flow (2, nel, lxb, lxb) at any order (interpolated like load_fld)."""
+    x, y = element_coords_2d(mesh, lx1)
+    gid, nglob = global_numbering_2d(vlex, lx1)
+    codes = ("v", "W", "V", "O") if adjoint else ("v", "W", "V")   # 1cyl.usr:126-132
+    mask = dirichlet_mask_2d(mesh, lx1, codes)
+    gmask = np.ones(nglob)                 # a node fixed in one copy is fixed in all
+    np.minimum.at(gmask, gid.ravel(), mask.ravel())
+    mask = gmask[gid]
+    ub = interp_field_2d(np.asarray(bf_u, dtype=np.float64), lx1)
+    if spng_str != 0.0:
+        spng = sponge_function([x, y], [xlspg, 0.0], [xrspg, 0.0])
+    else:
+        spng = np.zeros_like(x)
+    has_out = any(b[3].strip() == "O" for b in mesh.bcs) and not adjoint
+    m = dict(meta or {})
+    m["vert"] = vlex - 1
+    m["nvert"] = int(vlex.max())
+    return Case(ndim=2, nel=mesh.nel, lx1=lx1, x=x, y=y, gid=gid, nglob=nglob, mask=mask,
+                ub=ub, spng=spng, re=re, endtime=endtime, cfl=cfl, lxd=3 * lx1 // 2,
+                has_outflow=has_out, adjoint=adjoint, meta=m)
+
+
+def load_cylinder_case(casedir: str, lx1: int, *, session="1cyl", use_ma2=True, **kw) -> Case:
+    """Read ``<session>.re2/.ma2`` and ``BF_<session>0.f00001`` from a nekStab case directory."""
     import os
     mesh = nekio.read_re2(os.path.join(casedir, session + ".re2"))
     if use_ma2:
         vlex, _ = nekio.read_ma2(os.path.join(casedir, session + ".ma2"))
     else:
         vlex = vertex_ids_from_coords(mesh, periodic_pairs=[(1, mesh.yc.min(), mesh.yc.max())])
-    x, y = element_coords_2d(mesh, lx1)
-    gid, nglob = global_numbering_2d(vlex, lx1)
-    codes = ("v", "W", "V", "O") if adjoint else ("v", "W", "V")   # 1cyl.usr:126-132
-    mask = dirichlet_mask_2d(mesh, lx1, codes)
-    # a Dirichlet node shared with a neighbour is Dirichlet in every copy
-    gmask = np.ones(nglob)
-    np.minimum.at(gmask, gid.ravel(), mask.ravel())
-    mask = gmask[gid]
     bf = nekio.read_fld(os.path.join(casedir, "BF_%s0.f00001" % session))
-    ub = interp_field_2d(bf.u[:, :, 0], lx1)
-    if spng_str != 0.0:
-        spng = sponge_function([x, y], [xlspg, 0.0], [xrspg, 0.0])
-    else:
-        spng = np.zeros_like(x)
-    return Case(ndim=2, nel=mesh.nel, lx1=lx1, x=x, y=y, gid=gid, nglob=nglob, mask=mask,
-                ub=ub, spng=spng, re=re, endtime=endtime, cfl=cfl, lxd=3 * lx1 // 2,
-                has_outflow=not adjoint, adjoint=adjoint,
-                meta={"casedir": casedir, "session": session, "bf_lx1": bf.nx})
+    return build_case_2d(mesh, vlex, bf.u[:, :, 0], lx1,
+                         meta={"casedir": casedir, "session": session, "bf_lx1": bf.nx}, **kw)
+
+
+def save_case_npz(path: str, mesh: nekio.Re2Mesh, vlex: np.ndarray, bf_u: np.ndarray):
+    """Compact fixture of a case's *data* (mesh vertices, curves, BCs, vertex ids, base flow)."""
+    cur = np.array([[c[0], c[1]] + list(c[2]) for c in mesh.curves if c[3] == "C"], dtype=np.float64)
+    bce = np.array([[b[0], b[1]] for b in mesh.bcs], dtype=np.int32)
+    bcc = np.array([b[3] for b in mesh.bcs])
+    np.savez_compressed(path, xc=mesh.xc, yc=mesh.yc, curves=cur, bc_ef=bce, bc_code=bcc,
+                        vlex=vlex.astype(np.int32), bf_u=bf_u)
+
+
+def load_case_npz(path: str, lx1: int, **kw) -> Case:
+    z = np.load(path)
+    curves = [(int(r[0]), int(r[1]), r[2:7].copy(), "C") for r in z["curves"]]
+    bcs = [(int(ef[0]), int(ef[1]), np.zeros(5), str(cd)) for ef, cd in zip(z["bc_ef"], z["bc_code"])]
+    mesh = nekio.Re2Mesh(2, z["xc"].shape[0], z["xc"], z["yc"], None, curves, bcs)
+    return build_case_2d(mesh, z["vlex"].astype(np.int64), z["bf_u"].astype(np.float64), lx1,
+                         meta={"npz": path}, **kw)

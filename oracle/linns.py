@@ -287,16 +287,16 @@ class LinNS2D:
         if self.has_outflow:
             self._E = spla.splu(E)
         else:
-            one = sp.csc_matrix(np.ones((self.npr, 1)))
-            K = sp.bmat([[E, one], [one.T, None]]).tocsc()
-            self._E = spla.splu(K)
+            # constant null space: pin dof 0 (consistent rhs after `ortho`), then re-centre
+            self._E = spla.splu(E[1:, 1:].tocsc())
 
     def E_solve(self, g):
         """Solve (D B^-1 D^T) x = g   (zero-mean solution when E is singular)."""
         if self.has_outflow:
             return self._E.solve(g.ravel()).reshape(g.shape)
-        rhs = np.concatenate([g.ravel(), [0.0]])
-        return self._E.solve(rhs)[:-1].reshape(g.shape)
+        gg = g.ravel() - g.mean()                      # [UPSTREAM navier1.f ortho]
+        x = np.concatenate([[0.0], self._E.solve(gg[1:])])
+        return (x - x.mean()).reshape(g.shape)
 
     # ---------------- one nek_advance() in perturbation mode ----------------
     def new_state(self, q):

@@ -1,0 +1,67 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: long CPU test")
+
+
+def _gpu_available():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def make_oracle(case, **kw):
+    from oracle.linns import LinNS2D
+    return LinNS2D(x=case.x, y=case.y, gid=case.gid, nglob=case.nglob, mask=case.mask, ub=case.ub,
+                   spng=case.spng, re=case.re, endtime=case.endtime, lxd=case.lxd,
+                   has_outflow=case.has_outflow, **kw)
+
+
+@pytest.fixture(scope="session")
+def case6():
+    from nekstab_amd import mesh
+    return mesh.load_case_npz(os.path.join(GOLDEN, "cylinder_case.npz"), 6)
+
+
+@pytest.fixture(scope="session")
+def oracle6(case6):
+    return make_oracle(case6)
+
+
+@pytest.fixture(scope="session")
+def oracle6_nosolve(case6):
+    return make_oracle(case6, build_solvers=False)
+
+
+@pytest.fixture(scope="session")
+def hip6(case6):
+    if not _gpu_available():
+        pytest.skip("no GPU")
+    from nekstab_amd.capi import NekStabHip
+    h = NekStabHip(case6, case6.meta["vert"], case6.meta["nvert"], tol_helm=1e-13, tol_pres=1e-13,
+                   tol_relative=0, schwarz_layers=2, max_helm_iter=120, max_pres_iter=48)
+    yield h
+    h.close()
+
+
+@pytest.fixture(scope="session")
+def modes():
+    return np.load(os.path.join(GOLDEN, "cylinder_modes.npz"))
+
+
+@pytest.fixture(scope="session")
+def spectre():
+    return np.load(os.path.join(GOLDEN, "cylinder_spectre.npz"))

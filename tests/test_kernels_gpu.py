@@ -1,0 +1,92 @@
+"""Kernel-level parity: every HIP building block of the time step against the
+CPU oracle (oracle/linns.py) on the reference's cylinder mesh at lx1=6, through
+the C-ABI test hooks.  Tolerance: 1e-12 relative (fp64, same arithmetic up to
+summation order)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+@pytest.fixture(scope="module")
+def fields(case6):
+    rng = np.random.default_rng(7)
+    u = np.sin(0.7 * case6.x) * np.cos(0.5 * case6.y) + 0.1 * rng.standard_normal(case6.x.shape)
+    v = np.cos(0.3 * case6.x) * np.sin(0.9 * case6.y) + 0.1 * rng.standard_normal(case6.x.shape)
+    p = rng.standard_normal((case6.nel, 4, 4))
+    return u, v, p
+
+
+def test_info(hip6, oracle6_nosolve):
+    assert hip6.nsteps == oracle6_nosolve.nsteps == 100          # header pin: istep 101
+    assert abs(hip6.dt - oracle6_nosolve.dt) < 1e-15
+
+
+def test_axhelm(hip6, oracle6_nosolve, fields):
+    o = oracle6_nosolve
+    u = fields[0]
+    assert rel(hip6.t_axhelm(u, 0.02, 183.3), o.axhelm(u, 0.02, 183.3)) < 1e-12
+
+
+def test_dssum(hip6, oracle6_nosolve, fields):
+    assert rel(hip6.t_dssum(fields[0]), oracle6_nosolve.dssum(fields[0])) < 1e-13
+
+
+def test_opdiv(hip6, oracle6_nosolve, fields):
+    assert rel(hip6.t_opdiv(fields[0], fields[1]), oracle6_nosolve.opdiv(fields[0], fields[1])) < 1e-12
+
+
+def test_opgradt(hip6, oracle6_nosolve, fields):
+    gx, gy = hip6.t_opgradt(fields[2])
+    ox, oy = oracle6_nosolve.opgradt(fields[2])
+    assert rel(gx, ox) < 1e-12 and rel(gy, oy) < 1e-12
+
+
+@pytest.mark.parametrize("adjoint", [False, True])
+def test_convect(hip6, oracle6_nosolve, fields, adjoint):
+    o = oracle6_nosolve
+    u, v = fields[0], fields[1]
+    U, V = o.ub
+    bx = -o.spng * u * o.bm1
+    by = -o.spng * v * o.bm1
+    if not adjoint:
+        bx -= o.convect(u, v, U) + o.convect(U, V, u)
+        by -= o.convect(u, v, V) + o.convect(U, V, v)
+    else:
+        ax, ay = o.convect_adj(u, v, U, V)
+        bx += -ax + o.convect(U, V, u)
+        by += -ay + o.convect(U, V, v)
+    gx, gy = hip6.t_convect(u, v, adjoint)
+    assert rel(gx, bx) < 1e-12 and rel(gy, by) < 1e-12
+
+
+def test_eapply(hip6, oracle6_nosolve, fields):
+    o = oracle6_nosolve
+    p = fields[2]
+    wx, wy = o.opgradt(p)
+    fac = o.binvm1 * o.mask
+    ref = o.opdiv(fac * o.dssum(wx * o.mask), fac * o.dssum(wy * o.mask))
+    assert rel(hip6.t_eapply(p), ref) < 1e-12
+
+
+def test_helm_solve(hip6, oracle6, fields):
+    o = oracle6
+    rx, ry = fields[0] * o.bm1, fields[1] * o.bm1
+    h1, h2 = o.nu, (11.0 / 6.0) / o.dt
+    ox, oy, it = hip6.t_helm_solve(rx, ry, 3)
+    ex, ey = o.helm_solve(rx, h1, h2), o.helm_solve(ry, h1, h2)
+    print("helmholtz iterations", it)
+    assert rel(ox, ex) < 1e-9 and rel(oy, ey) < 1e-9
+
+
+def test_pres_solve(hip6, oracle6, fields):
+    o = oracle6
+    g = -o.opdiv(fields[0] * o.mask, fields[1] * o.mask)
+    x, it = hip6.t_pres_solve(g)
+    ref = o.E_solve(g)
+    print("pressure iterations", it)
+    assert rel(x, ref) < 1e-7
