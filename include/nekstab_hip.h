@@ -79,6 +79,7 @@ int nsk_get_info(nsk_ctx* ctx, double* dt, int* nsteps, long long* nstate,
                  long long* nvel, long long* npres);
 int nsk_set_nsteps(nsk_ctx* ctx, int nsteps);   /* test hook: shorten the map (dt unchanged) */
 int nsk_set_tolerances(nsk_ctx* ctx, double tol_helm, double tol_pres, int relative);
+int nsk_set_option(nsk_ctx* ctx, const char* name, double value);   /* "use_graph", "min_pres_iter", ... */
 
 /* allocate(Q(k_dim+1)) (core/eigensolvers.f:170) */
 int nsk_vec_alloc(nsk_ctx* ctx, int n, nsk_vec* out);
@@ -121,6 +122,8 @@ typedef struct {
   long long pres_iters;
   long long unconverged;    /* solves that hit the cap */
   double last_helm_res, last_pres_res;
+  long long max_helm_iter, max_pres_iter;   /* worst single solve */
+  long long budget_helm, budget_pres;       /* iterations currently launched per solve */
 } nsk_stats;
 int nsk_get_stats(nsk_ctx* ctx, nsk_stats* s);
 

@@ -35,7 +35,9 @@ class NskCase(C.Structure):
 
 class NskStats(C.Structure):
     _fields_ = [("steps", C.c_longlong), ("helm_iters", C.c_longlong), ("pres_iters", C.c_longlong),
-                ("unconverged", C.c_longlong), ("last_helm_res", C.c_double), ("last_pres_res", C.c_double)]
+                ("unconverged", C.c_longlong), ("last_helm_res", C.c_double), ("last_pres_res", C.c_double),
+                ("max_helm_iter", C.c_longlong), ("max_pres_iter", C.c_longlong),
+                ("budget_helm", C.c_longlong), ("budget_pres", C.c_longlong)]
 
 
 # every symbol include/nekstab_hip.h declares: (restype, argtypes)
@@ -48,6 +50,7 @@ SYMBOLS = {
     "nsk_get_info": (C.c_int, [_vp, _dp, C.POINTER(C.c_int), _lp, _lp, _lp]),
     "nsk_set_nsteps": (C.c_int, [_vp, C.c_int]),
     "nsk_set_tolerances": (C.c_int, [_vp, C.c_double, C.c_double, C.c_int]),
+    "nsk_set_option": (C.c_int, [_vp, C.c_char_p, C.c_double]),
     "nsk_vec_alloc": (C.c_int, [_vp, C.c_int, _vpp]),
     "nsk_vec_free": (C.c_int, [_vp, C.c_int, _vpp]),
     "nsk_vec_upload": (C.c_int, [_vp, _vp, _dp, _dp, _dp]),
@@ -216,6 +219,9 @@ class NekStabHip:
 
     def set_tolerances(self, th, tp, relative=0):
         self._chk(self.lib.nsk_set_tolerances(self.ctx, th, tp, relative))
+
+    def set_option(self, name, value):
+        self._chk(self.lib.nsk_set_option(self.ctx, name.encode(), float(value)))
 
     def stats(self):
         s = NskStats()

@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -47,8 +48,14 @@ struct nsk_ctx {
   long long nloc = 0, npr = 0, nstate = 0;
   double dt = 0, re = 0, endtime = 0;
   int nsteps = 0;
-  int max_helm = 60, max_pres = 40, min_pres = 1, layers = 1;
-  int cur_helm = 0, cur_pres = 0;       // adaptive launch budgets
+  int max_helm = 60, max_pres = 40, min_pres = 0, layers = 1;
+  int cur_helm[3] = {0, 0, 0}, cur_pres[3] = {0, 0, 0};       // adaptive launch budgets per BDF order
+  int use_graph = 1;
+  int in_test = 0;
+  int helm_guess = 1;
+  int debug = 0;
+  struct StepGraph { hipGraphExec_t exec = nullptr; int nh = -1, np = -1; } graphs[2][3];
+  double* scratch = nullptr;            // one state vector
   Dev d{};
   Stats hstats{};
   hipStream_t stream = nullptr;
@@ -92,6 +99,9 @@ static StepCoef make_coef(const nsk_ctx* c, int istep, int adjoint) {
   s.invdt = 1.0 / c->dt;
   s.k = k;
   s.adjoint = adjoint;
+  const bool g = c->helm_guess != 0;
+  s.xg[0] = (!g || istep <= 1) ? 0.0 : (istep == 2 ? 1.0 : 2.0);
+  s.xg[1] = (!g || istep <= 2) ? 0.0 : -1.0;
   return s;
 }
 
@@ -355,16 +365,17 @@ static int build(nsk_ctx* c, const nsk_case& cs) {
   // ---- state + solver work arrays
   if ((rc = dalloc(c, &d.u, 2 * nloc)) || (rc = dalloc(c, &d.p, npr)) || (rc = dalloc(c, &d.plag, npr)) ||
       (rc = dalloc(c, &d.pext, npr)) || (rc = dalloc(c, &d.ulag, 4 * nloc)) || (rc = dalloc(c, &d.exlag, 4 * nloc)) ||
-      (rc = dalloc(c, &d.bf, 2 * nloc)) || (rc = dalloc(c, &d.rloc, 2 * nloc)) || (rc = dalloc(c, &d.hx, 2 * nloc)) ||
+      (rc = dalloc(c, &d.bf, 2 * nloc)) || (rc = dalloc(c, &d.rloc, 2 * nloc)) || (rc = dalloc(c, &d.bloc, 2 * nloc)) || (rc = dalloc(c, &d.dulag, 4 * nloc)) || (rc = dalloc(c, &d.hx, 2 * nloc)) ||
       (rc = dalloc(c, &d.hr, 2 * nloc)) || (rc = dalloc(c, &d.hp, 2 * nloc)) || (rc = dalloc(c, &d.hs, 2 * nloc)) ||
-      (rc = dalloc(c, &d.hwl, 4 * nloc)) || (rc = dalloc(c, &d.hpart, (size_t)12 * c->nblk)) || (rc = dalloc(c, &d.hscal, 32)) ||
+      (rc = dalloc(c, &d.hwl, 4 * nloc)) || (rc = dalloc(c, &d.hpart, (size_t)16 * c->nblk)) || (rc = dalloc(c, &d.hscal, 32)) ||
       (rc = dalloc(c, &d.V, (size_t)(MAXMR + 1) * npr)) || (rc = dalloc(c, &d.Z, (size_t)MAXMR * npr)) ||
       (rc = dalloc(c, &d.yl, 2 * nloc)) || (rc = dalloc(c, &d.ec, (size_t)nel * 4)) ||
       (rc = dalloc(c, &d.gpart, (size_t)(MAXMR + 2) * c->nblk)) || (rc = dalloc(c, &d.gsc, 1)) ||
       (rc = dalloc(c, &d.stats, 1)) || (rc = dalloc(c, &c->wv1, 2 * nloc)) || (rc = dalloc(c, &c->wv2, 2 * nloc)) ||
-      (rc = dalloc(c, &c->wp1, npr)) || (rc = dalloc(c, &c->wp2, npr))) return rc;
+      (rc = dalloc(c, &c->wp1, npr)) || (rc = dalloc(c, &c->wp2, npr)) || (rc = dalloc(c, &c->scratch, (size_t)c->nstate))) return rc;
   if (d.nproj_max > 0)
-    if ((rc = dalloc(c, &d.PX, (size_t)d.nproj_max * npr)) || (rc = dalloc(c, &d.PEX, (size_t)d.nproj_max * npr))) return rc;
+    if ((rc = dalloc(c, &d.PX, (size_t)d.nproj_max * npr)) || (rc = dalloc(c, &d.PEX, (size_t)d.nproj_max * npr)) ||
+        (rc = dalloc(c, &d.PD, npr)) || (rc = dalloc(c, &d.PED, npr)) || (rc = dalloc(c, &d.ppart, (size_t)(MAXPROJ + 2) * c->nblk))) return rc;
   c->kblk = 256;
   if ((rc = dalloc(c, &c->kpart, (size_t)c->kblk * 1024)) || (rc = dalloc(c, &c->kout, 1024)) || (rc = dalloc(c, &c->kptr, 1024))) return rc;
   HIPCHK(hipHostMalloc((void**)&c->hpin, 4096 * sizeof(double)));
@@ -478,6 +489,15 @@ static int build(nsk_ctx* c, const nsk_case& cs) {
     HIPCHK(hipStreamSynchronize(c->stream));
     d.Aci = dA;
   }
+  {
+    std::vector<int> vtab((size_t)nvert * CVT, -1);
+    for (int v = 0; v < nvert; ++v) {
+      const int n = v_off[v + 1] - v_off[v];
+      if (n < 1 || n > CVT) return fail(NSK_EINVAL, "vertex valence outside 1.." + std::to_string(CVT));
+      for (int k = 0; k < n; ++k) vtab[(size_t)v * CVT + k] = v_ent[v_off[v] + k];
+    }
+    if ((rc = dupload(c, &d.vtab, vtab))) return rc;
+  }
   if ((rc = dupload(c, &d.v_off, v_off)) || (rc = dupload(c, &d.v_ent, v_ent)) || (rc = dupload(c, &d.evert, evert)) ||
       (rc = dalloc(c, &d.xc, nvert))) return rc;
 
@@ -524,7 +544,9 @@ static int build(nsk_ctx* c, const nsk_case& cs) {
     if ((rc = dupload(c, &d.p_off, p_off)) || (rc = dupload(c, &d.p_idx, p_idx)) || (rc = dupload(c, &d.p_inv, p_inv)) ||
         (rc = dupload(c, &d.p_invoff, p_invoff))) return rc;
   }
-  c->cur_helm = c->max_helm; c->cur_pres = c->max_pres;
+  for (int k = 0; k < 3; ++k) { c->cur_helm[k] = c->max_helm; c->cur_pres[k] = c->max_pres; }
+  if (const char* g = std::getenv("NSK_USE_GRAPH")) c->use_graph = std::atoi(g);
+  if (const char* g = std::getenv("NSK_DEBUG")) c->debug = std::atoi(g);
   HIPCHK(hipStreamSynchronize(c->stream));
   return 0;
 }
@@ -532,20 +554,18 @@ static int build(nsk_ctx* c, const nsk_case& cs) {
 // ---------------------------------------------------------------------------
 // one nek_advance() in perturbation mode
 // ---------------------------------------------------------------------------
-static int pres_solve_launch(nsk_ctx* c, double h2) {
+static int pres_solve_launch(nsk_ctx* c, double h2, int ord, int np) {
   Dev& d = c->d;
   const double scale = 1.0 / (h2 * std::sqrt(d.vol));
-  const int np = c->cur_pres;
   DISPATCH_N(c->N, {
     constexpr int NT = Cfg<N>::NT;
-    hipLaunchKernelGGL(k_gmres_scal, dim3(1), dim3(256), 0, c->stream, d, -1, scale, c->min_pres);
-    hipLaunchKernelGGL(k_gmres_update<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, -1);
+    if (d.nproj_max > 0 && !c->in_test) hipLaunchKernelGGL(k_proj_apply, dim3(c->nblk), dim3(256), 0, c->stream, d);
+    hipLaunchKernelGGL(k_gmres_update<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, -1, scale, c->min_pres, ord);
     for (int j = 0; j < np; ++j) {
-      hipLaunchKernelGGL(k_coarse, dim3((d.nvert + CROWS - 1) / CROWS), dim3(256), d.nvert * sizeof(double), c->stream, d);
+      hipLaunchKernelGGL(k_coarse, dim3((d.nvert + 4 * CROWS_W - 1) / (4 * CROWS_W)), dim3(256), d.nvert * sizeof(double), c->stream, d);
       hipLaunchKernelGGL(k_schwarz<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, (const double*)(d.V + (size_t)j * d.npr), d.Z + (size_t)j * d.npr, 1, 1);
       hipLaunchKernelGGL(k_divgs<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, (const double*)d.yl, d.V + (size_t)(j + 1) * d.npr, j, 1);
-      hipLaunchKernelGGL(k_gmres_scal, dim3(1), dim3(256), 0, c->stream, d, j, scale, c->min_pres);
-      if (j + 1 < np) hipLaunchKernelGGL(k_gmres_update<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, j);
+      hipLaunchKernelGGL(k_gmres_update<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, j, scale, c->min_pres, ord);
     }
   });
   return 0;
@@ -554,35 +574,116 @@ static int pres_solve_launch(nsk_ctx* c, double h2) {
 static int step(nsk_ctx* c, int istep, int adjoint) {
   Dev& d = c->d;
   const StepCoef sc = make_coef(c, istep, adjoint);
-  const int nh = c->cur_helm;
+  const int nh = c->cur_helm[sc.k - 1];
   DISPATCH_N(c->N, {
     constexpr int NT = Cfg<N>::NT;
     hipLaunchKernelGGL(k_convect<N>, dim3(c->nel), dim3(Cfg<N>::NTD), 0, c->stream, d, (const double*)d.u, d.bf, adjoint);
     hipLaunchKernelGGL(k_rhs<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, sc);
     for (int it = 0; it < nh; ++it)
       hipLaunchKernelGGL(k_helm<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, sc, it, (const double*)d.rloc);
-    hipLaunchKernelGGL(k_pres_rhs<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, (nh - 1) & 1, nh - 1);
+    hipLaunchKernelGGL(k_pres_rhs<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, sc, (nh - 1) & 1, nh - 1);
   });
-  int rc = pres_solve_launch(c, sc.h2);
+  int rc = pres_solve_launch(c, sc.h2, sc.k, c->cur_pres[sc.k - 1]);
   if (rc) return rc;
   DISPATCH_N(c->N, {
     hipLaunchKernelGGL(k_pres_update<N>, dim3(c->nblk), dim3(Cfg<N>::NT), 0, c->stream, d, sc);
   });
-  hipLaunchKernelGGL(k_vel_update, dim3((unsigned)((d.nloc + 255) / 256)), dim3(256), 0, c->stream, d, sc);
+  if (d.nproj_max > 0) {
+    DISPATCH_N(c->N, {
+      hipLaunchKernelGGL(k_vel_update_proj<N>, dim3(c->nblk), dim3(Cfg<N>::NT), 0, c->stream, d, sc);
+    });
+    hipLaunchKernelGGL(k_proj_update, dim3(c->nblk), dim3(256), 0, c->stream, d);
+  } else {
+    hipLaunchKernelGGL(k_vel_update, dim3((unsigned)((d.nloc + 255) / 256)), dim3(256), 0, c->stream, d, sc);
+  }
+  return 0;
+}
+
+static int ensure_graph(nsk_ctx* c, int k, int adjoint) {
+  nsk_ctx::StepGraph& g = c->graphs[adjoint][k - 1];
+  if (g.exec && g.nh == c->cur_helm[k - 1] && g.np == c->cur_pres[k - 1]) return 0;
+  if (g.exec) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }
+  hipGraph_t graph = nullptr;
+  HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeGlobal));
+  int rc = step(c, k, adjoint);
+  hipError_t e = hipStreamEndCapture(c->stream, &graph);
+  if (rc) return rc;
+  if (e != hipSuccess) return fail(NSK_EHIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+  HIPCHK(hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0));
+  HIPCHK(hipGraphDestroy(graph));
+  g.nh = c->cur_helm[k - 1]; g.np = c->cur_pres[k - 1];
   return 0;
 }
 
 static int run_map(nsk_ctx* c, int adjoint, double* f, const double* q) {
   Dev& d = c->d;
+  if (c->use_graph)
+    for (int k = 1; k <= 3; ++k) { int rc = ensure_graph(c, k, adjoint); if (rc) return rc; }
   HIPCHK(hipMemcpyAsync(d.u, q, 2 * d.nloc * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(d.p, q + 2 * d.nloc, d.npr * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
   for (int istep = 1; istep <= c->nsteps; ++istep) {
-    int rc = step(c, istep, adjoint);
-    if (rc) return rc;
+    if (c->use_graph) {
+      HIPCHK(hipGraphLaunch(c->graphs[adjoint][std::min(istep, 3) - 1].exec, c->stream));
+    } else {
+      int rc = step(c, istep, adjoint);
+      if (rc) return rc;
+      if (c->debug) {
+        GmresScal G; double hs[32];
+        HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(hipMemcpy(&G, d.gsc, sizeof(G), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(hs, d.hscal, sizeof(hs), hipMemcpyDeviceToHost));
+        fprintf(stderr, "step %3d: |g|=%.3e |g'|=%.3e nit=%d resid=%.3e nproj=%d pcnt=%d st_n=%.3e  helm ref %.3e %.3e\n", istep, G.gnorm0, G.beta0, G.nit, G.resid, G.nproj, G.pcnt, G.st_n, hs[16], hs[17]);
+      }
+    }
   }
   HIPCHK(hipMemcpyAsync(f, d.u, 2 * d.nloc * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(f + 2 * d.nloc, d.p, d.npr * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
   return 0;
+}
+
+// run one map with the adaptive launch budgets: every inner solve early-exits on its
+// own convergence flag; a solve that runs out of launched iterations is counted on the
+// device and the whole map is redone with larger budgets.
+static int run_map_adaptive(nsk_ctx* c, int adjoint, double* f, const double* q) {
+  const double* src = q;
+  if (f == q) {
+    HIPCHK(hipMemcpyAsync(c->scratch, q, c->nstate * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    src = c->scratch;
+  }
+  for (;;) {
+    HIPCHK(hipMemsetAsync(c->d.stats, 0, sizeof(Stats), c->stream));
+    int rc = run_map(c, adjoint, f, src);
+    if (rc) return rc;
+    Stats h;
+    HIPCHK(hipMemcpyAsync(&h, c->d.stats, sizeof(Stats), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->hstats.helm_iters += h.helm_iters; c->hstats.pres_iters += h.pres_iters; c->hstats.steps += c->nsteps;
+    c->hstats.max_helm = std::max(c->hstats.max_helm, h.max_helm); c->hstats.max_pres = std::max(c->hstats.max_pres, h.max_pres);
+    c->hstats.last_helm_res = h.last_helm_res; c->hstats.last_pres_res = h.last_pres_res;
+    for (int k = 0; k < 3; ++k) {
+      c->hstats.max_helm_k[k] = std::max(c->hstats.max_helm_k[k], h.max_helm_k[k]);
+      c->hstats.max_pres_k[k] = std::max(c->hstats.max_pres_k[k], h.max_pres_k[k]);
+    }
+    if (h.unconverged == 0) {
+      for (int k = 0; k < 3; ++k) {
+        if (k + 1 > c->nsteps) break;
+        const int th = std::min(c->max_helm, (int)h.max_helm_k[k] + 2), tp = std::min(c->max_pres, (int)h.max_pres_k[k] + 2);
+        if (th > c->cur_helm[k] || th < c->cur_helm[k] - 1) c->cur_helm[k] = th;
+        if (tp > c->cur_pres[k] || tp < c->cur_pres[k] - 1) c->cur_pres[k] = tp;
+      }
+      return 0;
+    }
+    bool capped = true;
+    for (int k = 0; k < 3; ++k) capped = capped && c->cur_helm[k] >= c->max_helm && c->cur_pres[k] >= c->max_pres;
+    if (capped) {
+      c->hstats.unconverged += h.unconverged;
+      return fail(NSK_ENOCONV, "inner solve hit its iteration cap (" + std::to_string(h.unconverged) + " solves)");
+    }
+    for (int k = 0; k < 3; ++k) {
+      c->cur_helm[k] = std::min(c->max_helm, 2 * c->cur_helm[k] + 4);
+      c->cur_pres[k] = std::min(c->max_pres, 2 * c->cur_pres[k] + 4);
+    }
+  }
 }
 
 // ===========================================================================
@@ -607,6 +708,7 @@ int nsk_init(const nsk_case* cs, nsk_ctx** out) {
 int nsk_finalize(nsk_ctx* c) {
   if (!c) return 0;
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  for (auto& a : c->graphs) for (auto& g : a) if (g.exec) (void)hipGraphExecDestroy(g.exec);
   for (void* p : c->allocs) (void)hipFree(p);
   if (c->hpin) (void)hipHostFree(c->hpin);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -633,6 +735,21 @@ int nsk_set_nsteps(nsk_ctx* c, int nsteps) {
 int nsk_set_tolerances(nsk_ctx* c, double th, double tp, int relative) {
   if (!c) return fail(NSK_EINVAL, "null ctx");
   c->d.tol_helm = th; c->d.tol_pres = tp; c->d.tol_relative = relative;
+  for (auto& a : c->graphs) for (auto& g : a) g.nh = -1;   // Dev is captured by value: re-capture
+  for (int k = 0; k < 3; ++k) { c->cur_helm[k] = c->max_helm; c->cur_pres[k] = c->max_pres; }
+  return 0;
+}
+
+int nsk_set_option(nsk_ctx* c, const char* name, double value) {
+  if (!c || !name) return fail(NSK_EINVAL, "bad argument");
+  const std::string n(name);
+  if (n == "use_graph") c->use_graph = (int)value;
+  else if (n == "min_pres_iter") c->min_pres = (int)value;
+  else if (n == "helm_guess") c->helm_guess = (int)value;
+  else if (n == "budget_helm") { for (int k = 0; k < 3; ++k) c->cur_helm[k] = std::min(c->max_helm, std::max(1, (int)value)); }
+  else if (n == "budget_pres") { for (int k = 0; k < 3; ++k) c->cur_pres[k] = std::min(c->max_pres, std::max(1, (int)value)); }
+  else return fail(NSK_EINVAL, "unknown option " + n);
+  for (auto& a : c->graphs) for (auto& g : a) g.nh = -1;
   return 0;
 }
 
@@ -681,40 +798,34 @@ int nsk_vec_download(nsk_ctx* c, nsk_vec v, double* vx, double* vy, double* pr) 
 
 int nsk_get_stats(nsk_ctx* c, nsk_stats* s) {
   if (!c || !s) return fail(NSK_EINVAL, "bad argument");
-  HIPCHK(hipStreamSynchronize(c->stream));
-  Stats h;
-  HIPCHK(hipMemcpy(&h, c->d.stats, sizeof(Stats), hipMemcpyDeviceToHost));
+  const Stats& h = c->hstats;
   s->steps = h.steps; s->helm_iters = h.helm_iters; s->pres_iters = h.pres_iters;
   s->unconverged = h.unconverged; s->last_helm_res = h.last_helm_res; s->last_pres_res = h.last_pres_res;
+  s->max_helm_iter = h.max_helm; s->max_pres_iter = h.max_pres;
+  s->budget_helm = c->cur_helm[2]; s->budget_pres = c->cur_pres[2];
   return 0;
 }
 
 int nsk_matvec(nsk_ctx* c, int mode, nsk_vec fv, nsk_vec qv) {
   if (!c || !fv || !qv) return fail(NSK_EINVAL, "bad argument");
   double* f = (double*)fv; const double* q = (const double*)qv;
-  HIPCHK(hipMemsetAsync(c->d.stats, 0, sizeof(Stats), c->stream));
+  c->hstats = Stats{};
   int rc = 0;
   switch (mode) {
-    case NSK_DIRECT: rc = run_map(c, 0, f, q); break;
-    case NSK_ADJOINT: rc = run_map(c, 1, f, q); break;
+    case NSK_DIRECT: rc = run_map_adaptive(c, 0, f, q); break;
+    case NSK_ADJOINT: rc = run_map_adaptive(c, 1, f, q); break;
     case NSK_DIRECT_ADJOINT:                                     // core/matvec.f:343-346
-      rc = run_map(c, 0, f, q);
-      if (!rc) rc = run_map(c, 1, f, f);
+      rc = run_map_adaptive(c, 0, f, q);
+      if (!rc) rc = run_map_adaptive(c, 1, f, f);
       break;
     case NSK_NEWTON:                                             // core/matvec.f:398-401
       if (f == q) return fail(NSK_EINVAL, "newton map needs f != q");
-      rc = run_map(c, 0, f, q);
+      rc = run_map_adaptive(c, 0, f, q);
       if (!rc) hipLaunchKernelGGL(k_axpby, dim3((unsigned)((c->nstate + 255) / 256)), dim3(256), 0, c->stream, f, -1.0, q, 1.0, c->nstate);
       break;
     default: return fail(NSK_EINVAL, "unknown mode");
   }
-  if (rc) return rc;
-  Stats h;
-  HIPCHK(hipMemcpyAsync(&h, c->d.stats, sizeof(Stats), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
-  c->hstats = h;
-  if (h.unconverged > 0) return fail(NSK_ENOCONV, "inner solve hit its iteration cap (" + std::to_string(h.unconverged) + " solves)");
-  return 0;
+  return rc;
 }
 
 // ---- Krylov vector algebra ------------------------------------------------
@@ -899,6 +1010,7 @@ int nsk_test_helm_solve(nsk_ctx* c, const double* rx, const double* ry, int orde
   Dev& d = c->d;
   HIPCHK(hipMemcpy(d.rloc, rx, c->nloc * sizeof(double), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(d.rloc + c->nloc, ry, c->nloc * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(d.bloc, d.rloc, 2 * c->nloc * sizeof(double), hipMemcpyDeviceToDevice));
   HIPCHK(hipMemset(d.stats, 0, sizeof(Stats)));
   const StepCoef sc = make_coef(c, order, 0);
   const int nh = c->max_helm;
@@ -924,13 +1036,14 @@ int nsk_test_pres_solve(nsk_ctx* c, const double* g, double* out, int* iters) {
   for (long long q = 0; q < c->npr; ++q) part[(q / c->MM) / c->EPB] += g[q] * g[q];
   HIPCHK(hipMemcpy(d.gpart, part.data(), c->nblk * sizeof(double), hipMemcpyHostToDevice));
   StepCoef sc = make_coef(c, 3, 0);
-  const int save = c->cur_pres; c->cur_pres = c->max_pres;
-  int rc = pres_solve_launch(c, 1.0);
-  c->cur_pres = save;
+  const int savep = d.nproj_max; d.nproj_max = 0; c->in_test = 1;
+  int rc = pres_solve_launch(c, 1.0, 3, c->max_pres);
+  c->in_test = 0;
   if (rc) return rc;
   sc.h2 = 1.0;
   DISPATCH_N(c->N, { hipLaunchKernelGGL(k_pres_update<N>, dim3(c->nblk), dim3(Cfg<N>::NT), 0, c->stream, d, sc); });
   HIPCHK(hipStreamSynchronize(c->stream));
+  d.nproj_max = savep;
   HIPCHK(hipMemcpy(out, d.p, c->npr * sizeof(double), hipMemcpyDeviceToHost));
   Stats h; HIPCHK(hipMemcpy(&h, d.stats, sizeof(Stats), hipMemcpyDeviceToHost));
   if (iters) *iters = (int)h.pres_iters;

@@ -16,6 +16,7 @@ struct StepCoef {                // order k = min(istep,3)  [UPSTREAM setordbd/s
   double invdt;
   int k;
   int adjoint;
+  double xg[2];                  // Helmholtz initial guess  du0 = xg0*du^{n-1} + xg1*du^{n-2}
 };
 
 struct GmresScal {               // device-resident small state of one pressure solve
@@ -27,7 +28,12 @@ struct GmresScal {               // device-resident small state of one pressure 
   double hinv;                   // 1 / h(j+1,j)
   double resid;                  // current residual estimate, Nek norm
   double y[MAXMR];
-  double aproj[MAXPROJ];         // projection coefficients of the rhs on the stored solutions
+  double gnorm0;                 // ||g|| before projection (reference of the relative tolerance)
+  double pa[MAXPROJ];            // projection coefficients a_i = (x_i, g)/n_i
+  double pn[MAXPROJ];            // n_i = (x_i, E x_i)
+  double st_n;                   // staged update of the projection space (committed by the next k_rhs)
+  int st_slot, st_pending;
+  int pcnt;                      // solutions absorbed so far
   int done;
   int nit;
   int nproj;                     // vectors currently in the projection space
@@ -35,6 +41,8 @@ struct GmresScal {               // device-resident small state of one pressure 
 
 struct Stats {
   long long helm_iters, pres_iters, unconverged, steps;
+  long long max_helm, max_pres;
+  long long max_helm_k[3], max_pres_k[3];   // per BDF order (separate graphs, separate budgets)
   double last_helm_res, last_pres_res;
 };
 
@@ -54,16 +62,16 @@ struct Dev {
   // gather-scatter (dssum) as a gather: CSR of co-located local nodes, ascending
   const int *gs_off, *gs_idx;
   // time-stepper state
-  double *u, *p, *plag, *pext, *ulag, *exlag, *bf, *rloc;
+  double *u, *p, *plag, *pext, *ulag, *exlag, *bf, *rloc, *bloc, *dulag;
   // Helmholtz CG (both components advance together)
   double *hx, *hr, *hp, *hs, *hwl, *hpart, *hscal;
   // pressure GMRES
   double *V, *Z, *yl, *ec, *xc, *gpart;
   GmresScal* gsc;
   // projection onto previous pressure solutions (E-orthonormal)
-  double *PX, *PEX;
+  double *PX, *PEX, *PD, *PED, *ppart;
   // coarse space
-  const int *v_off, *v_ent, *evert;
+  const int *v_off, *v_ent, *evert, *vtab;
   const double* Aci;
   // restricted additive Schwarz patches
   const int *p_off, *p_idx;

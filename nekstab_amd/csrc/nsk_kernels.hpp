@@ -57,6 +57,19 @@ __device__ inline void sum_partials(const double* part, int n, double (&out)[NV]
   for (int q = 0; q < NV; ++q) out[q] = v[q];
 }
 
+// sums nq arrays of n per-block partials into sh[0..nq): waves take different q, fixed order
+__device__ inline void sum_partials_multi(const double* part, int n, int nq, double* sh, int tid, int nthreads) {
+  const int lane = tid & 63, w = tid >> 6, nw = nthreads >> 6;
+  for (int q = w; q < nq; q += nw) {
+    double s = 0.0;
+    for (int k = lane; k < n; k += 64) s += part[(size_t)q * n + k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if (lane == 0) sh[q] = s;
+  }
+  __syncthreads();
+}
+
 __device__ inline double gs_gather(const double* __restrict__ f, const int* __restrict__ off,
                                    const int* __restrict__ idx, long long l) {
   const int a = off[l], b = off[l + 1];
@@ -308,13 +321,27 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_rhs(Dev d, StepCoef sc) {
   const int j = nd / N, i = nd % N;
   const long long l = e * NN + nd, nl = d.nloc;
   load_basis<N, EPB>(d, sD, sDt, sJ12, sD12, tid, NT);
+  if (d.nproj_max > 0 && blockIdx.x == 0 && tid == 0) {
+    GmresScal* G = d.gsc;
+    if (G->st_pending) {
+      G->st_pending = 0;
+      if (G->st_n > 0.0) {
+        G->pn[G->st_slot] = G->st_n;
+        G->pcnt += 1;
+        G->nproj = (G->pcnt < d.nproj_max) ? G->pcnt : d.nproj_max;
+      } else {              // degenerate direction: drop the whole space and start again
+        G->pcnt = 0; G->nproj = 0;
+      }
+    }
+  }
   double u[2] = {0, 0}, bfv[2] = {0, 0}, bm = 0, g1 = 0, g2 = 0, g4 = 0;
   if (act) {
     bm = d.bm1[l]; g1 = d.g1[l]; g2 = d.g2[l]; g4 = d.g4[l];
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       const long long lc = c * nl + l;
-      u[c] = d.u[lc];
+      const double un = d.u[lc];
+      u[c] = un + sc.xg[0] * d.dulag[lc] + sc.xg[1] * d.dulag[2 * nl + lc];   // u^n + du0 (extrapolated guess)
       su[(c * EPB + el) * NN + nd] = u[c];
       const double bn = d.bf[lc];
       const double e1 = d.exlag[lc], e2 = d.exlag[2 * nl + lc];
@@ -322,9 +349,9 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_rhs(Dev d, StepCoef sc) {
       d.exlag[2 * nl + lc] = e1;
       d.exlag[lc] = bn;
       const double l1 = d.ulag[lc], l2 = d.ulag[2 * nl + lc];
-      b += bm * (sc.bd[1] * u[c] + sc.bd[2] * l1 + sc.bd[3] * l2) * sc.invdt;   // makebdfp
+      b += bm * (sc.bd[1] * un + sc.bd[2] * l1 + sc.bd[3] * l2) * sc.invdt;   // makebdfp
       d.ulag[2 * nl + lc] = l1;                                      // lagfieldp
-      d.ulag[lc] = u[c];
+      d.ulag[lc] = un;
       bfv[c] = b;
     }
     if (nd < MM) {                                                   // extrapprp
@@ -345,8 +372,11 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_rhs(Dev d, StepCoef sc) {
   double au[2];
   axhelm_tiles<N, EPB, 2>(sD, sDt, su, st1, st2, act, el, j, i, g1, g2, g4, au);
   if (act) {
-    d.rloc[l] = bfv[0] + gx - (d.nu * au[0] + sc.h2 * bm * u[0]);
-    d.rloc[nl + l] = bfv[1] + gy - (d.nu * au[1] + sc.h2 * bm * u[1]);
+    const double bx = bfv[0] + gx, by = bfv[1] + gy;                 // rhs of H u* = b
+    d.bloc[l] = bx;
+    d.bloc[nl + l] = by;
+    d.rloc[l] = bx - (d.nu * au[0] + sc.h2 * bm * u[0]);
+    d.rloc[nl + l] = by - (d.nu * au[1] + sc.h2 * bm * u[1]);
   }
 }
 
@@ -364,7 +394,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_helm(Dev d, StepCoef sc, int it,
   constexpr int NN = C::NN, EPB = C::EPB, NT = C::NT;
   __shared__ double sD[NN], sDt[NN];
   __shared__ double sz[2 * EPB * NN], st1[2 * EPB * NN], st2[2 * EPB * NN];
-  __shared__ double sred[6 * 16];
+  __shared__ double sred[8 * 16];
   const int tid = threadIdx.x, el = tid / NN, nd = tid % NN;
   const long long e = (long long)blockIdx.x * EPB + el;
   const bool act = (el < EPB) && (e < d.nel);
@@ -374,14 +404,14 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_helm(Dev d, StepCoef sc, int it,
   double alpha[2] = {0, 0}, beta[2] = {0, 0}, gam[2] = {0, 0};
   bool done[2] = {false, false};
   if (it > 0) {
-    double s[6];
-    sum_partials<6>(d.hpart + (size_t)ppar * 6 * d.nblk, d.nblk, s, sred, tid, NT);
+    double s[8];
+    sum_partials<8>(d.hpart + (size_t)ppar * 8 * d.nblk, d.nblk, s, sred, tid, NT);
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       const double* old = d.hscal + ppar * 8 + c * 4;
       const double g = s[c * 3 + 0], del = s[c * 3 + 1], rr = s[c * 3 + 2];
       const double res = sqrt(rr / d.vol);
-      const double ref = (it == 1) ? res : d.hscal[16 + c];
+      const double ref = (it == 1) ? sqrt(s[6 + c] / d.vol) : d.hscal[16 + c];   // ||b||: H u* = b
       const double tol = d.tol_relative ? d.tol_helm * ref : d.tol_helm;
       done[c] = (it > 1 && old[2] != 0.0) || (res <= tol) || !(g > 0.0);
       gam[c] = g;
@@ -394,14 +424,14 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_helm(Dev d, StepCoef sc, int it,
         const bool was = (it > 1 && old[2] != 0.0);
         cur[0] = g; cur[1] = alpha[c]; cur[2] = done[c] ? 1.0 : 0.0;
         cur[3] = was ? old[3] : res;
-        if (it == 1) d.hscal[16 + c] = res;
-        if (done[c] && !was && c == 0) atomicAdd((unsigned long long*)&d.stats->helm_iters, (unsigned long long)(it - 1));
+        if (it == 1) d.hscal[16 + c] = ref;
+        if (done[c] && !was) { if (c == 0) atomicAdd((unsigned long long*)&d.stats->helm_iters, (unsigned long long)(it - 1)); atomicMax((unsigned long long*)&d.stats->max_helm, (unsigned long long)(it - 1)); atomicMax((unsigned long long*)&d.stats->max_helm_k[sc.k - 1], (unsigned long long)(it - 1)); }
       }
     }
     if (done[0] && done[1]) return;
   }
   load_basis<N, EPB>(d, sD, sDt, nullptr, nullptr, tid, NT);
-  double r[2] = {0, 0}, z[2] = {0, 0}, bm = 0, g1 = 0, g2 = 0, g4 = 0, mk = 0, mi = 0, di = 0;
+  double r[2] = {0, 0}, z[2] = {0, 0}, bb[2] = {0, 0}, bm = 0, g1 = 0, g2 = 0, g4 = 0, mk = 0, mi = 0, di = 0;
   if (act) {
     bm = d.bm1[l]; g1 = d.g1[l]; g2 = d.g2[l]; g4 = d.g4[l]; mk = d.mask[l]; mi = d.minv[l];
     di = d.dinv[(size_t)(sc.k - 1) * nl + l];
@@ -410,6 +440,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_helm(Dev d, StepCoef sc, int it,
       const long long lc = c * nl + l;
       if (it == 0) {
         r[c] = mk * gs_gather(rhs + c * nl, d.gs_off, d.gs_idx, l);
+        bb[c] = mk * gs_gather(d.bloc + c * nl, d.gs_off, d.gs_idx, l);
         d.hx[lc] = 0.0; d.hp[lc] = 0.0; d.hs[lc] = 0.0; d.hr[lc] = r[c];
       } else if (!done[c]) {
         const double w = mk * gs_gather(d.hwl + ((size_t)ppar * 2 + c) * nl, d.gs_off, d.gs_idx, l);
@@ -430,7 +461,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_helm(Dev d, StepCoef sc, int it,
   __syncthreads();
   double au[2];
   axhelm_tiles<N, EPB, 2>(sD, sDt, sz, st1, st2, act, el, j, i, g1, g2, g4, au);
-  double v[6] = {0, 0, 0, 0, 0, 0};
+  double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (act) {
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
@@ -439,10 +470,11 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_helm(Dev d, StepCoef sc, int it,
       v[c * 3 + 0] = r[c] * z[c] * mi;
       v[c * 3 + 1] = z[c] * wl;
       v[c * 3 + 2] = r[c] * r[c] * mi;
+      v[6 + c] = bb[c] * bb[c] * mi;
     }
   }
-  block_reduce<6>(v, sred, tid, NT);
-  if (tid < 6) d.hpart[((size_t)par * 6 + tid) * d.nblk + blockIdx.x] = v[tid];
+  block_reduce<8>(v, sred, tid, NT);
+  if (tid < 8) d.hpart[((size_t)par * 8 + tid) * d.nblk + blockIdx.x] = v[tid];
 }
 
 // ---------------------------------------------------------------------------
@@ -450,20 +482,20 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_helm(Dev d, StepCoef sc, int it,
 //     also verifies that the Helmholtz solve converged.   [UPSTREAM incomprp]
 // ---------------------------------------------------------------------------
 template <int N>
-__global__ __launch_bounds__(Cfg<N>::NT) void k_pres_rhs(Dev d, int helm_par, int check_helm) {
+__global__ __launch_bounds__(Cfg<N>::NT) void k_pres_rhs(Dev d, StepCoef sc, int helm_par, int check_helm) {
   using C = Cfg<N>;
   constexpr int NN = C::NN, M = C::M, MM = C::MM, EPB = C::EPB, NT = C::NT, NM = N * M;
   __shared__ double sJ12[NM], sD12[NM];
   __shared__ double su[2 * EPB * NN], sA[4 * EPB * NM];
-  __shared__ double sred[16];
+  __shared__ double sred[8 * 16];
   const int tid = threadIdx.x, el = tid / NN, nd = tid % NN;
   const long long e = (long long)blockIdx.x * EPB + el;
   const bool act = (el < EPB) && (e < d.nel);
   const long long l = e * NN + nd, nl = d.nloc;
   load_basis<N, EPB>(d, nullptr, nullptr, sJ12, sD12, tid, NT);
   if (check_helm && blockIdx.x == 0) {       // last partials -> final residual of the velocity solve
-    double s[6];
-    sum_partials<6>(d.hpart + (size_t)helm_par * 6 * d.nblk, d.nblk, s, sred, tid, NT);
+    double s[8];
+    sum_partials<8>(d.hpart + (size_t)helm_par * 8 * d.nblk, d.nblk, s, sred, tid, NT);
     if (tid == 0) {
       double worst = 0.0; int bad = 0;
       for (int c = 0; c < 2; ++c) {
@@ -473,7 +505,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_pres_rhs(Dev d, int helm_par, in
         const double rr = was ? d.hscal[helm_par * 8 + c * 4 + 3] : res;
         worst = fmax(worst, rr);
         if (!was && !(res <= tol)) bad = 1;
-        if (!was && c == 0) atomicAdd((unsigned long long*)&d.stats->helm_iters, (unsigned long long)check_helm);
+        if (!was) { if (c == 0) atomicAdd((unsigned long long*)&d.stats->helm_iters, (unsigned long long)check_helm); atomicMax((unsigned long long*)&d.stats->max_helm, (unsigned long long)check_helm); atomicMax((unsigned long long*)&d.stats->max_helm_k[sc.k - 1], (unsigned long long)check_helm); }
       }
       d.stats->last_helm_res = worst;
       if (bad) atomicAdd((unsigned long long*)&d.stats->unconverged, 1ull);
@@ -482,20 +514,64 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_pres_rhs(Dev d, int helm_par, in
   if (act) {
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-      const double us = d.u[c * nl + l] + d.hx[c * nl + l];
-      d.u[c * nl + l] = us;
+      const long long lc = c * nl + l;
+      const double l1 = d.dulag[lc], l2 = d.dulag[2 * nl + lc];
+      const double du = sc.xg[0] * l1 + sc.xg[1] * l2 + d.hx[lc];     // guess + CG correction
+      d.dulag[2 * nl + lc] = l1;
+      d.dulag[lc] = du;
+      const double us = d.u[lc] + du;
+      d.u[lc] = us;
       su[(c * EPB + el) * NN + nd] = us;
     }
   }
   __syncthreads();
   const double div = opdiv_tiles<N, EPB>(sJ12, sD12, su, sA, act, el, nd, d, e);
   double v[1] = {0.0};
-  if (act && nd < MM) {
-    const double g = -div;
+  double g = 0.0;
+  const bool pact = act && nd < MM;
+  if (pact) {
+    g = -div;
     d.V[e * MM + nd] = g;
     v[0] = g * g;
   }
   block_reduce<1>(v, sred, tid, NT);
+  if (tid == 0) d.gpart[blockIdx.x] = v[0];
+  if (d.nproj_max > 0) {                       // (x_i, g) for the stored solutions
+    if (tid == 0) d.ppart[(size_t)MAXPROJ * d.nblk + blockIdx.x] = v[0];
+    const int np = d.gsc->nproj;
+    for (int k = 0; k < np; ++k) {
+      double t[1] = {pact ? g * d.PX[(size_t)k * d.npr + e * MM + nd] : 0.0};
+      block_reduce<1>(t, sred, tid, NT);
+      if (tid == 0) d.ppart[(size_t)k * d.nblk + blockIdx.x] = t[0];
+    }
+  }
+}
+
+// g' = g - sum_i a_i E x_i,  a_i = (x_i,g)/n_i   [UPSTREAM navier4.f setrhsp / projh]
+__global__ __launch_bounds__(256) void k_proj_apply(Dev d) {
+  __shared__ double sh[MAXPROJ + 1];
+  __shared__ double sred[16];
+  const int tid = threadIdx.x;
+  GmresScal* G = d.gsc;
+  const int np = G->nproj;
+  sum_partials_multi(d.ppart, d.nblk, np, sh, tid, 256);
+  if (blockIdx.x == 0) {
+    double gg[1];
+    sum_partials<1>(d.ppart + (size_t)MAXPROJ * d.nblk, d.nblk, gg, sred, tid, 256);
+    if (tid == 0) G->gnorm0 = sqrt(gg[0]);
+  }
+  if (tid < np) sh[tid] = sh[tid] / G->pn[tid];
+  __syncthreads();
+  if (blockIdx.x == 0 && tid < np) G->pa[tid] = sh[tid];
+  double v[1] = {0.0};
+  const long long q = (long long)blockIdx.x * 256 + tid;
+  if (q < d.npr) {
+    double g = d.V[q];
+    for (int k = 0; k < np; ++k) g -= sh[k] * d.PEX[(size_t)k * d.npr + q];
+    d.V[q] = g;
+    v[0] = g * g;
+  }
+  block_reduce<1>(v, sred, tid, 256);
   if (tid == 0) d.gpart[blockIdx.x] = v[0];
 }
 
@@ -506,83 +582,76 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_pres_rhs(Dev d, int helm_par, in
 // this build's own; only the converged solution is part of the discretisation]
 // ---------------------------------------------------------------------------
 
-// scalar work after the dots of iteration j (j = -1: start-up norm of g)
-__global__ void k_gmres_scal(Dev d, int j, double scale, int min_iter) {
-  __shared__ double sred[16];
-  __shared__ double sh[MAXMR + 2];
-  const int tid = threadIdx.x, NT = blockDim.x;
-  GmresScal* G = d.gsc;
-  if (j >= 0 && G->done) return;
-  const int nv = (j < 0) ? 1 : j + 2;
-  for (int q = 0; q < nv; ++q) {
-    double v[1];
-    sum_partials<1>(d.gpart + (size_t)q * d.nblk, d.nblk, v, sred, tid, NT);
-    if (tid == 0) sh[q] = v[0];
-  }
-  __syncthreads();
-  if (tid != 0) return;
-  if (j < 0) {
-    const double b0 = sqrt(sh[0]);
-    G->beta0 = b0; G->g[0] = b0; G->done = 0; G->nit = 0;
-    G->hinv = (b0 > 0.0) ? 1.0 / b0 : 0.0;
-    G->resid = b0 * scale;
-    for (int q = 0; q < MAXMR + 2; ++q) G->hcol[q] = 0.0;
-    if (!(b0 > 0.0)) { G->done = 1; }
-    return;
-  }
-  // classical Gram-Schmidt column: h_i = (w, v_i), h_{j+1} from Pythagoras
-  double ww = sh[j + 1], s2 = 0.0;
-  for (int q = 0; q <= j; ++q) { G->hcol[q] = sh[q]; s2 += sh[q] * sh[q]; }
-  double hn2 = ww - s2;
-  if (hn2 < 0.0) hn2 = 0.0;
-  const double hn = sqrt(hn2);
-  G->hcol[j + 1] = hn;
-  G->hinv = (hn > 0.0) ? 1.0 / hn : 0.0;
-  // Givens update of the Hessenberg least-squares problem
-  double col[MAXMR + 2];
-  for (int q = 0; q <= j; ++q) col[q] = sh[q];
-  col[j + 1] = hn;
-  for (int q = 0; q < j; ++q) {
-    const double t = G->cs[q] * col[q] + G->sn[q] * col[q + 1];
-    col[q + 1] = -G->sn[q] * col[q] + G->cs[q] * col[q + 1];
-    col[q] = t;
-  }
-  const double rho = sqrt(col[j] * col[j] + col[j + 1] * col[j + 1]);
-  const double cj = (rho > 0.0) ? col[j] / rho : 1.0, sj = (rho > 0.0) ? col[j + 1] / rho : 0.0;
-  G->cs[j] = cj; G->sn[j] = sj;
-  col[j] = rho;
-  for (int q = 0; q <= j; ++q) G->R[j * MAXMR + q] = col[q];
-  const double gj = G->g[j];
-  G->g[j] = cj * gj;
-  G->g[j + 1] = -sj * gj;
-  G->nit = j + 1;
-  const double res = fabs(G->g[j + 1]) * scale;
-  G->resid = res;
-  const double tol = d.tol_relative ? d.tol_pres * G->beta0 * scale : d.tol_pres;
-  if ((res <= tol && (j + 1) >= min_iter) || !(hn > 0.0)) {
-    G->done = 1;
-    atomicAdd((unsigned long long*)&d.stats->pres_iters, (unsigned long long)(j + 1));
-    d.stats->last_pres_res = res;
-  }
-}
-
-// v_{j+1} = (w - sum_i h_i v_i) / h_{j+1,j}  (j = -1: v_0 = g / |g|), plus the
-// element-corner restriction ec[e][c] = sum_k hat_c(k) v(e,k) for the coarse solve
+// One GMRES bookkeeping kernel per iteration: every workgroup re-sums the dot-product
+// partials (fixed order => identical values everywhere), workgroup 0 additionally advances
+// the Givens / least-squares state and the convergence flag, and all workgroups form
+//   v_{j+1} = (w - sum_i h_i v_i) / h_{j+1,j}      (j = -1: v_0 = g'/|g'|)
+// plus the element-corner restriction ec[e][c] = sum_k hat_c(k) v(e,k) for the coarse solve.
 template <int N>
-__global__ __launch_bounds__(Cfg<N>::NT) void k_gmres_update(Dev d, int j) {
+__global__ __launch_bounds__(Cfg<N>::NT) void k_gmres_update(Dev d, int j, double scale, int min_iter, int ord) {
   using C = Cfg<N>;
-  constexpr int NN = C::NN, MM = C::MM, EPB = C::EPB;
+  constexpr int NN = C::NN, MM = C::MM, EPB = C::EPB, NT = C::NT;
   __shared__ double sv[EPB * MM];
+  __shared__ double sh[MAXMR + 2];
   const int tid = threadIdx.x, el = tid / NN, nd = tid % NN;
   const long long e = (long long)blockIdx.x * EPB + el;
   const bool act = (el < EPB) && (e < d.nel);
-  const GmresScal* G = d.gsc;
-  if (G->done) return;
+  GmresScal* G = d.gsc;
+  if (j >= 0 && G->done) return;
+  const int nv = (j < 0) ? 1 : j + 2;
+  sum_partials_multi(d.gpart, d.nblk, nv, sh, tid, NT);
+  double hn;
+  if (j < 0) hn = sqrt(sh[0]);
+  else {
+    double s2 = 0.0;
+    for (int q = 0; q <= j; ++q) s2 += sh[q] * sh[q];
+    const double hn2 = sh[j + 1] - s2;
+    hn = sqrt(hn2 > 0.0 ? hn2 : 0.0);
+  }
+  const double hinv = (hn > 0.0) ? 1.0 / hn : 0.0;
+  if (blockIdx.x == 0 && tid == 0) {
+    if (j < 0) {
+      G->beta0 = hn; G->g[0] = hn; G->nit = 0; G->resid = hn * scale;
+      if (d.nproj_max <= 0) G->gnorm0 = hn;
+      const double tol0 = d.tol_relative ? d.tol_pres * G->gnorm0 * scale : d.tol_pres;
+      const int dn = (!(hn > 0.0) || (min_iter <= 0 && hn * scale <= tol0)) ? 1 : 0;
+      if (dn) d.stats->last_pres_res = hn * scale;
+      G->done = dn;
+    } else {
+      double col[MAXMR + 2];
+      for (int q = 0; q <= j; ++q) col[q] = sh[q];
+      col[j + 1] = hn;
+      for (int q = 0; q < j; ++q) {
+        const double t = G->cs[q] * col[q] + G->sn[q] * col[q + 1];
+        col[q + 1] = -G->sn[q] * col[q] + G->cs[q] * col[q + 1];
+        col[q] = t;
+      }
+      const double rho = sqrt(col[j] * col[j] + col[j + 1] * col[j + 1]);
+      const double cj = (rho > 0.0) ? col[j] / rho : 1.0, sj = (rho > 0.0) ? col[j + 1] / rho : 0.0;
+      G->cs[j] = cj; G->sn[j] = sj;
+      col[j] = rho;
+      for (int q = 0; q <= j; ++q) G->R[j * MAXMR + q] = col[q];
+      const double gj = G->g[j];
+      G->g[j] = cj * gj;
+      G->g[j + 1] = -sj * gj;
+      G->nit = j + 1;
+      const double res = fabs(sj * gj) * scale;
+      G->resid = res;
+      const double tol = d.tol_relative ? d.tol_pres * G->gnorm0 * scale : d.tol_pres;
+      if ((res <= tol && (j + 1) >= min_iter) || !(hn > 0.0)) {
+        atomicAdd((unsigned long long*)&d.stats->pres_iters, (unsigned long long)(j + 1));
+        atomicMax((unsigned long long*)&d.stats->max_pres, (unsigned long long)(j + 1));
+        atomicMax((unsigned long long*)&d.stats->max_pres_k[ord - 1], (unsigned long long)(j + 1));
+        d.stats->last_pres_res = res;
+        G->done = 1;
+      }
+    }
+  }
   if (act && nd < MM) {
     const long long q = e * MM + nd;
     double w = d.V[(size_t)(j + 1) * d.npr + q];
-    for (int k = 0; k <= j; ++k) w -= G->hcol[k] * d.V[(size_t)k * d.npr + q];
-    w *= G->hinv;
+    for (int k = 0; k <= j; ++k) w -= sh[k] * d.V[(size_t)k * d.npr + q];
+    w *= hinv;
     d.V[(size_t)(j + 1) * d.npr + q] = w;
     sv[el * MM + nd] = w;
   }
@@ -594,31 +663,39 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_gmres_update(Dev d, int j) {
   }
 }
 
-// coarse solve: r_c = gather of element-corner restrictions; x_c = Aci r_c.
-// Every workgroup rebuilds r_c in LDS (cheap, L2-resident) then does its rows.
-constexpr int CROWS = 32;
+// coarse solve: r_c = gather of element-corner restrictions (padded vertex table);
+// x_c = Aci r_c with one wavefront per CROWS_W rows, lanes striding the (symmetric) row.
+constexpr int CVT = 8;            // table width = max elements around a vertex
+constexpr int CROWS_W = 2;
 __global__ __launch_bounds__(256) void k_coarse(Dev d) {
   extern __shared__ double srcv[];            // nvert
-  __shared__ double sp[256];
   const int tid = threadIdx.x;
   if (d.gsc->done) return;
   for (int v = tid; v < d.nvert; v += 256) {
-    double s = 0.0;
-    for (int k = d.v_off[v]; k < d.v_off[v + 1]; ++k) s += d.ec[d.v_ent[k]];
+    const int4 a = reinterpret_cast<const int4*>(d.vtab)[2 * v], b = reinterpret_cast<const int4*>(d.vtab)[2 * v + 1];
+    double s = d.ec[a.x];
+    if (a.y >= 0) s += d.ec[a.y];
+    if (a.z >= 0) s += d.ec[a.z];
+    if (a.w >= 0) s += d.ec[a.w];
+    if (b.x >= 0) s += d.ec[b.x];
+    if (b.y >= 0) s += d.ec[b.y];
+    if (b.z >= 0) s += d.ec[b.z];
+    if (b.w >= 0) s += d.ec[b.w];
     srcv[v] = s;
   }
   __syncthreads();
-  const int r = tid % CROWS, part = tid / CROWS;         // 8 column slices per row
-  const int row = blockIdx.x * CROWS + r;
-  double s = 0.0;
-  if (row < d.nvert)
-    for (int c = part; c < d.nvert; c += 256 / CROWS) s += d.Aci[(size_t)c * d.nvert + row] * srcv[c];
-  sp[tid] = s;
-  __syncthreads();
-  if (tid < CROWS && row < d.nvert) {
-    double t = 0.0;
-    for (int k = 0; k < 256 / CROWS; ++k) t += sp[k * CROWS + tid];
-    d.xc[row] = t;
+  const int lane = tid & 63, w = tid >> 6;
+#pragma unroll
+  for (int rr = 0; rr < CROWS_W; ++rr) {
+    const int row = (blockIdx.x * 4 + w) * CROWS_W + rr;
+    if (row < d.nvert) {
+      const double* A = d.Aci + (size_t)row * d.nvert;
+      double s = 0.0;
+      for (int c = lane; c < d.nvert; c += 64) s += A[c] * srcv[c];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+      if (lane == 0) d.xc[row] = s;
+    }
   }
 }
 
@@ -760,6 +837,11 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_pres_update(Dev d, StepCoef sc) 
     const long long q = e * MM + nd;
     double x = 0.0;
     for (int k = 0; k < nit; ++k) x += sy[k] * d.Z[(size_t)k * d.npr + q];
+    if (d.nproj_max > 0) {
+      d.PD[q] = x;                                   // GMRES correction delta
+      const int np = G->nproj;
+      for (int k = 0; k < np; ++k) x += G->pa[k] * d.PX[(size_t)k * d.npr + q];
+    }
     const double dp = sc.h2 * x;
     d.p[q] = d.pext[q] + dp;
     sP[(0 * EPB + el) * MM + nd] = dp * d.w2rx[q];
@@ -776,6 +858,88 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_pres_update(Dev d, StepCoef sc) 
     d.yl[d.nloc + l] = gy;
   }
   if (blockIdx.x == 0 && tid == 0 && !G->done) atomicAdd((unsigned long long*)&d.stats->unconverged, 1ull);
+}
+
+// velocity correction fused with E*dp for the projection space:
+//   v = B^-1 mask dssum(yl);  u += v/h2;  E delta = D v / h2 - sum a_i E x_i;  dots (E x_i, delta), (delta, E delta)
+template <int N>
+__global__ __launch_bounds__(Cfg<N>::NT) void k_vel_update_proj(Dev d, StepCoef sc) {
+  using C = Cfg<N>;
+  constexpr int NN = C::NN, M = C::M, MM = C::MM, EPB = C::EPB, NT = C::NT, NM = N * M;
+  __shared__ double sJ12[NM], sD12[NM];
+  __shared__ double su[2 * EPB * NN], sA[4 * EPB * NM];
+  __shared__ double sred[16];
+  const int tid = threadIdx.x, el = tid / NN, nd = tid % NN;
+  const long long e = (long long)blockIdx.x * EPB + el;
+  const bool act = (el < EPB) && (e < d.nel);
+  const GmresScal* G = d.gsc;
+  load_basis<N, EPB>(d, nullptr, nullptr, sJ12, sD12, tid, NT);
+  if (act) {
+    const long long l = e * NN + nd;
+    const double bi = d.binv[l];
+    const double vx = bi * gs_gather(d.yl, d.gs_off, d.gs_idx, l);
+    const double vy = bi * gs_gather(d.yl + d.nloc, d.gs_off, d.gs_idx, l);
+    d.u[l] += vx / sc.h2;
+    d.u[d.nloc + l] += vy / sc.h2;
+    su[(0 * EPB + el) * NN + nd] = vx;
+    su[(1 * EPB + el) * NN + nd] = vy;
+  }
+  if (G->nit == 0) return;                      // nothing new to absorb
+  __syncthreads();
+  const double w = opdiv_tiles<N, EPB>(sJ12, sD12, su, sA, act, el, nd, d, e);
+  const bool pact = act && nd < MM;
+  const long long q = e * MM + nd;
+  const int np = G->nproj;
+  double del = 0.0, edel = 0.0;
+  if (pact) {
+    edel = w / sc.h2;
+    for (int k = 0; k < np; ++k) edel -= G->pa[k] * d.PEX[(size_t)k * d.npr + q];
+    del = d.PD[q];
+    d.PED[q] = edel;
+  }
+  for (int k = 0; k <= np; ++k) {
+    double t[1] = {0.0};
+    if (pact) t[0] = (k < np) ? del * d.PEX[(size_t)k * d.npr + q] : del * edel;
+    block_reduce<1>(t, sred, tid, NT);
+    if (tid == 0) d.ppart[(size_t)k * d.nblk + blockIdx.x] = t[0];
+  }
+}
+
+// absorb the newest solution into the E-orthogonal projection space (slot = pcnt mod nmax):
+//   x_s <- a_s x_s + (delta - sum_{i!=s} c_i/n_i x_i)      [UPSTREAM navier4.f gensolnp / updtseth]
+__global__ __launch_bounds__(256) void k_proj_update(Dev d) {
+  __shared__ double sh[MAXPROJ + 1];
+  __shared__ double cf[MAXPROJ];
+  const int tid = threadIdx.x;
+  GmresScal* G = d.gsc;
+  if (G->nit == 0) return;
+  const int np = G->nproj, nmax = d.nproj_max;
+  const int s = G->pcnt % nmax;
+  sum_partials_multi(d.ppart, d.nblk, np + 1, sh, tid, 256);
+  const double as = (s < np) ? G->pa[s] : 0.0;
+  if (tid < np) cf[tid] = (tid == s) ? 0.0 : sh[tid] / G->pn[tid];
+  __syncthreads();
+  const long long q = (long long)blockIdx.x * 256 + tid;
+  if (q < d.npr) {
+    double x = d.PD[q], ex = d.PED[q];
+    for (int k = 0; k < np; ++k) {
+      if (k == s) continue;
+      x -= cf[k] * d.PX[(size_t)k * d.npr + q];
+      ex -= cf[k] * d.PEX[(size_t)k * d.npr + q];
+    }
+    if (s < np) {
+      x += as * d.PX[(size_t)s * d.npr + q];
+      ex += as * d.PEX[(size_t)s * d.npr + q];
+    }
+    d.PX[(size_t)s * d.npr + q] = x;
+    d.PEX[(size_t)s * d.npr + q] = ex;
+  }
+  if (blockIdx.x == 0 && tid == 0) {
+    double nn = sh[np];                                   // (delta, E delta)
+    for (int k = 0; k < np; ++k) if (k != s) nn -= sh[k] * sh[k] / G->pn[k];
+    if (s < np) nn += as * as * G->pn[s] + 2.0 * as * sh[s];
+    G->st_n = nn; G->st_slot = s; G->st_pending = 1;
+  }
 }
 
 // u^{n+1} = u* + (h2 B)^-1 mask dssum(D^T dp)      [UPSTREAM opbinv]
