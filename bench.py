@@ -1,0 +1,139 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: Arnoldi steps (time-stepper matvec + orthogonalisation) of the
+Re=50 cylinder, lx1=8, E=1996, k_dim=128 (BASELINE.json configs[1]) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one Arnoldi step = nsteps(=183) linearised Navier-Stokes time steps + one
+two-pass projection against the current Krylov basis.  With the default K = 128 the timed
+region *is* the k_dim = 128 factorisation, so `wall_time_kdim_s` is the leading-eigenpair
+wall time the metric asks for.  N > 1: independent replicas, one process per GPU (element
+sharding of dssum over RCCL is not built yet -- DESIGN.md "multi-GPU"); value = all Arnoldi
+steps of all ranks / max-over-ranks time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=128)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--lx1", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=16, help="oracle time steps in the CPU sample")
+    ap.add_argument("--tol-helm", type=float, default=1e-11)
+    ap.add_argument("--tol-pres", type=float, default=1e-1)
+    return ap.parse_args()
+
+
+def cpu_baseline(case, nsteps_map, sample_steps):
+    """oracle/ (numpy/scipy restatement, sparse direct solves) timed on the host: a bounded
+    sample of `sample_steps` time steps of the same case, extrapolated to one matvec."""
+    import numpy as np
+    from oracle.linns import LinNS2D
+    t0 = time.perf_counter()
+    o = LinNS2D(x=case.x, y=case.y, gid=case.gid, nglob=case.nglob, mask=case.mask, ub=case.ub,
+                spng=case.spng, re=case.re, endtime=case.endtime, lxd=case.lxd, has_outflow=case.has_outflow)
+    setup = time.perf_counter() - t0
+    rng = np.random.default_rng(1)
+    q = (rng.standard_normal(case.x.shape) * case.mask, rng.standard_normal(case.x.shape) * case.mask,
+         np.zeros((case.nel, case.lx1 - 2, case.lx1 - 2)))
+    o.matvec(q, nsteps=3)            # builds the three Helmholtz factorisations (orders 1,2,3)
+    t0 = time.perf_counter()
+    o.matvec(q, nsteps=sample_steps)
+    per_step = (time.perf_counter() - t0) / sample_steps
+    return {"value": 1.0 / (per_step * nsteps_map), "unit": "matvecs/s", "cores": 1, "kind": "port",
+            "sample": "%d of %d time steps of one matvec (lx1=%d, E=%d), oracle/linns.py with sparse-LU solves; "
+                      "setup %.0fs excluded" % (sample_steps, nsteps_map, case.lx1, case.nel, setup),
+            "s_per_time_step": per_step}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ["HIP_VISIBLE_DEVICES"] = str(local)     # before anything touches the GPU
+    import numpy as np
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+    from nekstab_amd import krylov, mesh, seed
+    from nekstab_amd.capi import NekStabHip
+
+    case = mesh.load_case_npz(os.path.join(ROOT, "tests", "golden", "cylinder_case.npz"), a.lx1)
+    h = NekStabHip(case, case.meta["vert"], case.meta["nvert"], tol_helm=a.tol_helm, tol_pres=a.tol_pres,
+                   tol_relative=1, schwarz_layers=2, max_helm_iter=100, max_pres_iter=48, nproj=8)
+    k_dim = a.steps
+    Q = h.alloc(k_dim + a.warmup + 2)
+    qx, qy = seed.add_noise(case)
+    h.upload(Q[0], qx, qy, np.zeros(h.npres))
+    h.scal(Q[0], 1.0 / h.norm(Q[0]))
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    H = np.zeros((k_dim + a.warmup + 2, k_dim + a.warmup + 1))
+    # warm-up steps: also settle the adaptive launch budgets / graph captures
+    krylov.arnoldi_factorization(h, Q, H, 1, a.warmup, 0)
+    barrier()
+    t0 = time.perf_counter()
+    stats = {}
+    krylov.arnoldi_factorization(h, Q, H, a.warmup + 1, a.warmup + a.steps, 0, stats=stats)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    st = h.stats()
+    # dominant kernel, timed with HIP events on the library's own stream
+    kern = h.bench_kernel("helm", 200)
+    P = h.nvel
+    alg_bytes = 148.0 * 2 * P                       # K3+K4+K5, 148 B/pt/component, two components per launch
+    achieved = alg_bytes / (kern["avg_us"] * 1e-6) / 1e9
+    out = {
+        "metric": "Arnoldi matvecs/sec + wall-time to k_dim=128 eigenpairs, cylinder Re=50",
+        "value": world * a.steps / elapsed, "unit": "matvecs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "cylinder Re=50 direct Arnoldi (BASELINE configs[1]): E=%d, lx1=%d, lxd=%d, nsteps=%d/matvec, k_dim=%d"
+                   % (case.nel, case.lx1, case.lxd, h.nsteps, a.steps),
+                   "base_flow": "reference BF_1cyl0.f00001 (committed fixture), seed = add_noise",
+                   "tolerances": "Helmholtz |b-Hu|<=%g|b|, pressure |g-E dp|<=%g|g| (matvec parity vs oracle 1e-9, tests/)" % (a.tol_helm, a.tol_pres),
+                   "parallelism": "replicas x%d" % world if world > 1 else "1 GPU"},
+        "wall_time_kdim_s": elapsed if a.steps >= 128 else None,
+        "matvec_s_mean": float(np.mean(stats["matvec_s"])), "orth_s_mean": float(np.mean(stats["orth_s"])),
+        "helm_iters_per_step": st["helm_iters"] / max(st["steps"], 1), "pres_iters_per_step": st["pres_iters"] / max(st["steps"], 1),
+        "roofline": {"bound": "hbm", "kernel": "k_helm<%d>" % case.lx1, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                     "frac": achieved / 8000.0, "traffic": None, "avg_launch_us": kern["avg_us"],
+                     "algorithmic_bytes_per_launch": alg_bytes,
+                     "note": "working set (~30 MB) is Infinity-Cache resident: see DESIGN.md"},
+    }
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(case, h.nsteps, a.cpu_steps)
+    if rank == 0:
+        print(json.dumps(out))
+    h.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -127,6 +127,10 @@ typedef struct {
 } nsk_stats;
 int nsk_get_stats(nsk_ctx* ctx, nsk_stats* s);
 
+/* measurement hook for bench.py: average duration (us) of `reps` back-to-back launches of a hot
+ * kernel ("helm"), HIP events on the library's stream, full work in every launch */
+int nsk_bench_kernel(nsk_ctx* ctx, const char* name, int reps, double* avg_us);
+
 /* ---- kernel-level test hooks (parity against oracle/, tests/test_kernels_gpu.py) ---- */
 int nsk_test_axhelm(nsk_ctx* ctx, const double* u, double h1, double h2, double* out); /* local */
 int nsk_test_dssum(nsk_ctx* ctx, const double* u, double* out);

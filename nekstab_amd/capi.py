@@ -66,6 +66,7 @@ SYMBOLS = {
     "nsk_basis_gemm": (C.c_int, [_vp, _vpp, C.c_int, _dp, C.c_int]),
     "nsk_basis_gemv": (C.c_int, [_vp, _vpp, C.c_int, _dp, _dp, _vp, _vp]),
     "nsk_seed_noise": (C.c_int, [_vp, _vp]),
+    "nsk_bench_kernel": (C.c_int, [_vp, C.c_char_p, C.c_int, _dp]),
     "nsk_get_stats": (C.c_int, [_vp, C.POINTER(NskStats)]),
     "nsk_test_axhelm": (C.c_int, [_vp, _dp, C.c_double, C.c_double, _dp]),
     "nsk_test_dssum": (C.c_int, [_vp, _dp, _dp]),
@@ -222,6 +223,11 @@ class NekStabHip:
 
     def set_option(self, name, value):
         self._chk(self.lib.nsk_set_option(self.ctx, name.encode(), float(value)))
+
+    def bench_kernel(self, name, reps=200):
+        us = C.c_double()
+        self._chk(self.lib.nsk_bench_kernel(self.ctx, name.encode(), reps, C.byref(us)))
+        return {"kernel": name, "avg_us": us.value, "reps": reps}
 
     def stats(self):
         s = NskStats()

@@ -291,6 +291,17 @@ static int build(nsk_ctx* c, const nsk_case& cs) {
     for (long long l = 0; l < nloc; ++l)
       for (int k = 0; k < grp_cnt[l]; ++k) gs_idx[gs_off[l] + k] = srt[grp_start[l] + k].second;
   }
+  {
+    std::vector<int4> tab(nloc);
+    for (long long l = 0; l < nloc; ++l) {
+      const int n = gs_off[l + 1] - gs_off[l];
+      int v[4] = {-1, -1, -1, -1};
+      if (n <= 4) for (int k = 0; k < n; ++k) v[k] = gs_idx[gs_off[l] + k];
+      else v[0] = -2;
+      tab[l] = make_int4(v[0], v[1], v[2], v[3]);
+    }
+    if ((rc = dupload(c, &d.gs_tab, tab))) return rc;
+  }
   auto dssum_h = [&](const std::vector<double>& f) {
     std::vector<double> o(nloc);
     for (long long l = 0; l < nloc; ++l) { double s = 0; for (int k = gs_off[l]; k < gs_off[l + 1]; ++k) s += f[gs_idx[k]]; o[l] = s; }
@@ -746,6 +757,7 @@ int nsk_set_option(nsk_ctx* c, const char* name, double value) {
   if (n == "use_graph") c->use_graph = (int)value;
   else if (n == "min_pres_iter") c->min_pres = (int)value;
   else if (n == "helm_guess") c->helm_guess = (int)value;
+  else if (n == "dbg") { int v = (int)value; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), &v, sizeof(int))); }
   else if (n == "budget_helm") { for (int k = 0; k < 3; ++k) c->cur_helm[k] = std::min(c->max_helm, std::max(1, (int)value)); }
   else if (n == "budget_pres") { for (int k = 0; k < 3; ++k) c->cur_pres[k] = std::min(c->max_pres, std::max(1, (int)value)); }
   else return fail(NSK_EINVAL, "unknown option " + n);
@@ -950,6 +962,38 @@ int nsk_basis_gemv(nsk_ctx* c, const nsk_vec* Q, int k, const double* y_re, cons
 int nsk_seed_noise(nsk_ctx* c, nsk_vec v) {
   (void)c; (void)v;
   return fail(NSK_EINVAL, "nsk_seed_noise: build the seed on the host (nekstab_amd.seed) and upload it");
+}
+
+// average duration of one hot kernel, measured with HIP events on the library's stream
+int nsk_bench_kernel(nsk_ctx* c, const char* name, int reps, double* avg_us) {
+  if (!c || !name || reps < 1 || !avg_us) return fail(NSK_EINVAL, "bad argument");
+  const std::string n(name);
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+  Dev d = c->d;
+  float ms = 0.f;
+  if (n == "helm") {
+    d.tol_helm = 0.0; d.tol_relative = 0;                       // never converge: every launch does full work
+    const StepCoef sc = make_coef(c, 3, 0);
+    const int cyc = 8;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    DISPATCH_N(c->N, {
+      for (int r = 0; r < cyc; ++r)                               // warm
+        hipLaunchKernelGGL(k_helm<N>, dim3(c->nblk), dim3(Cfg<N>::NT), 0, c->stream, d, sc, r % cyc, (const double*)d.rloc);
+      HIPCHK(hipEventRecord(e0, c->stream));
+      for (int r = 0; r < reps; ++r)
+        hipLaunchKernelGGL(k_helm<N>, dim3(c->nblk), dim3(Cfg<N>::NT), 0, c->stream, d, sc, r % cyc, (const double*)d.rloc);
+      HIPCHK(hipEventRecord(e1, c->stream));
+    });
+  } else {
+    return fail(NSK_EINVAL, "unknown kernel " + n);
+  }
+  HIPCHK(hipEventSynchronize(e1));
+  HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+  *avg_us = 1e3 * ms / reps;
+  HIPCHK(hipEventDestroy(e0)); HIPCHK(hipEventDestroy(e1));
+  HIPCHK(hipMemsetAsync(c->d.stats, 0, sizeof(Stats), c->stream));
+  return 0;
 }
 
 // ---- test hooks -------------------------------------------------------------

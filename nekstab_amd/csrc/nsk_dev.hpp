@@ -61,6 +61,7 @@ struct Dev {
   const double *cUr, *cUs, *GUx, *GUy, *GVx, *GVy;
   // gather-scatter (dssum) as a gather: CSR of co-located local nodes, ascending
   const int *gs_off, *gs_idx;
+  const int4* gs_tab;
   // time-stepper state
   double *u, *p, *plag, *pext, *ulag, *exlag, *bf, *rloc, *bloc, *dulag;
   // Helmholtz CG (both components advance together)

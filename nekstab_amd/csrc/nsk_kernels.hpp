@@ -10,6 +10,8 @@
 
 namespace nsk {
 
+__device__ int g_dbg = 0;     // developer ablation switches (bit mask), 0 in production
+
 template <int N>
 struct Cfg {
   static constexpr int NN = N * N, M = N - 2, MM = M * M, ND = 3 * N / 2, NDD = ND * ND;
@@ -17,6 +19,32 @@ struct Cfg {
   static constexpr int NT = ((EPB * NN + 63) / 64) * 64;
   static constexpr int NTD = ((NDD + 63) / 64) * 64;
 };
+
+// Workgroup barrier that orders LDS traffic only: global loads issued earlier stay in
+// flight across it (hipcc's __syncthreads() drains vmcnt as well, which serialises every
+// dependent-latency chain in these small kernels).
+__device__ inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// ---------------------------------------------------------------------------
+// wave64 sum with DPP row shifts / row broadcasts (total lands in lane 63): ~6 dependent
+// v_mov_dpp+v_add_f64 steps instead of 6 ds_bpermute round trips through the LDS crossbar.
+// ---------------------------------------------------------------------------
+template <int CTRL, int RM>
+__device__ inline double dpp_get(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, RM, 0xf, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, RM, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ inline double wave_sum63(double x) {
+  x += dpp_get<0x111, 0xf>(x);      // row_shr:1
+  x += dpp_get<0x112, 0xf>(x);      // row_shr:2
+  x += dpp_get<0x114, 0xf>(x);      // row_shr:4
+  x += dpp_get<0x118, 0xf>(x);      // row_shr:8   -> lane 15 of every row = row sum
+  x += dpp_get<0x142, 0xa>(x);      // row_bcast:15 into rows 1,3
+  x += dpp_get<0x143, 0xc>(x);      // row_bcast:31 into rows 2,3 -> lane 63 = wave sum
+  return x;
+}
 
 // ---------------------------------------------------------------------------
 // deterministic block reduction of NV values; every thread gets the result
@@ -26,19 +54,17 @@ __device__ inline void block_reduce(double (&v)[NV], double* sred, int tid, int 
   const int lane = tid & 63, w = tid >> 6, nw = (nthreads + 63) >> 6;
 #pragma unroll
   for (int q = 0; q < NV; ++q) {
-    double x = v[q];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o, 64);
-    if (lane == 0) sred[q * 16 + w] = x;
+    const double x = wave_sum63(v[q]);
+    if (lane == 63) sred[q * 16 + w] = x;
   }
-  __syncthreads();
+  lds_barrier();
 #pragma unroll
   for (int q = 0; q < NV; ++q) {
     double s = 0.0;
     for (int k = 0; k < nw; ++k) s += sred[q * 16 + k];
     v[q] = s;
   }
-  __syncthreads();
+  lds_barrier();
 }
 
 // sum NV arrays of `n` per-block partials (stride `n`), fixed order, all threads get it
@@ -63,20 +89,45 @@ __device__ inline void sum_partials_multi(const double* part, int n, int nq, dou
   for (int q = w; q < nq; q += nw) {
     double s = 0.0;
     for (int k = lane; k < n; k += 64) s += part[(size_t)q * n + k];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
-    if (lane == 0) sh[q] = s;
+    s = wave_sum63(s);
+    if (lane == 63) sh[q] = s;
   }
-  __syncthreads();
+  lds_barrier();
 }
 
-__device__ inline double gs_gather(const double* __restrict__ f, const int* __restrict__ off,
-                                   const int* __restrict__ idx, long long l) {
-  const int a = off[l], b = off[l + 1];
-  if (b - a == 1) return f[l];
+// dssum as a gather: co-located local nodes (self included, ascending => every copy sums in
+// the same order) in a 4-wide table; valence > 4 falls back to the CSR lists.
+__device__ inline double gs_gather(const double* __restrict__ f, const Dev& d, long long l) {
+  const int4 t = d.gs_tab[l];
+  if (t.y < 0 && t.x >= 0) return f[l];
+  if (t.x >= 0) {
+    double s = f[t.x] + f[t.y];
+    if (t.z >= 0) s += f[t.z];
+    if (t.w >= 0) s += f[t.w];
+    return s;
+  }
   double s = 0.0;
-  for (int k = a; k < b; ++k) s += f[idx[k]];
+  for (int k = d.gs_off[l]; k < d.gs_off[l + 1]; ++k) s += f[d.gs_idx[k]];
   return s;
+}
+
+// two-phase form: issue the value loads as soon as the table entry is known, sum later
+struct GsVals { double a, b, c, d; };
+__device__ inline GsVals gs_load(const double* __restrict__ f, const int4 t, long long l) {
+  GsVals v;
+  v.a = f[t.x >= 0 ? t.x : l];
+  v.b = (t.y >= 0) ? f[t.y] : 0.0;
+  v.c = (t.z >= 0) ? f[t.z] : 0.0;
+  v.d = (t.w >= 0) ? f[t.w] : 0.0;
+  return v;
+}
+__device__ inline double gs_sum(const GsVals& v, const double* __restrict__ f, const Dev& d, const int4 t, long long l) {
+  if (t.x < 0) {
+    double s = 0.0;
+    for (int k = d.gs_off[l]; k < d.gs_off[l + 1]; ++k) s += f[d.gs_idx[k]];
+    return s;
+  }
+  return ((v.a + v.b) + v.c) + v.d;
 }
 
 // ---------------------------------------------------------------------------
@@ -102,7 +153,7 @@ __device__ inline void axhelm_tiles(const double* sD, const double* sDt, const d
       st2[(c * EPB + el) * NN + j * N + i] = g2 * us + g4 * ur;
     }
   }
-  __syncthreads();
+  lds_barrier();
   if (act) {
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
@@ -138,7 +189,7 @@ __device__ inline double opdiv_tiles(const double* sJ12, const double* sD12, con
     sA[(2 * EPB + el) * NM + nd] = a1v;
     sA[(3 * EPB + el) * NM + nd] = a2v;
   }
-  __syncthreads();
+  lds_barrier();
   double div = 0.0;
   if (act && nd < MM) {
     const int b = nd / M, a = nd % M;
@@ -179,7 +230,7 @@ __device__ inline void opgradt_tiles(const double* sJ12, const double* sD12, con
     sB[(2 * EPB + el) * NM + nd] = b1y;
     sB[(3 * EPB + el) * NM + nd] = b2y;
   }
-  __syncthreads();
+  lds_barrier();
   gx = 0.0; gy = 0.0;
   if (act) {
     const int j = nd / N, i = nd % N;
@@ -401,64 +452,108 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_helm(Dev d, StepCoef sc, int it,
   const int j = nd / N, i = nd % N;
   const long long l = e * NN + nd, nl = d.nloc;
   const int par = it & 1, ppar = par ^ 1;
-  double alpha[2] = {0, 0}, beta[2] = {0, 0}, gam[2] = {0, 0};
-  bool done[2] = {false, false};
+  // ---- phase A: issue every independent global load before anything waits
+  double o[8] = {0, 0, 0, 0, 0, 0, 0, 0}, refn[2] = {0, 0};
+  if (it > 1) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) o[q] = d.hscal[ppar * 8 + q];
+    refn[0] = d.hscal[16]; refn[1] = d.hscal[17];
+  }
+  double ps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (it > 0) {
-    double s[8];
-    sum_partials<8>(d.hpart + (size_t)ppar * 8 * d.nblk, d.nblk, s, sred, tid, NT);
+    const double* part = d.hpart + (size_t)ppar * 8 * d.nblk;
+    for (int k = tid; k < d.nblk; k += NT) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) ps[q] += part[(size_t)q * d.nblk + k];
+    }
+  }
+  int4 tab = make_int4(0, -1, -1, -1);
+  double bm = 0, g1 = 0, g2 = 0, g4 = 0, mk = 0, mi = 0, di = 0;
+  double rold[2] = {0, 0}, pold[2] = {0, 0}, sold[2] = {0, 0}, xold[2] = {0, 0};
+  if (act) {
+    tab = d.gs_tab[l];
+    bm = d.bm1[l]; g1 = d.g1[l]; g2 = d.g2[l]; g4 = d.g4[l]; mk = d.mask[l]; mi = d.minv[l];
+    di = d.dinv[(size_t)(sc.k - 1) * nl + l];
+    if (it > 0) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const long long lc = c * nl + l;
+        rold[c] = d.hr[lc]; pold[c] = d.hp[lc]; sold[c] = d.hs[lc]; xold[c] = d.hx[lc];
+      }
+    }
+  }
+  const double dreg = (tid < NN) ? d.D[tid] : 0.0;
+  if (it > 1 && o[2] != 0.0 && o[6] != 0.0) {        // both components finished earlier
+    if (blockIdx.x == 0 && tid < 8) d.hscal[par * 8 + tid] = o[tid];
+    return;
+  }
+  // ---- phase B: gathers of the neighbours' unassembled values (need the table entry)
+  GsVals gv[2], gb[2];
+  if (act) {
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-      const double* old = d.hscal + ppar * 8 + c * 4;
-      const double g = s[c * 3 + 0], del = s[c * 3 + 1], rr = s[c * 3 + 2];
+      if (it == 0) { gv[c] = gs_load(rhs + c * nl, tab, l); gb[c] = gs_load(d.bloc + c * nl, tab, l); }
+      else gv[c] = gs_load(d.hwl + ((size_t)ppar * 2 + c) * nl, tab, l);
+    }
+  }
+  // ---- phase C: scalars of this iteration from the previous kernel's partials
+  double alpha[2] = {0, 0}, beta[2] = {0, 0};
+  bool done[2] = {false, false};
+  if (it > 0) {
+    block_reduce<8>(ps, sred, tid, NT);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const double g = ps[c * 3 + 0], del = ps[c * 3 + 1], rr = ps[c * 3 + 2];
       const double res = sqrt(rr / d.vol);
-      const double ref = (it == 1) ? sqrt(s[6 + c] / d.vol) : d.hscal[16 + c];   // ||b||: H u* = b
+      const double ref = (it == 1) ? sqrt(ps[6 + c] / d.vol) : refn[c];   // ||b||: H u* = b
       const double tol = d.tol_relative ? d.tol_helm * ref : d.tol_helm;
-      done[c] = (it > 1 && old[2] != 0.0) || (res <= tol) || !(g > 0.0);
-      gam[c] = g;
+      const bool was = (it > 1 && o[c * 4 + 2] != 0.0);
+      done[c] = was || (res <= tol) || !(g > 0.0);
       if (!done[c]) {
         if (it == 1) { beta[c] = 0.0; alpha[c] = g / del; }
-        else { beta[c] = g / old[0]; alpha[c] = g / (del - beta[c] * g / old[1]); }
+        else { beta[c] = g / o[c * 4 + 0]; alpha[c] = g / (del - beta[c] * g / o[c * 4 + 1]); }
       }
       if (blockIdx.x == 0 && tid == 0) {
         double* cur = d.hscal + par * 8 + c * 4;
-        const bool was = (it > 1 && old[2] != 0.0);
         cur[0] = g; cur[1] = alpha[c]; cur[2] = done[c] ? 1.0 : 0.0;
-        cur[3] = was ? old[3] : res;
+        cur[3] = was ? o[c * 4 + 3] : res;
         if (it == 1) d.hscal[16 + c] = ref;
-        if (done[c] && !was) { if (c == 0) atomicAdd((unsigned long long*)&d.stats->helm_iters, (unsigned long long)(it - 1)); atomicMax((unsigned long long*)&d.stats->max_helm, (unsigned long long)(it - 1)); atomicMax((unsigned long long*)&d.stats->max_helm_k[sc.k - 1], (unsigned long long)(it - 1)); }
+        if (done[c] && !was) {
+          if (c == 0) atomicAdd((unsigned long long*)&d.stats->helm_iters, (unsigned long long)(it - 1));
+          atomicMax((unsigned long long*)&d.stats->max_helm, (unsigned long long)(it - 1));
+          atomicMax((unsigned long long*)&d.stats->max_helm_k[sc.k - 1], (unsigned long long)(it - 1));
+        }
       }
     }
     if (done[0] && done[1]) return;
   }
-  load_basis<N, EPB>(d, sD, sDt, nullptr, nullptr, tid, NT);
-  double r[2] = {0, 0}, z[2] = {0, 0}, bb[2] = {0, 0}, bm = 0, g1 = 0, g2 = 0, g4 = 0, mk = 0, mi = 0, di = 0;
+  // ---- phase D: vector updates, next local A z, dot-product partials
+  if (tid < NN) { sD[tid] = dreg; sDt[(tid % N) * N + tid / N] = dreg; }
+  double r[2] = {0, 0}, z[2] = {0, 0}, bb[2] = {0, 0};
   if (act) {
-    bm = d.bm1[l]; g1 = d.g1[l]; g2 = d.g2[l]; g4 = d.g4[l]; mk = d.mask[l]; mi = d.minv[l];
-    di = d.dinv[(size_t)(sc.k - 1) * nl + l];
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       const long long lc = c * nl + l;
       if (it == 0) {
-        r[c] = mk * gs_gather(rhs + c * nl, d.gs_off, d.gs_idx, l);
-        bb[c] = mk * gs_gather(d.bloc + c * nl, d.gs_off, d.gs_idx, l);
+        r[c] = mk * gs_sum(gv[c], rhs + c * nl, d, tab, l);
+        bb[c] = mk * gs_sum(gb[c], d.bloc + c * nl, d, tab, l);
         d.hx[lc] = 0.0; d.hp[lc] = 0.0; d.hs[lc] = 0.0; d.hr[lc] = r[c];
       } else if (!done[c]) {
-        const double w = mk * gs_gather(d.hwl + ((size_t)ppar * 2 + c) * nl, d.gs_off, d.gs_idx, l);
-        const double rold = d.hr[lc];
-        const double pn = di * rold + beta[c] * d.hp[lc];
-        const double sn = w + beta[c] * d.hs[lc];
+        const double w = mk * gs_sum(gv[c], d.hwl + ((size_t)ppar * 2 + c) * nl, d, tab, l);
+        const double pn = di * rold[c] + beta[c] * pold[c];
+        const double sn = w + beta[c] * sold[c];
         d.hp[lc] = pn; d.hs[lc] = sn;
-        d.hx[lc] += alpha[c] * pn;
-        r[c] = rold - alpha[c] * sn;
+        d.hx[lc] = xold[c] + alpha[c] * pn;
+        r[c] = rold[c] - alpha[c] * sn;
         d.hr[lc] = r[c];
       } else {
-        r[c] = d.hr[lc];
+        r[c] = rold[c];
       }
       z[c] = di * r[c];
       sz[(c * EPB + el) * NN + nd] = z[c];
     }
   }
-  __syncthreads();
+  lds_barrier();
   double au[2];
   axhelm_tiles<N, EPB, 2>(sD, sDt, sz, st1, st2, act, el, j, i, g1, g2, g4, au);
   double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -692,9 +787,8 @@ __global__ __launch_bounds__(256) void k_coarse(Dev d) {
       const double* A = d.Aci + (size_t)row * d.nvert;
       double s = 0.0;
       for (int c = lane; c < d.nvert; c += 64) s += A[c] * srcv[c];
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
-      if (lane == 0) d.xc[row] = s;
+      s = wave_sum63(s);
+      if (lane == 63) d.xc[row] = s;
     }
   }
 }
@@ -793,8 +887,8 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_divgs(Dev d, const double* __res
   if (act) {
     const long long l = e * NN + nd;
     const double bi = d.binv[l];
-    su[(0 * EPB + el) * NN + nd] = bi * gs_gather(yl, d.gs_off, d.gs_idx, l);
-    su[(1 * EPB + el) * NN + nd] = bi * gs_gather(yl + d.nloc, d.gs_off, d.gs_idx, l);
+    su[(0 * EPB + el) * NN + nd] = bi * gs_gather(yl, d, l);
+    su[(1 * EPB + el) * NN + nd] = bi * gs_gather(yl + d.nloc, d, l);
   }
   __syncthreads();
   const double w = opdiv_tiles<N, EPB>(sJ12, sD12, su, sA, act, el, nd, d, e);
@@ -877,8 +971,8 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_vel_update_proj(Dev d, StepCoef 
   if (act) {
     const long long l = e * NN + nd;
     const double bi = d.binv[l];
-    const double vx = bi * gs_gather(d.yl, d.gs_off, d.gs_idx, l);
-    const double vy = bi * gs_gather(d.yl + d.nloc, d.gs_off, d.gs_idx, l);
+    const double vx = bi * gs_gather(d.yl, d, l);
+    const double vy = bi * gs_gather(d.yl + d.nloc, d, l);
     d.u[l] += vx / sc.h2;
     d.u[d.nloc + l] += vy / sc.h2;
     su[(0 * EPB + el) * NN + nd] = vx;
@@ -947,8 +1041,8 @@ __global__ void k_vel_update(Dev d, StepCoef sc) {
   const long long l = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (l >= d.nloc) return;
   const double f = d.binv[l] / sc.h2;
-  d.u[l] += f * gs_gather(d.yl, d.gs_off, d.gs_idx, l);
-  d.u[d.nloc + l] += f * gs_gather(d.yl + d.nloc, d.gs_off, d.gs_idx, l);
+  d.u[l] += f * gs_gather(d.yl, d, l);
+  d.u[d.nloc + l] += f * gs_gather(d.yl + d.nloc, d, l);
 }
 
 // ---------------------------------------------------------------------------
@@ -1038,7 +1132,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_axhelm_test(Dev d, const double*
 
 __global__ void k_dssum_test(Dev d, const double* __restrict__ u, double* __restrict__ out) {
   const long long l = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (l < d.nloc) out[l] = gs_gather(u, d.gs_off, d.gs_idx, l);
+  if (l < d.nloc) out[l] = gs_gather(u, d, l);
 }
 
 template <int N>

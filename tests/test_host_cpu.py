@@ -1,0 +1,106 @@
+"""CPU-side checks: the C-ABI library loads and exports every declared symbol, file formats,
+case preparation, the seed, and the multi-process timing reduction used by bench.py."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from tests.conftest import GOLDEN, ROOT
+
+
+def test_capi_exports_every_declared_symbol():
+    import __graft_entry__ as g
+    g.build()
+    from nekstab_amd import capi
+    lib = capi.load_library()
+    hdr = open(os.path.join(ROOT, "include", "nekstab_hip.h")).read()
+    declared = set(re.findall(r"\b(nsk_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/nekstab_hip.h but not exported"
+    assert declared == set(capi.SYMBOLS), (declared ^ set(capi.SYMBOLS))
+
+
+def test_no_cpu_fallback_without_gpu(case6):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from nekstab_amd.capi import NekStabHip, NskError
+    with pytest.raises(NskError):
+        NekStabHip(case6, case6.meta["vert"], case6.meta["nvert"])
+
+
+def test_product_never_imports_oracle():
+    for root, _, files in os.walk(os.path.join(ROOT, "nekstab_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp")):
+                txt = open(os.path.join(root, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt, f
+
+
+def test_fld_roundtrip(tmp_path):
+    from nekstab_amd import nekio
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((2, 7, 1, 6, 6)); u = rng.standard_normal((2, 7, 1, 6, 6)); p = rng.standard_normal((7, 1, 6, 6))
+    f = str(tmp_path / "tst0.f00001")
+    nekio.write_fld(f, x=x, u=u, p=p, time=1.0, istep=101)
+    r = nekio.read_fld(f)
+    assert r.istep == 101 and r.rdcode == "XUP" and r.nx == 6
+    assert np.array_equal(r.x, x) and np.array_equal(r.u, u) and np.array_equal(r.p, p)
+
+
+def test_spectre_writer_format(tmp_path, spectre):
+    from nekstab_amd import nekio
+    H = spectre["Hd"][:12]
+    f = str(tmp_path / "Spectre_Hd.dat")
+    nekio.write_spectre(f, H[:, 0] + 1j * H[:, 1], H[:, 2])
+    back = nekio.read_spectre(f)
+    assert np.allclose(back, H, rtol=2e-7, atol=1e-30)
+    line = open(f).readline()
+    assert len(line.rstrip("\n")) == 45 and "E" in line           # (3E15.7)
+
+
+def test_case_numbering_and_masks(case6):
+    c = case6
+    assert c.nel == 1996 and c.nglob == c.gid.max() + 1
+    gx = np.zeros(c.nglob); gx[c.gid.ravel()] = c.x.ravel()
+    assert np.abs(gx[c.gid] - c.x).max() < 2e-6                   # copies of a node coincide (fp32 mesh file)
+    gy = np.zeros(c.nglob); gy[c.gid.ravel()] = c.y.ravel()
+    dy = np.abs(gy[c.gid] - c.y)
+    assert set(np.unique(np.round(dy[dy > 1e-5]))) <= {32.0}       # only the periodic y pair differs
+    r = np.hypot(c.x, c.y)
+    assert np.all(c.mask[r < 0.5 + 1e-6] == 0) and np.all(c.ub[:, r < 0.5 + 1e-6] == 0)   # wall nodes
+    assert np.all(c.mask[np.abs(c.x + 16) < 1e-9] == 0)           # inflow 'v'
+    assert np.all(c.mask[np.abs(c.x - 50) < 1e-9] == 1)           # outflow 'O' stays free (direct)
+    assert c.spng.max() == 1.0 and np.all(c.spng[(c.x > -12.6) & (c.x < 46.6)] == 0)
+
+
+def test_seed_is_deterministic_and_continuous(case6):
+    from nekstab_amd import seed
+    a = seed.add_noise(case6); b = seed.add_noise(case6)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    g = np.zeros(case6.nglob); g[case6.gid.ravel()] = a[0].ravel()
+    assert np.abs(g[case6.gid] - a[0]).max() == 0.0               # single-valued on shared nodes
+    assert np.all(a[0][case6.mask == 0] == 0)
+
+
+def test_two_rank_gloo_timing_reduction(tmp_path):
+    """bench.py's N>1 protocol (barrier, max-over-ranks time, aggregate = sum of units / max time)
+    on two CPU processes with gloo."""
+    script = tmp_path / "w.py"
+    script.write_text(
+        "import os, time, torch, torch.distributed as dist\n"
+        "dist.init_process_group('gloo')\n"
+        "r = dist.get_rank(); dist.barrier(); t0 = time.perf_counter(); time.sleep(0.05 * (r + 1)); dist.barrier()\n"
+        "t = torch.tensor([0.05 * (r + 1)], dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX)\n"
+        "units = torch.tensor([10.0]); dist.all_reduce(units)\n"
+        "assert abs(t.item() - 0.1) < 1e-12 and units.item() == 20.0\n"
+        "print('ok', r)\n")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29611", str(script)],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.count("ok") == 2

@@ -1,0 +1,66 @@
+"""Pins of the CPU oracle against the reference's committed data:
+field-header step counts, mass-matrix sum, mode normalisation, the eigen-relation of the
+reference's own eigenmode with the reference's own eigenvalue."""
+import numpy as np
+import pytest
+
+from tests.conftest import make_oracle
+
+
+def test_nsteps_and_dt_lx1_6(oracle6_nosolve, modes):
+    o = oracle6_nosolve
+    assert o.nsteps == 100 and abs(o.dt - 0.01) < 1e-15
+    assert int(modes["dRe_istep"]) == o.nsteps + 1           # header holds the DO-loop exit value
+
+
+def test_nsteps_lx1_8(modes):
+    from nekstab_amd import mesh
+    import os
+    from tests.conftest import GOLDEN
+    c8 = mesh.load_case_npz(os.path.join(GOLDEN, "cylinder_case.npz"), 8)
+    o = make_oracle(c8, build_solvers=False)
+    assert o.nsteps == 183
+    assert int(modes["aRe_istep"]) == o.nsteps + 1
+    # mode normalisation at lx1=8 (adjoint files): |Re|^2 + |Im|^2 = 1 under bm1s
+    a = (modes["aRe_u"][0].astype(float), modes["aRe_u"][1].astype(float))
+    b = (modes["aIm_u"][0].astype(float), modes["aIm_u"][1].astype(float))
+    assert abs(o.inner(a, a) + o.inner(b, b) - 1.0) < 1e-6
+
+
+def test_mass_matrix_and_mode_norm(oracle6_nosolve, modes):
+    o = oracle6_nosolve
+    assert abs(o.volvm1 - (66.0 * 32.0 - np.pi / 4.0)) < 1e-6   # box minus the unit-diameter cylinder
+    a = (modes["dRe_u"][0].astype(float), modes["dRe_u"][1].astype(float))
+    b = (modes["dIm_u"][0].astype(float), modes["dIm_u"][1].astype(float))
+    assert abs(o.inner(a, a) + o.inner(b, b) - 1.0) < 1e-6      # core/eigensolvers.f:619-622
+    w = o.bm1                                                    # without the sponge mask the norm is ~1.018
+    full = sum(np.sum(x * w * x) for x in a + b)
+    assert full > 1.01
+
+
+@pytest.mark.slow
+def test_eigen_relation_direct(oracle6, modes, spectre):
+    """M (dRe + i dIm) = mu (dRe + i dIm): Rayleigh quotient of the oracle's matvec on the
+    reference's eigenmode equals the reference's eigenvalue to its 7 printed digits."""
+    o = oracle6
+    J = o.J12
+    mu = complex(spectre["Hd"][0, 0], spectre["Hd"][0, 1])
+    qr = (modes["dRe_u"][0].astype(float), modes["dRe_u"][1].astype(float), J @ modes["dRe_p"].astype(float) @ J.T)
+    qi = (modes["dIm_u"][0].astype(float), modes["dIm_u"][1].astype(float), J @ modes["dIm_p"].astype(float) @ J.T)
+    fr, fi = o.matvec(qr), o.matvec(qi)
+    ray = (o.inner(qr, fr) + o.inner(qi, fi)) + 1j * (o.inner(qr, fi) - o.inner(qi, fr))
+    assert abs(ray - mu) < 2e-7
+    er = [fr[k] - (mu.real * qr[k] - mu.imag * qi[k]) for k in range(2)]
+    ei = [fi[k] - (mu.imag * qr[k] + mu.real * qi[k]) for k in range(2)]
+    assert np.sqrt(o.inner(er, er) + o.inner(ei, ei)) < 1e-5      # fp32 mode storage + eigen_tol 1e-6
+
+
+def test_spectre_tables_consistent(spectre):
+    """lambda = log(mu)/T links Spectre_H and Spectre_NS (core/eigensolvers.f:593-595)."""
+    from nekstab_amd.krylov import log_transform
+    for op in ("d", "a"):
+        H, NS = spectre["H" + op], spectre["NS" + op]
+        lam = log_transform(H[:, 0] + 1j * H[:, 1], 1.0)
+        ok = np.abs(H[:, 0] + 1j * H[:, 1]) > 1e-3
+        assert np.abs(lam.real[ok] - NS[ok, 0]).max() < 2e-5
+        assert np.abs(np.abs(lam.imag[ok]) - np.abs(NS[ok, 1])).max() < 2e-5
