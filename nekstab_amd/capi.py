@@ -95,6 +95,13 @@ def load_library(path: str | None = None):
         raise FileNotFoundError(
             f"{p} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(there is no CPU fallback for the hot path)")
+    try:
+        # load order matters on this image: PyTorch-ROCm bundles its own HIP runtime; if this
+        # library pulls in /opt/rocm's copy first, the process ends up with two runtimes and the
+        # second one to initialise sees no device.  torch first => one shared runtime.
+        import torch  # noqa: F401
+    except Exception:
+        pass
     lib = C.CDLL(p)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)          # AttributeError if the export is missing
