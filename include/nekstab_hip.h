@@ -124,6 +124,7 @@ typedef struct {
   double last_helm_res, last_pres_res;
   long long max_helm_iter, max_pres_iter;   /* worst single solve */
   long long budget_helm, budget_pres;       /* iterations currently launched per solve */
+  long long recaptures, retries;            /* graph re-captures / maps redone with larger budgets (since init) */
 } nsk_stats;
 int nsk_get_stats(nsk_ctx* ctx, nsk_stats* s);
 

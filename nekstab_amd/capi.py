@@ -37,7 +37,8 @@ class NskStats(C.Structure):
     _fields_ = [("steps", C.c_longlong), ("helm_iters", C.c_longlong), ("pres_iters", C.c_longlong),
                 ("unconverged", C.c_longlong), ("last_helm_res", C.c_double), ("last_pres_res", C.c_double),
                 ("max_helm_iter", C.c_longlong), ("max_pres_iter", C.c_longlong),
-                ("budget_helm", C.c_longlong), ("budget_pres", C.c_longlong)]
+                ("budget_helm", C.c_longlong), ("budget_pres", C.c_longlong),
+                ("recaptures", C.c_longlong), ("retries", C.c_longlong)]
 
 
 # every symbol include/nekstab_hip.h declares: (restype, argtypes)

@@ -53,6 +53,7 @@ struct nsk_ctx {
   int use_graph = 1;
   int in_test = 0;
   int helm_guess = 1;
+  long long recaptures = 0, retries = 0;
   int debug = 0;
   struct StepGraph { hipGraphExec_t exec = nullptr; int nh = -1, np = -1; } graphs[2][3];
   double* scratch = nullptr;            // one state vector
@@ -187,7 +188,7 @@ static int build(nsk_ctx* c, const nsk_case& cs) {
   d.tol_helm = cs.tol_helm > 0 ? cs.tol_helm : 1e-9;
   d.tol_pres = cs.tol_pres > 0 ? cs.tol_pres : 1e-7;
   d.tol_relative = cs.tol_relative; d.max_mr = c->max_pres; d.has_outflow = cs.has_outflow;
-  d.nproj_max = std::min(cs.nproj, MAXPROJ);
+  d.nproj_max = cs.has_outflow ? std::min(cs.nproj, MAXPROJ) : 0;   // projection space needs a non-singular E (todo)
 
   // ---- bases
   std::vector<double> z1, w1, z2, w2, zd, wd;
@@ -499,6 +500,16 @@ static int build(nsk_ctx* c, const nsk_case& cs) {
     }
     HIPCHK(hipStreamSynchronize(c->stream));
     d.Aci = dA;
+    {
+      std::vector<double> Ah(Ac.size());
+      HIPCHK(hipMemcpy(Ah.data(), dA, Ah.size() * sizeof(double), hipMemcpyDeviceToHost));
+      const int lda = ((nvert + 255) / 256) * 256;
+      if (lda > 3072) return fail(NSK_EINVAL, "coarse space too large for k_coarse (nvert > 3072)");
+      d.coarse_lda = lda;
+      std::vector<float> Af((size_t)nvert * lda, 0.0f);
+      for (int r = 0; r < nvert; ++r) for (int q = 0; q < nvert; ++q) Af[(size_t)r * lda + q] = (float)Ah[(size_t)r * nvert + q];
+      if ((rc = dupload(c, &d.Acif, Af))) return rc;
+    }
   }
   {
     std::vector<int> vtab((size_t)nvert * CVT, -1);
@@ -515,12 +526,13 @@ static int build(nsk_ctx* c, const nsk_case& cs) {
   // ---- restricted additive Schwarz patches: own Gauss nodes + `layers` rows of every neighbour
   {
     const int L = c->layers;
-    std::vector<int> p_off(nel + 1, 0), p_idx;
-    std::vector<long long> p_invoff(nel + 1, 0);
-    std::vector<float> p_inv;
+    const int PS = (((M + 2 * L) * (M + 2 * L) + 3) / 4) * 4;
+    if (PS > 2 * NN) return fail(NSK_EINVAL, "schwarz_layers too large for this lx1");
+    d.p_stride = PS;
+    std::vector<int> p_idx((size_t)nel * PS, -1);
+    std::vector<float> p_inv((size_t)nel * PS * MM, 0.0f);
     std::vector<int> pe, pr;            // patch dof -> (element, local Gauss index)
     std::vector<double> A;
-    std::vector<char> shared(NN);
     for (int e = 0; e < nel; ++e) {
       pe.clear(); pr.clear();
       for (int k = 0; k < MM; ++k) { pe.push_back(e); pr.push_back(k); }
@@ -540,20 +552,19 @@ static int build(nsk_ctx* c, const nsk_case& cs) {
         if (b0 == 0 && b1 == M && a0 == 0 && a1 == M) continue;    // degenerate adjacency (wraps both ways)
         for (int b = b0; b < b1; ++b) for (int a = a0; a < a1; ++a) { pe.push_back(f); pr.push_back(b * M + a); }
       }
-      const int np = (int)pe.size();
+      int np = (int)pe.size();
+      if (np > PS) { np = PS; pe.resize(PS); pr.resize(PS); }       // irregular vertex: drop the excess overlap
       A.assign((size_t)np * np, 0.0);
       for (int q = 0; q < np; ++q)
         for (int r = 0; r < np; ++r) A[(size_t)r * np + q] = Eentry(pe[r], pr[r], pe[q], pr[q]);
       if (!cs.has_outflow) { double tr = 0; for (int q = 0; q < np; ++q) tr += A[(size_t)q * np + q]; for (int q = 0; q < np; ++q) A[(size_t)q * np + q] += 1e-10 * tr / np; }
       if (!invert_dense(A, np)) return fail(NSK_EINVAL, "singular Schwarz patch");
-      p_off[e + 1] = p_off[e] + np;
-      p_invoff[e + 1] = p_invoff[e] + (long long)np * MM;
-      for (int q = 0; q < np; ++q) p_idx.push_back(pe[q] * MM + pr[q]);
-      for (int q = 0; q < np; ++q)                       // [q][own row], own row fastest
-        for (int r = 0; r < MM; ++r) p_inv.push_back((float)A[(size_t)r * np + q]);
+      for (int q = 0; q < np; ++q) {
+        p_idx[(size_t)e * PS + q] = pe[q] * MM + pr[q];
+        for (int r = 0; r < MM; ++r) p_inv[(size_t)e * PS * MM + ((size_t)(q / 4) * MM + r) * 4 + (q % 4)] = (float)A[(size_t)r * np + q];   // [q/4][own row][q%4]
+      }
     }
-    if ((rc = dupload(c, &d.p_off, p_off)) || (rc = dupload(c, &d.p_idx, p_idx)) || (rc = dupload(c, &d.p_inv, p_inv)) ||
-        (rc = dupload(c, &d.p_invoff, p_invoff))) return rc;
+    if ((rc = dupload(c, &d.p_idx, p_idx)) || (rc = dupload(c, &d.p_inv, p_inv))) return rc;
   }
   for (int k = 0; k < 3; ++k) { c->cur_helm[k] = c->max_helm; c->cur_pres[k] = c->max_pres; }
   if (const char* g = std::getenv("NSK_USE_GRAPH")) c->use_graph = std::atoi(g);
@@ -570,10 +581,11 @@ static int pres_solve_launch(nsk_ctx* c, double h2, int ord, int np) {
   const double scale = 1.0 / (h2 * std::sqrt(d.vol));
   DISPATCH_N(c->N, {
     constexpr int NT = Cfg<N>::NT;
+    if (!d.has_outflow && !c->in_test) hipLaunchKernelGGL(k_ortho, dim3(c->nblk), dim3(256), 0, c->stream, d);
     if (d.nproj_max > 0 && !c->in_test) hipLaunchKernelGGL(k_proj_apply, dim3(c->nblk), dim3(256), 0, c->stream, d);
     hipLaunchKernelGGL(k_gmres_update<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, -1, scale, c->min_pres, ord);
     for (int j = 0; j < np; ++j) {
-      hipLaunchKernelGGL(k_coarse, dim3((d.nvert + 4 * CROWS_W - 1) / (4 * CROWS_W)), dim3(256), d.nvert * sizeof(double), c->stream, d);
+      hipLaunchKernelGGL(k_coarse, dim3((d.nvert + 4 * CROWS_W - 1) / (4 * CROWS_W)), dim3(256), d.coarse_lda * sizeof(double), c->stream, d);
       hipLaunchKernelGGL(k_schwarz<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, (const double*)(d.V + (size_t)j * d.npr), d.Z + (size_t)j * d.npr, 1, 1);
       hipLaunchKernelGGL(k_divgs<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, (const double*)d.yl, d.V + (size_t)(j + 1) * d.npr, j, 1);
       hipLaunchKernelGGL(k_gmres_update<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, j, scale, c->min_pres, ord);
@@ -621,6 +633,7 @@ static int ensure_graph(nsk_ctx* c, int k, int adjoint) {
   if (rc) return rc;
   if (e != hipSuccess) return fail(NSK_EHIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
   HIPCHK(hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0));
+  c->recaptures++;
   HIPCHK(hipGraphDestroy(graph));
   g.nh = c->cur_helm[k - 1]; g.np = c->cur_pres[k - 1];
   return 0;
@@ -678,9 +691,12 @@ static int run_map_adaptive(nsk_ctx* c, int adjoint, double* f, const double* q)
     if (h.unconverged == 0) {
       for (int k = 0; k < 3; ++k) {
         if (k + 1 > c->nsteps) break;
-        const int th = std::min(c->max_helm, (int)h.max_helm_k[k] + 2), tp = std::min(c->max_pres, (int)h.max_pres_k[k] + 2);
-        if (th > c->cur_helm[k] || th < c->cur_helm[k] - 1) c->cur_helm[k] = th;
-        if (tp > c->cur_pres[k] || tp < c->cur_pres[k] - 1) c->cur_pres[k] = tp;
+        // grow at once (with head-room), shrink only when clearly oversized: every change re-captures a graph
+        const int nh = (int)h.max_helm_k[k] + 2, npp = (int)h.max_pres_k[k] + 2;
+        if (nh > c->cur_helm[k]) c->cur_helm[k] = std::min(c->max_helm, nh + 1);
+        else if (nh < c->cur_helm[k] - 4) c->cur_helm[k] = std::min(c->max_helm, nh + 1);
+        if (npp > c->cur_pres[k]) c->cur_pres[k] = std::min(c->max_pres, npp + 1);
+        else if (npp < c->cur_pres[k] - 4) c->cur_pres[k] = std::min(c->max_pres, npp + 1);
       }
       return 0;
     }
@@ -690,6 +706,7 @@ static int run_map_adaptive(nsk_ctx* c, int adjoint, double* f, const double* q)
       c->hstats.unconverged += h.unconverged;
       return fail(NSK_ENOCONV, "inner solve hit its iteration cap (" + std::to_string(h.unconverged) + " solves)");
     }
+    c->retries++;
     for (int k = 0; k < 3; ++k) {
       c->cur_helm[k] = std::min(c->max_helm, 2 * c->cur_helm[k] + 4);
       c->cur_pres[k] = std::min(c->max_pres, 2 * c->cur_pres[k] + 4);
@@ -815,6 +832,7 @@ int nsk_get_stats(nsk_ctx* c, nsk_stats* s) {
   s->unconverged = h.unconverged; s->last_helm_res = h.last_helm_res; s->last_pres_res = h.last_pres_res;
   s->max_helm_iter = h.max_helm; s->max_pres_iter = h.max_pres;
   s->budget_helm = c->cur_helm[2]; s->budget_pres = c->cur_pres[2];
+  s->recaptures = c->recaptures; s->retries = c->retries;
   return 0;
 }
 

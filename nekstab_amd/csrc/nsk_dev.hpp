@@ -74,8 +74,11 @@ struct Dev {
   // coarse space
   const int *v_off, *v_ent, *evert, *vtab;
   const double* Aci;
+  const float* Acif;
   // restricted additive Schwarz patches
   const int *p_off, *p_idx;
+  int p_stride;
+  int coarse_lda;
   const float* p_inv;
   const long long* p_invoff;
   Stats* stats;

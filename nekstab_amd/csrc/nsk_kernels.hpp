@@ -452,6 +452,10 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_helm(Dev d, StepCoef sc, int it,
   const int j = nd / N, i = nd % N;
   const long long l = e * NN + nd, nl = d.nloc;
   const int par = it & 1, ppar = par ^ 1;
+  if (it > 2 && d.hscal[ppar * 8 + 2] != 0.0 && d.hscal[ppar * 8 + 6] != 0.0) {   // finished earlier: cheapest exit
+    if (blockIdx.x == 0 && tid < 8) d.hscal[par * 8 + tid] = d.hscal[ppar * 8 + tid];
+    return;
+  }
   // ---- phase A: issue every independent global load before anything waits
   double o[8] = {0, 0, 0, 0, 0, 0, 0, 0}, refn[2] = {0, 0};
   if (it > 1) {
@@ -631,6 +635,11 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_pres_rhs(Dev d, StepCoef sc, int
   }
   block_reduce<1>(v, sred, tid, NT);
   if (tid == 0) d.gpart[blockIdx.x] = v[0];
+  if (!d.has_outflow) {                        // sum(g) for `ortho` (pressure null space)
+    double t[1] = {g};
+    block_reduce<1>(t, sred, tid, NT);
+    if (tid == 0) d.gpart[(size_t)d.nblk + blockIdx.x] = t[0];
+  }
   if (d.nproj_max > 0) {                       // (x_i, g) for the stored solutions
     if (tid == 0) d.ppart[(size_t)MAXPROJ * d.nblk + blockIdx.x] = v[0];
     const int np = d.gsc->nproj;
@@ -640,6 +649,25 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_pres_rhs(Dev d, StepCoef sc, int
       if (tid == 0) d.ppart[(size_t)k * d.nblk + blockIdx.x] = t[0];
     }
   }
+}
+
+// all-Dirichlet / periodic velocity => E has the constant null space: remove the mean of the
+// right-hand side  [UPSTREAM navier1.f ortho]; recomputes the |g|^2 partials
+__global__ __launch_bounds__(256) void k_ortho(Dev d) {
+  __shared__ double sred[16];
+  const int tid = threadIdx.x;
+  double sm[1];
+  sum_partials<1>(d.gpart + d.nblk, d.nblk, sm, sred, tid, 256);
+  const double mean = sm[0] / (double)d.npr;
+  double v[1] = {0.0};
+  const long long q = (long long)blockIdx.x * 256 + tid;
+  if (q < d.npr) {
+    const double g = d.V[q] - mean;
+    d.V[q] = g;
+    v[0] = g * g;
+  }
+  block_reduce<1>(v, sred, tid, 256);
+  if (tid == 0) d.gpart[blockIdx.x] = v[0];
 }
 
 // g' = g - sum_i a_i E x_i,  a_i = (x_i,g)/n_i   [UPSTREAM navier4.f setrhsp / projh]
@@ -688,11 +716,15 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_gmres_update(Dev d, int j, doubl
   constexpr int NN = C::NN, MM = C::MM, EPB = C::EPB, NT = C::NT;
   __shared__ double sv[EPB * MM];
   __shared__ double sh[MAXMR + 2];
+  __shared__ double shat[4 * MM];
   const int tid = threadIdx.x, el = tid / NN, nd = tid % NN;
   const long long e = (long long)blockIdx.x * EPB + el;
   const bool act = (el < EPB) && (e < d.nel);
   GmresScal* G = d.gsc;
   if (j >= 0 && G->done) return;
+  const double hatv = (tid < 4 * MM) ? d.hat[tid] : 0.0;
+  double wnew = 0.0;
+  if (act && nd < MM) wnew = d.V[(size_t)(j + 1) * d.npr + e * MM + nd];
   const int nv = (j < 0) ? 1 : j + 2;
   sum_partials_multi(d.gpart, d.nblk, nv, sh, tid, NT);
   double hn;
@@ -742,18 +774,21 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_gmres_update(Dev d, int j, doubl
       }
     }
   }
+  if (tid < 4 * MM) shat[tid] = hatv;
   if (act && nd < MM) {
     const long long q = e * MM + nd;
-    double w = d.V[(size_t)(j + 1) * d.npr + q];
+    double w = wnew;
+#pragma unroll 8
     for (int k = 0; k <= j; ++k) w -= sh[k] * d.V[(size_t)k * d.npr + q];
     w *= hinv;
     d.V[(size_t)(j + 1) * d.npr + q] = w;
     sv[el * MM + nd] = w;
   }
-  __syncthreads();
+  lds_barrier();
   if (act && nd < 4) {
     double s = 0.0;
-    for (int k = 0; k < MM; ++k) s += d.hat[nd * MM + k] * sv[el * MM + k];
+#pragma unroll 6
+    for (int k = 0; k < MM; ++k) s += shat[nd * MM + k] * sv[el * MM + k];
     d.ec[e * 4 + nd] = s;
   }
 }
@@ -761,39 +796,56 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_gmres_update(Dev d, int j, doubl
 // coarse solve: r_c = gather of element-corner restrictions (padded vertex table);
 // x_c = Aci r_c with one wavefront per CROWS_W rows, lanes striding the (symmetric) row.
 constexpr int CVT = 8;            // table width = max elements around a vertex
-constexpr int CROWS_W = 2;
+constexpr int CROWS_W = 2;        // rows per wavefront, processed together
+// Acif: row-major fp32, leading dimension lda = nvert rounded up to 256 (zero padded) so that
+// every lane streams float4 (4 columns) per load and a wave covers 256 columns per step.
 __global__ __launch_bounds__(256) void k_coarse(Dev d) {
-  extern __shared__ double srcv[];            // nvert
+  extern __shared__ double srcv[];            // lda
   const int tid = threadIdx.x;
   if (d.gsc->done) return;
-  for (int v = tid; v < d.nvert; v += 256) {
-    const int4 a = reinterpret_cast<const int4*>(d.vtab)[2 * v], b = reinterpret_cast<const int4*>(d.vtab)[2 * v + 1];
-    double s = d.ec[a.x];
-    if (a.y >= 0) s += d.ec[a.y];
-    if (a.z >= 0) s += d.ec[a.z];
-    if (a.w >= 0) s += d.ec[a.w];
-    if (b.x >= 0) s += d.ec[b.x];
-    if (b.y >= 0) s += d.ec[b.y];
-    if (b.z >= 0) s += d.ec[b.z];
-    if (b.w >= 0) s += d.ec[b.w];
-    srcv[v] = s;
-  }
-  __syncthreads();
+  const int nv = d.nvert, lda = d.coarse_lda;
   const int lane = tid & 63, w = tid >> 6;
+  const int row0 = (blockIdx.x * 4 + w) * CROWS_W;
+  const bool rok = row0 < nv, r1 = row0 + 1 < nv;
+  // issue the matrix loads first (they do not depend on anything)
+  constexpr int MAXIT = 12;                   // lda <= 3072
+  const int nit = lda / 256;
+  float4 a0[MAXIT], a1[MAXIT];
+  const float4* A0 = reinterpret_cast<const float4*>(d.Acif + (size_t)(rok ? row0 : 0) * lda) + lane;
+  const float4* A1 = reinterpret_cast<const float4*>(d.Acif + (size_t)(r1 ? row0 + 1 : 0) * lda) + lane;
 #pragma unroll
-  for (int rr = 0; rr < CROWS_W; ++rr) {
-    const int row = (blockIdx.x * 4 + w) * CROWS_W + rr;
-    if (row < d.nvert) {
-      const double* A = d.Aci + (size_t)row * d.nvert;
-      double s = 0.0;
-      for (int c = lane; c < d.nvert; c += 64) s += A[c] * srcv[c];
-      s = wave_sum63(s);
-      if (lane == 63) d.xc[row] = s;
+  for (int i = 0; i < MAXIT; ++i)
+    if (i < nit) { a0[i] = A0[i * 64]; a1[i] = A1[i * 64]; }
+  for (int v = tid; v < lda; v += 256) {
+    double sv = 0.0;
+    if (v < nv) {
+      const int4 a = reinterpret_cast<const int4*>(d.vtab)[2 * v], b = reinterpret_cast<const int4*>(d.vtab)[2 * v + 1];
+      const double e0 = d.ec[a.x];
+      const double e1 = (a.y >= 0) ? d.ec[a.y] : 0.0, e2 = (a.z >= 0) ? d.ec[a.z] : 0.0, e3 = (a.w >= 0) ? d.ec[a.w] : 0.0;
+      const double e4 = (b.x >= 0) ? d.ec[b.x] : 0.0, e5 = (b.y >= 0) ? d.ec[b.y] : 0.0, e6 = (b.z >= 0) ? d.ec[b.z] : 0.0;
+      const double e7 = (b.w >= 0) ? d.ec[b.w] : 0.0;
+      sv = ((((((e0 + e1) + e2) + e3) + e4) + e5) + e6) + e7;
     }
+    srcv[v] = sv;
+  }
+  lds_barrier();
+  double s0 = 0, s1 = 0;
+#pragma unroll
+  for (int i = 0; i < MAXIT; ++i)
+    if (i < nit) {
+      const double* x = srcv + i * 256 + lane * 4;
+      s0 += (double)a0[i].x * x[0] + (double)a0[i].y * x[1] + (double)a0[i].z * x[2] + (double)a0[i].w * x[3];
+      s1 += (double)a1[i].x * x[0] + (double)a1[i].y * x[1] + (double)a1[i].z * x[2] + (double)a1[i].w * x[3];
+    }
+  s0 = wave_sum63(s0); s1 = wave_sum63(s1);
+  if (lane == 63) {
+    if (rok) d.xc[row0] = s0;
+    if (r1) d.xc[row0 + 1] = s1;
   }
 }
 
 // z_j = RAS(v_j) + R^T x_c ;  yl = D^T z_j  (unassembled velocity-space)
+// patch tables have a fixed stride PS per element: idx[e*PS + k] (-1 padded), inverse [e][k][MM] fp32
 template <int N>
 __global__ __launch_bounds__(Cfg<N>::NT) void k_schwarz(Dev d, const double* __restrict__ vin,
                                                         double* __restrict__ zout, int use_coarse,
@@ -808,29 +860,54 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_schwarz(Dev d, const double* __r
   const long long e = (long long)blockIdx.x * EPB + el;
   const bool act = (el < EPB) && (e < d.nel);
   if (check_done && d.gsc->done) return;
-  load_basis<N, EPB>(d, nullptr, nullptr, sJ12, sD12, tid, NT);
-  int p0 = 0, np = 0;
+  const int PS = d.p_stride;
+  // front-load: patch indices (2 per thread is enough for PS <= 2*NN), metrics, coarse values, basis
+  int i0 = -1, i1 = -1;
   if (act) {
-    p0 = d.p_off[e]; np = d.p_off[e + 1] - p0;
-    for (int k = nd; k < np; k += NN) sr[el * MAXP + k] = vin[d.p_idx[p0 + k]];
+    if (nd < PS) i0 = d.p_idx[e * PS + nd];
+    if (nd + NN < PS) i1 = d.p_idx[e * PS + nd + NN];
   }
-  __syncthreads();
-  if (act && nd < MM) {
-    const float* A = d.p_inv + d.p_invoff[e];      // [np][MM], own rows, k fastest
-    double z = 0.0;
-    for (int k = 0; k < np; ++k) z += (double)A[(size_t)k * MM + nd] * sr[el * MAXP + k];
-    if (use_coarse) {
-#pragma unroll
-      for (int c = 0; c < 4; ++c) z += d.hat[c * MM + nd] * d.xc[d.evert[e * 4 + c]];
+  const bool pact = act && nd < MM;
+  const long long q = e * MM + nd;
+  double m0 = 0, m1 = 0, m2 = 0, m3 = 0, zc = 0;
+  int4 ev = make_int4(0, 0, 0, 0);
+  if (pact) {
+    m0 = d.w2rx[q]; m1 = d.w2sx[q]; m2 = d.w2ry[q]; m3 = d.w2sy[q];
+    if (use_coarse) ev = reinterpret_cast<const int4*>(d.evert)[e];
+  }
+  double j12a = 0, d12a = 0;
+  if (tid < NM) { j12a = d.J12[tid]; d12a = d.D12[tid]; }
+  const double v0 = (i0 >= 0) ? vin[i0] : 0.0, v1 = (i1 >= 0) ? vin[i1] : 0.0;
+  if (pact && use_coarse)
+    zc = d.hat[0 * MM + nd] * d.xc[ev.x] + d.hat[1 * MM + nd] * d.xc[ev.y] + d.hat[2 * MM + nd] * d.xc[ev.z] + d.hat[3 * MM + nd] * d.xc[ev.w];
+  if (tid < NM) { sJ12[tid] = j12a; sD12[tid] = d12a; }
+  if (act) {
+    if (nd < PS) sr[el * MAXP + nd] = v0;
+    if (nd + NN < PS) sr[el * MAXP + nd + NN] = v1;
+  }
+  lds_barrier();
+  if (pact) {
+    // inverse stored [e][k/4][own row][4] fp32: one float4 per lane per 4 patch dofs
+    const float4* A = reinterpret_cast<const float4*>(d.p_inv + (size_t)e * PS * MM) + nd;
+    const double* r = sr + el * MAXP;
+    double z0 = 0, z1 = 0, z2 = 0, z3 = 0;
+    const int nq = PS / 4;                                        // PS is a multiple of 4
+#pragma unroll 8
+    for (int k4 = 0; k4 < nq; ++k4) {
+      const float4 a = A[(size_t)k4 * MM];
+      z0 += (double)a.x * r[4 * k4 + 0];
+      z1 += (double)a.y * r[4 * k4 + 1];
+      z2 += (double)a.z * r[4 * k4 + 2];
+      z3 += (double)a.w * r[4 * k4 + 3];
     }
-    const long long q = e * MM + nd;
+    const double z = ((z0 + z1) + (z2 + z3)) + zc;
     zout[q] = z;
-    sP[(0 * EPB + el) * MM + nd] = z * d.w2rx[q];
-    sP[(1 * EPB + el) * MM + nd] = z * d.w2sx[q];
-    sP[(2 * EPB + el) * MM + nd] = z * d.w2ry[q];
-    sP[(3 * EPB + el) * MM + nd] = z * d.w2sy[q];
+    sP[(0 * EPB + el) * MM + nd] = z * m0;
+    sP[(1 * EPB + el) * MM + nd] = z * m1;
+    sP[(2 * EPB + el) * MM + nd] = z * m2;
+    sP[(3 * EPB + el) * MM + nd] = z * m3;
   }
-  __syncthreads();
+  lds_barrier();
   double gx, gy;
   opgradt_tiles<N, EPB>(sJ12, sD12, sP, sB, act, el, nd, gx, gy);
   if (act) {
@@ -878,29 +955,45 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_divgs(Dev d, const double* __res
   constexpr int NN = C::NN, M = C::M, MM = C::MM, EPB = C::EPB, NT = C::NT, NM = N * M;
   __shared__ double sJ12[NM], sD12[NM];
   __shared__ double su[2 * EPB * NN], sA[4 * EPB * NM];
-  __shared__ double sred[16];
+  __shared__ double sdot[(MAXMR + 2) * 4];
   const int tid = threadIdx.x, el = tid / NN, nd = tid % NN;
   const long long e = (long long)blockIdx.x * EPB + el;
   const bool act = (el < EPB) && (e < d.nel);
   if (check_done && d.gsc->done) return;
-  load_basis<N, EPB>(d, nullptr, nullptr, sJ12, sD12, tid, NT);
+  const long long l = e * NN + nd;
+  int4 tab = make_int4(0, -1, -1, -1);
+  double bi = 0;
+  if (act) { tab = d.gs_tab[l]; bi = d.binv[l]; }
+  double j12a = 0, d12a = 0;
+  if (tid < NM) { j12a = d.J12[tid]; d12a = d.D12[tid]; }
+  GsVals g0, g1;
+  if (act) { g0 = gs_load(yl, tab, l); g1 = gs_load(yl + d.nloc, tab, l); }
+  if (tid < NM) { sJ12[tid] = j12a; sD12[tid] = d12a; }
   if (act) {
-    const long long l = e * NN + nd;
-    const double bi = d.binv[l];
-    su[(0 * EPB + el) * NN + nd] = bi * gs_gather(yl, d, l);
-    su[(1 * EPB + el) * NN + nd] = bi * gs_gather(yl + d.nloc, d, l);
+    su[(0 * EPB + el) * NN + nd] = bi * gs_sum(g0, yl, d, tab, l);
+    su[(1 * EPB + el) * NN + nd] = bi * gs_sum(g1, yl + d.nloc, d, tab, l);
   }
-  __syncthreads();
+  lds_barrier();
   const double w = opdiv_tiles<N, EPB>(sJ12, sD12, su, sA, act, el, nd, d, e);
   const bool pact = act && nd < MM;
   const long long q = e * MM + nd;
   if (pact) wout[q] = w;
   if (j >= 0) {
+    const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll 4
     for (int k = 0; k <= j + 1; ++k) {
-      double v[1] = {0.0};
-      if (pact) v[0] = w * ((k <= j) ? d.V[(size_t)k * d.npr + q] : w);
-      block_reduce<1>(v, sred, tid, NT);
-      if (tid == 0) d.gpart[(size_t)k * d.nblk + blockIdx.x] = v[0];
+      double x = 0.0;
+      if (pact) x = w * ((k <= j) ? d.V[(size_t)k * d.npr + q] : w);
+      x = wave_sum63(x);
+      if (lane == 63) sdot[k * 4 + wv] = x;
+    }
+    lds_barrier();
+    constexpr int NW = NT / 64;
+    if (tid <= j + 1) {
+      double t = 0.0;
+#pragma unroll
+      for (int ww = 0; ww < NW; ++ww) t += sdot[tid * 4 + ww];
+      d.gpart[(size_t)tid * d.nblk + blockIdx.x] = t;
     }
   }
 }
