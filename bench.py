@@ -108,6 +108,15 @@ def main():
     P = h.nvel
     alg_bytes = 148.0 * 2 * P                       # K3+K4+K5, 148 B/pt/component, two components per launch
     achieved = alg_bytes / (kern["avg_us"] * 1e-6) / 1e9
+    # HBM-side traffic per full-work launch from the committed PMC passes (profiles/, separate
+    # --pmc FETCH_SIZE / WRITE_SIZE runs; gfx950 correction: FETCH_SIZE counts 1/2 of the bytes,
+    # calibrated here on k_gradt whose byte count is known) -- only valid for the profiled config.
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc_fetch_write_per_kernel.json")
+    if os.path.exists(pmc) and a.lx1 == 8:
+        rec = json.load(open(pmc)).get("void nsk::k_helm<8>")
+        if rec:
+            traffic = (2.0 * rec["fetch_kb_p90"] + rec["write_kb_p90"]) * 1024.0
     out = {
         "metric": "Arnoldi matvecs/sec + wall-time to k_dim=128 eigenpairs, cylinder Re=50",
         "value": world * a.steps / elapsed, "unit": "matvecs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -122,7 +131,7 @@ def main():
         "matvec_s_mean": float(np.mean(stats["matvec_s"])), "orth_s_mean": float(np.mean(stats["orth_s"])),
         "helm_iters_per_step": st["helm_iters"] / max(st["steps"], 1), "pres_iters_per_step": st["pres_iters"] / max(st["steps"], 1),
         "roofline": {"bound": "hbm", "kernel": "k_helm<%d>" % case.lx1, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                     "frac": achieved / 8000.0, "traffic": None, "avg_launch_us": kern["avg_us"],
+                     "frac": achieved / 8000.0, "traffic": traffic, "avg_launch_us": kern["avg_us"],
                      "algorithmic_bytes_per_launch": alg_bytes,
                      "note": "working set (~30 MB) is Infinity-Cache resident: see DESIGN.md"},
     }

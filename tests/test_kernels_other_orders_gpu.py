@@ -1,0 +1,43 @@
+"""Kernel parity at the other polynomial orders the reference's SIZE lists (lx1 = 8, 10, 12;
+lxd = 12, 15, 18) on the cylinder mesh -- oracle operators only, no solves."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+@pytest.mark.parametrize("lx1", [8, 10, 12])
+def test_operators(lx1):
+    from nekstab_amd import mesh
+    from nekstab_amd.capi import NekStabHip
+    from tests.conftest import GOLDEN, make_oracle
+    case = mesh.load_case_npz(os.path.join(GOLDEN, "cylinder_case.npz"), lx1)
+    o = make_oracle(case, build_solvers=False)
+    h = NekStabHip(case, case.meta["vert"], case.meta["nvert"], schwarz_layers=1)
+    assert (h.nsteps, abs(h.dt - o.dt) < 1e-15) == (o.nsteps, True)
+    rng = np.random.default_rng(lx1)
+    u = np.sin(0.7 * case.x) * np.cos(0.5 * case.y) + 0.1 * rng.standard_normal(case.x.shape)
+    v = np.cos(0.3 * case.x) * np.sin(0.9 * case.y) + 0.1 * rng.standard_normal(case.x.shape)
+    p = rng.standard_normal((case.nel, lx1 - 2, lx1 - 2))
+    assert rel(h.t_axhelm(u, 0.02, 300.0), o.axhelm(u, 0.02, 300.0)) < 1e-12
+    assert rel(h.t_dssum(u), o.dssum(u)) < 1e-13
+    assert rel(h.t_opdiv(u, v), o.opdiv(u, v)) < 1e-12
+    gx, gy = h.t_opgradt(p); ox, oy = o.opgradt(p)
+    assert rel(gx, ox) < 1e-12 and rel(gy, oy) < 1e-12
+    U, V = o.ub
+    bx = -o.spng * u * o.bm1 - (o.convect(u, v, U) + o.convect(U, V, u))
+    by = -o.spng * v * o.bm1 - (o.convect(u, v, V) + o.convect(U, V, v))
+    cx, cy = h.t_convect(u, v, False)
+    assert rel(cx, bx) < 1e-12 and rel(cy, by) < 1e-12
+    wx, wy = o.opgradt(p)
+    fac = o.binvm1 * o.mask
+    ref = o.opdiv(fac * o.dssum(wx * o.mask), fac * o.dssum(wy * o.mask))
+    assert rel(h.t_eapply(p), ref) < 1e-12
+    # one full time step through the solvers is exercised at lx1=6/8 in test_matvec_gpu.py
+    h.close()
