@@ -49,13 +49,13 @@ struct nsk_ctx {
   double dt = 0, re = 0, endtime = 0;
   int nsteps = 0;
   int max_helm = 60, max_pres = 40, min_pres = 0, layers = 1;
-  int cur_helm[3] = {0, 0, 0}, cur_pres[3] = {0, 0, 0};       // adaptive launch budgets per BDF order
+  int cur_helm[5] = {0, 0, 0, 0, 0}, cur_pres[5] = {0, 0, 0, 0, 0};       // adaptive launch budgets per BDF order
   int use_graph = 1;
   int in_test = 0;
   int helm_guess = 1;
   long long recaptures = 0, retries = 0;
   int debug = 0;
-  struct StepGraph { hipGraphExec_t exec = nullptr; int nh = -1, np = -1; } graphs[2][3];
+  struct StepGraph { hipGraphExec_t exec = nullptr; int nh = -1, np = -1; } graphs[2][5];
   double* scratch = nullptr;            // one state vector
   Dev d{};
   Stats hstats{};
@@ -101,8 +101,11 @@ static StepCoef make_coef(const nsk_ctx* c, int istep, int adjoint) {
   s.k = k;
   s.adjoint = adjoint;
   const bool g = c->helm_guess != 0;
-  s.xg[0] = (!g || istep <= 1) ? 0.0 : (istep == 2 ? 1.0 : 2.0);
-  s.xg[1] = (!g || istep <= 2) ? 0.0 : -1.0;
+  // du0: nothing / previous / linear / quadratic extrapolation of the previous increments
+  static const double XG[4][3] = {{0, 0, 0}, {1, 0, 0}, {2, -1, 0}, {3, -3, 1}};
+  const int gi = !g ? 0 : std::min(istep, 4) - 1;
+  for (int q = 0; q < 3; ++q) s.xg[q] = XG[gi][q];
+  s.cls = istep <= 3 ? istep - 1 : (istep <= 6 ? 3 : 4);
   return s;
 }
 
@@ -361,7 +364,7 @@ static int build(nsk_ctx* c, const nsk_case& cs) {
         }
     std::vector<double> dAs = dssum_h(dA), bs = dssum_h(bm1);
     const double bd0[3] = {1.0, 1.5, 11.0 / 6.0};
-    for (int k = 0; k < 3; ++k)
+    for (int k = 0; k < 5; ++k)
       for (long long l = 0; l < nloc; ++l) dinv[(size_t)k * nloc + l] = mask[l] / (d.nu * dAs[l] + bd0[k] / c->dt * bs[l]);
   }
 
@@ -377,7 +380,7 @@ static int build(nsk_ctx* c, const nsk_case& cs) {
   // ---- state + solver work arrays
   if ((rc = dalloc(c, &d.u, 2 * nloc)) || (rc = dalloc(c, &d.p, npr)) || (rc = dalloc(c, &d.plag, npr)) ||
       (rc = dalloc(c, &d.pext, npr)) || (rc = dalloc(c, &d.ulag, 4 * nloc)) || (rc = dalloc(c, &d.exlag, 4 * nloc)) ||
-      (rc = dalloc(c, &d.bf, 2 * nloc)) || (rc = dalloc(c, &d.rloc, 2 * nloc)) || (rc = dalloc(c, &d.bloc, 2 * nloc)) || (rc = dalloc(c, &d.dulag, 4 * nloc)) || (rc = dalloc(c, &d.hx, 2 * nloc)) ||
+      (rc = dalloc(c, &d.bf, 2 * nloc)) || (rc = dalloc(c, &d.rloc, 2 * nloc)) || (rc = dalloc(c, &d.bloc, 2 * nloc)) || (rc = dalloc(c, &d.dulag, 6 * nloc)) || (rc = dalloc(c, &d.hx, 2 * nloc)) ||
       (rc = dalloc(c, &d.hr, 2 * nloc)) || (rc = dalloc(c, &d.hp, 2 * nloc)) || (rc = dalloc(c, &d.hs, 2 * nloc)) ||
       (rc = dalloc(c, &d.hwl, 4 * nloc)) || (rc = dalloc(c, &d.hpart, (size_t)16 * c->nblk)) || (rc = dalloc(c, &d.hscal, 32)) ||
       (rc = dalloc(c, &d.V, (size_t)(MAXMR + 1) * npr)) || (rc = dalloc(c, &d.Z, (size_t)MAXMR * npr)) ||
@@ -566,7 +569,7 @@ static int build(nsk_ctx* c, const nsk_case& cs) {
     }
     if ((rc = dupload(c, &d.p_idx, p_idx)) || (rc = dupload(c, &d.p_inv, p_inv))) return rc;
   }
-  for (int k = 0; k < 3; ++k) { c->cur_helm[k] = c->max_helm; c->cur_pres[k] = c->max_pres; }
+  for (int k = 0; k < 5; ++k) { c->cur_helm[k] = c->max_helm; c->cur_pres[k] = c->max_pres; }
   if (const char* g = std::getenv("NSK_USE_GRAPH")) c->use_graph = std::atoi(g);
   if (const char* g = std::getenv("NSK_DEBUG")) c->debug = std::atoi(g);
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -597,7 +600,7 @@ static int pres_solve_launch(nsk_ctx* c, double h2, int ord, int np) {
 static int step(nsk_ctx* c, int istep, int adjoint) {
   Dev& d = c->d;
   const StepCoef sc = make_coef(c, istep, adjoint);
-  const int nh = c->cur_helm[sc.k - 1];
+  const int nh = c->cur_helm[sc.cls];
   DISPATCH_N(c->N, {
     constexpr int NT = Cfg<N>::NT;
     hipLaunchKernelGGL(k_convect<N>, dim3(c->nel), dim3(Cfg<N>::NTD), 0, c->stream, d, (const double*)d.u, d.bf, adjoint);
@@ -606,7 +609,7 @@ static int step(nsk_ctx* c, int istep, int adjoint) {
       hipLaunchKernelGGL(k_helm<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, sc, it, (const double*)d.rloc);
     hipLaunchKernelGGL(k_pres_rhs<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, sc, (nh - 1) & 1, nh - 1);
   });
-  int rc = pres_solve_launch(c, sc.h2, sc.k, c->cur_pres[sc.k - 1]);
+  int rc = pres_solve_launch(c, sc.h2, sc.cls, c->cur_pres[sc.cls]);
   if (rc) return rc;
   DISPATCH_N(c->N, {
     hipLaunchKernelGGL(k_pres_update<N>, dim3(c->nblk), dim3(Cfg<N>::NT), 0, c->stream, d, sc);
@@ -622,32 +625,35 @@ static int step(nsk_ctx* c, int istep, int adjoint) {
   return 0;
 }
 
-static int ensure_graph(nsk_ctx* c, int k, int adjoint) {
-  nsk_ctx::StepGraph& g = c->graphs[adjoint][k - 1];
-  if (g.exec && g.nh == c->cur_helm[k - 1] && g.np == c->cur_pres[k - 1]) return 0;
+static const int CLS_ISTEP[5] = {1, 2, 3, 4, 7};        // a representative step of every class
+static inline int step_class(int istep) { return istep <= 3 ? istep - 1 : (istep <= 6 ? 3 : 4); }
+
+static int ensure_graph(nsk_ctx* c, int cls, int adjoint) {
+  nsk_ctx::StepGraph& g = c->graphs[adjoint][cls];
+  if (g.exec && g.nh == c->cur_helm[cls] && g.np == c->cur_pres[cls]) return 0;
   if (g.exec) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }
   hipGraph_t graph = nullptr;
   HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeGlobal));
-  int rc = step(c, k, adjoint);
+  int rc = step(c, CLS_ISTEP[cls], adjoint);
   hipError_t e = hipStreamEndCapture(c->stream, &graph);
   if (rc) return rc;
   if (e != hipSuccess) return fail(NSK_EHIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
   HIPCHK(hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0));
   c->recaptures++;
   HIPCHK(hipGraphDestroy(graph));
-  g.nh = c->cur_helm[k - 1]; g.np = c->cur_pres[k - 1];
+  g.nh = c->cur_helm[cls]; g.np = c->cur_pres[cls];
   return 0;
 }
 
 static int run_map(nsk_ctx* c, int adjoint, double* f, const double* q) {
   Dev& d = c->d;
   if (c->use_graph)
-    for (int k = 1; k <= 3; ++k) { int rc = ensure_graph(c, k, adjoint); if (rc) return rc; }
+    for (int k = 0; k < 5; ++k) { int rc = ensure_graph(c, k, adjoint); if (rc) return rc; }
   HIPCHK(hipMemcpyAsync(d.u, q, 2 * d.nloc * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(d.p, q + 2 * d.nloc, d.npr * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
   for (int istep = 1; istep <= c->nsteps; ++istep) {
     if (c->use_graph) {
-      HIPCHK(hipGraphLaunch(c->graphs[adjoint][std::min(istep, 3) - 1].exec, c->stream));
+      HIPCHK(hipGraphLaunch(c->graphs[adjoint][step_class(istep)].exec, c->stream));
     } else {
       int rc = step(c, istep, adjoint);
       if (rc) return rc;
@@ -684,13 +690,13 @@ static int run_map_adaptive(nsk_ctx* c, int adjoint, double* f, const double* q)
     c->hstats.helm_iters += h.helm_iters; c->hstats.pres_iters += h.pres_iters; c->hstats.steps += c->nsteps;
     c->hstats.max_helm = std::max(c->hstats.max_helm, h.max_helm); c->hstats.max_pres = std::max(c->hstats.max_pres, h.max_pres);
     c->hstats.last_helm_res = h.last_helm_res; c->hstats.last_pres_res = h.last_pres_res;
-    for (int k = 0; k < 3; ++k) {
+    for (int k = 0; k < 5; ++k) {
       c->hstats.max_helm_k[k] = std::max(c->hstats.max_helm_k[k], h.max_helm_k[k]);
       c->hstats.max_pres_k[k] = std::max(c->hstats.max_pres_k[k], h.max_pres_k[k]);
     }
     if (h.unconverged == 0) {
-      for (int k = 0; k < 3; ++k) {
-        if (k + 1 > c->nsteps) break;
+      for (int k = 0; k < 5; ++k) {
+        if (CLS_ISTEP[k] > c->nsteps) break;
         // grow at once (with head-room), shrink only when clearly oversized: every change re-captures a graph
         const int nh = (int)h.max_helm_k[k] + 2, npp = (int)h.max_pres_k[k] + 2;
         if (nh > c->cur_helm[k]) c->cur_helm[k] = std::min(c->max_helm, nh + 1);
@@ -701,13 +707,13 @@ static int run_map_adaptive(nsk_ctx* c, int adjoint, double* f, const double* q)
       return 0;
     }
     bool capped = true;
-    for (int k = 0; k < 3; ++k) capped = capped && c->cur_helm[k] >= c->max_helm && c->cur_pres[k] >= c->max_pres;
+    for (int k = 0; k < 5; ++k) capped = capped && c->cur_helm[k] >= c->max_helm && c->cur_pres[k] >= c->max_pres;
     if (capped) {
       c->hstats.unconverged += h.unconverged;
       return fail(NSK_ENOCONV, "inner solve hit its iteration cap (" + std::to_string(h.unconverged) + " solves)");
     }
     c->retries++;
-    for (int k = 0; k < 3; ++k) {
+    for (int k = 0; k < 5; ++k) {
       c->cur_helm[k] = std::min(c->max_helm, 2 * c->cur_helm[k] + 4);
       c->cur_pres[k] = std::min(c->max_pres, 2 * c->cur_pres[k] + 4);
     }
@@ -764,7 +770,7 @@ int nsk_set_tolerances(nsk_ctx* c, double th, double tp, int relative) {
   if (!c) return fail(NSK_EINVAL, "null ctx");
   c->d.tol_helm = th; c->d.tol_pres = tp; c->d.tol_relative = relative;
   for (auto& a : c->graphs) for (auto& g : a) g.nh = -1;   // Dev is captured by value: re-capture
-  for (int k = 0; k < 3; ++k) { c->cur_helm[k] = c->max_helm; c->cur_pres[k] = c->max_pres; }
+  for (int k = 0; k < 5; ++k) { c->cur_helm[k] = c->max_helm; c->cur_pres[k] = c->max_pres; }
   return 0;
 }
 
@@ -775,8 +781,8 @@ int nsk_set_option(nsk_ctx* c, const char* name, double value) {
   else if (n == "min_pres_iter") c->min_pres = (int)value;
   else if (n == "helm_guess") c->helm_guess = (int)value;
   else if (n == "dbg") { int v = (int)value; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), &v, sizeof(int))); }
-  else if (n == "budget_helm") { for (int k = 0; k < 3; ++k) c->cur_helm[k] = std::min(c->max_helm, std::max(1, (int)value)); }
-  else if (n == "budget_pres") { for (int k = 0; k < 3; ++k) c->cur_pres[k] = std::min(c->max_pres, std::max(1, (int)value)); }
+  else if (n == "budget_helm") { for (int k = 0; k < 5; ++k) c->cur_helm[k] = std::min(c->max_helm, std::max(1, (int)value)); }
+  else if (n == "budget_pres") { for (int k = 0; k < 5; ++k) c->cur_pres[k] = std::min(c->max_pres, std::max(1, (int)value)); }
   else return fail(NSK_EINVAL, "unknown option " + n);
   for (auto& a : c->graphs) for (auto& g : a) g.nh = -1;
   return 0;
@@ -831,7 +837,7 @@ int nsk_get_stats(nsk_ctx* c, nsk_stats* s) {
   s->steps = h.steps; s->helm_iters = h.helm_iters; s->pres_iters = h.pres_iters;
   s->unconverged = h.unconverged; s->last_helm_res = h.last_helm_res; s->last_pres_res = h.last_pres_res;
   s->max_helm_iter = h.max_helm; s->max_pres_iter = h.max_pres;
-  s->budget_helm = c->cur_helm[2]; s->budget_pres = c->cur_pres[2];
+  s->budget_helm = c->cur_helm[4]; s->budget_pres = c->cur_pres[4];
   s->recaptures = c->recaptures; s->retries = c->retries;
   return 0;
 }
@@ -936,27 +942,19 @@ int nsk_orth(nsk_ctx* c, nsk_vec fv, const nsk_vec* Q, int j, double* h, double*
 }
 
 int nsk_basis_gemm(nsk_ctx* c, nsk_vec* Q, int k, const double* Z, int ldz) {
-  if (!c || !Q || !Z || k < 1 || k > 1024 || ldz < k) return fail(NSK_EINVAL, "bad argument");
-  // out-of-place in column chunks, then copy back
-  const int CH = 8;
-  double* dZ = nullptr; int rc = dalloc(c, &dZ, (size_t)k * ldz);
-  if (rc) return rc;
+  if (!c || !Q || !Z || k < 1 || k > 256 || ldz < k) return fail(NSK_EINVAL, "bad argument (k <= 256)");
+  double* dZ = nullptr; double** dQ = nullptr; int rc;
+  if ((rc = dalloc(c, &dZ, (size_t)k * ldz)) || (rc = dalloc(c, &dQ, k))) return rc;
   HIPCHK(hipMemcpy(dZ, Z, (size_t)k * ldz * sizeof(double), hipMemcpyHostToDevice));   // Z column-major: Z[c*ldz + q]
-  std::vector<double*> tmp(k);
-  for (int q = 0; q < k; ++q) { if ((rc = dalloc(c, &tmp[q], (size_t)c->nstate))) return rc; }
-  double** dQ = nullptr; double** dT = nullptr;
-  if ((rc = dalloc(c, &dQ, k)) || (rc = dalloc(c, &dT, k))) return rc;
   HIPCHK(hipMemcpy(dQ, Q, k * sizeof(double*), hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(dT, tmp.data(), k * sizeof(double*), hipMemcpyHostToDevice));
-  for (int c0 = 0; c0 < k; c0 += CH) {
-    const int nc = std::min(CH, k - c0);
-    hipLaunchKernelGGL(k_basis_comb, dim3((unsigned)((c->nstate + 255) / 256)), dim3(256), 0, c->stream, (const double* const*)dQ, k, (const double*)dZ, ldz, c0, nc, (double* const*)(dT + c0), c->nstate);
-  }
-  for (int q = 0; q < k; ++q) HIPCHK(hipMemcpyAsync(Q[q], tmp[q], c->nstate * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  const unsigned grid = (unsigned)((c->nstate + 63) / 64);                              // 4 waves x 16 entries
+  const int ct = (k + 15) / 16;
+#define NSK_GEMM(CT) hipLaunchKernelGGL(k_basis_gemm_mfma<CT>, dim3(grid), dim3(256), 0, c->stream, (double* const*)dQ, k, (const double*)dZ, ldz, c->nstate)
+  if (ct <= 1) NSK_GEMM(1); else if (ct <= 2) NSK_GEMM(2); else if (ct <= 4) NSK_GEMM(4); else if (ct <= 8) NSK_GEMM(8); else NSK_GEMM(16);
+#undef NSK_GEMM
   HIPCHK(hipStreamSynchronize(c->stream));
-  for (int q = 0; q < k; ++q) { nsk_vec v = tmp[q]; nsk_vec_free(c, 1, &v); }
-  nsk_vec a = dZ, b = dQ, e = dT;
-  nsk_vec_free(c, 1, &a); nsk_vec_free(c, 1, &b); nsk_vec_free(c, 1, &e);
+  nsk_vec a = dZ, b = dQ;
+  nsk_vec_free(c, 1, &a); nsk_vec_free(c, 1, &b);
   return 0;
 }
 

@@ -16,7 +16,8 @@ struct StepCoef {                // order k = min(istep,3)  [UPSTREAM setordbd/s
   double invdt;
   int k;
   int adjoint;
-  double xg[2];                  // Helmholtz initial guess  du0 = xg0*du^{n-1} + xg1*du^{n-2}
+  double xg[3];                  // Helmholtz initial guess  du0 = xg0*du^{n-1} + xg1*du^{n-2} + xg2*du^{n-3}
+  int cls;                       // step class 0..4 (istep 1,2,3, 4-6, >=7): one captured graph + budget each
 };
 
 struct GmresScal {               // device-resident small state of one pressure solve
@@ -42,7 +43,7 @@ struct GmresScal {               // device-resident small state of one pressure 
 struct Stats {
   long long helm_iters, pres_iters, unconverged, steps;
   long long max_helm, max_pres;
-  long long max_helm_k[3], max_pres_k[3];   // per BDF order (separate graphs, separate budgets)
+  long long max_helm_k[5], max_pres_k[5];   // per step class (separate graphs, separate budgets)
   double last_helm_res, last_pres_res;
 };
 

@@ -392,7 +392,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_rhs(Dev d, StepCoef sc) {
     for (int c = 0; c < 2; ++c) {
       const long long lc = c * nl + l;
       const double un = d.u[lc];
-      u[c] = un + sc.xg[0] * d.dulag[lc] + sc.xg[1] * d.dulag[2 * nl + lc];   // u^n + du0 (extrapolated guess)
+      u[c] = un + sc.xg[0] * d.dulag[lc] + sc.xg[1] * d.dulag[2 * nl + lc] + sc.xg[2] * d.dulag[4 * nl + lc];   // u^n + du0 (extrapolated guess)
       su[(c * EPB + el) * NN + nd] = u[c];
       const double bn = d.bf[lc];
       const double e1 = d.exlag[lc], e2 = d.exlag[2 * nl + lc];
@@ -525,7 +525,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_helm(Dev d, StepCoef sc, int it,
         if (done[c] && !was) {
           if (c == 0) atomicAdd((unsigned long long*)&d.stats->helm_iters, (unsigned long long)(it - 1));
           atomicMax((unsigned long long*)&d.stats->max_helm, (unsigned long long)(it - 1));
-          atomicMax((unsigned long long*)&d.stats->max_helm_k[sc.k - 1], (unsigned long long)(it - 1));
+          atomicMax((unsigned long long*)&d.stats->max_helm_k[sc.cls], (unsigned long long)(it - 1));
         }
       }
     }
@@ -604,7 +604,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_pres_rhs(Dev d, StepCoef sc, int
         const double rr = was ? d.hscal[helm_par * 8 + c * 4 + 3] : res;
         worst = fmax(worst, rr);
         if (!was && !(res <= tol)) bad = 1;
-        if (!was) { if (c == 0) atomicAdd((unsigned long long*)&d.stats->helm_iters, (unsigned long long)check_helm); atomicMax((unsigned long long*)&d.stats->max_helm, (unsigned long long)check_helm); atomicMax((unsigned long long*)&d.stats->max_helm_k[sc.k - 1], (unsigned long long)check_helm); }
+        if (!was) { if (c == 0) atomicAdd((unsigned long long*)&d.stats->helm_iters, (unsigned long long)check_helm); atomicMax((unsigned long long*)&d.stats->max_helm, (unsigned long long)check_helm); atomicMax((unsigned long long*)&d.stats->max_helm_k[sc.cls], (unsigned long long)check_helm); }
       }
       d.stats->last_helm_res = worst;
       if (bad) atomicAdd((unsigned long long*)&d.stats->unconverged, 1ull);
@@ -614,8 +614,9 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_pres_rhs(Dev d, StepCoef sc, int
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       const long long lc = c * nl + l;
-      const double l1 = d.dulag[lc], l2 = d.dulag[2 * nl + lc];
-      const double du = sc.xg[0] * l1 + sc.xg[1] * l2 + d.hx[lc];     // guess + CG correction
+      const double l1 = d.dulag[lc], l2 = d.dulag[2 * nl + lc], l3 = d.dulag[4 * nl + lc];
+      const double du = sc.xg[0] * l1 + sc.xg[1] * l2 + sc.xg[2] * l3 + d.hx[lc];     // guess + CG correction
+      d.dulag[4 * nl + lc] = l2;
       d.dulag[2 * nl + lc] = l1;
       d.dulag[lc] = du;
       const double us = d.u[lc] + du;
@@ -643,10 +644,19 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_pres_rhs(Dev d, StepCoef sc, int
   if (d.nproj_max > 0) {                       // (x_i, g) for the stored solutions
     if (tid == 0) d.ppart[(size_t)MAXPROJ * d.nblk + blockIdx.x] = v[0];
     const int np = d.gsc->nproj;
+    __shared__ double sdot[MAXPROJ * 4];
+    const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll 4
     for (int k = 0; k < np; ++k) {
-      double t[1] = {pact ? g * d.PX[(size_t)k * d.npr + e * MM + nd] : 0.0};
-      block_reduce<1>(t, sred, tid, NT);
-      if (tid == 0) d.ppart[(size_t)k * d.nblk + blockIdx.x] = t[0];
+      double t = pact ? g * d.PX[(size_t)k * d.npr + e * MM + nd] : 0.0;
+      t = wave_sum63(t);
+      if (lane == 63) sdot[k * 4 + wv] = t;
+    }
+    lds_barrier();
+    if (tid < np) {
+      double t = 0.0;
+      for (int ww = 0; ww < NT / 64; ++ww) t += sdot[tid * 4 + ww];
+      d.ppart[(size_t)tid * d.nblk + blockIdx.x] = t;
     }
   }
 }
@@ -736,6 +746,13 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_gmres_update(Dev d, int j, doubl
     hn = sqrt(hn2 > 0.0 ? hn2 : 0.0);
   }
   const double hinv = (hn > 0.0) ? 1.0 / hn : 0.0;
+  __shared__ double scs[MAXMR], ssn[MAXMR], scol[MAXMR + 2];
+  __shared__ double sgj;
+  if (blockIdx.x == 0 && j >= 0) {        // Givens history -> LDS with parallel loads
+    if (tid < j) { scs[tid] = G->cs[tid]; ssn[tid] = G->sn[tid]; }
+    if (tid == 0) sgj = G->g[j];
+    lds_barrier();
+  }
   if (blockIdx.x == 0 && tid == 0) {
     if (j < 0) {
       G->beta0 = hn; G->g[0] = hn; G->nit = 0; G->resid = hn * scale;
@@ -745,12 +762,12 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_gmres_update(Dev d, int j, doubl
       if (dn) d.stats->last_pres_res = hn * scale;
       G->done = dn;
     } else {
-      double col[MAXMR + 2];
+      double* col = scol;
       for (int q = 0; q <= j; ++q) col[q] = sh[q];
       col[j + 1] = hn;
       for (int q = 0; q < j; ++q) {
-        const double t = G->cs[q] * col[q] + G->sn[q] * col[q + 1];
-        col[q + 1] = -G->sn[q] * col[q] + G->cs[q] * col[q + 1];
+        const double t = scs[q] * col[q] + ssn[q] * col[q + 1];
+        col[q + 1] = -ssn[q] * col[q] + scs[q] * col[q + 1];
         col[q] = t;
       }
       const double rho = sqrt(col[j] * col[j] + col[j + 1] * col[j + 1]);
@@ -758,7 +775,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_gmres_update(Dev d, int j, doubl
       G->cs[j] = cj; G->sn[j] = sj;
       col[j] = rho;
       for (int q = 0; q <= j; ++q) G->R[j * MAXMR + q] = col[q];
-      const double gj = G->g[j];
+      const double gj = sgj;
       G->g[j] = cj * gj;
       G->g[j + 1] = -sj * gj;
       G->nit = j + 1;
@@ -768,7 +785,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_gmres_update(Dev d, int j, doubl
       if ((res <= tol && (j + 1) >= min_iter) || !(hn > 0.0)) {
         atomicAdd((unsigned long long*)&d.stats->pres_iters, (unsigned long long)(j + 1));
         atomicMax((unsigned long long*)&d.stats->max_pres, (unsigned long long)(j + 1));
-        atomicMax((unsigned long long*)&d.stats->max_pres_k[ord - 1], (unsigned long long)(j + 1));
+        atomicMax((unsigned long long*)&d.stats->max_pres_k[ord], (unsigned long long)(j + 1));
         d.stats->last_pres_res = res;
         G->done = 1;
       }
@@ -1005,21 +1022,24 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_pres_update(Dev d, StepCoef sc) 
   constexpr int NN = C::NN, M = C::M, MM = C::MM, EPB = C::EPB, NT = C::NT, NM = N * M;
   __shared__ double sJ12[NM], sD12[NM];
   __shared__ double sP[4 * EPB * MM], sB[4 * EPB * NM];
-  __shared__ double sy[MAXMR];
+  __shared__ double sy[MAXMR], sg[MAXMR], sR[MAXMR * MAXMR];
   const int tid = threadIdx.x, el = tid / NN, nd = tid % NN;
   const long long e = (long long)blockIdx.x * EPB + el;
   const bool act = (el < EPB) && (e < d.nel);
   const GmresScal* G = d.gsc;
   const int nit = G->nit;
+  for (int k = tid; k < nit * nit; k += NT) { const int cc = k / nit, rr = k % nit; sR[cc * MAXMR + rr] = G->R[cc * MAXMR + rr]; }
+  if (tid < nit) sg[tid] = G->g[tid];
   load_basis<N, EPB>(d, nullptr, nullptr, sJ12, sD12, tid, NT);
-  if (tid == 0) {                      // back substitution R y = g (nit <= MAXMR)
+  lds_barrier();
+  if (tid == 0) {                      // back substitution R y = g (nit <= MAXMR), from LDS
     for (int q = nit - 1; q >= 0; --q) {
-      double s = G->g[q];
-      for (int k = q + 1; k < nit; ++k) s -= G->R[k * MAXMR + q] * sy[k];
-      sy[q] = s / G->R[q * MAXMR + q];
+      double s = sg[q];
+      for (int k = q + 1; k < nit; ++k) s -= sR[k * MAXMR + q] * sy[k];
+      sy[q] = s / sR[q * MAXMR + q];
     }
   }
-  __syncthreads();
+  lds_barrier();
   if (act && nd < MM) {
     const long long q = e * MM + nd;
     double x = 0.0;
@@ -1084,11 +1104,20 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_vel_update_proj(Dev d, StepCoef 
     del = d.PD[q];
     d.PED[q] = edel;
   }
+  __shared__ double sdot[(MAXPROJ + 1) * 4];
+  const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll 4
   for (int k = 0; k <= np; ++k) {
-    double t[1] = {0.0};
-    if (pact) t[0] = (k < np) ? del * d.PEX[(size_t)k * d.npr + q] : del * edel;
-    block_reduce<1>(t, sred, tid, NT);
-    if (tid == 0) d.ppart[(size_t)k * d.nblk + blockIdx.x] = t[0];
+    double t = 0.0;
+    if (pact) t = (k < np) ? del * d.PEX[(size_t)k * d.npr + q] : del * edel;
+    t = wave_sum63(t);
+    if (lane == 63) sdot[k * 4 + wv] = t;
+  }
+  lds_barrier();
+  if (tid <= np) {
+    double t = 0.0;
+    for (int ww = 0; ww < NT / 64; ++ww) t += sdot[tid * 4 + ww];
+    d.ppart[(size_t)tid * d.nblk + blockIdx.x] = t;
   }
 }
 
@@ -1200,6 +1229,44 @@ __global__ void k_basis_comb(const double* const* __restrict__ Q, int k, const d
     for (int q = 0; q < k; ++q) s += Q[q][l] * Z[(size_t)(c0 + c) * ldz + q];
     out[c][l] = s;
   }
+}
+
+// Basis rotation  Q(:,1:k) <- Q(:,1:k) Z  (schur_condensation, core/eigensolvers.f:466-474) on the fp64
+// matrix cores: per wavefront  D(16 x 16) += A(16 x 4) B(4 x 16)  with  A = Z^T tile (new vector c x old
+// vector q), B = Q^T tile (old vector q x 16 consecutive state entries), so the 16 state entries sit on
+// the lanes (coalesced loads and stores) and the accumulator rows are the new vectors.  In place: a wave
+// reads all k old values of its 16 entries before it writes any.   v_mfma_f64_16x16x4_f64 layouts:
+// A[lane&15][lane>>4], B[lane>>4][lane&15], D: col = lane&15, row = (lane>>4) + 4*reg.
+typedef double mfma_d4 __attribute__((ext_vector_type(4)));
+template <int CT>
+__global__ __launch_bounds__(256) void k_basis_gemm_mfma(double* const* __restrict__ Q, int k,
+                                                         const double* __restrict__ Z, int ldz, long long n) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const long long i0 = ((long long)blockIdx.x * 4 + wv) * 16;
+  if (i0 >= n) return;
+  const int n16 = lane & 15, kk = lane >> 4;
+  const long long i = i0 + n16;
+  const bool iok = i < n;
+  mfma_d4 acc[CT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) acc[ct] = (mfma_d4){0.0, 0.0, 0.0, 0.0};
+  for (int q0 = 0; q0 < k; q0 += 4) {
+    const int q = q0 + kk;
+    const double b = (q < k && iok) ? Q[q][i] : 0.0;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      const int c = ct * 16 + n16;
+      const double a = (c < k && q < k) ? Z[(size_t)c * ldz + q] : 0.0;      // Z is column-major: Z(q,c)
+      acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[ct], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int c = ct * 16 + kk + 4 * r;
+      if (c < k && iok) Q[c][i] = acc[ct][r];
+    }
 }
 
 // local axhelm for tests

@@ -91,6 +91,26 @@ def test_basis_gemm_and_gemv(hip6, case6):
     hip6.free(dv)
 
 
+@pytest.mark.parametrize("k", [5, 33, 130])
+def test_basis_gemm_mfma_sizes(hip6, case6, k):
+    """nsk_basis_gemm runs on v_mfma_f64_16x16x4_f64; asymmetric Z, sizes that exercise every
+    column-tile template and the k % 4 / k % 16 tails."""
+    rng = np.random.default_rng(k)
+    vs = [(rng.standard_normal(case6.x.shape), rng.standard_normal(case6.x.shape),
+           rng.standard_normal((case6.nel, 4, 4))) for _ in range(k)]
+    dv = hip6.alloc(k)
+    for d, v in zip(dv, vs):
+        hip6.upload(d, *v)
+    Z = rng.standard_normal((k, k))
+    hip6.basis_gemm(dv, Z)
+    for j in (0, 1, k // 2, k - 1):
+        got = hip6.download(dv[j])
+        for c in range(3):
+            ref = sum(vs[q][c] * Z[q, j] for q in range(k))
+            assert np.abs(got[c] - ref).max() < 1e-11 * np.sqrt(k)
+    hip6.free(dv)
+
+
 def test_eigen_relation_of_reference_mode(hip6, oracle6_nosolve, modes, spectre):
     """KAT without the oracle in the loop: M(dRe + i dIm) = mu (dRe + i dIm) with mu from the
     reference's Spectre_Hd.dat and the reference's own eigenmode files (fp32)."""
@@ -130,4 +150,24 @@ def test_arnoldi_leading_pair_matches_reference_table(hip6, case6, spectre):
     assert abs(lead - mu) < 5e-6
     lam = krylov.log_transform(np.array([lead]), 1.0)[0]
     assert abs(lam - complex(*spectre["NSd_conv"][0])) < 1e-5
+    hip6.free(res.Q + [v0, v1])
+
+
+def test_krylov_schur_restarts_on_device(hip6, case6, spectre):
+    """Small Krylov space + Schur condensation (core/eigensolvers.f:395-499) with the basis rotation
+    on the matrix cores: converges to the same leading pair as the reference's 200-vector Arnoldi."""
+    from nekstab_amd import seed
+    hip6.set_tolerances(1e-11, 1e-2, 1)
+    hip6.set_nsteps(100)
+    qx, qy = seed.add_noise(case6)
+    v0, v1 = hip6.alloc(2)
+    hip6.upload(v0, qx, qy, np.zeros(hip6.npres))
+    hip6.scal(v0, 1.0 / hip6.norm(v0))
+    hip6.matvec(v1, v0, 0)
+    res = krylov.krylov_schur(hip6, v1, 48, schur_tgt=2, eigen_tol=1e-6, schur_del=0.10, max_restarts=12)
+    mu = complex(spectre["Hd"][0, 0], spectre["Hd"][0, 1])
+    lead = res.vals[np.argmin(np.abs(res.vals - mu))]
+    print("restarts", res.schur_cnt, "matvecs", res.matvecs, "lead", lead, "wall", res.wall)
+    assert res.schur_cnt >= 1
+    assert abs(lead - mu) < 5e-6
     hip6.free(res.Q + [v0, v1])
