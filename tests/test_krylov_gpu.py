@@ -1,4 +1,6 @@
 """Krylov vector algebra and the end-to-end Arnoldi on the device, through the C-ABI."""
+import os
+
 import numpy as np
 import pytest
 
@@ -143,13 +145,50 @@ def test_arnoldi_leading_pair_matches_reference_table(hip6, case6, spectre):
     hip6.upload(v0, qx, qy, np.zeros(hip6.npres))
     hip6.scal(v0, 1.0 / hip6.norm(v0))
     hip6.matvec(v1, v0, 0)                    # the reference seeds with M * noise (core/eigensolvers.f:234)
-    res = krylov.krylov_schur(hip6, v1, 150, schur_tgt=0)
+    res = krylov.krylov_schur(hip6, v1, 200, schur_tgt=0)      # k_dim = 200 as in 1cyl.par:8
     mu = complex(spectre["Hd"][0, 0], spectre["Hd"][0, 1])
     lead = res.vals[np.argmin(np.abs(res.vals - mu))]
     print("leading Ritz value", lead, "residual", res.residual[np.argmin(np.abs(res.vals - mu))], "wall", res.wall)
     assert abs(lead - mu) < 5e-6
     lam = krylov.log_transform(np.array([lead]), 1.0)[0]
     assert abs(lam - complex(*spectre["NSd_conv"][0])) < 1e-5
+    # Every converged row of the reference table is reproduced.  The leading pair and the real mode
+    # 0.9166919 agree to the table's 7 digits; the sub-dominant wake branch is far more sensitive to the
+    # inner-solver tolerances (it moves by 1e-3 when ours are loosened to 1e-8/0.3, by 1e-6 when tightened,
+    # scripts/compare_spectrum.py) and the reference ran with loose absolute tolerances: <= 1e-4 there.
+    ref = spectre["Hd"]
+    ok = 0
+    for n, r in enumerate(ref[ref[:, 2] < 1e-8]):
+        z = complex(r[0], r[1])
+        j = np.argmin(np.abs(res.vals - z))
+        if res.residual[j] < 1e-7:
+            assert abs(res.vals[j] - z) < (5e-6 if n < 3 else 1e-4), (z, res.vals[j])
+            ok += 1
+    print("matched converged reference rows:", ok)
+    assert ok >= 9
+    # outpost_ks: files in the reference's formats; eigenmode 1 equals the reference's dRe/dIm up to phase
+    import tempfile
+    from nekstab_amd import nekio, outpost
+    from tests.conftest import make_oracle
+    with tempfile.TemporaryDirectory() as td:
+        files = outpost.outpost_ks(hip6, res, case6, td, evop="d", eigen_tol=1e-6, maxmodes=4)
+        assert os.path.basename(files[0]) == "dRe1cyl0.f00001" and os.path.basename(files[1]) == "dIm1cyl0.f00001"
+        tab = nekio.read_spectre(os.path.join(td, "Spectre_Hd.dat"))
+        assert tab.shape == (200, 3) and abs(complex(tab[0, 0], tab[0, 1]) - mu) < 5e-6 or abs(complex(tab[0, 0], -tab[0, 1]) - mu) < 5e-6
+        fr, fi = nekio.read_fld(files[0]), nekio.read_fld(files[1])
+        assert fr.istep == 101 and fr.rdcode == "XUP" and fr.wdsize == 4
+    o = make_oracle(case6, build_solvers=False)
+    w = o.bm1s()
+    ours = (fr.u[0, :, 0] + 1j * fi.u[0, :, 0], fr.u[1, :, 0] + 1j * fi.u[1, :, 0])
+    mods = np.load(os.path.join(os.path.dirname(__file__), "golden", "cylinder_modes.npz"))
+    refm = (mods["dRe_u"][0] + 1j * mods["dIm_u"][0], mods["dRe_u"][1] + 1j * mods["dIm_u"][1])
+    if lead.imag < 0:
+        ours = tuple(np.conj(a) for a in ours)
+    ov = sum(np.sum(np.conj(a) * w * b) for a, b in zip(refm, ours))
+    print("mode overlap |<ref,ours>| =", abs(ov))
+    assert abs(abs(ov) - 1.0) < 1e-4
+    diff = sum(np.sum(w * np.abs(b * np.conj(ov) / abs(ov) - a) ** 2) for a, b in zip(refm, ours))
+    assert np.sqrt(diff) < 2e-3                                        # fp32 files, eigen_tol 1e-6 in the reference
     hip6.free(res.Q + [v0, v1])
 
 

@@ -95,3 +95,27 @@ def test_adjoint_eigen_relation_lx1_8(modes, spectre):
     print("adjoint rayleigh", ray, "reference", mu)
     assert abs(ray - mu) < 5e-7
     h.close()
+
+
+def test_composed_maps(hip6, oracle6, modes):
+    """transient_growth_map = adjoint(forward(q)) (core/matvec.f:343-346) and
+    newton_linearized_map = forward(q) - q (core/matvec.f:398-401)."""
+    o = oracle6
+    q = _mode(o, modes, "dRe")
+    hip6.set_tolerances(1e-13, 1e-6, 1)
+    hip6.set_nsteps(3)
+    vq, vf = hip6.alloc(2)
+    hip6.upload(vq, *q)
+    hip6.matvec(vf, vq, 2)
+    f = hip6.download(vf)
+    ref = o.matvec(o.matvec(q, adjoint=False, nsteps=3), adjoint=True, nsteps=3)
+    assert relL2(o, f, ref) < 1e-9
+    hip6.matvec(vf, vq, 3)
+    f = hip6.download(vf)
+    fw = o.matvec(q, adjoint=False, nsteps=3)
+    ref = tuple(a - b for a, b in zip(fw, q))
+    num = np.sqrt(sum(np.sum(o.bm1 * (x - y) ** 2) for x, y in zip(f[:2], ref[:2])))
+    den = np.sqrt(sum(np.sum(o.bm1 * y ** 2) for y in fw[:2]))
+    assert num / den < 1e-9
+    hip6.set_nsteps(100)
+    hip6.free([vq, vf])
