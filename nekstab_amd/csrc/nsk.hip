@@ -57,6 +57,7 @@ struct nsk_ctx {
   int debug = 0;
   struct StepGraph { hipGraphExec_t exec = nullptr; int nh = -1, np = -1; } graphs[2][5];
   double* scratch = nullptr;            // one state vector
+  double* rc_big = nullptr;             // coarse restriction for nvert > 3072
   Dev d{};
   Stats hstats{};
   hipStream_t stream = nullptr;
@@ -507,11 +508,11 @@ static int build(nsk_ctx* c, const nsk_case& cs) {
       std::vector<double> Ah(Ac.size());
       HIPCHK(hipMemcpy(Ah.data(), dA, Ah.size() * sizeof(double), hipMemcpyDeviceToHost));
       const int lda = ((nvert + 255) / 256) * 256;
-      if (lda > 3072) return fail(NSK_EINVAL, "coarse space too large for k_coarse (nvert > 3072)");
       d.coarse_lda = lda;
       std::vector<float> Af((size_t)nvert * lda, 0.0f);
       for (int r = 0; r < nvert; ++r) for (int q = 0; q < nvert; ++q) Af[(size_t)r * lda + q] = (float)Ah[(size_t)r * nvert + q];
       if ((rc = dupload(c, &d.Acif, Af))) return rc;
+      if (lda > 3072 && (rc = dalloc(c, &c->rc_big, lda))) return rc;
     }
   }
   {
@@ -588,7 +589,12 @@ static int pres_solve_launch(nsk_ctx* c, double h2, int ord, int np) {
     if (d.nproj_max > 0 && !c->in_test) hipLaunchKernelGGL(k_proj_apply, dim3(c->nblk), dim3(256), 0, c->stream, d);
     hipLaunchKernelGGL(k_gmres_update<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, -1, scale, c->min_pres, ord);
     for (int j = 0; j < np; ++j) {
-      hipLaunchKernelGGL(k_coarse, dim3((d.nvert + 4 * CROWS_W - 1) / (4 * CROWS_W)), dim3(256), d.coarse_lda * sizeof(double), c->stream, d);
+      if (d.coarse_lda <= 3072) {
+        hipLaunchKernelGGL(k_coarse, dim3((d.nvert + 4 * CROWS_W - 1) / (4 * CROWS_W)), dim3(256), d.coarse_lda * sizeof(double), c->stream, d);
+      } else {
+        hipLaunchKernelGGL(k_coarse_restrict, dim3(d.coarse_lda / 256), dim3(256), 0, c->stream, d, c->rc_big);
+        hipLaunchKernelGGL(k_coarse_big, dim3((d.nvert + 3) / 4), dim3(256), 0, c->stream, d, (const double*)c->rc_big);
+      }
       hipLaunchKernelGGL(k_schwarz<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, (const double*)(d.V + (size_t)j * d.npr), d.Z + (size_t)j * d.npr, 1, 1);
       hipLaunchKernelGGL(k_divgs<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, (const double*)d.yl, d.V + (size_t)(j + 1) * d.npr, j, 1);
       hipLaunchKernelGGL(k_gmres_update<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, j, scale, c->min_pres, ord);

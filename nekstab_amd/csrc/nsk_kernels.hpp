@@ -732,7 +732,9 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_gmres_update(Dev d, int j, doubl
   const bool act = (el < EPB) && (e < d.nel);
   GmresScal* G = d.gsc;
   if (j >= 0 && G->done) return;
-  const double hatv = (tid < 4 * MM) ? d.hat[tid] : 0.0;
+  double hatv[(4 * MM + NT - 1) / NT];
+#pragma unroll
+  for (int r = 0; r < (4 * MM + NT - 1) / NT; ++r) hatv[r] = (tid + r * NT < 4 * MM) ? d.hat[tid + r * NT] : 0.0;
   double wnew = 0.0;
   if (act && nd < MM) wnew = d.V[(size_t)(j + 1) * d.npr + e * MM + nd];
   const int nv = (j < 0) ? 1 : j + 2;
@@ -791,7 +793,8 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_gmres_update(Dev d, int j, doubl
       }
     }
   }
-  if (tid < 4 * MM) shat[tid] = hatv;
+#pragma unroll
+  for (int r = 0; r < (4 * MM + NT - 1) / NT; ++r) if (tid + r * NT < 4 * MM) shat[tid + r * NT] = hatv[r];
   if (act && nd < MM) {
     const long long q = e * MM + nd;
     double w = wnew;
@@ -859,6 +862,41 @@ __global__ __launch_bounds__(256) void k_coarse(Dev d) {
     if (rok) d.xc[row0] = s0;
     if (r1) d.xc[row0 + 1] = s1;
   }
+}
+
+// large coarse spaces (nvert > 3072, e.g. the 2x2-refined mesh): streaming variant, the vertex
+// restriction r_c is built once per launch in global memory by a separate tiny kernel.
+__global__ __launch_bounds__(256) void k_coarse_restrict(Dev d, double* __restrict__ rc) {
+  if (d.gsc->done) return;
+  const int v = blockIdx.x * 256 + threadIdx.x;
+  if (v >= d.coarse_lda) return;
+  double sv = 0.0;
+  if (v < d.nvert) {
+    const int4 a = reinterpret_cast<const int4*>(d.vtab)[2 * v], b = reinterpret_cast<const int4*>(d.vtab)[2 * v + 1];
+    const double e0 = d.ec[a.x];
+    const double e1 = (a.y >= 0) ? d.ec[a.y] : 0.0, e2 = (a.z >= 0) ? d.ec[a.z] : 0.0, e3 = (a.w >= 0) ? d.ec[a.w] : 0.0;
+    const double e4 = (b.x >= 0) ? d.ec[b.x] : 0.0, e5 = (b.y >= 0) ? d.ec[b.y] : 0.0, e6 = (b.z >= 0) ? d.ec[b.z] : 0.0;
+    const double e7 = (b.w >= 0) ? d.ec[b.w] : 0.0;
+    sv = ((((((e0 + e1) + e2) + e3) + e4) + e5) + e6) + e7;
+  }
+  rc[v] = sv;
+}
+__global__ __launch_bounds__(256) void k_coarse_big(Dev d, const double* __restrict__ rc) {
+  if (d.gsc->done) return;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + w;
+  if (row >= d.nvert) return;
+  const float4* A = reinterpret_cast<const float4*>(d.Acif + (size_t)row * d.coarse_lda) + lane;
+  const int nit = d.coarse_lda / 256;
+  double s = 0.0;
+#pragma unroll 8
+  for (int i = 0; i < nit; ++i) {
+    const float4 a = A[i * 64];
+    const double* x = rc + i * 256 + lane * 4;
+    s += (double)a.x * x[0] + (double)a.y * x[1] + (double)a.z * x[2] + (double)a.w * x[3];
+  }
+  s = wave_sum63(s);
+  if (lane == 63) d.xc[row] = s;
 }
 
 // z_j = RAS(v_j) + R^T x_c ;  yl = D^T z_j  (unassembled velocity-space)

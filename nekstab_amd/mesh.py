@@ -306,3 +306,72 @@ def load_case_npz(path: str, lx1: int, **kw) -> Case:
     mesh = nekio.Re2Mesh(2, z["xc"].shape[0], z["xc"], z["yc"], None, curves, bcs)
     return build_case_2d(mesh, z["vlex"].astype(np.int64), z["bf_u"].astype(np.float64), lx1,
                          meta={"npz": path}, **kw)
+
+
+# ----------------------------------------------------------------------------
+# uniform 2x2 refinement of a Case (BASELINE config 3: E ~ 8k)
+# ----------------------------------------------------------------------------
+
+def refine_case_2x2(case: Case) -> Case:
+    """Split every element into 2x2 children.  Child geometry / base flow are the parent's
+    polynomials evaluated on the children's GLL nodes (exactly conforming); vertex ids by
+    coordinate matching (periodic in y), Dirichlet faces inherited."""
+    from scipy.spatial import cKDTree
+    n = case.lx1
+    z = gauss_lobatto_legendre(n)[0]
+    Jh = [interp_matrix(z, 0.5 * (z - 1.0)), interp_matrix(z, 0.5 * (z + 1.0))]     # lower / upper half
+    nel = case.nel
+
+    def split(f):                      # (..., nel, n, n) -> (..., 4 nel, n, n), child order (qs, qr)
+        out = []
+        for qs in range(2):
+            for qr in range(2):
+                out.append(np.einsum("ai,bj,...ij->...ab", Jh[qs], Jh[qr], f, optimize=True))
+        o = np.stack(out, axis=-3)     # (..., nel, 4, n, n)
+        return o.reshape(f.shape[:-3] + (4 * nel, n, n))
+
+    x, y, ub = split(case.x), split(case.y), split(case.ub)
+    # face flags of the parent from its nodal mask (interior face nodes all fixed)
+    pm = case.mask
+    f_sm = np.all(pm[:, 0, 1:-1] == 0, axis=1); f_sp = np.all(pm[:, -1, 1:-1] == 0, axis=1)
+    f_rm = np.all(pm[:, 1:-1, 0] == 0, axis=1); f_rp = np.all(pm[:, 1:-1, -1] == 0, axis=1)
+    mask = np.ones((nel, 4, n, n))
+    for qs in range(2):
+        for qr in range(2):
+            c = qs * 2 + qr
+            if qs == 0: mask[f_sm, c, 0, :] = 0.0
+            if qs == 1: mask[f_sp, c, -1, :] = 0.0
+            if qr == 0: mask[f_rm, c, :, 0] = 0.0
+            if qr == 1: mask[f_rp, c, :, -1] = 0.0
+    mask = mask.reshape(4 * nel, n, n)
+    # vertex ids from corner coordinates, periodic in y
+    cx = np.stack([x[:, 0, 0], x[:, 0, -1], x[:, -1, 0], x[:, -1, -1]], axis=1)
+    cy = np.stack([y[:, 0, 0], y[:, 0, -1], y[:, -1, 0], y[:, -1, -1]], axis=1)
+    ymin, ymax = case.y.min(), case.y.max()
+    pts = np.stack([cx.ravel(), np.where(np.abs(cy.ravel() - ymax) < 1e-6, ymin, cy.ravel())], axis=1)
+    tree = cKDTree(pts)
+    parent = np.arange(len(pts))
+
+    def find(a):
+        while parent[a] != a:
+            parent[a] = parent[parent[a]]
+            a = parent[a]
+        return a
+    for a, b in tree.query_pairs(r=2e-5):
+        ra, rb = find(a), find(b)
+        if ra != rb:
+            parent[max(ra, rb)] = min(ra, rb)
+    roots = np.array([find(a) for a in range(len(pts))])
+    _, vid = np.unique(roots, return_inverse=True)
+    vlex = vid.reshape(4 * nel, 4) + 1
+    gid, nglob = global_numbering_2d(vlex, n)
+    gmask = np.ones(nglob)
+    np.minimum.at(gmask, gid.ravel(), mask.ravel())
+    mask = gmask[gid]
+    spng = sponge_function([x, y], [5.0, 0.0], [5.0, 0.0]) if case.spng.max() > 0 else np.zeros_like(x)
+    m = dict(case.meta)
+    m["vert"] = vlex - 1
+    m["nvert"] = int(vlex.max())
+    return Case(ndim=2, nel=4 * nel, lx1=n, x=x, y=y, gid=gid, nglob=nglob, mask=mask, ub=ub, spng=spng,
+                re=case.re, endtime=case.endtime, cfl=case.cfl, lxd=case.lxd, has_outflow=case.has_outflow,
+                adjoint=case.adjoint, meta=m)

@@ -41,3 +41,35 @@ def test_operators(lx1):
     assert rel(h.t_eapply(p), ref) < 1e-12
     # one full time step through the solvers is exercised at lx1=6/8 in test_matvec_gpu.py
     h.close()
+
+
+@pytest.mark.parametrize("lx1", [10, 12])
+def test_full_steps_other_orders(lx1, modes):
+    """Whole time steps (all solver kernels) at lx1 = 10 and 12: the result is finite, discretely
+    divergence free to the solver tolerance, and its energy agrees with the lx1=6 oracle-checked
+    result to the resolution difference (regression for the lx1=12 staging bug)."""
+    from nekstab_amd import mesh
+    from nekstab_amd.capi import NekStabHip
+    from nekstab_amd.quadrature import gauss_legendre, gauss_lobatto_legendre, interp_matrix
+    from tests.conftest import GOLDEN
+    case = mesh.load_case_npz(os.path.join(GOLDEN, "cylinder_case.npz"), lx1)
+    h = NekStabHip(case, case.meta["vert"], case.meta["nvert"], tol_helm=1e-11, tol_pres=1e-3, tol_relative=1,
+                   nproj=8, max_helm_iter=150, max_pres_iter=48)
+    u = mesh.interp_field_2d(modes["dRe_u"].astype(np.float64), lx1)
+    p1 = mesh.interp_field_2d(modes["dRe_p"].astype(np.float64), lx1)
+    J = interp_matrix(gauss_lobatto_legendre(lx1)[0], gauss_legendre(lx1 - 2)[0])
+    vq, vf = h.alloc(2)
+    h.upload(vq, u[0], u[1], J @ p1 @ J.T)
+    e0 = h.dot(vq, vq)
+    h.set_nsteps(6)
+    h.matvec(vf, vq, 0)
+    f = h.download(vf)
+    assert all(np.all(np.isfinite(a)) for a in f)
+    div = h.t_opdiv(f[0], f[1])
+    div0 = h.t_opdiv(u[0] + 0.01 * case.x * case.mask, u[1])          # scale of a non-solenoidal field
+    assert np.abs(div).max() < 1e-6 * np.abs(div0).max()
+    e1 = h.dot(vf, vf)
+    # the reference mode decays/rotates with |mu|^(2*6*dt): energy ratio close to that of the eigenvalue
+    mu_abs = abs(0.7387113 + 0.6972442j)
+    assert abs(e1 / e0 - mu_abs ** (2 * 6 * h.dt)) < 2e-3
+    h.close()
