@@ -49,13 +49,13 @@ struct nsk_ctx {
   double dt = 0, re = 0, endtime = 0;
   int nsteps = 0;
   int max_helm = 60, max_pres = 40, min_pres = 0, layers = 1;
-  int cur_helm[5] = {0, 0, 0, 0, 0}, cur_pres[5] = {0, 0, 0, 0, 0};       // adaptive launch budgets per BDF order
+  int cur_helm[6] = {0, 0, 0, 0, 0, 0}, cur_pres[6] = {0, 0, 0, 0, 0, 0};       // adaptive launch budgets per BDF order
   int use_graph = 1;
   int in_test = 0;
   int helm_guess = 1;
   long long recaptures = 0, retries = 0;
   int debug = 0;
-  struct StepGraph { hipGraphExec_t exec = nullptr; int nh = -1, np = -1; } graphs[2][5];
+  struct StepGraph { hipGraphExec_t exec = nullptr; int nh = -1, np = -1; } graphs[2][6];
   double* scratch = nullptr;            // one state vector
   double* rc_big = nullptr;             // coarse restriction for nvert > 3072
   Dev d{};
@@ -106,7 +106,7 @@ static StepCoef make_coef(const nsk_ctx* c, int istep, int adjoint) {
   static const double XG[4][3] = {{0, 0, 0}, {1, 0, 0}, {2, -1, 0}, {3, -3, 1}};
   const int gi = !g ? 0 : std::min(istep, 4) - 1;
   for (int q = 0; q < 3; ++q) s.xg[q] = XG[gi][q];
-  s.cls = istep <= 3 ? istep - 1 : (istep <= 6 ? 3 : 4);
+  s.cls = istep <= 3 ? istep - 1 : (istep <= 6 ? 3 : (istep <= 16 ? 4 : 5));
   return s;
 }
 
@@ -365,7 +365,7 @@ static int build(nsk_ctx* c, const nsk_case& cs) {
         }
     std::vector<double> dAs = dssum_h(dA), bs = dssum_h(bm1);
     const double bd0[3] = {1.0, 1.5, 11.0 / 6.0};
-    for (int k = 0; k < 5; ++k)
+    for (int k = 0; k < 6; ++k)
       for (long long l = 0; l < nloc; ++l) dinv[(size_t)k * nloc + l] = mask[l] / (d.nu * dAs[l] + bd0[k] / c->dt * bs[l]);
   }
 
@@ -570,7 +570,7 @@ static int build(nsk_ctx* c, const nsk_case& cs) {
     }
     if ((rc = dupload(c, &d.p_idx, p_idx)) || (rc = dupload(c, &d.p_inv, p_inv))) return rc;
   }
-  for (int k = 0; k < 5; ++k) { c->cur_helm[k] = c->max_helm; c->cur_pres[k] = c->max_pres; }
+  for (int k = 0; k < 6; ++k) { c->cur_helm[k] = c->max_helm; c->cur_pres[k] = c->max_pres; }
   if (const char* g = std::getenv("NSK_USE_GRAPH")) c->use_graph = std::atoi(g);
   if (const char* g = std::getenv("NSK_DEBUG")) c->debug = std::atoi(g);
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -631,8 +631,8 @@ static int step(nsk_ctx* c, int istep, int adjoint) {
   return 0;
 }
 
-static const int CLS_ISTEP[5] = {1, 2, 3, 4, 7};        // a representative step of every class
-static inline int step_class(int istep) { return istep <= 3 ? istep - 1 : (istep <= 6 ? 3 : 4); }
+static const int CLS_ISTEP[6] = {1, 2, 3, 4, 7, 17};    // a representative step of every class
+static inline int step_class(int istep) { return istep <= 3 ? istep - 1 : (istep <= 6 ? 3 : (istep <= 16 ? 4 : 5)); }
 
 static int ensure_graph(nsk_ctx* c, int cls, int adjoint) {
   nsk_ctx::StepGraph& g = c->graphs[adjoint][cls];
@@ -654,7 +654,7 @@ static int ensure_graph(nsk_ctx* c, int cls, int adjoint) {
 static int run_map(nsk_ctx* c, int adjoint, double* f, const double* q) {
   Dev& d = c->d;
   if (c->use_graph)
-    for (int k = 0; k < 5; ++k) { int rc = ensure_graph(c, k, adjoint); if (rc) return rc; }
+    for (int k = 0; k < 6; ++k) { int rc = ensure_graph(c, k, adjoint); if (rc) return rc; }
   HIPCHK(hipMemcpyAsync(d.u, q, 2 * d.nloc * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(d.p, q + 2 * d.nloc, d.npr * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
   for (int istep = 1; istep <= c->nsteps; ++istep) {
@@ -668,6 +668,10 @@ static int run_map(nsk_ctx* c, int adjoint, double* f, const double* q) {
         HIPCHK(hipStreamSynchronize(c->stream));
         HIPCHK(hipMemcpy(&G, d.gsc, sizeof(G), hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(hs, d.hscal, sizeof(hs), hipMemcpyDeviceToHost));
+        Stats hs2; HIPCHK(hipMemcpy(&hs2, d.stats, sizeof(hs2), hipMemcpyDeviceToHost));
+        static long long ph = 0, pp = 0;
+        fprintf(stderr, "step %3d: helm_it=%lld pres_it=%lld ", istep, hs2.helm_iters - (istep == 1 ? 0 : ph), hs2.pres_iters - (istep == 1 ? 0 : pp));
+        ph = hs2.helm_iters; pp = hs2.pres_iters;
         fprintf(stderr, "step %3d: |g|=%.3e |g'|=%.3e nit=%d resid=%.3e nproj=%d pcnt=%d st_n=%.3e  helm ref %.3e %.3e\n", istep, G.gnorm0, G.beta0, G.nit, G.resid, G.nproj, G.pcnt, G.st_n, hs[16], hs[17]);
       }
     }
@@ -696,12 +700,12 @@ static int run_map_adaptive(nsk_ctx* c, int adjoint, double* f, const double* q)
     c->hstats.helm_iters += h.helm_iters; c->hstats.pres_iters += h.pres_iters; c->hstats.steps += c->nsteps;
     c->hstats.max_helm = std::max(c->hstats.max_helm, h.max_helm); c->hstats.max_pres = std::max(c->hstats.max_pres, h.max_pres);
     c->hstats.last_helm_res = h.last_helm_res; c->hstats.last_pres_res = h.last_pres_res;
-    for (int k = 0; k < 5; ++k) {
+    for (int k = 0; k < 6; ++k) {
       c->hstats.max_helm_k[k] = std::max(c->hstats.max_helm_k[k], h.max_helm_k[k]);
       c->hstats.max_pres_k[k] = std::max(c->hstats.max_pres_k[k], h.max_pres_k[k]);
     }
     if (h.unconverged == 0) {
-      for (int k = 0; k < 5; ++k) {
+      for (int k = 0; k < 6; ++k) {
         if (CLS_ISTEP[k] > c->nsteps) break;
         // grow at once (with head-room), shrink only when clearly oversized: every change re-captures a graph
         const int nh = (int)h.max_helm_k[k] + 2, npp = (int)h.max_pres_k[k] + 2;
@@ -713,13 +717,13 @@ static int run_map_adaptive(nsk_ctx* c, int adjoint, double* f, const double* q)
       return 0;
     }
     bool capped = true;
-    for (int k = 0; k < 5; ++k) capped = capped && c->cur_helm[k] >= c->max_helm && c->cur_pres[k] >= c->max_pres;
+    for (int k = 0; k < 6; ++k) capped = capped && c->cur_helm[k] >= c->max_helm && c->cur_pres[k] >= c->max_pres;
     if (capped) {
       c->hstats.unconverged += h.unconverged;
       return fail(NSK_ENOCONV, "inner solve hit its iteration cap (" + std::to_string(h.unconverged) + " solves)");
     }
     c->retries++;
-    for (int k = 0; k < 5; ++k) {
+    for (int k = 0; k < 6; ++k) {
       c->cur_helm[k] = std::min(c->max_helm, 2 * c->cur_helm[k] + 4);
       c->cur_pres[k] = std::min(c->max_pres, 2 * c->cur_pres[k] + 4);
     }
@@ -776,7 +780,7 @@ int nsk_set_tolerances(nsk_ctx* c, double th, double tp, int relative) {
   if (!c) return fail(NSK_EINVAL, "null ctx");
   c->d.tol_helm = th; c->d.tol_pres = tp; c->d.tol_relative = relative;
   for (auto& a : c->graphs) for (auto& g : a) g.nh = -1;   // Dev is captured by value: re-capture
-  for (int k = 0; k < 5; ++k) { c->cur_helm[k] = c->max_helm; c->cur_pres[k] = c->max_pres; }
+  for (int k = 0; k < 6; ++k) { c->cur_helm[k] = c->max_helm; c->cur_pres[k] = c->max_pres; }
   return 0;
 }
 
@@ -787,8 +791,8 @@ int nsk_set_option(nsk_ctx* c, const char* name, double value) {
   else if (n == "min_pres_iter") c->min_pres = (int)value;
   else if (n == "helm_guess") c->helm_guess = (int)value;
   else if (n == "dbg") { int v = (int)value; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), &v, sizeof(int))); }
-  else if (n == "budget_helm") { for (int k = 0; k < 5; ++k) c->cur_helm[k] = std::min(c->max_helm, std::max(1, (int)value)); }
-  else if (n == "budget_pres") { for (int k = 0; k < 5; ++k) c->cur_pres[k] = std::min(c->max_pres, std::max(1, (int)value)); }
+  else if (n == "budget_helm") { for (int k = 0; k < 6; ++k) c->cur_helm[k] = std::min(c->max_helm, std::max(1, (int)value)); }
+  else if (n == "budget_pres") { for (int k = 0; k < 6; ++k) c->cur_pres[k] = std::min(c->max_pres, std::max(1, (int)value)); }
   else return fail(NSK_EINVAL, "unknown option " + n);
   for (auto& a : c->graphs) for (auto& g : a) g.nh = -1;
   return 0;
@@ -843,7 +847,7 @@ int nsk_get_stats(nsk_ctx* c, nsk_stats* s) {
   s->steps = h.steps; s->helm_iters = h.helm_iters; s->pres_iters = h.pres_iters;
   s->unconverged = h.unconverged; s->last_helm_res = h.last_helm_res; s->last_pres_res = h.last_pres_res;
   s->max_helm_iter = h.max_helm; s->max_pres_iter = h.max_pres;
-  s->budget_helm = c->cur_helm[4]; s->budget_pres = c->cur_pres[4];
+  s->budget_helm = c->cur_helm[5]; s->budget_pres = c->cur_pres[5];
   s->recaptures = c->recaptures; s->retries = c->retries;
   return 0;
 }
@@ -984,6 +988,21 @@ int nsk_basis_gemv(nsk_ctx* c, const nsk_vec* Q, int k, const double* y_re, cons
 int nsk_seed_noise(nsk_ctx* c, nsk_vec v) {
   (void)c; (void)v;
   return fail(NSK_EINVAL, "nsk_seed_noise: build the seed on the host (nekstab_amd.seed) and upload it");
+}
+
+// diagnostic (NSK_STAMPS build): run `reps` full pressure iterations' k_divgs and dump the stamps
+int nsk_debug_stamps(nsk_ctx* c, unsigned long long* out, int nblk_max) {
+  if (!c || !out) return fail(NSK_EINVAL, "bad argument");
+  Dev& d = c->d;
+  if (!d.dbg) { int rc = dalloc(c, &d.dbg, (size_t)16 * (c->nblk + 8)); if (rc) return rc; }
+  HIPCHK(hipMemset(d.dbg, 0, (size_t)16 * (c->nblk + 8) * sizeof(unsigned long long)));
+  DISPATCH_N(c->N, {
+    for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(k_divgs<N>, dim3(c->nblk), dim3(Cfg<N>::NT), 0, c->stream, d, (const double*)d.yl, c->wp2, 5, 0);
+  });
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipMemcpy(out, d.dbg, (size_t)16 * std::min(nblk_max, c->nblk) * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  unsigned long long* p = d.dbg; d.dbg = nullptr; (void)p;
+  return 0;
 }
 
 // average duration of one hot kernel, measured with HIP events on the library's stream

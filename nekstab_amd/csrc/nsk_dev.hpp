@@ -17,7 +17,7 @@ struct StepCoef {                // order k = min(istep,3)  [UPSTREAM setordbd/s
   int k;
   int adjoint;
   double xg[3];                  // Helmholtz initial guess  du0 = xg0*du^{n-1} + xg1*du^{n-2} + xg2*du^{n-3}
-  int cls;                       // step class 0..4 (istep 1,2,3, 4-6, >=7): one captured graph + budget each
+  int cls;                       // step class 0..5 (istep 1,2,3, 4-6, 7-16, >=17): one captured graph + budget each
 };
 
 struct GmresScal {               // device-resident small state of one pressure solve
@@ -43,7 +43,7 @@ struct GmresScal {               // device-resident small state of one pressure 
 struct Stats {
   long long helm_iters, pres_iters, unconverged, steps;
   long long max_helm, max_pres;
-  long long max_helm_k[5], max_pres_k[5];   // per step class (separate graphs, separate budgets)
+  long long max_helm_k[6], max_pres_k[6];   // per step class (separate graphs, separate budgets)
   double last_helm_res, last_pres_res;
 };
 
@@ -83,6 +83,7 @@ struct Dev {
   const float* p_inv;
   const long long* p_invoff;
   Stats* stats;
+  unsigned long long* dbg;       // diagnostic stamps (NSK_STAMPS builds)
 };
 
 }  // namespace nsk

@@ -10,7 +10,13 @@
 
 namespace nsk {
 
-__device__ int g_dbg = 0;     // developer ablation switches (bit mask), 0 in production
+__device__ int g_dbg = 0;
+#ifdef NSK_STAMPS
+// diagnostic build only: wall-clock stamps (100 MHz s_memrealtime) of thread 0 of every workgroup
+#define NSK_STAMP(i) do { if (threadIdx.x == 0 && d.dbg) { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); d.dbg[(size_t)blockIdx.x * 16 + (i)] = t_; } } while (0)
+#else
+#define NSK_STAMP(i) do { } while (0)
+#endif     // developer ablation switches (bit mask), 0 in production
 
 template <int N>
 struct Cfg {
@@ -1014,7 +1020,9 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_divgs(Dev d, const double* __res
   const int tid = threadIdx.x, el = tid / NN, nd = tid % NN;
   const long long e = (long long)blockIdx.x * EPB + el;
   const bool act = (el < EPB) && (e < d.nel);
+  NSK_STAMP(0);
   if (check_done && d.gsc->done) return;
+  NSK_STAMP(1);
   const long long l = e * NN + nd;
   int4 tab = make_int4(0, -1, -1, -1);
   double bi = 0;
@@ -1028,8 +1036,10 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_divgs(Dev d, const double* __res
     su[(0 * EPB + el) * NN + nd] = bi * gs_sum(g0, yl, d, tab, l);
     su[(1 * EPB + el) * NN + nd] = bi * gs_sum(g1, yl + d.nloc, d, tab, l);
   }
+  NSK_STAMP(2);
   lds_barrier();
   const double w = opdiv_tiles<N, EPB>(sJ12, sD12, su, sA, act, el, nd, d, e);
+  NSK_STAMP(3);
   const bool pact = act && nd < MM;
   const long long q = e * MM + nd;
   if (pact) wout[q] = w;
@@ -1050,6 +1060,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_divgs(Dev d, const double* __res
       for (int ww = 0; ww < NW; ++ww) t += sdot[tid * 4 + ww];
       d.gpart[(size_t)tid * d.nblk + blockIdx.x] = t;
     }
+    NSK_STAMP(4);
   }
 }
 
