@@ -189,6 +189,7 @@ static int build(nsk_ctx* c, const nsk_case& cs) {
   HIPCHK(hipStreamCreate(&c->stream));
   Dev& d = c->d;
   d.nel = nel; d.nblk = c->nblk; d.nloc = nloc; d.npr = npr; d.nu = 1.0 / cs.re;
+  d.cs = nloc; d.ps = npr; d.npr_glob = npr;          // one rank: no ghost slots
   d.tol_helm = cs.tol_helm > 0 ? cs.tol_helm : 1e-9;
   d.tol_pres = cs.tol_pres > 0 ? cs.tol_pres : 1e-7;
   d.tol_relative = cs.tol_relative; d.max_mr = c->max_pres; d.has_outflow = cs.has_outflow;
@@ -379,15 +380,15 @@ static int build(nsk_ctx* c, const nsk_case& cs) {
       (rc = dupload(c, &d.gs_idx, gs_idx))) return rc;
 
   // ---- state + solver work arrays
-  if ((rc = dalloc(c, &d.u, 2 * nloc)) || (rc = dalloc(c, &d.p, npr)) || (rc = dalloc(c, &d.plag, npr)) ||
-      (rc = dalloc(c, &d.pext, npr)) || (rc = dalloc(c, &d.ulag, 4 * nloc)) || (rc = dalloc(c, &d.exlag, 4 * nloc)) ||
-      (rc = dalloc(c, &d.bf, 2 * nloc)) || (rc = dalloc(c, &d.rloc, 2 * nloc)) || (rc = dalloc(c, &d.bloc, 2 * nloc)) || (rc = dalloc(c, &d.dulag, 6 * nloc)) || (rc = dalloc(c, &d.hx, 2 * nloc)) ||
-      (rc = dalloc(c, &d.hr, 2 * nloc)) || (rc = dalloc(c, &d.hp, 2 * nloc)) || (rc = dalloc(c, &d.hs, 2 * nloc)) ||
-      (rc = dalloc(c, &d.hwl, 4 * nloc)) || (rc = dalloc(c, &d.hpart, (size_t)16 * c->nblk)) || (rc = dalloc(c, &d.hscal, 32)) ||
-      (rc = dalloc(c, &d.V, (size_t)(MAXMR + 1) * npr)) || (rc = dalloc(c, &d.Z, (size_t)MAXMR * npr)) ||
-      (rc = dalloc(c, &d.yl, 2 * nloc)) || (rc = dalloc(c, &d.ec, (size_t)nel * 4)) ||
+  if ((rc = dalloc(c, &d.u, 2 * d.cs)) || (rc = dalloc(c, &d.p, npr)) || (rc = dalloc(c, &d.plag, npr)) ||
+      (rc = dalloc(c, &d.pext, npr)) || (rc = dalloc(c, &d.ulag, 4 * d.cs)) || (rc = dalloc(c, &d.exlag, 4 * d.cs)) ||
+      (rc = dalloc(c, &d.bf, 2 * d.cs)) || (rc = dalloc(c, &d.rloc, 2 * d.cs)) || (rc = dalloc(c, &d.bloc, 2 * d.cs)) || (rc = dalloc(c, &d.dulag, 6 * d.cs)) || (rc = dalloc(c, &d.hx, 2 * d.cs)) ||
+      (rc = dalloc(c, &d.hr, 2 * d.cs)) || (rc = dalloc(c, &d.hp, 2 * d.cs)) || (rc = dalloc(c, &d.hs, 2 * d.cs)) ||
+      (rc = dalloc(c, &d.hwl, 4 * d.cs)) || (rc = dalloc(c, &d.hpart, (size_t)16 * c->nblk)) || (rc = dalloc(c, &d.hscal, 32)) ||
+      (rc = dalloc(c, &d.V, (size_t)(MAXMR + 1) * d.ps)) || (rc = dalloc(c, &d.Z, (size_t)MAXMR * npr)) ||
+      (rc = dalloc(c, &d.yl, 2 * d.cs)) || (rc = dalloc(c, &d.ec, (size_t)nel * 4)) ||
       (rc = dalloc(c, &d.gpart, (size_t)(MAXMR + 2) * c->nblk)) || (rc = dalloc(c, &d.gsc, 1)) ||
-      (rc = dalloc(c, &d.stats, 1)) || (rc = dalloc(c, &c->wv1, 2 * nloc)) || (rc = dalloc(c, &c->wv2, 2 * nloc)) ||
+      (rc = dalloc(c, &d.stats, 1)) || (rc = dalloc(c, &c->wv1, 2 * d.cs)) || (rc = dalloc(c, &c->wv2, 2 * d.cs)) ||
       (rc = dalloc(c, &c->wp1, npr)) || (rc = dalloc(c, &c->wp2, npr)) || (rc = dalloc(c, &c->scratch, (size_t)c->nstate))) return rc;
   if (d.nproj_max > 0)
     if ((rc = dalloc(c, &d.PX, (size_t)d.nproj_max * npr)) || (rc = dalloc(c, &d.PEX, (size_t)d.nproj_max * npr)) ||
@@ -595,8 +596,8 @@ static int pres_solve_launch(nsk_ctx* c, double h2, int ord, int np) {
         hipLaunchKernelGGL(k_coarse_restrict, dim3(d.coarse_lda / 256), dim3(256), 0, c->stream, d, c->rc_big);
         hipLaunchKernelGGL(k_coarse_big, dim3((d.nvert + 3) / 4), dim3(256), 0, c->stream, d, (const double*)c->rc_big);
       }
-      hipLaunchKernelGGL(k_schwarz<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, (const double*)(d.V + (size_t)j * d.npr), d.Z + (size_t)j * d.npr, 1, 1);
-      hipLaunchKernelGGL(k_divgs<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, (const double*)d.yl, d.V + (size_t)(j + 1) * d.npr, j, 1);
+      hipLaunchKernelGGL(k_schwarz<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, (const double*)(d.V + (size_t)j * d.ps), d.Z + (size_t)j * d.npr, 1, 1);
+      hipLaunchKernelGGL(k_divgs<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, (const double*)d.yl, d.V + (size_t)(j + 1) * d.ps, j, 1);
       hipLaunchKernelGGL(k_gmres_update<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, j, scale, c->min_pres, ord);
     }
   });
@@ -655,7 +656,8 @@ static int run_map(nsk_ctx* c, int adjoint, double* f, const double* q) {
   Dev& d = c->d;
   if (c->use_graph)
     for (int k = 0; k < 6; ++k) { int rc = ensure_graph(c, k, adjoint); if (rc) return rc; }
-  HIPCHK(hipMemcpyAsync(d.u, q, 2 * d.nloc * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(d.u, q, d.nloc * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(d.u + d.cs, q + d.nloc, d.nloc * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(d.p, q + 2 * d.nloc, d.npr * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
   for (int istep = 1; istep <= c->nsteps; ++istep) {
     if (c->use_graph) {
@@ -676,7 +678,8 @@ static int run_map(nsk_ctx* c, int adjoint, double* f, const double* q) {
       }
     }
   }
-  HIPCHK(hipMemcpyAsync(f, d.u, 2 * d.nloc * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(f, d.u, d.nloc * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(f + d.nloc, d.u + d.cs, d.nloc * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(f + 2 * d.nloc, d.p, d.npr * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
   return 0;
 }
@@ -1056,7 +1059,7 @@ int nsk_test_dssum(nsk_ctx* c, const double* u, double* out) {
 
 int nsk_test_opdiv(nsk_ctx* c, const double* u, const double* v, double* out) {
   HIPCHK(hipMemcpy(c->wv1, u, c->nloc * sizeof(double), hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(c->wv1 + c->nloc, v, c->nloc * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(c->wv1 + c->d.cs, v, c->nloc * sizeof(double), hipMemcpyHostToDevice));
   DISPATCH_N(c->N, { hipLaunchKernelGGL(k_opdiv_test<N>, dim3(c->nblk), dim3(Cfg<N>::NT), 0, c->stream, c->d, (const double*)c->wv1, c->wp1); });
   HIPCHK(hipStreamSynchronize(c->stream));
   HIPCHK(hipMemcpy(out, c->wp1, c->npr * sizeof(double), hipMemcpyDeviceToHost));
@@ -1068,17 +1071,17 @@ int nsk_test_opgradt(nsk_ctx* c, const double* p, double* ox, double* oy) {
   DISPATCH_N(c->N, { hipLaunchKernelGGL(k_gradt<N>, dim3(c->nblk), dim3(Cfg<N>::NT), 0, c->stream, c->d, (const double*)c->wp1, c->wv1); });
   HIPCHK(hipStreamSynchronize(c->stream));
   HIPCHK(hipMemcpy(ox, c->wv1, c->nloc * sizeof(double), hipMemcpyDeviceToHost));
-  HIPCHK(hipMemcpy(oy, c->wv1 + c->nloc, c->nloc * sizeof(double), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(oy, c->wv1 + c->d.cs, c->nloc * sizeof(double), hipMemcpyDeviceToHost));
   return 0;
 }
 
 int nsk_test_convect(nsk_ctx* c, int adjoint, const double* u, const double* v, double* ox, double* oy) {
   HIPCHK(hipMemcpy(c->wv1, u, c->nloc * sizeof(double), hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(c->wv1 + c->nloc, v, c->nloc * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(c->wv1 + c->d.cs, v, c->nloc * sizeof(double), hipMemcpyHostToDevice));
   DISPATCH_N(c->N, { hipLaunchKernelGGL(k_convect<N>, dim3(c->nel), dim3(Cfg<N>::NTD), 0, c->stream, c->d, (const double*)c->wv1, c->wv2, adjoint); });
   HIPCHK(hipStreamSynchronize(c->stream));
   HIPCHK(hipMemcpy(ox, c->wv2, c->nloc * sizeof(double), hipMemcpyDeviceToHost));
-  HIPCHK(hipMemcpy(oy, c->wv2 + c->nloc, c->nloc * sizeof(double), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(oy, c->wv2 + c->d.cs, c->nloc * sizeof(double), hipMemcpyDeviceToHost));
   return 0;
 }
 
@@ -1094,8 +1097,8 @@ int nsk_test_eapply(nsk_ctx* c, const double* p, double* out) {
 int nsk_test_helm_solve(nsk_ctx* c, const double* rx, const double* ry, int order, double* ox, double* oy, int* iters) {
   Dev& d = c->d;
   HIPCHK(hipMemcpy(d.rloc, rx, c->nloc * sizeof(double), hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(d.rloc + c->nloc, ry, c->nloc * sizeof(double), hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(d.bloc, d.rloc, 2 * c->nloc * sizeof(double), hipMemcpyDeviceToDevice));
+  HIPCHK(hipMemcpy(d.rloc + d.cs, ry, c->nloc * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(d.bloc, d.rloc, 2 * d.cs * sizeof(double), hipMemcpyDeviceToDevice));
   HIPCHK(hipMemset(d.stats, 0, sizeof(Stats)));
   const StepCoef sc = make_coef(c, order, 0);
   const int nh = c->max_helm;
@@ -1105,7 +1108,7 @@ int nsk_test_helm_solve(nsk_ctx* c, const double* rx, const double* ry, int orde
   });
   HIPCHK(hipStreamSynchronize(c->stream));
   HIPCHK(hipMemcpy(ox, d.hx, c->nloc * sizeof(double), hipMemcpyDeviceToHost));
-  HIPCHK(hipMemcpy(oy, d.hx + c->nloc, c->nloc * sizeof(double), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(oy, d.hx + d.cs, c->nloc * sizeof(double), hipMemcpyDeviceToHost));
   Stats h; HIPCHK(hipMemcpy(&h, d.stats, sizeof(Stats), hipMemcpyDeviceToHost));
   if (iters) *iters = (int)h.helm_iters;
   return 0;

@@ -50,6 +50,9 @@ struct Stats {
 struct Dev {
   int nel, nblk, nvert, adj_dummy;
   long long nloc, npr;
+  long long cs, ps;              // component stride of velocity-mesh arrays / stride of the GMRES basis V
+                                 // (= nloc, npr on one rank; + ghost slots when elements are sharded)
+  long long npr_glob;            // pressure dofs over all ranks
   double nu, dt, vol, tol_helm, tol_pres;
   int tol_relative, max_mr, has_outflow, nproj_max;
   // bases

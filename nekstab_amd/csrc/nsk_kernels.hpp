@@ -280,7 +280,7 @@ __global__ __launch_bounds__(Cfg<N>::NTD) void k_convect(Dev d, const double* __
   for (int k = tid; k < NDD; k += NT) sDd[k] = d.Dd[k];
   if (tid < NN) {
     su[0][tid] = uin[e * NN + tid];
-    su[1][tid] = uin[d.nloc + e * NN + tid];
+    su[1][tid] = uin[d.cs + e * NN + tid];
   }
   __syncthreads();
   // interpolate in r: st[c][j][a] = sum_i Jd[a][i] u[j][i]
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(Cfg<N>::NTD) void k_convect(Dev d, const double* __
     const long long l = e * NN + tid;
     const double sb = d.spng[l] * d.bm1[l];
     bf[l] = -(sb * su[0][tid] + s0);
-    bf[d.nloc + l] = -(sb * su[1][tid] + s1);
+    bf[d.cs + l] = -(sb * su[1][tid] + s1);
   }
 }
 
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_rhs(Dev d, StepCoef sc) {
   const long long e = (long long)blockIdx.x * EPB + el;
   const bool act = (el < EPB) && (e < d.nel);
   const int j = nd / N, i = nd % N;
-  const long long l = e * NN + nd, nl = d.nloc;
+  const long long l = e * NN + nd, nl = d.cs;
   load_basis<N, EPB>(d, sD, sDt, sJ12, sD12, tid, NT);
   if (d.nproj_max > 0 && blockIdx.x == 0 && tid == 0) {
     GmresScal* G = d.gsc;
@@ -456,7 +456,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_helm(Dev d, StepCoef sc, int it,
   const long long e = (long long)blockIdx.x * EPB + el;
   const bool act = (el < EPB) && (e < d.nel);
   const int j = nd / N, i = nd % N;
-  const long long l = e * NN + nd, nl = d.nloc;
+  const long long l = e * NN + nd, nl = d.cs;
   const int par = it & 1, ppar = par ^ 1;
   if (it > 2 && d.hscal[ppar * 8 + 2] != 0.0 && d.hscal[ppar * 8 + 6] != 0.0) {   // finished earlier: cheapest exit
     if (blockIdx.x == 0 && tid < 8) d.hscal[par * 8 + tid] = d.hscal[ppar * 8 + tid];
@@ -596,7 +596,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_pres_rhs(Dev d, StepCoef sc, int
   const int tid = threadIdx.x, el = tid / NN, nd = tid % NN;
   const long long e = (long long)blockIdx.x * EPB + el;
   const bool act = (el < EPB) && (e < d.nel);
-  const long long l = e * NN + nd, nl = d.nloc;
+  const long long l = e * NN + nd, nl = d.cs;
   load_basis<N, EPB>(d, nullptr, nullptr, sJ12, sD12, tid, NT);
   if (check_helm && blockIdx.x == 0) {       // last partials -> final residual of the velocity solve
     double s[8];
@@ -674,7 +674,7 @@ __global__ __launch_bounds__(256) void k_ortho(Dev d) {
   const int tid = threadIdx.x;
   double sm[1];
   sum_partials<1>(d.gpart + d.nblk, d.nblk, sm, sred, tid, 256);
-  const double mean = sm[0] / (double)d.npr;
+  const double mean = sm[0] / (double)d.npr_glob;
   double v[1] = {0.0};
   const long long q = (long long)blockIdx.x * 256 + tid;
   if (q < d.npr) {
@@ -742,7 +742,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_gmres_update(Dev d, int j, doubl
 #pragma unroll
   for (int r = 0; r < (4 * MM + NT - 1) / NT; ++r) hatv[r] = (tid + r * NT < 4 * MM) ? d.hat[tid + r * NT] : 0.0;
   double wnew = 0.0;
-  if (act && nd < MM) wnew = d.V[(size_t)(j + 1) * d.npr + e * MM + nd];
+  if (act && nd < MM) wnew = d.V[(size_t)(j + 1) * d.ps + e * MM + nd];
   const int nv = (j < 0) ? 1 : j + 2;
   sum_partials_multi(d.gpart, d.nblk, nv, sh, tid, NT);
   double hn;
@@ -805,9 +805,9 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_gmres_update(Dev d, int j, doubl
     const long long q = e * MM + nd;
     double w = wnew;
 #pragma unroll 8
-    for (int k = 0; k <= j; ++k) w -= sh[k] * d.V[(size_t)k * d.npr + q];
+    for (int k = 0; k <= j; ++k) w -= sh[k] * d.V[(size_t)k * d.ps + q];
     w *= hinv;
-    d.V[(size_t)(j + 1) * d.npr + q] = w;
+    d.V[(size_t)(j + 1) * d.ps + q] = w;
     sv[el * MM + nd] = w;
   }
   lds_barrier();
@@ -974,7 +974,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_schwarz(Dev d, const double* __r
   if (act) {
     const long long l = e * NN + nd;
     d.yl[l] = gx;
-    d.yl[d.nloc + l] = gy;
+    d.yl[d.cs + l] = gy;
   }
 }
 
@@ -1004,7 +1004,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_gradt(Dev d, const double* __res
   if (act) {
     const long long l = e * NN + nd;
     yl[l] = gx;
-    yl[d.nloc + l] = gy;
+    yl[d.cs + l] = gy;
   }
 }
 
@@ -1030,11 +1030,11 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_divgs(Dev d, const double* __res
   double j12a = 0, d12a = 0;
   if (tid < NM) { j12a = d.J12[tid]; d12a = d.D12[tid]; }
   GsVals g0, g1;
-  if (act) { g0 = gs_load(yl, tab, l); g1 = gs_load(yl + d.nloc, tab, l); }
+  if (act) { g0 = gs_load(yl, tab, l); g1 = gs_load(yl + d.cs, tab, l); }
   if (tid < NM) { sJ12[tid] = j12a; sD12[tid] = d12a; }
   if (act) {
     su[(0 * EPB + el) * NN + nd] = bi * gs_sum(g0, yl, d, tab, l);
-    su[(1 * EPB + el) * NN + nd] = bi * gs_sum(g1, yl + d.nloc, d, tab, l);
+    su[(1 * EPB + el) * NN + nd] = bi * gs_sum(g1, yl + d.cs, d, tab, l);
   }
   NSK_STAMP(2);
   lds_barrier();
@@ -1048,7 +1048,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_divgs(Dev d, const double* __res
 #pragma unroll 4
     for (int k = 0; k <= j + 1; ++k) {
       double x = 0.0;
-      if (pact) x = w * ((k <= j) ? d.V[(size_t)k * d.npr + q] : w);
+      if (pact) x = w * ((k <= j) ? d.V[(size_t)k * d.ps + q] : w);
       x = wave_sum63(x);
       if (lane == 63) sdot[k * 4 + wv] = x;
     }
@@ -1111,7 +1111,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_pres_update(Dev d, StepCoef sc) 
   if (act) {
     const long long l = e * NN + nd;
     d.yl[l] = gx;
-    d.yl[d.nloc + l] = gy;
+    d.yl[d.cs + l] = gy;
   }
   if (blockIdx.x == 0 && tid == 0 && !G->done) atomicAdd((unsigned long long*)&d.stats->unconverged, 1ull);
 }
@@ -1134,9 +1134,9 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_vel_update_proj(Dev d, StepCoef 
     const long long l = e * NN + nd;
     const double bi = d.binv[l];
     const double vx = bi * gs_gather(d.yl, d, l);
-    const double vy = bi * gs_gather(d.yl + d.nloc, d, l);
+    const double vy = bi * gs_gather(d.yl + d.cs, d, l);
     d.u[l] += vx / sc.h2;
-    d.u[d.nloc + l] += vy / sc.h2;
+    d.u[d.cs + l] += vy / sc.h2;
     su[(0 * EPB + el) * NN + nd] = vx;
     su[(1 * EPB + el) * NN + nd] = vy;
   }
@@ -1213,7 +1213,7 @@ __global__ void k_vel_update(Dev d, StepCoef sc) {
   if (l >= d.nloc) return;
   const double f = d.binv[l] / sc.h2;
   d.u[l] += f * gs_gather(d.yl, d, l);
-  d.u[d.nloc + l] += f * gs_gather(d.yl + d.nloc, d, l);
+  d.u[d.cs + l] += f * gs_gather(d.yl + d.cs, d, l);
 }
 
 // ---------------------------------------------------------------------------
@@ -1357,7 +1357,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_opdiv_test(Dev d, const double* 
   load_basis<N, EPB>(d, nullptr, nullptr, sJ12, sD12, tid, NT);
   if (act) {
     su[(0 * EPB + el) * NN + nd] = u[e * NN + nd];
-    su[(1 * EPB + el) * NN + nd] = u[d.nloc + e * NN + nd];
+    su[(1 * EPB + el) * NN + nd] = u[d.cs + e * NN + nd];
   }
   __syncthreads();
   const double w = opdiv_tiles<N, EPB>(sJ12, sD12, su, sA, act, el, nd, d, e);
