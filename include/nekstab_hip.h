@@ -128,6 +128,21 @@ typedef struct {
 } nsk_stats;
 int nsk_get_stats(nsk_ctx* ctx, nsk_stats* s);
 
+/* ---- element sharding: one shard per rank, cut out of a full-mesh context --------
+ * part[e] = owning rank of global element e.  The parent's set-up (geometry, Jacobi diagonal,
+ * Schwarz patches, coarse inverse) is replicated; state, halos and reductions are per rank.
+ * Vectors of a shard hold its own elements only ([vx | vy | pr], local element order = ascending
+ * global element id).  Ranks that live in one process ("virtual ranks", what the single-GPU tests
+ * use) advance in lock-step through nsk_group_matvec with loop-back copies as transport; ranks in
+ * separate processes use RCCL (build with -DNSK_WITH_RCCL, nsk_comm_init_rccl). */
+int nsk_shard_create(nsk_ctx* parent, const int* part, int rank, int nranks, nsk_ctx** out);
+int nsk_group_matvec(nsk_ctx** shards, int n, int mode, nsk_vec* f, nsk_vec* q);
+int nsk_group_test(nsk_ctx** shards, int n, int which, const double* const* in, double* const* out);  /* 0: dssum, 1: E apply */
+/* rank-local pieces of update_hessenberg_matrix: partial bm1s dots and the projection update;
+ * the host (or an all-reduce) sums the partial dots over the ranks */
+int nsk_local_dots(nsk_ctx* ctx, nsk_vec f, const nsk_vec* Q, int nq, double* out);
+int nsk_project_out(nsk_ctx* ctx, nsk_vec f, const nsk_vec* Q, int nq, const double* h);
+
 /* measurement hook for bench.py: average duration (us) of `reps` back-to-back launches of a hot
  * kernel ("helm"), HIP events on the library's stream, full work in every launch */
 int nsk_bench_kernel(nsk_ctx* ctx, const char* name, int reps, double* avg_us);

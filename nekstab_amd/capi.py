@@ -67,6 +67,11 @@ SYMBOLS = {
     "nsk_basis_gemm": (C.c_int, [_vp, _vpp, C.c_int, _dp, C.c_int]),
     "nsk_basis_gemv": (C.c_int, [_vp, _vpp, C.c_int, _dp, _dp, _vp, _vp]),
     "nsk_seed_noise": (C.c_int, [_vp, _vp]),
+    "nsk_shard_create": (C.c_int, [_vp, C.POINTER(C.c_int), C.c_int, C.c_int, _vpp]),
+    "nsk_group_matvec": (C.c_int, [_vpp, C.c_int, C.c_int, _vpp, _vpp]),
+    "nsk_group_test": (C.c_int, [_vpp, C.c_int, C.c_int, C.POINTER(_dp), C.POINTER(_dp)]),
+    "nsk_local_dots": (C.c_int, [_vp, _vp, _vpp, C.c_int, _dp]),
+    "nsk_project_out": (C.c_int, [_vp, _vp, _vpp, C.c_int, _dp]),
     "nsk_bench_kernel": (C.c_int, [_vp, C.c_char_p, C.c_int, _dp]),
     "nsk_get_stats": (C.c_int, [_vp, C.POINTER(NskStats)]),
     "nsk_test_axhelm": (C.c_int, [_vp, _dp, C.c_double, C.c_double, _dp]),

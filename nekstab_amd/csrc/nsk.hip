@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <utility>
 #include <string>
 #include <vector>
 
@@ -68,6 +69,24 @@ struct nsk_ctx {
   // work vectors for tests / setup
   double *wv1 = nullptr, *wv2 = nullptr, *wp1 = nullptr, *wp2 = nullptr;
   std::vector<double> bm1s_host;
+  // ---- host copies kept for element sharding (nsk_shard_create)
+  std::vector<long long> h_gid;
+  std::vector<int> h_pidx, h_evert;
+  int PS = 0, coarse_lda = 0;
+  // ---- shard state (rank-local context cut out of a full-mesh parent)
+  nsk_ctx* parent = nullptr;
+  int rank = 0, nranks = 1;
+  std::vector<int> elems;                               // owned global elements
+  int nvh = 0;                                          // velocity halo entries = ghost slots
+  const int *vh_off = nullptr, *vh_idx = nullptr;       // pack CSR
+  std::vector<int> peers, vh_poff, vh_pcnt;             // per peer: slice of [0, nvh)
+  double *vsend = nullptr, *vrecv = nullptr;            // [4][nvh]
+  int nps = 0, npg = 0;                                 // pressure halo: send entries / ghost entries
+  const int* ph_sidx = nullptr;
+  std::vector<int> ph_soff, ph_scnt, ph_goff, ph_gcnt;  // per peer
+  double *psend = nullptr, *precv = nullptr;
+  double* rc_part = nullptr;                            // coarse restriction (all vertices), summed over ranks
+  void* comm = nullptr;                                 // ncclComm_t when ranks are real processes
 };
 
 template <class T>
@@ -190,6 +209,8 @@ static int build(nsk_ctx* c, const nsk_case& cs) {
   Dev& d = c->d;
   d.nel = nel; d.nblk = c->nblk; d.nloc = nloc; d.npr = npr; d.nu = 1.0 / cs.re;
   d.cs = nloc; d.ps = npr; d.npr_glob = npr;          // one rank: no ghost slots
+  d.nranks = 1; d.rank = 0;
+  c->h_gid.assign(cs.gid, cs.gid + nloc);
   d.tol_helm = cs.tol_helm > 0 ? cs.tol_helm : 1e-9;
   d.tol_pres = cs.tol_pres > 0 ? cs.tol_pres : 1e-7;
   d.tol_relative = cs.tol_relative; d.max_mr = c->max_pres; d.has_outflow = cs.has_outflow;
@@ -509,7 +530,7 @@ static int build(nsk_ctx* c, const nsk_case& cs) {
       std::vector<double> Ah(Ac.size());
       HIPCHK(hipMemcpy(Ah.data(), dA, Ah.size() * sizeof(double), hipMemcpyDeviceToHost));
       const int lda = ((nvert + 255) / 256) * 256;
-      d.coarse_lda = lda;
+      d.coarse_lda = lda; c->coarse_lda = lda;
       std::vector<float> Af((size_t)nvert * lda, 0.0f);
       for (int r = 0; r < nvert; ++r) for (int q = 0; q < nvert; ++q) Af[(size_t)r * lda + q] = (float)Ah[(size_t)r * nvert + q];
       if ((rc = dupload(c, &d.Acif, Af))) return rc;
@@ -525,6 +546,7 @@ static int build(nsk_ctx* c, const nsk_case& cs) {
     }
     if ((rc = dupload(c, &d.vtab, vtab))) return rc;
   }
+  c->h_evert = evert;
   if ((rc = dupload(c, &d.v_off, v_off)) || (rc = dupload(c, &d.v_ent, v_ent)) || (rc = dupload(c, &d.evert, evert)) ||
       (rc = dalloc(c, &d.xc, nvert))) return rc;
 
@@ -569,6 +591,7 @@ static int build(nsk_ctx* c, const nsk_case& cs) {
         for (int r = 0; r < MM; ++r) p_inv[(size_t)e * PS * MM + ((size_t)(q / 4) * MM + r) * 4 + (q % 4)] = (float)A[(size_t)r * np + q];   // [q/4][own row][q%4]
       }
     }
+    c->h_pidx = p_idx; c->PS = PS;
     if ((rc = dupload(c, &d.p_idx, p_idx)) || (rc = dupload(c, &d.p_inv, p_inv))) return rc;
   }
   for (int k = 0; k < 6; ++k) { c->cur_helm[k] = c->max_helm; c->cur_pres[k] = c->max_pres; }
@@ -733,10 +756,78 @@ static int run_map_adaptive(nsk_ctx* c, int adjoint, double* f, const double* q)
   }
 }
 
+#include "nsk_shard.inc"
+
 // ===========================================================================
 // C-ABI
 // ===========================================================================
 extern "C" {
+
+// Cut the shard of `rank` (part[e] = owner of global element e) out of a full-mesh context.
+int nsk_shard_create(nsk_ctx* parent, const int* part, int rank, int nranks, nsk_ctx** out) {
+  if (!parent || !part || !out) return fail(NSK_EINVAL, "bad argument");
+  return shard_create(parent, part, rank, nranks, out);
+}
+
+// f_r = map(q_r) for the ranks living in this process, in lock-step (virtual ranks: all of them).
+int nsk_group_matvec(nsk_ctx** shards, int n, int mode, nsk_vec* f, nsk_vec* q) {
+  if (!shards || n < 1 || !f || !q) return fail(NSK_EINVAL, "bad argument");
+  if (mode != NSK_DIRECT && mode != NSK_ADJOINT) return fail(NSK_EINVAL, "sharded runs: direct or adjoint map");
+  std::vector<nsk_ctx*> G(shards, shards + n);
+  return group_run_map(G, mode == NSK_ADJOINT, (double* const*)f, (const double* const*)q);
+}
+
+// test hook: which = 0: dssum of a velocity-mesh field across shards; 1: E = D B^-1 D^T apply
+int nsk_group_test(nsk_ctx** shards, int n, int which, const double* const* in, double* const* out) {
+  std::vector<nsk_ctx*> G(shards, shards + n);
+  int rc;
+  if (which == 0) {
+    for (int r = 0; r < n; ++r) HIPCHK(hipMemcpyAsync(G[r]->d.rloc, in[r], G[r]->nloc * sizeof(double), hipMemcpyHostToDevice, G[r]->stream));
+    if ((rc = xchg_vel(G, &Dev::rloc, 0, 1))) return rc;
+    for (int r = 0; r < n; ++r) {
+      nsk_ctx* c = G[r];
+      hipLaunchKernelGGL(k_dssum_test, dim3((unsigned)((c->nloc + 255) / 256)), dim3(256), 0, c->stream, c->d, (const double*)c->d.rloc, c->wv2);
+      HIPCHK(hipMemcpyAsync(out[r], c->wv2, c->nloc * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    }
+  } else if (which == 1) {
+    for (int r = 0; r < n; ++r) HIPCHK(hipMemcpyAsync(G[r]->wp1, in[r], G[r]->npr * sizeof(double), hipMemcpyHostToDevice, G[r]->stream));
+    DISPATCH_N(G[0]->N, {
+      for (nsk_ctx* c : G) hipLaunchKernelGGL(k_gradt<N>, dim3(c->nblk), dim3(Cfg<N>::NT), 0, c->stream, c->d, (const double*)c->wp1, c->d.yl);
+      if ((rc = xchg_vel(G, &Dev::yl, 0, 2))) return rc;
+      for (nsk_ctx* c : G) hipLaunchKernelGGL(k_divgs<N>, dim3(c->nblk), dim3(Cfg<N>::NT), 0, c->stream, c->d, (const double*)c->d.yl, c->wp2, -1, 0);
+    });
+    for (int r = 0; r < n; ++r) HIPCHK(hipMemcpyAsync(out[r], G[r]->wp2, G[r]->npr * sizeof(double), hipMemcpyDeviceToHost, G[r]->stream));
+  } else return fail(NSK_EINVAL, "unknown test");
+  HIPCHK(hipStreamSynchronize(G[0]->stream));
+  return 0;
+}
+
+// rank-local part of the bm1s inner products (f, Q_k): the caller sums over ranks
+int nsk_local_dots(nsk_ctx* c, nsk_vec f, const nsk_vec* Q, int nq, double* out) {
+  if (!c || !f || !Q || !out || nq < 1) return fail(NSK_EINVAL, "bad argument");
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (nq > 1024) return fail(NSK_EINVAL, "too many vectors");
+  for (int k = 0; k < nq; ++k) ((double**)c->hpin)[k] = (double*)Q[k];
+  HIPCHK(hipMemcpyAsync(c->kptr, c->hpin, nq * sizeof(double*), hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_dots, dim3(c->kblk), dim3(256), 0, c->stream, (const double*)f, (const double* const*)c->kptr, nq, c->d.bm1s, c->nloc, c->kpart, c->kblk);
+  hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, c->stream, (const double*)c->kpart, nq, c->kblk, c->kout);
+  HIPCHK(hipMemcpyAsync(out, c->kout, nq * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// f -= sum_k h_k Q_k over the rank-local state (coefficients from the host)
+int nsk_project_out(nsk_ctx* c, nsk_vec f, const nsk_vec* Q, int nq, const double* h) {
+  if (!c || !f || !Q || !h || nq < 1 || nq > 1024) return fail(NSK_EINVAL, "bad argument");
+  HIPCHK(hipStreamSynchronize(c->stream));
+  for (int k = 0; k < nq; ++k) ((double**)c->hpin)[k] = (double*)Q[k];
+  HIPCHK(hipMemcpyAsync(c->kptr, c->hpin, nq * sizeof(double*), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(c->kout, h, nq * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_project_out, dim3((unsigned)((c->nstate + 255) / 256)), dim3(256), 0, c->stream, (double*)f, (const double* const*)c->kptr, nq, (const double*)c->kout, c->nstate);
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
 
 const char* nsk_last_error(void) { return g_err.c_str(); }
 
@@ -758,7 +849,7 @@ int nsk_finalize(nsk_ctx* c) {
   for (auto& a : c->graphs) for (auto& g : a) if (g.exec) (void)hipGraphExecDestroy(g.exec);
   for (void* p : c->allocs) (void)hipFree(p);
   if (c->hpin) (void)hipHostFree(c->hpin);
-  if (c->stream) (void)hipStreamDestroy(c->stream);
+  if (c->stream && !c->parent) (void)hipStreamDestroy(c->stream);      // shards share the parent's stream
   delete c;
   return 0;
 }

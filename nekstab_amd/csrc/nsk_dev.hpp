@@ -87,6 +87,12 @@ struct Dev {
   const long long* p_invoff;
   Stats* stats;
   unsigned long long* dbg;       // diagnostic stamps (NSK_STAMPS builds)
+  // element sharding (one shard per rank): nranks > 1 => the dot-product sums come from the
+  // all-reduced totals below instead of the local per-workgroup partials, and the ghost slots
+  // behind every velocity-mesh array / GMRES basis vector hold the neighbours' contributions
+  int nranks, rank;
+  double *htot;                  // [2 parities][8]  Helmholtz sums over all ranks
+  double *gtot;                  // [MAXMR + 2]      GMRES sums over all ranks
 };
 
 }  // namespace nsk

@@ -471,10 +471,15 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_helm(Dev d, StepCoef sc, int it,
   }
   double ps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (it > 0) {
-    const double* part = d.hpart + (size_t)ppar * 8 * d.nblk;
-    for (int k = tid; k < d.nblk; k += NT) {
+    if (d.nranks > 1) {                 // all-reduced totals (k_tot + all-reduce ran after the previous launch)
 #pragma unroll
-      for (int q = 0; q < 8; ++q) ps[q] += part[(size_t)q * d.nblk + k];
+      for (int q = 0; q < 8; ++q) ps[q] = (tid == 0) ? d.htot[ppar * 8 + q] : 0.0;
+    } else {
+      const double* part = d.hpart + (size_t)ppar * 8 * d.nblk;
+      for (int k = tid; k < d.nblk; k += NT) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) ps[q] += part[(size_t)q * d.nblk + k];
+      }
     }
   }
   int4 tab = make_int4(0, -1, -1, -1);
@@ -483,7 +488,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_helm(Dev d, StepCoef sc, int it,
   if (act) {
     tab = d.gs_tab[l];
     bm = d.bm1[l]; g1 = d.g1[l]; g2 = d.g2[l]; g4 = d.g4[l]; mk = d.mask[l]; mi = d.minv[l];
-    di = d.dinv[(size_t)(sc.k - 1) * nl + l];
+    di = d.dinv[(size_t)(sc.k - 1) * d.nloc + l];
     if (it > 0) {
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
@@ -600,7 +605,12 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_pres_rhs(Dev d, StepCoef sc, int
   load_basis<N, EPB>(d, nullptr, nullptr, sJ12, sD12, tid, NT);
   if (check_helm && blockIdx.x == 0) {       // last partials -> final residual of the velocity solve
     double s[8];
-    sum_partials<8>(d.hpart + (size_t)helm_par * 8 * d.nblk, d.nblk, s, sred, tid, NT);
+    if (d.nranks > 1) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) s[q] = d.htot[helm_par * 8 + q];
+    } else {
+      sum_partials<8>(d.hpart + (size_t)helm_par * 8 * d.nblk, d.nblk, s, sred, tid, NT);
+    }
     if (tid == 0) {
       double worst = 0.0; int bad = 0;
       for (int c = 0; c < 2; ++c) {
@@ -673,7 +683,8 @@ __global__ __launch_bounds__(256) void k_ortho(Dev d) {
   __shared__ double sred[16];
   const int tid = threadIdx.x;
   double sm[1];
-  sum_partials<1>(d.gpart + d.nblk, d.nblk, sm, sred, tid, 256);
+  if (d.nranks > 1) sm[0] = d.gtot[1];
+  else sum_partials<1>(d.gpart + d.nblk, d.nblk, sm, sred, tid, 256);
   const double mean = sm[0] / (double)d.npr_glob;
   double v[1] = {0.0};
   const long long q = (long long)blockIdx.x * 256 + tid;
@@ -744,7 +755,12 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_gmres_update(Dev d, int j, doubl
   double wnew = 0.0;
   if (act && nd < MM) wnew = d.V[(size_t)(j + 1) * d.ps + e * MM + nd];
   const int nv = (j < 0) ? 1 : j + 2;
-  sum_partials_multi(d.gpart, d.nblk, nv, sh, tid, NT);
+  if (d.nranks > 1) {
+    if (tid < nv) sh[tid] = d.gtot[tid];
+    lds_barrier();
+  } else {
+    sum_partials_multi(d.gpart, d.nblk, nv, sh, tid, NT);
+  }
   double hn;
   if (j < 0) hn = sqrt(sh[0]);
   else {
@@ -879,7 +895,7 @@ __global__ __launch_bounds__(256) void k_coarse_restrict(Dev d, double* __restri
   double sv = 0.0;
   if (v < d.nvert) {
     const int4 a = reinterpret_cast<const int4*>(d.vtab)[2 * v], b = reinterpret_cast<const int4*>(d.vtab)[2 * v + 1];
-    const double e0 = d.ec[a.x];
+    const double e0 = (a.x >= 0) ? d.ec[a.x] : 0.0;     // a vertex may have no element on this rank
     const double e1 = (a.y >= 0) ? d.ec[a.y] : 0.0, e2 = (a.z >= 0) ? d.ec[a.z] : 0.0, e3 = (a.w >= 0) ? d.ec[a.w] : 0.0;
     const double e4 = (b.x >= 0) ? d.ec[b.x] : 0.0, e5 = (b.y >= 0) ? d.ec[b.y] : 0.0, e6 = (b.z >= 0) ? d.ec[b.z] : 0.0;
     const double e7 = (b.w >= 0) ? d.ec[b.w] : 0.0;
@@ -1316,6 +1332,62 @@ __global__ __launch_bounds__(256) void k_basis_gemm_mfma(double* const* __restri
       const int c = ct * 16 + kk + 4 * r;
       if (c < k && iok) Q[c][i] = acc[ct][r];
     }
+}
+
+// ---------------------------------------------------------------------------
+// element sharding: halo of the gather-scatter and of the Schwarz overlap, rank-level sums
+// ---------------------------------------------------------------------------
+// sendbuf[c][k] = sum of this rank's copies of shared node k (one entry per (peer, shared global node))
+__global__ void k_halo_pack(const double* __restrict__ f, long long cstride, int ncomp, const int* __restrict__ off,
+                            const int* __restrict__ idx, int n, double* __restrict__ sendbuf) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  for (int c = 0; c < ncomp; ++c) {
+    double s = 0.0;
+    for (int i = off[k]; i < off[k + 1]; ++i) s += f[c * cstride + idx[i]];
+    sendbuf[(size_t)c * n + k] = s;
+  }
+}
+// ghost slots of every component <- received partial sums
+__global__ void k_halo_unpack(double* __restrict__ f, long long cstride, long long nloc, int ncomp, int n,
+                              const double* __restrict__ recvbuf) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  for (int c = 0; c < ncomp; ++c) f[c * cstride + nloc + k] = recvbuf[(size_t)c * n + k];
+}
+// pressure-vector halo (Schwarz overlap into neighbouring ranks' elements): plain gather / copy
+__global__ void k_phalo_pack(const double* __restrict__ v, const int* __restrict__ idx, int n, double* __restrict__ sendbuf) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) sendbuf[k] = v[idx[k]];
+}
+// rank-level totals of nv arrays of per-workgroup partials (fixed order), one workgroup
+__global__ __launch_bounds__(256) void k_tot(const double* __restrict__ part, int nblk, int nv, double* __restrict__ tot) {
+  __shared__ double sh[MAXMR + 8];
+  sum_partials_multi(part, nblk, nv, sh, threadIdx.x, 256);
+  if ((int)threadIdx.x < nv) tot[threadIdx.x] = sh[threadIdx.x];
+}
+// loop-back all-reduce for virtual ranks living in one process: every buffer <- sum of all (rank order)
+__global__ void k_loop_allreduce(double* const* __restrict__ bufs, int nr, int n) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  double s = 0.0;
+  for (int r = 0; r < nr; ++r) s += bufs[r][k];
+  for (int r = 0; r < nr; ++r) bufs[r][k] = s;
+}
+struct LoopPack { double* p[16]; };
+__global__ void k_loop_allreduce_pack(LoopPack pk, int nr, int n) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  double s = 0.0;
+  for (int r = 0; r < nr; ++r) s += pk.p[r][k];
+  for (int r = 0; r < nr; ++r) pk.p[r][k] = s;
+}
+// gather whole elements out of an element-major array (shard creation)
+template <class T>
+__global__ void k_slice_elems(const T* __restrict__ src, T* __restrict__ dst, const int* __restrict__ elems, int nel, int per) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)nel * per) return;
+  dst[t] = src[(size_t)elems[t / per] * per + t % per];
 }
 
 // local axhelm for tests

@@ -1,0 +1,191 @@
+"""Element-sharded execution: partition of the elements over ranks and a backend
+with the NekStabHip vector interface whose vectors are lists of per-rank device vectors.
+
+``ShardGroup`` drives R *virtual ranks* inside one process (lock-step launches, loop-back copies
+as transport) -- the mode the single-GPU tests use to prove that the sharded path reproduces the
+single-rank result.  With one process per GPU the same shard contexts talk over RCCL
+(``nsk_comm_init_rccl``; not exercised on the 1-GPU test box).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from .capi import NekStabHip, NskError, _dp
+
+
+def partition_rcb(case, nranks: int) -> np.ndarray:
+    """Recursive coordinate bisection of element centroids -> owner rank per element.
+    (The reference partitions with the .ma2 RSB tree; any partition of whole elements works.)"""
+    cx = case.x.mean(axis=(1, 2))
+    cy = case.y.mean(axis=(1, 2))
+    part = np.zeros(case.nel, dtype=np.int32)
+
+    def rec(idx, r0, nr):
+        if nr == 1:
+            part[idx] = r0
+            return
+        nl = nr // 2
+        span_x, span_y = np.ptp(cx[idx]), np.ptp(cy[idx])
+        key = cx[idx] if span_x >= span_y else cy[idx]
+        order = idx[np.argsort(key, kind="stable")]
+        cut = len(order) * nl // nr
+        rec(order[:cut], r0, nl)
+        rec(order[cut:], r0 + nl, nr - nl)
+
+    rec(np.arange(case.nel), 0, nranks)
+    return part
+
+
+class ShardVec:
+    def __init__(self, parts):
+        self.parts = parts            # one device handle per rank
+
+
+class ShardGroup:
+    """R virtual ranks of one full-mesh context; same interface as NekStabHip for krylov.py."""
+
+    def __init__(self, full: NekStabHip, case, nranks: int, part=None):
+        self.full, self.lib, self.R = full, full.lib, nranks
+        self.part = np.ascontiguousarray(partition_rcb(case, nranks) if part is None else part, dtype=np.int32)
+        self.nsteps, self.dt = full.nsteps, full.dt
+        self.nel, self.lx1, self.lx2 = full.nel, full.lx1, full.lx2
+        self.npres, self.nvel = full.npres, full.nvel
+        self.elems = [np.where(self.part == r)[0] for r in range(nranks)]
+        self.ctx = []
+        for r in range(nranks):
+            out = C.c_void_p()
+            self._chk(self.lib.nsk_shard_create(full.ctx, self.part.ctypes.data_as(C.POINTER(C.c_int)), r, nranks, C.byref(out)))
+            self.ctx.append(out)
+        self._arr = (C.c_void_p * nranks)(*[c.value for c in self.ctx])
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise NskError(rc, self.lib.nsk_last_error().decode())
+
+    def close(self):
+        for c in self.ctx:
+            self.lib.nsk_finalize(c)
+        self.ctx = []
+
+    # ---- vectors
+    def alloc(self, n=1):
+        per = []
+        for c in self.ctx:
+            arr = (C.c_void_p * n)()
+            self._chk(self.lib.nsk_vec_alloc(c, n, arr))
+            per.append([C.c_void_p(arr[i]) for i in range(n)])
+        return [ShardVec([per[r][i] for r in range(self.R)]) for i in range(n)]
+
+    def free(self, vecs):
+        for r, c in enumerate(self.ctx):
+            arr = (C.c_void_p * len(vecs))(*[v.parts[r].value for v in vecs])
+            self._chk(self.lib.nsk_vec_free(c, len(vecs), arr))
+
+    def upload(self, v, vx, vy, pr):
+        for r, c in enumerate(self.ctx):
+            e = self.elems[r]
+            a, b, p = (np.ascontiguousarray(f[e], dtype=np.float64) for f in (vx, vy, pr))
+            self._chk(self.lib.nsk_vec_upload(c, v.parts[r], a.ctypes.data_as(_dp), b.ctypes.data_as(_dp), p.ctypes.data_as(_dp)))
+
+    def download(self, v):
+        n, m = self.lx1, self.lx2
+        vx = np.empty((self.nel, n, n)); vy = np.empty((self.nel, n, n)); pr = np.empty((self.nel, m, m))
+        for r, c in enumerate(self.ctx):
+            e = self.elems[r]
+            a = np.empty((len(e), n, n)); b = np.empty((len(e), n, n)); p = np.empty((len(e), m, m))
+            self._chk(self.lib.nsk_vec_download(c, v.parts[r], a.ctypes.data_as(_dp), b.ctypes.data_as(_dp), p.ctypes.data_as(_dp)))
+            vx[e], vy[e], pr[e] = a, b, p
+        return vx, vy, pr
+
+    def group_test(self, which, field):
+        """kernel-level check across shards: which=0 dssum (velocity mesh), 1 E-apply (pressure mesh)"""
+        ins = [np.ascontiguousarray(field[e], dtype=np.float64) for e in self.elems]
+        outs = [np.empty_like(a) for a in ins]
+        ia = (_dp * self.R)(*[a.ctypes.data_as(_dp) for a in ins])
+        oa = (_dp * self.R)(*[a.ctypes.data_as(_dp) for a in outs])
+        self._chk(self.lib.nsk_group_test(self._arr, self.R, which, ia, oa))
+        full = np.empty_like(np.asarray(field, dtype=np.float64))
+        for e, o in zip(self.elems, outs):
+            full[e] = o
+        return full
+
+    # ---- operator
+    def matvec(self, f, q, mode=0):
+        fa = (C.c_void_p * self.R)(*[p.value for p in f.parts])
+        qa = (C.c_void_p * self.R)(*[p.value for p in q.parts])
+        rc = self.lib.nsk_group_matvec(self._arr, self.R, mode, fa, qa)
+        if rc != 0:
+            from .capi import NskStats
+            st = NskStats(); self.lib.nsk_get_stats(self.ctx[0], C.byref(st))
+            raise NskError(rc, self.lib.nsk_last_error().decode() + " stats=" + str({f: getattr(st, f) for f, _ in NskStats._fields_}))
+
+    def set_nsteps(self, n):
+        for c in self.ctx:
+            self._chk(self.lib.nsk_set_nsteps(c, n))
+        self.nsteps = n
+
+    # ---- vector algebra: rank-local kernels + a sum over ranks (all-reduce when ranks are processes)
+    def _dots(self, f, Q):
+        tot = np.zeros(len(Q))
+        for r, c in enumerate(self.ctx):
+            arr = (C.c_void_p * len(Q))(*[v.parts[r].value for v in Q])
+            out = np.zeros(len(Q))
+            self._chk(self.lib.nsk_local_dots(c, f.parts[r], arr, len(Q), out.ctypes.data_as(_dp)))
+            tot += out
+        return tot
+
+    def dot(self, p, q):
+        return float(self._dots(p, [q])[0])
+
+    def norm(self, p):
+        return float(np.sqrt(self.dot(p, p)))
+
+    def scal(self, p, a):
+        for r, c in enumerate(self.ctx):
+            self._chk(self.lib.nsk_scal(c, p.parts[r], a))
+
+    def axpy(self, p, a, q):
+        for r, c in enumerate(self.ctx):
+            self._chk(self.lib.nsk_axpy(c, p.parts[r], a, q.parts[r]))
+
+    def copy(self, dst, src):
+        for r, c in enumerate(self.ctx):
+            self._chk(self.lib.nsk_copy(c, dst.parts[r], src.parts[r]))
+
+    def zero(self, p):
+        for r, c in enumerate(self.ctx):
+            self._chk(self.lib.nsk_zero(c, p.parts[r]))
+
+    def orth(self, f, Q):
+        """update_hessenberg_matrix (core/krylov_decomposition.f:116-202): two projection passes
+        with globally summed coefficients, then normalisation."""
+        h = np.zeros(len(Q))
+        for _ in range(2):
+            if not Q:
+                break
+            cpass = self._dots(f, Q)
+            for r, c in enumerate(self.ctx):
+                arr = (C.c_void_p * len(Q))(*[v.parts[r].value for v in Q])
+                self._chk(self.lib.nsk_project_out(c, f.parts[r], arr, len(Q), cpass.ctypes.data_as(_dp)))
+            h += cpass
+        beta = self.norm(f)
+        self.scal(f, 1.0 / beta)
+        return h, beta
+
+    def basis_gemm(self, Q, Z):
+        k = len(Q)
+        Zc = np.asfortranarray(Z, dtype=np.float64)
+        for r, c in enumerate(self.ctx):
+            arr = (C.c_void_p * k)(*[v.parts[r].value for v in Q])
+            self._chk(self.lib.nsk_basis_gemm(c, arr, k, Zc.ctypes.data_as(_dp), Zc.shape[0]))
+
+    def basis_gemv(self, Q, y, re, im=None):
+        k = len(Q)
+        yr = np.ascontiguousarray(np.real(y), dtype=np.float64)
+        yi = np.ascontiguousarray(np.imag(y), dtype=np.float64)
+        for r, c in enumerate(self.ctx):
+            arr = (C.c_void_p * k)(*[v.parts[r].value for v in Q])
+            self._chk(self.lib.nsk_basis_gemv(c, arr, k, yr.ctypes.data_as(_dp), yi.ctypes.data_as(_dp) if im is not None else None,
+                                              re.parts[r], im.parts[r] if im is not None else None))
