@@ -137,6 +137,11 @@ int nsk_get_stats(nsk_ctx* ctx, nsk_stats* s);
  * separate processes use RCCL (build with -DNSK_WITH_RCCL, nsk_comm_init_rccl). */
 int nsk_shard_create(nsk_ctx* parent, const int* part, int rank, int nranks, nsk_ctx** out);
 int nsk_group_matvec(nsk_ctx** shards, int n, int mode, nsk_vec* f, nsk_vec* q);
+/* RCCL transport, one process per GPU: rank 0 creates the id, everybody calls init on its shard;
+ * afterwards nsk_group_matvec(&shard, 1, ...) exchanges halos / all-reduces over xGMI. */
+int nsk_comm_unique_id(unsigned char* out128);
+int nsk_comm_init_rccl(nsk_ctx* shard, const unsigned char* id128);
+int nsk_allreduce_host(nsk_ctx* shard, double* buf, int n);
 int nsk_group_test(nsk_ctx** shards, int n, int which, const double* const* in, double* const* out);  /* 0: dssum, 1: E apply */
 /* rank-local pieces of update_hessenberg_matrix: partial bm1s dots and the projection update;
  * the host (or an all-reduce) sums the partial dots over the ranks */

@@ -69,6 +69,9 @@ SYMBOLS = {
     "nsk_seed_noise": (C.c_int, [_vp, _vp]),
     "nsk_shard_create": (C.c_int, [_vp, C.POINTER(C.c_int), C.c_int, C.c_int, _vpp]),
     "nsk_group_matvec": (C.c_int, [_vpp, C.c_int, C.c_int, _vpp, _vpp]),
+    "nsk_comm_unique_id": (C.c_int, [_vp]),
+    "nsk_comm_init_rccl": (C.c_int, [_vp, _vp]),
+    "nsk_allreduce_host": (C.c_int, [_vp, _dp, C.c_int]),
     "nsk_group_test": (C.c_int, [_vpp, C.c_int, C.c_int, C.POINTER(_dp), C.POINTER(_dp)]),
     "nsk_local_dots": (C.c_int, [_vp, _vp, _vpp, C.c_int, _dp]),
     "nsk_project_out": (C.c_int, [_vp, _vp, _vpp, C.c_int, _dp]),

@@ -777,6 +777,37 @@ int nsk_group_matvec(nsk_ctx** shards, int n, int mode, nsk_vec* f, nsk_vec* q) 
   return group_run_map(G, mode == NSK_ADJOINT, (double* const*)f, (const double* const*)q);
 }
 
+// ---- RCCL transport for ranks in separate processes (one process per GPU) ----
+int nsk_comm_unique_id(unsigned char* out128) {
+  if (!out128) return fail(NSK_EINVAL, "bad argument");
+  if (!rccl_rt::load()) return fail(NSK_EHIP, "librccl not found");
+  rccl_rt::UniqueId id;
+  if (rccl_rt::GetUniqueId(&id) != 0) return fail(NSK_EHIP, "ncclGetUniqueId failed");
+  std::memcpy(out128, id.internal, 128);
+  return 0;
+}
+int nsk_comm_init_rccl(nsk_ctx* shard, const unsigned char* id128) {
+  if (!shard || !id128 || !shard->parent) return fail(NSK_EINVAL, "needs a shard context");
+  if (!rccl_rt::load()) return fail(NSK_EHIP, "librccl not found");
+  rccl_rt::UniqueId id;
+  std::memcpy(id.internal, id128, 128);
+  rccl_rt::Comm comm = nullptr;
+  if (rccl_rt::CommInitRank(&comm, shard->nranks, id, shard->rank) != 0) return fail(NSK_EHIP, "ncclCommInitRank failed");
+  shard->comm = comm;
+  return 0;
+}
+// sum a small host array over the ranks (Krylov inner products), through the device
+int nsk_allreduce_host(nsk_ctx* shard, double* buf, int n) {
+  if (!shard || !buf || n < 1 || n > 1024) return fail(NSK_EINVAL, "bad argument");
+  if (!shard->comm) return 0;                                   // single process: nothing to do
+  HIPCHK(hipMemcpyAsync(shard->kout, buf, n * sizeof(double), hipMemcpyHostToDevice, shard->stream));
+  if (rccl_rt::AllReduce(shard->kout, shard->kout, n, rccl_rt::kDouble, rccl_rt::kSum, shard->comm, shard->stream) != 0)
+    return fail(NSK_EHIP, "ncclAllReduce failed");
+  HIPCHK(hipMemcpyAsync(buf, shard->kout, n * sizeof(double), hipMemcpyDeviceToHost, shard->stream));
+  HIPCHK(hipStreamSynchronize(shard->stream));
+  return 0;
+}
+
 // test hook: which = 0: dssum of a velocity-mesh field across shards; 1: E = D B^-1 D^T apply
 int nsk_group_test(nsk_ctx** shards, int n, int which, const double* const* in, double* const* out) {
   std::vector<nsk_ctx*> G(shards, shards + n);
@@ -849,6 +880,7 @@ int nsk_finalize(nsk_ctx* c) {
   for (auto& a : c->graphs) for (auto& g : a) if (g.exec) (void)hipGraphExecDestroy(g.exec);
   for (void* p : c->allocs) (void)hipFree(p);
   if (c->hpin) (void)hipHostFree(c->hpin);
+  if (c->comm && rccl_rt::CommDestroy) (void)rccl_rt::CommDestroy(c->comm);
   if (c->stream && !c->parent) (void)hipStreamDestroy(c->stream);      // shards share the parent's stream
   delete c;
   return 0;

@@ -189,3 +189,117 @@ class ShardGroup:
             arr = (C.c_void_p * k)(*[v.parts[r].value for v in Q])
             self._chk(self.lib.nsk_basis_gemv(c, arr, k, yr.ctypes.data_as(_dp), yi.ctypes.data_as(_dp) if im is not None else None,
                                               re.parts[r], im.parts[r] if im is not None else None))
+
+
+class ShardRank:
+    """One rank of an element-sharded run, one process per GPU; halos and reductions over RCCL.
+
+    Every process builds the full-mesh parent context on its own GPU (replicated set-up), cuts its
+    shard, and joins the communicator whose id rank 0 created (``unique_id`` is exchanged by the
+    caller, e.g. with ``torch.distributed.broadcast``).  Same vector interface as NekStabHip, with
+    vectors holding this rank's elements only."""
+
+    def __init__(self, full: NekStabHip, case, rank: int, nranks: int, unique_id: bytes | None, part=None):
+        self.full, self.lib, self.rank, self.nranks = full, full.lib, rank, nranks
+        self.part = np.ascontiguousarray(partition_rcb(case, nranks) if part is None else part, dtype=np.int32)
+        self.elems = np.where(self.part == rank)[0]
+        self.nsteps, self.dt = full.nsteps, full.dt
+        self.lx1, self.lx2 = full.lx1, full.lx2
+        self.nel = len(self.elems)
+        self.npres, self.nvel = self.nel * self.lx2 ** 2, self.nel * self.lx1 ** 2
+        self.ctx = C.c_void_p()
+        self._chk(self.lib.nsk_shard_create(full.ctx, self.part.ctypes.data_as(C.POINTER(C.c_int)), rank, nranks, C.byref(self.ctx)))
+        if unique_id is not None:
+            buf = C.create_string_buffer(bytes(unique_id), 128)
+            self._chk(self.lib.nsk_comm_init_rccl(self.ctx, C.cast(buf, C.c_void_p)))
+        self._one = (C.c_void_p * 1)(self.ctx.value)
+
+    @staticmethod
+    def new_unique_id(lib) -> bytes:
+        buf = C.create_string_buffer(128)
+        rc = lib.nsk_comm_unique_id(C.cast(buf, C.c_void_p))
+        if rc != 0:
+            raise NskError(rc, lib.nsk_last_error().decode())
+        return buf.raw
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise NskError(rc, self.lib.nsk_last_error().decode())
+
+    def close(self):
+        if self.ctx:
+            self.lib.nsk_finalize(self.ctx)
+            self.ctx = C.c_void_p()
+
+    def alloc(self, n=1):
+        arr = (C.c_void_p * n)()
+        self._chk(self.lib.nsk_vec_alloc(self.ctx, n, arr))
+        return [C.c_void_p(arr[i]) for i in range(n)]
+
+    def free(self, vecs):
+        arr = (C.c_void_p * len(vecs))(*[v.value for v in vecs])
+        self._chk(self.lib.nsk_vec_free(self.ctx, len(vecs), arr))
+
+    def upload(self, v, vx, vy, pr):
+        """vx, vy, pr: full-mesh arrays; this rank keeps its own elements."""
+        a, b, p = (np.ascontiguousarray(f[self.elems], dtype=np.float64) for f in (vx, vy, pr))
+        self._chk(self.lib.nsk_vec_upload(self.ctx, v, a.ctypes.data_as(_dp), b.ctypes.data_as(_dp), p.ctypes.data_as(_dp)))
+
+    def download_local(self, v):
+        n, m = self.lx1, self.lx2
+        a = np.empty((self.nel, n, n)); b = np.empty((self.nel, n, n)); p = np.empty((self.nel, m, m))
+        self._chk(self.lib.nsk_vec_download(self.ctx, v, a.ctypes.data_as(_dp), b.ctypes.data_as(_dp), p.ctypes.data_as(_dp)))
+        return a, b, p
+
+    def matvec(self, f, q, mode=0):
+        fa = (C.c_void_p * 1)(f.value)
+        qa = (C.c_void_p * 1)(q.value)
+        self._chk(self.lib.nsk_group_matvec(self._one, 1, mode, fa, qa))
+
+    def set_nsteps(self, n):
+        self._chk(self.lib.nsk_set_nsteps(self.ctx, n))
+        self.nsteps = n
+
+    def _dots(self, f, Q):
+        arr = (C.c_void_p * len(Q))(*[v.value for v in Q])
+        out = np.zeros(len(Q))
+        self._chk(self.lib.nsk_local_dots(self.ctx, f, arr, len(Q), out.ctypes.data_as(_dp)))
+        self._chk(self.lib.nsk_allreduce_host(self.ctx, out.ctypes.data_as(_dp), len(Q)))     # sum over ranks
+        return out
+
+    def dot(self, p, q):
+        return float(self._dots(p, [q])[0])
+
+    def norm(self, p):
+        return float(np.sqrt(self.dot(p, p)))
+
+    def scal(self, p, a):
+        self._chk(self.lib.nsk_scal(self.ctx, p, a))
+
+    def axpy(self, p, a, q):
+        self._chk(self.lib.nsk_axpy(self.ctx, p, a, q))
+
+    def copy(self, dst, src):
+        self._chk(self.lib.nsk_copy(self.ctx, dst, src))
+
+    def zero(self, p):
+        self._chk(self.lib.nsk_zero(self.ctx, p))
+
+    def orth(self, f, Q):
+        h = np.zeros(len(Q))
+        for _ in range(2):
+            if not Q:
+                break
+            cpass = self._dots(f, Q)
+            arr = (C.c_void_p * len(Q))(*[v.value for v in Q])
+            self._chk(self.lib.nsk_project_out(self.ctx, f, arr, len(Q), cpass.ctypes.data_as(_dp)))
+            h += cpass
+        beta = self.norm(f)
+        self.scal(f, 1.0 / beta)
+        return h, beta
+
+    def basis_gemm(self, Q, Z):
+        k = len(Q)
+        Zc = np.asfortranarray(Z, dtype=np.float64)
+        arr = (C.c_void_p * k)(*[v.value for v in Q])
+        self._chk(self.lib.nsk_basis_gemm(self.ctx, arr, k, Zc.ctypes.data_as(_dp), Zc.shape[0]))

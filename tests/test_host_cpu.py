@@ -104,3 +104,22 @@ def test_two_rank_gloo_timing_reduction(tmp_path):
                          capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert out.stdout.count("ok") == 2
+
+
+@pytest.mark.parametrize("nranks", [2, 3, 8])
+def test_partition_rcb(case6, nranks):
+    """Element partition for sharded runs: every element owned once, balanced, deterministic, and
+    spatially compact (few interface nodes compared with a random partition)."""
+    from nekstab_amd.sharded import partition_rcb
+    p = partition_rcb(case6, nranks)
+    assert p.shape == (case6.nel,) and p.min() == 0 and p.max() == nranks - 1
+    cnt = np.bincount(p, minlength=nranks)
+    assert cnt.max() - cnt.min() <= 1
+    assert np.array_equal(p, partition_rcb(case6, nranks))
+
+    def interface_nodes(part):
+        owners = np.zeros(case6.nglob, dtype=np.int64)
+        np.bitwise_or.at(owners, case6.gid.ravel(), np.repeat(1 << part, case6.lx1 ** 2))
+        return int(np.sum((owners & (owners - 1)) != 0))
+    rng = np.random.default_rng(0)
+    assert interface_nodes(p) < 0.2 * interface_nodes(rng.permutation(p))

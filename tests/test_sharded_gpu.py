@@ -56,3 +56,52 @@ def test_sharded_matvec_equals_single_rank(hip6, case6, oracle6_nosolve, modes, 
     assert np.abs(got[2] - ref[2]).max() < 1e-5 * np.abs(ref[2]).max()
     g.free([sq, sf]); g.close()
     hip6.free([vq, vf]); hip6.set_nsteps(100)
+
+
+def test_sharded_arnoldi_matches_single_rank(hip6, case6):
+    """The host Arnoldi (nekstab_amd/krylov.py) runs unchanged on sharded vectors: same Hessenberg
+    matrix as the single-rank run (globally summed projections, rank-local updates)."""
+    from nekstab_amd import krylov, seed
+    from nekstab_amd.sharded import ShardGroup
+    hip6.set_tolerances(1e-11, 1e-2, 1)
+    hip6.set_nsteps(20)
+    qx, qy = seed.add_noise(case6)
+    pr = np.zeros((case6.nel, 4, 4))
+    v0 = hip6.alloc(1)[0]
+    hip6.upload(v0, qx, qy, pr)
+    r1 = krylov.krylov_schur(hip6, v0, 6, schur_tgt=0)
+    g = ShardGroup(hip6, case6, 3)
+    g.set_nsteps(20)
+    s0 = g.alloc(1)[0]
+    g.upload(s0, qx, qy, pr)
+    r2 = krylov.krylov_schur(g, s0, 6, schur_tgt=0)
+    assert np.abs(r1.H - r2.H).max() < 1e-9 * np.abs(r1.H).max()
+    assert np.abs(np.sort_complex(r1.vals) - np.sort_complex(r2.vals)).max() < 1e-9
+    g.free(r2.Q + [s0]); g.close()
+    hip6.free(r1.Q + [v0]); hip6.set_nsteps(100)
+
+
+def test_rccl_transport_single_rank_plumbing(hip6, case6, oracle6_nosolve, modes):
+    """The RCCL path (dlopen, communicator, all-reduce on the library stream) on a 1-rank
+    communicator: same result as the plain context.  (send/recv between ranks needs >= 2 GPUs.)"""
+    from nekstab_amd.sharded import ShardRank
+    q = _mode(oracle6_nosolve, modes)
+    hip6.set_tolerances(1e-12, 1e-6, 1)
+    hip6.set_nsteps(3)
+    vq, vf = hip6.alloc(2)
+    hip6.upload(vq, *q)
+    hip6.matvec(vf, vq, 0)
+    ref = hip6.download(vf)
+    uid = ShardRank.new_unique_id(hip6.lib)
+    assert len(uid) == 128
+    s = ShardRank(hip6, case6, 0, 1, uid)
+    s.set_nsteps(3)
+    a, b = s.alloc(2)
+    s.upload(a, *q)
+    assert abs(s.dot(a, a) - hip6.dot(vq, vq)) < 1e-12 * hip6.dot(vq, vq)
+    s.matvec(b, a, 0)
+    got = s.download_local(b)
+    for x, y in zip(got, ref):
+        assert np.abs(x - y).max() <= 1e-12 * np.abs(y).max()
+    s.free([a, b]); s.close()
+    hip6.free([vq, vf]); hip6.set_nsteps(100)
