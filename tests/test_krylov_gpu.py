@@ -210,3 +210,28 @@ def test_krylov_schur_restarts_on_device(hip6, case6, spectre):
     assert res.schur_cnt >= 1
     assert abs(lead - mu) < 5e-6
     hip6.free(res.Q + [v0, v1])
+
+
+def test_checkpoint_restart(hip6, case6, tmp_path):
+    """arnoldi_checkpoint + restart (core/eigensolvers.f:802-905, :284-325, core/IO.f:15-60): a
+    factorisation resumed from the KRY/HES files of step 5 reproduces the uninterrupted one."""
+    from nekstab_amd import checkpoint, seed
+    hip6.set_tolerances(1e-11, 1e-2, 1)
+    hip6.set_nsteps(10)
+    qx, qy = seed.add_noise(case6)
+    k = 8
+    Q = hip6.alloc(k + 1)
+    hip6.upload(Q[0], qx, qy, np.zeros(hip6.npres))
+    hip6.scal(Q[0], 1.0 / hip6.norm(Q[0]))
+    H = np.zeros((k + 1, k))
+    d = str(tmp_path)
+    krylov.arnoldi_factorization(hip6, Q, H, 1, k, 0,
+                                 log=lambda m, Hm, dt: checkpoint.arnoldi_checkpoint(hip6, case6, Q, Hm, m, d))
+    assert os.path.exists(os.path.join(d, "KRY1cyl0.f00009")) and os.path.exists(os.path.join(d, "HES1cyl0008"))
+    assert os.path.exists(os.path.join(d, "Spectre_Hd0005.dat"))
+    Q2, H2, ms = checkpoint.load_checkpoint(hip6, case6, d, k, 5)
+    assert ms == 6 and np.array_equal(H2[:6, :5], H[:6, :5])
+    krylov.arnoldi_factorization(hip6, Q2, H2, ms, k, 0)
+    assert np.abs(H2 - H).max() < 1e-8 * np.abs(H).max()
+    hip6.free(Q + Q2)
+    hip6.set_nsteps(100)
