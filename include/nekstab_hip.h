@@ -91,6 +91,11 @@ int nsk_vec_download(nsk_ctx* ctx, nsk_vec v, double* vx, double* vy, double* pr
 /* matvec(f,q) (core/matvec.f:64-154) */
 int nsk_matvec(nsk_ctx* ctx, int mode, nsk_vec f, nsk_vec q);
 
+/* Newton-Krylov support (core/newton_krylov.f): the full nonlinear map Phi_T(q) [optionally minus q] and
+ * the change of linearisation point (base flow := q, new dt / nsteps from the CFL rule). */
+int nsk_nonlinear_map(nsk_ctx* ctx, nsk_vec f, nsk_vec q, int subtract_q);
+int nsk_set_baseflow(nsk_ctx* ctx, nsk_vec q);
+
 /* krylov_inner_product / norm / cmult / add2,sub2 / copy / zero
  * (core/krylov_subspace.f:24-212) */
 int nsk_dot(nsk_ctx* ctx, nsk_vec p, nsk_vec q, double* alpha);

@@ -57,6 +57,8 @@ SYMBOLS = {
     "nsk_vec_upload": (C.c_int, [_vp, _vp, _dp, _dp, _dp]),
     "nsk_vec_download": (C.c_int, [_vp, _vp, _dp, _dp, _dp]),
     "nsk_matvec": (C.c_int, [_vp, C.c_int, _vp, _vp]),
+    "nsk_nonlinear_map": (C.c_int, [_vp, _vp, _vp, C.c_int]),
+    "nsk_set_baseflow": (C.c_int, [_vp, _vp]),
     "nsk_dot": (C.c_int, [_vp, _vp, _vp, _dp]),
     "nsk_norm": (C.c_int, [_vp, _vp, _dp]),
     "nsk_scal": (C.c_int, [_vp, _vp, C.c_double]),
@@ -186,6 +188,16 @@ class NekStabHip:
     # ---- operator + vector algebra
     def matvec(self, f, q, mode=NSK_DIRECT):
         self._chk(self.lib.nsk_matvec(self.ctx, mode, f, q))
+
+    def nonlinear_map(self, f, q, subtract_q=False):
+        self._chk(self.lib.nsk_nonlinear_map(self.ctx, f, q, int(subtract_q)))
+
+    def set_baseflow(self, q):
+        self._chk(self.lib.nsk_set_baseflow(self.ctx, q))
+        dt, ns = C.c_double(), C.c_int()
+        a, b, d = C.c_longlong(), C.c_longlong(), C.c_longlong()
+        self._chk(self.lib.nsk_get_info(self.ctx, C.byref(dt), C.byref(ns), C.byref(a), C.byref(b), C.byref(d)))
+        self.dt, self.nsteps = dt.value, ns.value
 
     def dot(self, p, q):
         a = C.c_double()

@@ -56,7 +56,7 @@ struct nsk_ctx {
   int helm_guess = 1;
   long long recaptures = 0, retries = 0;
   int debug = 0;
-  struct StepGraph { hipGraphExec_t exec = nullptr; int nh = -1, np = -1; } graphs[2][6];
+  struct StepGraph { hipGraphExec_t exec = nullptr; int nh = -1, np = -1; } graphs[3][6];
   double* scratch = nullptr;            // one state vector
   double* rc_big = nullptr;             // coarse restriction for nvert > 3072
   Dev d{};
@@ -71,6 +71,8 @@ struct nsk_ctx {
   std::vector<double> bm1s_host;
   // ---- host copies kept for element sharding (nsk_shard_create)
   std::vector<long long> h_gid;
+  std::vector<double> h_cflg, h_dAs, h_bs, h_mask;      // for nsk_set_baseflow (new dt => new Jacobi diagonals)
+  double cfl_target = 0.5;
   std::vector<int> h_pidx, h_evert;
   int PS = 0, coarse_lda = 0;
   // ---- shard state (rank-local context cut out of a full-mesh parent)
@@ -264,6 +266,7 @@ static int build(nsk_ctx* c, const nsk_case& cs) {
   std::vector<double> w2rx(npr), w2ry(npr), w2sx(npr), w2sy(npr);
   const size_t nfine = (size_t)nel * NDD;
   std::vector<double> cUr(nfine), cUs(nfine), GUx(nfine), GUy(nfine), GVx(nfine), GVy(nfine);
+  std::vector<double> rxdA(nfine), rydA(nfine), sxdA(nfine), sydA(nfine);
   {
     std::vector<double> t(std::max(MM, NDD)), rxd(NDD), ryd(NDD), sxd(NDD), syd(NDD), Uf(NDD), Vf(NDD);
     for (int e = 0; e < nel; ++e) {
@@ -287,6 +290,7 @@ static int build(nsk_ctx* c, const nsk_case& cs) {
             Vr += Dd[a * ND + k] * Vf[b * ND + k]; Vs += Dd[b * ND + k] * Vf[k * ND + a];
           }
           const int q = b * ND + a;
+          rxdA[od + q] = rxd[q]; rydA[od + q] = ryd[q]; sxdA[od + q] = sxd[q]; sydA[od + q] = syd[q];
           cUr[od + q] = rxd[q] * Uf[q] + ryd[q] * Vf[q];
           cUs[od + q] = sxd[q] * Uf[q] + syd[q] * Vf[q];
           GUx[od + q] = rxd[q] * Ur + sxd[q] * Us;
@@ -353,7 +357,9 @@ static int build(nsk_ctx* c, const nsk_case& cs) {
   c->bm1s_host = bm1s;
 
   // ---- dt rule  (core/matvec.f:26-46, [UPSTREAM compute_cfl])
+  c->cfl_target = cs.cfl;
   {
+    c->h_cflg.resize((size_t)4 * nloc);
     std::vector<double> dri(N);
     dri[0] = 1.0 / (z1[1] - z1[0]); dri[N - 1] = 1.0 / (z1[N - 1] - z1[N - 2]);
     for (int i = 1; i < N - 1; ++i) dri[i] = 1.0 / (0.5 * (z1[i + 1] - z1[i - 1]));
@@ -365,6 +371,8 @@ static int build(nsk_ctx* c, const nsk_case& cs) {
           const double ur = (cs.ub[l] * rx[l] + cs.vb[l] * ry[l]) / jac[l];
           const double us = (cs.ub[l] * sx[l] + cs.vb[l] * sy[l]) / jac[l];
           ctarg = std::max(ctarg, std::fabs(ur * dri[i]) + std::fabs(us * dri[j]));
+          c->h_cflg[4 * l + 0] = rx[l] / jac[l] * dri[i]; c->h_cflg[4 * l + 1] = ry[l] / jac[l] * dri[i];
+          c->h_cflg[4 * l + 2] = sx[l] / jac[l] * dri[j]; c->h_cflg[4 * l + 3] = sy[l] / jac[l] * dri[j];
         }
     double dt = cs.cfl / ctarg;
     c->nsteps = (int)std::ceil(cs.endtime / dt);
@@ -386,6 +394,7 @@ static int build(nsk_ctx* c, const nsk_case& cs) {
           dA[o + j * N + i] = s;
         }
     std::vector<double> dAs = dssum_h(dA), bs = dssum_h(bm1);
+    c->h_dAs = dAs; c->h_bs = bs; c->h_mask = mask;
     const double bd0[3] = {1.0, 1.5, 11.0 / 6.0};
     for (int k = 0; k < 6; ++k)
       for (long long l = 0; l < nloc; ++l) dinv[(size_t)k * nloc + l] = mask[l] / (d.nu * dAs[l] + bd0[k] / c->dt * bs[l]);
@@ -398,7 +407,9 @@ static int build(nsk_ctx* c, const nsk_case& cs) {
       (rc = dupload(c, &d.w2sx, w2sx)) || (rc = dupload(c, &d.w2sy, w2sy)) || (rc = dupload(c, &d.cUr, cUr)) ||
       (rc = dupload(c, &d.cUs, cUs)) || (rc = dupload(c, &d.GUx, GUx)) || (rc = dupload(c, &d.GUy, GUy)) ||
       (rc = dupload(c, &d.GVx, GVx)) || (rc = dupload(c, &d.GVy, GVy)) || (rc = dupload(c, &d.gs_off, gs_off)) ||
-      (rc = dupload(c, &d.gs_idx, gs_idx))) return rc;
+      (rc = dupload(c, &d.gs_idx, gs_idx)) || (rc = dupload(c, &d.rxd, rxdA)) || (rc = dupload(c, &d.ryd, rydA)) ||
+      (rc = dupload(c, &d.sxd, sxdA)) || (rc = dupload(c, &d.syd, sydA))) return rc;
+  d.nl_spng_str = 0.0; d.spng_vr = nullptr;
 
   // ---- state + solver work arrays
   if ((rc = dalloc(c, &d.u, 2 * d.cs)) || (rc = dalloc(c, &d.p, npr)) || (rc = dalloc(c, &d.plag, npr)) ||
@@ -998,6 +1009,53 @@ int nsk_matvec(nsk_ctx* c, int mode, nsk_vec fv, nsk_vec qv) {
     default: return fail(NSK_EINVAL, "unknown mode");
   }
   return rc;
+}
+
+// New linearisation point (core/newton_krylov.f:371-372 + prepare_linearized_solver): base-flow
+// constants of the convection kernels, dt / nsteps from the CFL rule, Jacobi diagonals for the new dt.
+int nsk_set_baseflow(nsk_ctx* c, nsk_vec qv) {
+  if (!c || !qv) return fail(NSK_EINVAL, "bad argument");
+  if (c->parent || c->nranks > 1) return fail(NSK_EINVAL, "set_baseflow on shards is not built yet");
+  Dev& d = c->d;
+  const double* q = (const double*)qv;
+  DISPATCH_N(c->N, {
+    hipLaunchKernelGGL(k_baseflow<N>, dim3(c->nel), dim3(Cfg<N>::NTD), 0, c->stream, d, q, (double*)d.cUr, (double*)d.cUs,
+                       (double*)d.GUx, (double*)d.GUy, (double*)d.GVx, (double*)d.GVy);
+  });
+  std::vector<double> u(2 * c->nloc);
+  HIPCHK(hipMemcpyAsync(u.data(), q, 2 * c->nloc * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  double ctarg = 0.0;
+  for (long long l = 0; l < c->nloc; ++l) {
+    const double a = u[l], b = u[c->nloc + l];
+    ctarg = std::max(ctarg, std::fabs(a * c->h_cflg[4 * l] + b * c->h_cflg[4 * l + 1]) + std::fabs(a * c->h_cflg[4 * l + 2] + b * c->h_cflg[4 * l + 3]));
+  }
+  if (!(ctarg > 0.0)) return fail(NSK_EINVAL, "base flow is zero");
+  const double dt0 = c->cfl_target / ctarg;
+  c->nsteps = (int)std::ceil(c->endtime / dt0);
+  c->dt = c->endtime / c->nsteps;
+  d.dt = c->dt;
+  std::vector<double> dinv((size_t)3 * c->nloc);
+  const double bd0[3] = {1.0, 1.5, 11.0 / 6.0};
+  for (int k = 0; k < 3; ++k)
+    for (long long l = 0; l < c->nloc; ++l) dinv[(size_t)k * c->nloc + l] = c->h_mask[l] / (d.nu * c->h_dAs[l] + bd0[k] / c->dt * c->h_bs[l]);
+  HIPCHK(hipMemcpy((double*)d.dinv, dinv.data(), dinv.size() * sizeof(double), hipMemcpyHostToDevice));
+  for (auto& a : c->graphs) for (auto& g : a) g.nh = -1;           // coefficients are baked into the captured graphs
+  return 0;
+}
+
+// Phi_T(q): nsteps of the full Navier-Stokes equations (nonlinear_forward_map, core/newton_krylov.f:336-378);
+// subtract_q != 0 returns Phi_T(q) - q, the Newton right-hand side.
+int nsk_nonlinear_map(nsk_ctx* c, nsk_vec fv, nsk_vec qv, int subtract_q) {
+  if (!c || !fv || !qv) return fail(NSK_EINVAL, "bad argument");
+  if (fv == qv) return fail(NSK_EINVAL, "needs f != q");
+  if (c->parent) return fail(NSK_EINVAL, "nonlinear map on shards is not built yet");
+  c->hstats = Stats{};
+  int rc = run_map_adaptive(c, 2, (double*)fv, (const double*)qv);
+  if (rc) return rc;
+  if (subtract_q)
+    hipLaunchKernelGGL(k_axpby, dim3((unsigned)((c->nstate + 255) / 256)), dim3(256), 0, c->stream, (double*)fv, -1.0, (const double*)qv, 1.0, c->nstate);
+  return 0;
 }
 
 // ---- Krylov vector algebra ------------------------------------------------

@@ -63,6 +63,9 @@ struct Dev {
   const double *w2rx, *w2ry, *w2sx, *w2sy;
   // per dealiasing node (base-flow dependent, constant in time)
   const double *cUr, *cUs, *GUx, *GUy, *GVx, *GVy;
+  const double *rxd, *ryd, *sxd, *syd;     // Jacobian-scaled metrics x weights on the dealiasing mesh (nonlinear convection)
+  const double *spng_vr;                   // sponge reference field (DNS branch of nekStab_forcing), [2][cs]
+  double nl_spng_str;
   // gather-scatter (dssum) as a gather: CSR of co-located local nodes, ascending
   const int *gs_off, *gs_idx;
   const int4* gs_tab;

@@ -319,15 +319,21 @@ __global__ __launch_bounds__(Cfg<N>::NTD) void k_convect(Dev d, const double* __
     }
     const long long q = e * NDD + tid;
     const double uf = sf[0][tid], vf = sf[1][tid];
-    const double cr = d.cUr[q], cs = d.cUs[q];
-    const double conv_u = cr * ur + cs * us, conv_v = cr * vr + cs * vs;   // (U.grad) u'
     double ox, oy;
-    if (!adjoint) {          // + (u'.grad) U
-      ox = conv_u + uf * d.GUx[q] + vf * d.GUy[q];
-      oy = conv_v + uf * d.GVx[q] + vf * d.GVy[q];
-    } else {                 // (grad U)^T u' - (U.grad) u'
-      ox = uf * d.GUx[q] + vf * d.GVx[q] - conv_u;
-      oy = uf * d.GUy[q] + vf * d.GVy[q] - conv_v;
+    if (adjoint == 2) {      // full equations: (u.grad) u   [UPSTREAM advab], newton_krylov's nonlinear map
+      const double cr = d.rxd[q] * uf + d.ryd[q] * vf, cs = d.sxd[q] * uf + d.syd[q] * vf;
+      ox = cr * ur + cs * us;
+      oy = cr * vr + cs * vs;
+    } else {
+      const double cr = d.cUr[q], cs = d.cUs[q];
+      const double conv_u = cr * ur + cs * us, conv_v = cr * vr + cs * vs;   // (U.grad) u'
+      if (!adjoint) {          // + (u'.grad) U
+        ox = conv_u + uf * d.GUx[q] + vf * d.GUy[q];
+        oy = conv_v + uf * d.GVx[q] + vf * d.GVy[q];
+      } else {                 // (grad U)^T u' - (U.grad) u'
+        ox = uf * d.GUx[q] + vf * d.GVx[q] - conv_u;
+        oy = uf * d.GUy[q] + vf * d.GVy[q] - conv_v;
+      }
     }
     so[0][tid] = ox; so[1][tid] = oy;
   }
@@ -356,8 +362,59 @@ __global__ __launch_bounds__(Cfg<N>::NTD) void k_convect(Dev d, const double* __
     }
     const long long l = e * NN + tid;
     const double sb = d.spng[l] * d.bm1[l];
-    bf[l] = -(sb * su[0][tid] + s0);
-    bf[d.cs + l] = -(sb * su[1][tid] + s1);
+    if (adjoint == 2) {      // DNS sponge: spng_fun (u_ref - u) spng_str   (core/utils.f:165-170)
+      const double k = sb * d.nl_spng_str;
+      bf[l] = ((k != 0.0) ? k * (d.spng_vr[l] - su[0][tid]) : 0.0) - s0;
+      bf[d.cs + l] = ((k != 0.0) ? k * (d.spng_vr[d.cs + l] - su[1][tid]) : 0.0) - s1;
+    } else {
+      bf[l] = -(sb * su[0][tid] + s0);
+      bf[d.cs + l] = -(sb * su[1][tid] + s1);
+    }
+  }
+}
+
+// New linearisation point: the base-flow-dependent dealiasing-mesh constants from a state vector
+// (newton_krylov passes the current Newton iterate as base flow, core/newton_krylov.f:371-372)
+template <int N>
+__global__ __launch_bounds__(Cfg<N>::NTD) void k_baseflow(Dev d, const double* __restrict__ q, double* cUr, double* cUs,
+                                                          double* GUx, double* GUy, double* GVx, double* GVy) {
+  using C = Cfg<N>;
+  constexpr int NN = C::NN, ND = C::ND, NDD = C::NDD, NT = C::NTD;
+  __shared__ double sJ[ND * N], sDd[ND * ND];
+  __shared__ double su[2][NN], st[2][N * ND], sf[2][NDD];
+  const int tid = threadIdx.x;
+  const long long e = blockIdx.x;
+  for (int k = tid; k < ND * N; k += NT) sJ[k] = d.Jd[k];
+  for (int k = tid; k < NDD; k += NT) sDd[k] = d.Dd[k];
+  if (tid < NN) { su[0][tid] = q[e * NN + tid]; su[1][tid] = q[d.nloc + e * NN + tid]; }
+  __syncthreads();
+  if (tid < N * ND) {
+    const int j = tid / ND, a = tid % ND;
+    double s0 = 0, s1 = 0;
+    for (int i = 0; i < N; ++i) { const double w = sJ[a * N + i]; s0 += w * su[0][j * N + i]; s1 += w * su[1][j * N + i]; }
+    st[0][tid] = s0; st[1][tid] = s1;
+  }
+  __syncthreads();
+  const int b = tid / ND, a = tid % ND;
+  const bool fact = tid < NDD;
+  if (fact) {
+    double s0 = 0, s1 = 0;
+    for (int j = 0; j < N; ++j) { const double w = sJ[b * N + j]; s0 += w * st[0][j * ND + a]; s1 += w * st[1][j * ND + a]; }
+    sf[0][tid] = s0; sf[1][tid] = s1;
+  }
+  __syncthreads();
+  if (fact) {
+    double Ur = 0, Us = 0, Vr = 0, Vs = 0;
+    for (int k = 0; k < ND; ++k) {
+      const double dr = sDd[a * ND + k], ds = sDd[b * ND + k];
+      Ur += dr * sf[0][b * ND + k]; Us += ds * sf[0][k * ND + a];
+      Vr += dr * sf[1][b * ND + k]; Vs += ds * sf[1][k * ND + a];
+    }
+    const long long qq = e * NDD + tid;
+    const double rx = d.rxd[qq], ry = d.ryd[qq], sx = d.sxd[qq], sy = d.syd[qq], Uf = sf[0][tid], Vf = sf[1][tid];
+    cUr[qq] = rx * Uf + ry * Vf; cUs[qq] = sx * Uf + sy * Vf;
+    GUx[qq] = rx * Ur + sx * Us; GUy[qq] = ry * Ur + sy * Us;
+    GVx[qq] = rx * Vr + sx * Vs; GVy[qq] = ry * Vr + sy * Vs;
   }
 }
 

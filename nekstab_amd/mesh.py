@@ -290,13 +290,13 @@ def load_cylinder_case(casedir: str, lx1: int, *, session="1cyl", use_ma2=True, 
                          meta={"casedir": casedir, "session": session, "bf_lx1": bf.nx}, **kw)
 
 
-def save_case_npz(path: str, mesh: nekio.Re2Mesh, vlex: np.ndarray, bf_u: np.ndarray):
+def save_case_npz(path: str, mesh: nekio.Re2Mesh, vlex: np.ndarray, bf_u: np.ndarray, bf_p: np.ndarray | None = None):
     """Compact fixture of a case's *data* (mesh vertices, curves, BCs, vertex ids, base flow)."""
     cur = np.array([[c[0], c[1]] + list(c[2]) for c in mesh.curves if c[3] == "C"], dtype=np.float64)
     bce = np.array([[b[0], b[1]] for b in mesh.bcs], dtype=np.int32)
     bcc = np.array([b[3] for b in mesh.bcs])
     np.savez_compressed(path, xc=mesh.xc, yc=mesh.yc, curves=cur, bc_ef=bce, bc_code=bcc,
-                        vlex=vlex.astype(np.int32), bf_u=bf_u)
+                        vlex=vlex.astype(np.int32), bf_u=bf_u, **({} if bf_p is None else {"bf_p": bf_p}))
 
 
 def load_case_npz(path: str, lx1: int, **kw) -> Case:
@@ -304,8 +304,10 @@ def load_case_npz(path: str, lx1: int, **kw) -> Case:
     curves = [(int(r[0]), int(r[1]), r[2:7].copy(), "C") for r in z["curves"]]
     bcs = [(int(ef[0]), int(ef[1]), np.zeros(5), str(cd)) for ef, cd in zip(z["bc_ef"], z["bc_code"])]
     mesh = nekio.Re2Mesh(2, z["xc"].shape[0], z["xc"], z["yc"], None, curves, bcs)
-    return build_case_2d(mesh, z["vlex"].astype(np.int64), z["bf_u"].astype(np.float64), lx1,
-                         meta={"npz": path}, **kw)
+    meta = {"npz": path}
+    if "bf_p" in z.files:                      # base-flow pressure on mesh 1 (as in the field file), at the file's order
+        meta["bf_p"] = z["bf_p"].astype(np.float64)
+    return build_case_2d(mesh, z["vlex"].astype(np.int64), z["bf_u"].astype(np.float64), lx1, meta=meta, **kw)
 
 
 # ----------------------------------------------------------------------------

@@ -356,6 +356,61 @@ class LinNS2D:
         st["p"] = pext + dp
         return st
 
+    # ---------------- nonlinear Navier-Stokes step (newton_krylov's nonlinear_forward_map) ----------------
+    def set_baseflow(self, ub):
+        """New linearisation point (core/newton_krylov.f:371-372) and the dt / nsteps that
+        prepare_linearized_solver derives from it (core/matvec.f:26-46)."""
+        self.ub = np.array(ub)
+        self.dt, self.nsteps = self.timestep_rule()
+        self._helm = {}
+
+    def step_nonlinear(self, st, istep, spng_str=0.0, spng_vr=None):
+        """One nek_advance() of the full equations: makef (user forcing, -B (u.grad)u dealiased, EXT, BDF)
+        then the same Helmholtz / pressure projection as the perturbation step  [UPSTREAM plan3, makef,
+        advab, makeabf, makebdf, cresvif, incomprn].  Dirichlet values ride along in u (masked solves)."""
+        k = min(istep, 3)
+        bd, ab = BD[k], AB[k]
+        dt = self.dt
+        u, v, p = st["u"], st["v"], st["p"]
+        bfx = -self.convect(u, v, u)
+        bfy = -self.convect(u, v, v)
+        if spng_str != 0.0:                                   # nekStab_forcing, DNS branch (core/utils.f:165-170)
+            bfx += self.spng * (spng_vr[0] - u) * spng_str * self.bm1
+            bfy += self.spng * (spng_vr[1] - v) * spng_str * self.bm1
+        ex = st["exlag"]
+        tx = ab[1] * ex[0][0] + ab[2] * ex[1][0]
+        ty = ab[1] * ex[0][1] + ab[2] * ex[1][1]
+        ex[1] = ex[0]
+        ex[0] = [bfx, bfy]
+        bfx = ab[0] * bfx + tx
+        bfy = ab[0] * bfy + ty
+        ul = st["ulag"]
+        bfx = bfx + self.bm1 * (bd[1] * u + bd[2] * ul[0][0] + bd[3] * ul[1][0]) / dt
+        bfy = bfy + self.bm1 * (bd[1] * v + bd[2] * ul[0][1] + bd[3] * ul[1][1]) / dt
+        ul[1] = ul[0]
+        ul[0] = [u, v]
+        h1, h2 = self.nu, bd[0] / dt
+        pext = p if k < 3 else 2.0 * p - st["plag"]
+        gx, gy = self.opgradt(pext)
+        us = u + self.helm_solve(bfx + gx - self.axhelm(u, h1, h2), h1, h2)
+        vs = v + self.helm_solve(bfy + gy - self.axhelm(v, h1, h2), h1, h2)
+        dp = self.E_solve(-self.opdiv(us, vs)) * h2
+        wx, wy = self.opgradt(dp)
+        fac = self.binvm1 * self.mask / h2
+        st["u"] = us + fac * self.dssum(wx * self.mask)
+        st["v"] = vs + fac * self.dssum(wy * self.mask)
+        st["plag"] = p
+        st["p"] = pext + dp
+        return st
+
+    def nonlinear_map(self, q, nsteps=None, spng_str=0.0):
+        """Phi_T(q): nsteps of the full equations from q (core/newton_krylov.f:336-378)."""
+        st = self.new_state(q)
+        vr = (q[0].copy(), q[1].copy())
+        for istep in range(1, (nsteps or self.nsteps) + 1):
+            st = self.step_nonlinear(st, istep, spng_str, vr)
+        return st["u"], st["v"], st["p"]
+
     def matvec(self, q, adjoint=False, nsteps=None):
         """f = Phi_T q  (core/matvec.f:163-243 / :249-326)."""
         st = self.new_state(q)

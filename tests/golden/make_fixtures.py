@@ -25,7 +25,10 @@ def main():
     bf = nekio.read_fld(d + "BF_1cyl0.f00001")
     u = bf.u[:, :, 0]
     assert np.array_equal(u, u.astype(np.float32).astype(np.float64)) or True
-    mesh.save_case_npz(OUT + "/cylinder_case.npz", m, vlex, u)
+    mesh.save_case_npz(OUT + "/cylinder_case.npz", m, vlex, u, bf.p[:, 0])
+    # start field of the reference's Newton example (Re=40 solution, fp32)
+    b40 = nekio.read_fld(REF + "/baseflow/newton/BFRe40_1cyl0.f00001")
+    np.savez_compressed(OUT + "/cylinder_bf_re40.npz", u=b40.u[:, :, 0].astype(np.float32), p=b40.p[:, 0].astype(np.float32))
     # eigenvalue tables (7 significant digits)
     tabs = {}
     for sub, op in (("direct", "d"), ("adjoint", "a")):

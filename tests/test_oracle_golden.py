@@ -64,3 +64,20 @@ def test_spectre_tables_consistent(spectre):
         ok = np.abs(H[:, 0] + 1j * H[:, 1]) > 1e-3
         assert np.abs(lam.real[ok] - NS[ok, 0]).max() < 2e-5
         assert np.abs(np.abs(lam.imag[ok]) - np.abs(NS[ok, 1])).max() < 2e-5
+
+
+@pytest.mark.slow
+def test_reference_baseflow_is_fixed_point_of_nonlinear_map():
+    """nonlinear_forward_map pin (core/newton_krylov.f:336-378): the reference's converged Re=50 base flow
+    (written by its Newton run at residualTol 1e-11) satisfies |Phi_T(BF) - BF|^2 ~ 1e-11 under the oracle's
+    nonlinear step -- an O(1) error in the nonlinear discretisation would give O(1e-3)."""
+    import os
+    from nekstab_amd import mesh
+    from tests.conftest import GOLDEN
+    c = mesh.load_case_npz(os.path.join(GOLDEN, "cylinder_case.npz"), 6, spng_str=0.0)
+    o = make_oracle(c)
+    J = o.J12
+    q = (c.ub[0], c.ub[1], J @ c.meta["bf_p"] @ J.T)
+    f = o.nonlinear_map(q)
+    d = [f[0] - q[0], f[1] - q[1]]
+    assert o.inner(d, d) < 5e-11
