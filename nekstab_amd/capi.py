@@ -59,6 +59,7 @@ SYMBOLS = {
     "nsk_matvec": (C.c_int, [_vp, C.c_int, _vp, _vp]),
     "nsk_nonlinear_map": (C.c_int, [_vp, _vp, _vp, C.c_int]),
     "nsk_set_baseflow": (C.c_int, [_vp, _vp]),
+    "nsk_set_orbit": (C.c_int, [_vp, _vp, C.c_double, _vp]),
     "nsk_dot": (C.c_int, [_vp, _vp, _vp, _dp]),
     "nsk_norm": (C.c_int, [_vp, _vp, _dp]),
     "nsk_scal": (C.c_int, [_vp, _vp, C.c_double]),
@@ -194,6 +195,13 @@ class NekStabHip:
 
     def set_baseflow(self, q):
         self._chk(self.lib.nsk_set_baseflow(self.ctx, q))
+        dt, ns = C.c_double(), C.c_int()
+        a, b, d = C.c_longlong(), C.c_longlong(), C.c_longlong()
+        self._chk(self.lib.nsk_get_info(self.ctx, C.byref(dt), C.byref(ns), C.byref(a), C.byref(b), C.byref(d)))
+        self.dt, self.nsteps = dt.value, ns.value
+
+    def set_orbit(self, q0, spng_str=0.0, end=None):
+        self._chk(self.lib.nsk_set_orbit(self.ctx, q0, float(spng_str), end))
         dt, ns = C.c_double(), C.c_int()
         a, b, d = C.c_longlong(), C.c_longlong(), C.c_longlong()
         self._chk(self.lib.nsk_get_info(self.ctx, C.byref(dt), C.byref(ns), C.byref(a), C.byref(b), C.byref(d)))

@@ -89,6 +89,10 @@ struct nsk_ctx {
   double *psend = nullptr, *precv = nullptr;
   double* rc_part = nullptr;                            // coarse restriction (all vertices), summed over ranks
   void* comm = nullptr;                                 // ncclComm_t when ranks are real processes
+  // ---- time-periodic base flow (Floquet)
+  double* orbit[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  const double* steady[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  int orbit_steps = 0;
 };
 
 template <class T>
@@ -409,7 +413,7 @@ static int build(nsk_ctx* c, const nsk_case& cs) {
       (rc = dupload(c, &d.GVx, GVx)) || (rc = dupload(c, &d.GVy, GVy)) || (rc = dupload(c, &d.gs_off, gs_off)) ||
       (rc = dupload(c, &d.gs_idx, gs_idx)) || (rc = dupload(c, &d.rxd, rxdA)) || (rc = dupload(c, &d.ryd, rydA)) ||
       (rc = dupload(c, &d.sxd, sxdA)) || (rc = dupload(c, &d.syd, sydA))) return rc;
-  d.nl_spng_str = 0.0; d.spng_vr = nullptr;
+  d.nl_spng_str = 0.0; d.spng_vr = nullptr; d.bstep = nullptr; d.bf_stride = 0;
 
   // ---- state + solver work arrays
   if ((rc = dalloc(c, &d.u, 2 * d.cs)) || (rc = dalloc(c, &d.p, npr)) || (rc = dalloc(c, &d.plag, npr)) ||
@@ -693,6 +697,10 @@ static int run_map(nsk_ctx* c, int adjoint, double* f, const double* q) {
   HIPCHK(hipMemcpyAsync(d.u, q, d.nloc * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(d.u + d.cs, q + d.nloc, d.nloc * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(d.p, q + 2 * d.nloc, d.npr * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  if (d.bf_stride) {
+    if (adjoint != 2 && c->nsteps > c->orbit_steps) return fail(NSK_EINVAL, "map longer than the stored base-flow orbit");
+    HIPCHK(hipMemsetAsync(d.bstep, 0, sizeof(int), c->stream));
+  }
   for (int istep = 1; istep <= c->nsteps; ++istep) {
     if (c->use_graph) {
       HIPCHK(hipGraphLaunch(c->graphs[adjoint][step_class(istep)].exec, c->stream));
@@ -1041,6 +1049,63 @@ int nsk_set_baseflow(nsk_ctx* c, nsk_vec qv) {
     for (long long l = 0; l < c->nloc; ++l) dinv[(size_t)k * c->nloc + l] = c->h_mask[l] / (d.nu * c->h_dAs[l] + bd0[k] / c->dt * c->h_bs[l]);
   HIPCHK(hipMemcpy((double*)d.dinv, dinv.data(), dinv.size() * sizeof(double), hipMemcpyHostToDevice));
   for (auto& a : c->graphs) for (auto& g : a) g.nh = -1;           // coefficients are baked into the captured graphs
+  return 0;
+}
+
+// Time-periodic base flow for Floquet analysis (uparam(1)=3.11, core/matvec.f:191-236, core/eigensolvers.f:201-210):
+// integrate the full equations from q0 over one period T = endtime (DNS sponge towards the initial field with
+// strength spng_str, core/utils.f:165-170) and store the base-flow constants of every step; the linearised
+// maps then read slot istep-1 at step istep.  Returns Phi_T(q0) in `end` (periodicity check) if not NULL.
+int nsk_set_orbit(nsk_ctx* c, nsk_vec q0v, double spng_str, nsk_vec end) {
+  if (!c || !q0v) return fail(NSK_EINVAL, "bad argument");
+  if (c->parent) return fail(NSK_EINVAL, "orbit on shards is not built yet");
+  Dev& d = c->d;
+  const double* q0 = (const double*)q0v;
+  if (d.bf_stride) {                                            // back to the steady arrays first
+    d.cUr = c->steady[0]; d.cUs = c->steady[1]; d.GUx = c->steady[2]; d.GUy = c->steady[3]; d.GVx = c->steady[4]; d.GVy = c->steady[5];
+    d.bf_stride = 0;
+  }
+  int rc = nsk_set_baseflow(c, q0v);                            // dt, nsteps from the CFL of the initial field
+  if (rc) return rc;
+  const long long nfine = (long long)c->nel * c->NDD;
+  for (int k = 0; k < 6; ++k) {
+    if (c->orbit[k]) { nsk_vec v = c->orbit[k]; nsk_vec_free(c, 1, &v); c->orbit[k] = nullptr; }
+    if ((rc = dalloc(c, &c->orbit[k], (size_t)c->nsteps * nfine))) return rc;
+  }
+  double* vr = nullptr;
+  if ((rc = dalloc(c, &vr, 2 * d.cs))) return rc;
+  HIPCHK(hipMemcpyAsync(vr, q0, d.nloc * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(vr + d.cs, q0 + d.nloc, d.nloc * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  d.spng_vr = vr; d.nl_spng_str = spng_str;
+  if (!d.bstep && (rc = dalloc(c, &d.bstep, 4))) return rc;
+  for (auto& a : c->graphs) for (auto& g : a) g.nh = -1;
+  for (int k = 0; k < 6; ++k) { c->cur_helm[k] = c->max_helm; c->cur_pres[k] = c->max_pres; }
+  HIPCHK(hipMemsetAsync(d.stats, 0, sizeof(Stats), c->stream));
+  HIPCHK(hipMemcpyAsync(d.u, q0, d.nloc * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(d.u + d.cs, q0 + d.nloc, d.nloc * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(d.p, q0 + 2 * d.nloc, d.npr * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  for (int istep = 1; istep <= c->nsteps; ++istep) {
+    const long long off = (long long)(istep - 1) * nfine;
+    DISPATCH_N(c->N, {
+      hipLaunchKernelGGL(k_baseflow<N>, dim3(c->nel), dim3(Cfg<N>::NTD), 0, c->stream, d, (const double*)d.u, c->orbit[0] + off, c->orbit[1] + off,
+                         c->orbit[2] + off, c->orbit[3] + off, c->orbit[4] + off, c->orbit[5] + off);
+    });
+    if ((rc = step(c, istep, 2))) return rc;
+  }
+  Stats h;
+  HIPCHK(hipMemcpyAsync(&h, d.stats, sizeof(Stats), hipMemcpyDeviceToHost, c->stream));
+  if (end) {
+    double* f = (double*)end;
+    HIPCHK(hipMemcpyAsync(f, d.u, d.nloc * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(f + d.nloc, d.u + d.cs, d.nloc * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(f + 2 * d.nloc, d.p, d.npr * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  }
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (h.unconverged > 0) return fail(NSK_ENOCONV, "inner solve hit its iteration cap while integrating the base-flow orbit");
+  c->steady[0] = d.cUr; c->steady[1] = d.cUs; c->steady[2] = d.GUx; c->steady[3] = d.GUy; c->steady[4] = d.GVx; c->steady[5] = d.GVy;
+  d.cUr = c->orbit[0]; d.cUs = c->orbit[1]; d.GUx = c->orbit[2]; d.GUy = c->orbit[3]; d.GVx = c->orbit[4]; d.GVy = c->orbit[5];
+  d.bf_stride = nfine; c->orbit_steps = c->nsteps;
+  for (auto& a : c->graphs) for (auto& g : a) g.nh = -1;
   return 0;
 }
 

@@ -66,6 +66,8 @@ struct Dev {
   const double *rxd, *ryd, *sxd, *syd;     // Jacobian-scaled metrics x weights on the dealiasing mesh (nonlinear convection)
   const double *spng_vr;                   // sponge reference field (DNS branch of nekStab_forcing), [2][cs]
   double nl_spng_str;
+  int* bstep;                              // time-periodic base flow (Floquet): device step counter and the
+  long long bf_stride;                     // stride between the stored per-step base-flow constants (0: steady)
   // gather-scatter (dssum) as a gather: CSR of co-located local nodes, ascending
   const int *gs_off, *gs_idx;
   const int4* gs_tab;

@@ -325,14 +325,16 @@ __global__ __launch_bounds__(Cfg<N>::NTD) void k_convect(Dev d, const double* __
       ox = cr * ur + cs * us;
       oy = cr * vr + cs * vs;
     } else {
-      const double cr = d.cUr[q], cs = d.cUs[q];
+      // base-flow constants: steady, or slot `*bstep` of the stored periodic orbit (Floquet, core/matvec.f:200-236)
+      const long long qb = q + (d.bf_stride ? (long long)(*d.bstep) * d.bf_stride : 0);
+      const double cr = d.cUr[qb], cs = d.cUs[qb];
       const double conv_u = cr * ur + cs * us, conv_v = cr * vr + cs * vs;   // (U.grad) u'
       if (!adjoint) {          // + (u'.grad) U
-        ox = conv_u + uf * d.GUx[q] + vf * d.GUy[q];
-        oy = conv_v + uf * d.GVx[q] + vf * d.GVy[q];
+        ox = conv_u + uf * d.GUx[qb] + vf * d.GUy[qb];
+        oy = conv_v + uf * d.GVx[qb] + vf * d.GVy[qb];
       } else {                 // (grad U)^T u' - (U.grad) u'
-        ox = uf * d.GUx[q] + vf * d.GVx[q] - conv_u;
-        oy = uf * d.GUy[q] + vf * d.GVy[q] - conv_v;
+        ox = uf * d.GUx[qb] + vf * d.GVx[qb] - conv_u;
+        oy = uf * d.GUy[qb] + vf * d.GVy[qb] - conv_v;
       }
     }
     so[0][tid] = ox; so[1][tid] = oy;
@@ -435,6 +437,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_rhs(Dev d, StepCoef sc) {
   const int j = nd / N, i = nd % N;
   const long long l = e * NN + nd, nl = d.cs;
   load_basis<N, EPB>(d, sD, sDt, sJ12, sD12, tid, NT);
+  if (d.bf_stride && sc.adjoint != 2 && blockIdx.x == 0 && tid == 0) *d.bstep += 1;     // next step reads the next orbit slot
   if (d.nproj_max > 0 && blockIdx.x == 0 && tid == 0) {
     GmresScal* G = d.gsc;
     if (G->st_pending) {
