@@ -46,6 +46,11 @@ def main():
         modes[key + "_p"] = f.p[:, 0].astype(np.float32)
         modes[key + "_istep"] = f.istep
     np.savez_compressed(OUT + "/cylinder_modes.npz", **modes)
+    # periodic orbit of the Floquet examples (fp64 snapshot, period in the header) + both multiplier tables
+    fl = nekio.read_fld(REF + "/stability/direct_Floquet/BF_1cyl0.f00001")
+    np.savez_compressed(OUT + "/cylinder_upo.npz", u=fl.u[:, :, 0], p=fl.p[:, 0], period=fl.time,
+                        spectre_Hd=nekio.read_spectre(REF + "/stability/direct_Floquet/Spectre_Hd.dat"),
+                        spectre_Ha=nekio.read_spectre(REF + "/stability/adjoint_Floquet/Spectre_Ha.dat"))
     for f in ("cylinder_case.npz", "cylinder_spectre.npz", "cylinder_modes.npz"):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

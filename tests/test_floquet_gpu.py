@@ -47,3 +47,34 @@ def test_floquet_multipliers():
         j = np.argmin(np.abs(res.vals - w))
         assert abs(res.vals[j] - w) < tol
     h.close()
+
+
+def test_adjoint_floquet_lx1_8():
+    """uparam(1)=3.21 at lx1=8 (examples/cylinder/stability/adjoint_Floquet): adjoint operator over the
+    forward-integrated periodic base flow, outflow boundary unchanged (1cyl.usr:126 only switches for 3.2).
+    Leading pair of the reference table: 0.9662098 -+ 0.0073784 i."""
+    from nekstab_amd import krylov, mesh, seed
+    from nekstab_amd.capi import NekStabHip
+    from nekstab_amd.quadrature import gauss_legendre, gauss_lobatto_legendre, interp_matrix
+    z = np.load(os.path.join(GOLDEN, "cylinder_upo.npz"))
+    case = mesh.load_case_npz(os.path.join(GOLDEN, "cylinder_case.npz"), 8, endtime=float(z["period"]))
+    u = mesh.interp_field_2d(z["u"], 8)
+    p1 = mesh.interp_field_2d(z["p"], 8)
+    case.ub[:] = u
+    h = NekStabHip(case, case.meta["vert"], case.meta["nvert"], tol_helm=1e-11, tol_pres=1e-2, tol_relative=1,
+                   nproj=8, max_helm_iter=150, max_pres_iter=48)
+    J = interp_matrix(gauss_lobatto_legendre(8)[0], gauss_legendre(6)[0])
+    q0 = h.alloc(1)[0]
+    h.upload(q0, u[0], u[1], J @ p1 @ J.T)
+    h.set_orbit(q0, spng_str=1.7)
+    qx, qy = seed.add_noise(case)
+    v0, v1 = h.alloc(2)
+    h.upload(v0, qx, qy, np.zeros(h.npres))
+    h.scal(v0, 1.0 / h.norm(v0))
+    h.matvec(v1, v0, 1)
+    res = krylov.krylov_schur(h, v1, 28, mode=1, schur_tgt=0)
+    ref = complex(z["spectre_Ha"][5, 0], abs(z["spectre_Ha"][5, 1]))
+    j = np.argmin(np.abs(res.vals - ref))
+    print("reference", ref, "ours", res.vals[j], "residual", res.residual[j])
+    assert abs(res.vals[j] - ref) < 2e-5
+    h.close()
