@@ -1246,6 +1246,12 @@ int nsk_debug_stamps(nsk_ctx* c, unsigned long long* out, int nblk_max) {
   if (!d.dbg) { int rc = dalloc(c, &d.dbg, (size_t)16 * (c->nblk + 8)); if (rc) return rc; }
   HIPCHK(hipMemset(d.dbg, 0, (size_t)16 * (c->nblk + 8) * sizeof(unsigned long long)));
   DISPATCH_N(c->N, {
+    if (nblk_max < 0) {
+      Dev dd = d; dd.tol_helm = 0.0; dd.tol_relative = 0;
+      const StepCoef sc = make_coef(c, 3, 0);
+      for (int r = 0; r < 6; ++r) hipLaunchKernelGGL(k_helm<N>, dim3(c->nblk), dim3(Cfg<N>::NT), 0, c->stream, dd, sc, r, (const double*)d.rloc);
+      nblk_max = -nblk_max;
+    } else
     for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(k_divgs<N>, dim3(c->nblk), dim3(Cfg<N>::NT), 0, c->stream, d, (const double*)d.yl, c->wp2, 5, 0);
   });
   HIPCHK(hipStreamSynchronize(c->stream));

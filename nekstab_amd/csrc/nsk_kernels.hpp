@@ -30,6 +30,13 @@ struct Cfg {
 // flight across it (hipcc's __syncthreads() drains vmcnt as well, which serialises every
 // dependent-latency chain in these small kernels).
 __device__ inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// Element tiles are private to one wavefront when an element has exactly 64 nodes (lx1 = 8): LDS operations
+// of one wave execute in issue order, so the write -> read hand-off inside a tile helper needs no s_barrier.
+template <int NN>
+__device__ inline void tile_barrier() {
+  if constexpr (NN == 64) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+  else { lds_barrier(); }
+}
 
 // ---------------------------------------------------------------------------
 // wave64 sum with DPP row shifts / row broadcasts (total lands in lane 63): ~6 dependent
@@ -159,7 +166,7 @@ __device__ inline void axhelm_tiles(const double* sD, const double* sDt, const d
       st2[(c * EPB + el) * NN + j * N + i] = g2 * us + g4 * ur;
     }
   }
-  lds_barrier();
+  tile_barrier<N * N>();
   if (act) {
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
@@ -195,7 +202,7 @@ __device__ inline double opdiv_tiles(const double* sJ12, const double* sD12, con
     sA[(2 * EPB + el) * NM + nd] = a1v;
     sA[(3 * EPB + el) * NM + nd] = a2v;
   }
-  lds_barrier();
+  tile_barrier<N * N>();
   double div = 0.0;
   if (act && nd < MM) {
     const int b = nd / M, a = nd % M;
@@ -236,7 +243,7 @@ __device__ inline void opgradt_tiles(const double* sJ12, const double* sD12, con
     sB[(2 * EPB + el) * NM + nd] = b1y;
     sB[(3 * EPB + el) * NM + nd] = b2y;
   }
-  lds_barrier();
+  tile_barrier<N * N>();
   gx = 0.0; gy = 0.0;
   if (act) {
     const int j = nd / N, i = nd % N;
@@ -518,6 +525,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_helm(Dev d, StepCoef sc, int it,
   const int j = nd / N, i = nd % N;
   const long long l = e * NN + nd, nl = d.cs;
   const int par = it & 1, ppar = par ^ 1;
+  NSK_STAMP(0);
   if (it > 2 && d.hscal[ppar * 8 + 2] != 0.0 && d.hscal[ppar * 8 + 6] != 0.0) {   // finished earlier: cheapest exit
     if (blockIdx.x == 0 && tid < 8) d.hscal[par * 8 + tid] = d.hscal[ppar * 8 + tid];
     return;
@@ -562,6 +570,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_helm(Dev d, StepCoef sc, int it,
     if (blockIdx.x == 0 && tid < 8) d.hscal[par * 8 + tid] = o[tid];
     return;
   }
+  NSK_STAMP(1);
   // ---- phase B: gathers of the neighbours' unassembled values (need the table entry)
   GsVals gv[2], gb[2];
   if (act) {
@@ -571,6 +580,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_helm(Dev d, StepCoef sc, int it,
       else gv[c] = gs_load(d.hwl + ((size_t)ppar * 2 + c) * nl, tab, l);
     }
   }
+  NSK_STAMP(2);
   // ---- phase C: scalars of this iteration from the previous kernel's partials
   double alpha[2] = {0, 0}, beta[2] = {0, 0};
   bool done[2] = {false, false};
@@ -602,6 +612,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_helm(Dev d, StepCoef sc, int it,
     }
     if (done[0] && done[1]) return;
   }
+  NSK_STAMP(3);
   // ---- phase D: vector updates, next local A z, dot-product partials
   if (tid < NN) { sD[tid] = dreg; sDt[(tid % N) * N + tid / N] = dreg; }
   double r[2] = {0, 0}, z[2] = {0, 0}, bb[2] = {0, 0};
@@ -628,9 +639,11 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_helm(Dev d, StepCoef sc, int it,
       sz[(c * EPB + el) * NN + nd] = z[c];
     }
   }
+  NSK_STAMP(4);
   lds_barrier();
   double au[2];
   axhelm_tiles<N, EPB, 2>(sD, sDt, sz, st1, st2, act, el, j, i, g1, g2, g4, au);
+  NSK_STAMP(5);
   double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (act) {
 #pragma unroll
@@ -644,7 +657,9 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_helm(Dev d, StepCoef sc, int it,
     }
   }
   block_reduce<8>(v, sred, tid, NT);
+  NSK_STAMP(6);
   if (tid < 8) d.hpart[((size_t)par * 8 + tid) * d.nblk + blockIdx.x] = v[tid];
+  NSK_STAMP(7);
 }
 
 // ---------------------------------------------------------------------------

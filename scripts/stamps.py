@@ -23,3 +23,13 @@ d = np.diff(rel, axis=1)
 for i, name in enumerate(["done-flag load", "loads+gs gather -> LDS", "opdiv (2 barriers)", "dots + partials"]):
     print("%-28s med %.2f us  p90 %.2f" % (name, np.median(d[:, i]), np.percentile(d[:, i], 90)))
 print("kernel end (last stamp) max %.2f us" % rel[:, 4].max())
+
+out = np.zeros(16 * nb, dtype=np.uint64)
+rc = fn(h.ctx, out.ctypes.data, -nb); assert rc == 0
+t = out.reshape(nb, 16)[:, :8].astype(np.int64)
+rel = (t - t[:, 0].min()) * 0.01
+print("k_helm (it=5): block start spread max %.2f us" % rel[:, 0].max())
+d = np.diff(rel, axis=1)
+for i, name in enumerate(["flag check", "issue phase-A loads", "issue gs loads (needs table)", "partials reduce -> alpha,beta", "updates + LDS write (waits loads)", "axhelm", "block_reduce<8>", "store partials"]):
+    if i < 7: print("%-36s med %.2f us  p90 %.2f" % (name, np.median(d[:, i]), np.percentile(d[:, i], 90)))
+print("kernel end max %.2f us" % rel[:, 7].max())
