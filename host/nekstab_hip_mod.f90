@@ -15,6 +15,7 @@ module nekstab_hip
     integer(c_int) :: has_outflow
     real(c_double) :: tol_helm, tol_pres
     integer(c_int) :: tol_relative, schwarz_layers, max_helm_iter, max_pres_iter, nproj
+    type(c_ptr) :: z = c_null_ptr, wb = c_null_ptr      ! hexahedral cases (ndim = 3) only
   end type
 
   interface

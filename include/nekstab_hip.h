@@ -20,7 +20,7 @@ extern "C" {
 #endif
 
 typedef struct nsk_ctx nsk_ctx;
-typedef void* nsk_vec;               /* device state vector [vx | vy | pr] */
+typedef void* nsk_vec;               /* device state vector [vx | vy | pr]  (3-D: [vx | vy | vz | pr]) */
 
 enum nsk_status {
   NSK_OK = 0,
@@ -41,7 +41,7 @@ enum nsk_mode {          /* `evop`, core/matvec.f:124-151 */
 /* Case description = what Nek5000 holds in COMMON when nekStab_init runs
  * (core/usr_extra.f:72-132): geometry, numbering, masks, base flow, sponge. */
 typedef struct {
-  int ndim;                 /* 2 (3 reserved) */
+  int ndim;                 /* 2: quadrilaterals; 3: hexahedra (arrays [nel*lx1^3], z / wb / 8 vertices per element) */
   int nel;                  /* elements on this rank */
   int lx1;                  /* GLL points per direction: 6, 8, 10 or 12 (SIZE:13) */
   int lxd;                  /* dealiasing points, 3*lx1/2 (SIZE:14) */
@@ -66,6 +66,8 @@ typedef struct {
   int max_helm_iter;        /* iteration caps per solve */
   int max_pres_iter;
   int nproj;                /* pressure projection space (residualProj; mxprev, SIZE:33); 0 = off */
+  const double* z;          /* ndim = 3: zm1 */
+  const double* wb;         /* ndim = 3: third base-flow component (wbase, core/NEKSTAB:26) */
 } nsk_case;
 
 /* nekStab_init + prepare_linearized_solver (core/usr_extra.f:72-132, core/matvec.f:1-52):
@@ -87,6 +89,9 @@ int nsk_vec_free(nsk_ctx* ctx, int n, nsk_vec* v);
 /* nopcopy / outpost / load_files (core/utils.f:471-550, core/IO.f:15-60) */
 int nsk_vec_upload(nsk_ctx* ctx, nsk_vec v, const double* vx, const double* vy, const double* pr);
 int nsk_vec_download(nsk_ctx* ctx, nsk_vec v, double* vx, double* vy, double* pr);
+/* hexahedral contexts (krylov_vector carries vz, core/krylov_subspace.f:9-11) */
+int nsk_vec_upload3(nsk_ctx* ctx, nsk_vec v, const double* vx, const double* vy, const double* vz, const double* pr);
+int nsk_vec_download3(nsk_ctx* ctx, nsk_vec v, double* vx, double* vy, double* vz, double* pr);
 
 /* matvec(f,q) (core/matvec.f:64-154) */
 int nsk_matvec(nsk_ctx* ctx, int mode, nsk_vec f, nsk_vec q);
@@ -171,6 +176,8 @@ int nsk_test_eapply(nsk_ctx* ctx, const double* p, double* out);   /* D B^-1 D^T
 int nsk_test_helm_solve(nsk_ctx* ctx, const double* rx, const double* ry, int order,
                         double* ox, double* oy, int* iters);
 int nsk_test_pres_solve(nsk_ctx* ctx, const double* g, double* out, int* iters);
+/* 3-D element operators, packed arrays: which = 1 weak divergence, 2 D^T p, 3 convection (a = mode), 5 Helmholtz solve (a = order) */
+int nsk_test_op3(nsk_ctx* ctx, int which, const double* in, double* out, int a, int* iters);
 
 #ifdef __cplusplus
 }

@@ -30,6 +30,7 @@ class NskCase(C.Structure):
         ("has_outflow", C.c_int), ("tol_helm", C.c_double), ("tol_pres", C.c_double),
         ("tol_relative", C.c_int), ("schwarz_layers", C.c_int),
         ("max_helm_iter", C.c_int), ("max_pres_iter", C.c_int), ("nproj", C.c_int),
+        ("z", _dp), ("wb", _dp),
     ]
 
 
@@ -56,6 +57,8 @@ SYMBOLS = {
     "nsk_vec_free": (C.c_int, [_vp, C.c_int, _vpp]),
     "nsk_vec_upload": (C.c_int, [_vp, _vp, _dp, _dp, _dp]),
     "nsk_vec_download": (C.c_int, [_vp, _vp, _dp, _dp, _dp]),
+    "nsk_vec_upload3": (C.c_int, [_vp, _vp, _dp, _dp, _dp, _dp]),
+    "nsk_vec_download3": (C.c_int, [_vp, _vp, _dp, _dp, _dp, _dp]),
     "nsk_matvec": (C.c_int, [_vp, C.c_int, _vp, _vp]),
     "nsk_nonlinear_map": (C.c_int, [_vp, _vp, _vp, C.c_int]),
     "nsk_set_baseflow": (C.c_int, [_vp, _vp]),
@@ -88,6 +91,7 @@ SYMBOLS = {
     "nsk_test_eapply": (C.c_int, [_vp, _dp, _dp]),
     "nsk_test_helm_solve": (C.c_int, [_vp, _dp, _dp, C.c_int, _dp, _dp, C.POINTER(C.c_int)]),
     "nsk_test_pres_solve": (C.c_int, [_vp, _dp, _dp, C.POINTER(C.c_int)]),
+    "nsk_test_op3": (C.c_int, [_vp, C.c_int, _dp, _dp, C.c_int, C.POINTER(C.c_int)]),
 }
 
 
@@ -136,18 +140,22 @@ class NekStabHip:
         self.lib = load_library()
         c = case
         f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+        self.ndim = int(getattr(c, "ndim", 2))
         self._keep = dict(x=f64(c.x), y=f64(c.y), gid=np.ascontiguousarray(c.gid, dtype=np.int64),
                           mask=f64(c.mask), ub=f64(c.ub[0]), vb=f64(c.ub[1]), spng=f64(c.spng),
                           vert=np.ascontiguousarray(vert, dtype=np.int64))
         k = self._keep
-        cs = NskCase(ndim=2, nel=c.nel, lx1=c.lx1, lxd=c.lxd, nglob=c.nglob,
+        if self.ndim == 3:
+            k["z"], k["wb"] = f64(c.z), f64(c.ub[2])
+        cs = NskCase(ndim=self.ndim, nel=c.nel, lx1=c.lx1, lxd=c.lxd, nglob=c.nglob,
                      x=_p(k["x"]), y=_p(k["y"]), gid=k["gid"].ctypes.data_as(_lp), mask=_p(k["mask"]),
                      ub=_p(k["ub"]), vb=_p(k["vb"]), spng=_p(k["spng"]),
                      vert=k["vert"].ctypes.data_as(_lp), nvert=int(nvert),
                      re=c.re, endtime=c.endtime, cfl=c.cfl, has_outflow=int(c.has_outflow),
                      tol_helm=tol_helm, tol_pres=tol_pres, tol_relative=tol_relative,
                      schwarz_layers=schwarz_layers, max_helm_iter=max_helm_iter,
-                     max_pres_iter=max_pres_iter, nproj=nproj)
+                     max_pres_iter=max_pres_iter, nproj=nproj,
+                     z=_p(k["z"]) if self.ndim == 3 else None, wb=_p(k["wb"]) if self.ndim == 3 else None)
         self.ctx = C.c_void_p()
         self._chk(self.lib.nsk_init(C.byref(cs), C.byref(self.ctx)))
         dt, ns = C.c_double(), C.c_int()
@@ -174,6 +182,17 @@ class NekStabHip:
     def free(self, vecs):
         arr = (C.c_void_p * len(vecs))(*[v.value for v in vecs])
         self._chk(self.lib.nsk_vec_free(self.ctx, len(vecs), arr))
+
+    def upload3(self, v, vx, vy, vz, pr):
+        vx, vy, vz, pr = (np.ascontiguousarray(a, dtype=np.float64) for a in (vx, vy, vz, pr))
+        assert vx.size == self.nvel and vy.size == self.nvel and vz.size == self.nvel and pr.size == self.npres
+        self._chk(self.lib.nsk_vec_upload3(self.ctx, v, _p(vx), _p(vy), _p(vz), _p(pr)))
+
+    def download3(self, v):
+        n, m = self.lx1, self.lx2
+        vx = np.empty((self.nel, n, n, n)); vy = np.empty_like(vx); vz = np.empty_like(vx); pr = np.empty((self.nel, m, m, m))
+        self._chk(self.lib.nsk_vec_download3(self.ctx, v, _p(vx), _p(vy), _p(vz), _p(pr)))
+        return vx, vy, vz, pr
 
     def upload(self, v, vx, vy, pr):
         vx, vy, pr = (np.ascontiguousarray(a, dtype=np.float64) for a in (vx, vy, pr))
@@ -309,6 +328,15 @@ class NekStabHip:
         ox = np.empty_like(rx); oy = np.empty_like(rx); it = C.c_int()
         self._chk(self.lib.nsk_test_helm_solve(self.ctx, _p(rx), _p(ry), order, _p(ox), _p(oy), C.byref(it)))
         return ox, oy, it.value
+
+    def t_op3(self, which, inp, a=0):
+        """3-D element operators on packed arrays (nsk_test_op3)."""
+        n, m = self.lx1, self.lx2
+        inp = np.ascontiguousarray(inp, dtype=np.float64)
+        out = np.empty((self.nel, m, m, m)) if which in (1, 6, 7) else np.empty((3, self.nel, n, n, n))
+        it = C.c_int()
+        self._chk(self.lib.nsk_test_op3(self.ctx, which, _p(inp), _p(out), int(a), C.byref(it)))
+        return (out, it.value) if which == 5 else out
 
     def t_pres_solve(self, g):
         g = np.ascontiguousarray(g); out = np.empty_like(g); it = C.c_int()

@@ -21,6 +21,7 @@
 #include "../../include/nekstab_hip.h"
 #include "nsk_basis.hpp"
 #include "nsk_kernels.hpp"
+#include "nsk3_kernels.hpp"
 
 using namespace nsk;
 
@@ -34,17 +35,21 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
       return fail(NSK_EHIP, std::string(#x) + ": " + hipGetErrorString(e_) + " @" + std::to_string(__LINE__)); \
   } while (0)
 
-#define DISPATCH_N(n, ...)                                         \
-  switch (n) {                                                     \
-    case 6: { constexpr int N = 6; __VA_ARGS__; } break;           \
-    case 8: { constexpr int N = 8; __VA_ARGS__; } break;           \
-    case 10: { constexpr int N = 10; __VA_ARGS__; } break;         \
-    case 12: { constexpr int N = 12; __VA_ARGS__; } break;         \
-    default: return fail(NSK_EINVAL, "unsupported lx1");           \
+// kernel set = (dimension, lx1): key = lx1 for quadrilaterals (namespace k2), 100 + lx1 for hexahedra (k3)
+#define DISPATCH_N(n, ...)                                                                      \
+  switch (n) {                                                                                  \
+    case 6: { using namespace nsk::k2; constexpr int N = 6; __VA_ARGS__; } break;               \
+    case 8: { using namespace nsk::k2; constexpr int N = 8; __VA_ARGS__; } break;               \
+    case 10: { using namespace nsk::k2; constexpr int N = 10; __VA_ARGS__; } break;             \
+    case 12: { using namespace nsk::k2; constexpr int N = 12; __VA_ARGS__; } break;             \
+    case 106: { using namespace nsk::k3; constexpr int N = 6; __VA_ARGS__; } break;             \
+    case 108: { using namespace nsk::k3; constexpr int N = 8; __VA_ARGS__; } break;             \
+    default: return fail(NSK_EINVAL, "unsupported lx1");                                        \
   }
 
 struct nsk_ctx {
   int N = 0, NN = 0, M = 0, MM = 0, ND = 0, NDD = 0, EPB = 0, NT = 0, NTD = 0;
+  int ndim = 2, key = 0;                // key selects the kernel set (DISPATCH_N)
   int nel = 0, nblk = 0, nvert = 0;
   long long nloc = 0, npr = 0, nstate = 0;
   double dt = 0, re = 0, endtime = 0;
@@ -139,7 +144,7 @@ static StepCoef make_coef(const nsk_ctx* c, int istep, int adjoint) {
 // E-apply helper used by setup, tests and the projection space
 // ---------------------------------------------------------------------------
 static int eapply(nsk_ctx* c, const double* pin, double* wout) {
-  DISPATCH_N(c->N, {
+  DISPATCH_N(c->key, {
     hipLaunchKernelGGL(k_gradt<N>, dim3(c->nblk), dim3(Cfg<N>::NT), 0, c->stream, c->d, pin, c->d.yl);
     hipLaunchKernelGGL(k_divgs<N>, dim3(c->nblk), dim3(Cfg<N>::NT), 0, c->stream, c->d, (const double*)c->d.yl, wout, -1, 0);
   });
@@ -196,7 +201,8 @@ __global__ void k_gj_update(double* __restrict__ A, int n, int k, const double* 
 // ---------------------------------------------------------------------------
 static int build(nsk_ctx* c, const nsk_case& cs) {
   const int N = cs.lx1, NN = N * N, M = N - 2, MM = M * M, ND = cs.lxd > 0 ? cs.lxd : 3 * N / 2, NDD = ND * ND;
-  if (cs.ndim != 2) return fail(NSK_EINVAL, "only ndim=2 in this build");
+  if (cs.ndim != 2) return fail(NSK_EINVAL, "build(): ndim must be 2");
+  c->ndim = 2; c->key = cs.lx1; c->d.ndim = 2;
   if (!(N == 6 || N == 8 || N == 10 || N == 12)) return fail(NSK_EINVAL, "lx1 must be 6, 8, 10 or 12");
   if (ND != 3 * N / 2) return fail(NSK_EINVAL, "lxd must be 3*lx1/2");
   const int nel = cs.nel;
@@ -616,19 +622,24 @@ static int build(nsk_ctx* c, const nsk_case& cs) {
   return 0;
 }
 
+#include "nsk3_setup.inc"
+
 // ---------------------------------------------------------------------------
 // one nek_advance() in perturbation mode
 // ---------------------------------------------------------------------------
 static int pres_solve_launch(nsk_ctx* c, double h2, int ord, int np) {
   Dev& d = c->d;
   const double scale = 1.0 / (h2 * std::sqrt(d.vol));
-  DISPATCH_N(c->N, {
+  DISPATCH_N(c->key, {
     constexpr int NT = Cfg<N>::NT;
     if (!d.has_outflow && !c->in_test) hipLaunchKernelGGL(k_ortho, dim3(c->nblk), dim3(256), 0, c->stream, d);
     if (d.nproj_max > 0 && !c->in_test) hipLaunchKernelGGL(k_proj_apply, dim3(c->nblk), dim3(256), 0, c->stream, d);
     hipLaunchKernelGGL(k_gmres_update<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, -1, scale, c->min_pres, ord);
     for (int j = 0; j < np; ++j) {
-      if (d.coarse_lda <= 3072) {
+      if (c->ndim == 3) {
+        hipLaunchKernelGGL(k_coarse_restrict_csr, dim3(d.coarse_lda / 256), dim3(256), 0, c->stream, d, c->rc_big);
+        hipLaunchKernelGGL(k_coarse_big, dim3((d.nvert + 3) / 4), dim3(256), 0, c->stream, d, (const double*)c->rc_big);
+      } else if (d.coarse_lda <= 3072) {
         hipLaunchKernelGGL(k_coarse, dim3((d.nvert + 4 * CROWS_W - 1) / (4 * CROWS_W)), dim3(256), d.coarse_lda * sizeof(double), c->stream, d);
       } else {
         hipLaunchKernelGGL(k_coarse_restrict, dim3(d.coarse_lda / 256), dim3(256), 0, c->stream, d, c->rc_big);
@@ -636,6 +647,7 @@ static int pres_solve_launch(nsk_ctx* c, double h2, int ord, int np) {
       }
       hipLaunchKernelGGL(k_schwarz<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, (const double*)(d.V + (size_t)j * d.ps), d.Z + (size_t)j * d.npr, 1, 1);
       hipLaunchKernelGGL(k_divgs<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, (const double*)d.yl, d.V + (size_t)(j + 1) * d.ps, j, 1);
+      if (c->ndim == 3) hipLaunchKernelGGL(k_gmres_reorth<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, j);
       hipLaunchKernelGGL(k_gmres_update<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, j, scale, c->min_pres, ord);
     }
   });
@@ -646,7 +658,7 @@ static int step(nsk_ctx* c, int istep, int adjoint) {
   Dev& d = c->d;
   const StepCoef sc = make_coef(c, istep, adjoint);
   const int nh = c->cur_helm[sc.cls];
-  DISPATCH_N(c->N, {
+  DISPATCH_N(c->key, {
     constexpr int NT = Cfg<N>::NT;
     hipLaunchKernelGGL(k_convect<N>, dim3(c->nel), dim3(Cfg<N>::NTD), 0, c->stream, d, (const double*)d.u, d.bf, adjoint);
     hipLaunchKernelGGL(k_rhs<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, sc);
@@ -656,11 +668,11 @@ static int step(nsk_ctx* c, int istep, int adjoint) {
   });
   int rc = pres_solve_launch(c, sc.h2, sc.cls, c->cur_pres[sc.cls]);
   if (rc) return rc;
-  DISPATCH_N(c->N, {
+  DISPATCH_N(c->key, {
     hipLaunchKernelGGL(k_pres_update<N>, dim3(c->nblk), dim3(Cfg<N>::NT), 0, c->stream, d, sc);
   });
   if (d.nproj_max > 0) {
-    DISPATCH_N(c->N, {
+    DISPATCH_N(c->key, {
       hipLaunchKernelGGL(k_vel_update_proj<N>, dim3(c->nblk), dim3(Cfg<N>::NT), 0, c->stream, d, sc);
     });
     hipLaunchKernelGGL(k_proj_update, dim3(c->nblk), dim3(256), 0, c->stream, d);
@@ -694,9 +706,9 @@ static int run_map(nsk_ctx* c, int adjoint, double* f, const double* q) {
   Dev& d = c->d;
   if (c->use_graph)
     for (int k = 0; k < 6; ++k) { int rc = ensure_graph(c, k, adjoint); if (rc) return rc; }
-  HIPCHK(hipMemcpyAsync(d.u, q, d.nloc * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-  HIPCHK(hipMemcpyAsync(d.u + d.cs, q + d.nloc, d.nloc * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-  HIPCHK(hipMemcpyAsync(d.p, q + 2 * d.nloc, d.npr * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  for (int cc = 0; cc < c->ndim; ++cc)
+    HIPCHK(hipMemcpyAsync(d.u + cc * d.cs, q + cc * d.nloc, d.nloc * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(d.p, q + c->ndim * d.nloc, d.npr * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
   if (d.bf_stride) {
     if (adjoint != 2 && c->nsteps > c->orbit_steps) return fail(NSK_EINVAL, "map longer than the stored base-flow orbit");
     HIPCHK(hipMemsetAsync(d.bstep, 0, sizeof(int), c->stream));
@@ -720,9 +732,9 @@ static int run_map(nsk_ctx* c, int adjoint, double* f, const double* q) {
       }
     }
   }
-  HIPCHK(hipMemcpyAsync(f, d.u, d.nloc * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-  HIPCHK(hipMemcpyAsync(f + d.nloc, d.u + d.cs, d.nloc * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-  HIPCHK(hipMemcpyAsync(f + 2 * d.nloc, d.p, d.npr * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  for (int cc = 0; cc < c->ndim; ++cc)
+    HIPCHK(hipMemcpyAsync(f + cc * d.nloc, d.u + cc * d.cs, d.nloc * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(f + c->ndim * d.nloc, d.p, d.npr * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
   return 0;
 }
 
@@ -785,6 +797,7 @@ extern "C" {
 // Cut the shard of `rank` (part[e] = owner of global element e) out of a full-mesh context.
 int nsk_shard_create(nsk_ctx* parent, const int* part, int rank, int nranks, nsk_ctx** out) {
   if (!parent || !part || !out) return fail(NSK_EINVAL, "bad argument");
+  if (parent->ndim != 2) return fail(NSK_EINVAL, "element sharding: 2-D only in this build");
   return shard_create(parent, part, rank, nranks, out);
 }
 
@@ -841,7 +854,7 @@ int nsk_group_test(nsk_ctx** shards, int n, int which, const double* const* in, 
     }
   } else if (which == 1) {
     for (int r = 0; r < n; ++r) HIPCHK(hipMemcpyAsync(G[r]->wp1, in[r], G[r]->npr * sizeof(double), hipMemcpyHostToDevice, G[r]->stream));
-    DISPATCH_N(G[0]->N, {
+    DISPATCH_N(G[0]->key, {
       for (nsk_ctx* c : G) hipLaunchKernelGGL(k_gradt<N>, dim3(c->nblk), dim3(Cfg<N>::NT), 0, c->stream, c->d, (const double*)c->wp1, c->d.yl);
       if ((rc = xchg_vel(G, &Dev::yl, 0, 2))) return rc;
       for (nsk_ctx* c : G) hipLaunchKernelGGL(k_divgs<N>, dim3(c->nblk), dim3(Cfg<N>::NT), 0, c->stream, c->d, (const double*)c->d.yl, c->wp2, -1, 0);
@@ -859,7 +872,7 @@ int nsk_local_dots(nsk_ctx* c, nsk_vec f, const nsk_vec* Q, int nq, double* out)
   if (nq > 1024) return fail(NSK_EINVAL, "too many vectors");
   for (int k = 0; k < nq; ++k) ((double**)c->hpin)[k] = (double*)Q[k];
   HIPCHK(hipMemcpyAsync(c->kptr, c->hpin, nq * sizeof(double*), hipMemcpyHostToDevice, c->stream));
-  hipLaunchKernelGGL(k_dots, dim3(c->kblk), dim3(256), 0, c->stream, (const double*)f, (const double* const*)c->kptr, nq, c->d.bm1s, c->nloc, c->kpart, c->kblk);
+  hipLaunchKernelGGL(k_dots, dim3(c->kblk), dim3(256), 0, c->stream, (const double*)f, (const double* const*)c->kptr, nq, c->d.bm1s, c->nloc, c->kpart, c->kblk, c->ndim);
   hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, c->stream, (const double*)c->kpart, nq, c->kblk, c->kout);
   HIPCHK(hipMemcpyAsync(out, c->kout, nq * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -887,7 +900,7 @@ int nsk_init(const nsk_case* cs, nsk_ctx** out) {
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
     return fail(NSK_EHIP, "no HIP device: libnekstab_hip has no CPU fallback");
   nsk_ctx* c = new nsk_ctx();
-  int rc = build(c, *cs);
+  int rc = (cs->ndim == 3) ? build3(c, *cs) : build(c, *cs);
   if (rc) { std::string keep = g_err; nsk_finalize(c); g_err = keep; return rc; }
   *out = c;
   return 0;
@@ -968,6 +981,7 @@ int nsk_vec_free(nsk_ctx* c, int n, nsk_vec* v) {
 
 int nsk_vec_upload(nsk_ctx* c, nsk_vec v, const double* vx, const double* vy, const double* pr) {
   if (!c || !v) return fail(NSK_EINVAL, "bad argument");
+  if (c->ndim != 2) return fail(NSK_EINVAL, "3-D context: use nsk_vec_upload3");
   double* p = (double*)v;
   HIPCHK(hipStreamSynchronize(c->stream));
   if (vx) HIPCHK(hipMemcpy(p, vx, c->nloc * sizeof(double), hipMemcpyHostToDevice));
@@ -978,11 +992,36 @@ int nsk_vec_upload(nsk_ctx* c, nsk_vec v, const double* vx, const double* vy, co
 
 int nsk_vec_download(nsk_ctx* c, nsk_vec v, double* vx, double* vy, double* pr) {
   if (!c || !v) return fail(NSK_EINVAL, "bad argument");
+  if (c->ndim != 2) return fail(NSK_EINVAL, "3-D context: use nsk_vec_download3");
   const double* p = (const double*)v;
   HIPCHK(hipStreamSynchronize(c->stream));
   if (vx) HIPCHK(hipMemcpy(vx, p, c->nloc * sizeof(double), hipMemcpyDeviceToHost));
   if (vy) HIPCHK(hipMemcpy(vy, p + c->nloc, c->nloc * sizeof(double), hipMemcpyDeviceToHost));
   if (pr) HIPCHK(hipMemcpy(pr, p + 2 * c->nloc, c->npr * sizeof(double), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int nsk_vec_upload3(nsk_ctx* c, nsk_vec v, const double* vx, const double* vy, const double* vz, const double* pr) {
+  if (!c || !v) return fail(NSK_EINVAL, "bad argument");
+  if (c->ndim != 3) return fail(NSK_EINVAL, "nsk_vec_upload3 needs a 3-D context");
+  double* p = (double*)v;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  const double* src[3] = {vx, vy, vz};
+  for (int k = 0; k < 3; ++k)
+    if (src[k]) HIPCHK(hipMemcpy(p + k * c->nloc, src[k], c->nloc * sizeof(double), hipMemcpyHostToDevice));
+  if (pr) HIPCHK(hipMemcpy(p + 3 * c->nloc, pr, c->npr * sizeof(double), hipMemcpyHostToDevice));
+  return 0;
+}
+
+int nsk_vec_download3(nsk_ctx* c, nsk_vec v, double* vx, double* vy, double* vz, double* pr) {
+  if (!c || !v) return fail(NSK_EINVAL, "bad argument");
+  if (c->ndim != 3) return fail(NSK_EINVAL, "nsk_vec_download3 needs a 3-D context");
+  const double* p = (const double*)v;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  double* dst[3] = {vx, vy, vz};
+  for (int k = 0; k < 3; ++k)
+    if (dst[k]) HIPCHK(hipMemcpy(dst[k], p + k * c->nloc, c->nloc * sizeof(double), hipMemcpyDeviceToHost));
+  if (pr) HIPCHK(hipMemcpy(pr, p + 3 * c->nloc, c->npr * sizeof(double), hipMemcpyDeviceToHost));
   return 0;
 }
 
@@ -1026,17 +1065,23 @@ int nsk_set_baseflow(nsk_ctx* c, nsk_vec qv) {
   if (c->parent || c->nranks > 1) return fail(NSK_EINVAL, "set_baseflow on shards is not built yet");
   Dev& d = c->d;
   const double* q = (const double*)qv;
-  DISPATCH_N(c->N, {
+  DISPATCH_N(c->key, {
     hipLaunchKernelGGL(k_baseflow<N>, dim3(c->nel), dim3(Cfg<N>::NTD), 0, c->stream, d, q, (double*)d.cUr, (double*)d.cUs,
                        (double*)d.GUx, (double*)d.GUy, (double*)d.GVx, (double*)d.GVy);
   });
-  std::vector<double> u(2 * c->nloc);
-  HIPCHK(hipMemcpyAsync(u.data(), q, 2 * c->nloc * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  const int nd = c->ndim;
+  std::vector<double> u((size_t)nd * c->nloc);
+  HIPCHK(hipMemcpyAsync(u.data(), q, (size_t)nd * c->nloc * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   double ctarg = 0.0;
   for (long long l = 0; l < c->nloc; ++l) {
-    const double a = u[l], b = u[c->nloc + l];
-    ctarg = std::max(ctarg, std::fabs(a * c->h_cflg[4 * l] + b * c->h_cflg[4 * l + 1]) + std::fabs(a * c->h_cflg[4 * l + 2] + b * c->h_cflg[4 * l + 3]));
+    double s = 0.0;
+    for (int a = 0; a < nd; ++a) {
+      double t = 0.0;
+      for (int cc = 0; cc < nd; ++cc) t += u[(size_t)cc * c->nloc + l] * c->h_cflg[(size_t)nd * nd * l + a * nd + cc];
+      s += std::fabs(t);
+    }
+    ctarg = std::max(ctarg, s);
   }
   if (!(ctarg > 0.0)) return fail(NSK_EINVAL, "base flow is zero");
   const double dt0 = c->cfl_target / ctarg;
@@ -1059,6 +1104,7 @@ int nsk_set_baseflow(nsk_ctx* c, nsk_vec qv) {
 int nsk_set_orbit(nsk_ctx* c, nsk_vec q0v, double spng_str, nsk_vec end) {
   if (!c || !q0v) return fail(NSK_EINVAL, "bad argument");
   if (c->parent) return fail(NSK_EINVAL, "orbit on shards is not built yet");
+  if (c->ndim != 2) return fail(NSK_EINVAL, "time-periodic base flows: 2-D only in this build");
   Dev& d = c->d;
   const double* q0 = (const double*)q0v;
   if (d.bf_stride) {                                            // back to the steady arrays first
@@ -1086,7 +1132,7 @@ int nsk_set_orbit(nsk_ctx* c, nsk_vec q0v, double spng_str, nsk_vec end) {
   HIPCHK(hipMemcpyAsync(d.p, q0 + 2 * d.nloc, d.npr * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
   for (int istep = 1; istep <= c->nsteps; ++istep) {
     const long long off = (long long)(istep - 1) * nfine;
-    DISPATCH_N(c->N, {
+    DISPATCH_N(c->key, {
       hipLaunchKernelGGL(k_baseflow<N>, dim3(c->nel), dim3(Cfg<N>::NTD), 0, c->stream, d, (const double*)d.u, c->orbit[0] + off, c->orbit[1] + off,
                          c->orbit[2] + off, c->orbit[3] + off, c->orbit[4] + off, c->orbit[5] + off);
     });
@@ -1128,7 +1174,7 @@ static int dots_to_device(nsk_ctx* c, const double* f, const nsk_vec* Q, int nq)
   if (nq > 1024) return fail(NSK_EINVAL, "too many vectors");
   for (int k = 0; k < nq; ++k) ((double**)c->hpin)[k] = (double*)Q[k];
   HIPCHK(hipMemcpyAsync(c->kptr, c->hpin, nq * sizeof(double*), hipMemcpyHostToDevice, c->stream));
-  hipLaunchKernelGGL(k_dots, dim3(c->kblk), dim3(256), 0, c->stream, f, (const double* const*)c->kptr, nq, c->d.bm1s, c->nloc, c->kpart, c->kblk);
+  hipLaunchKernelGGL(k_dots, dim3(c->kblk), dim3(256), 0, c->stream, f, (const double* const*)c->kptr, nq, c->d.bm1s, c->nloc, c->kpart, c->kblk, c->ndim);
   hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, c->stream, (const double*)c->kpart, nq, c->kblk, c->kout);
   return 0;
 }
@@ -1245,7 +1291,7 @@ int nsk_debug_stamps(nsk_ctx* c, unsigned long long* out, int nblk_max) {
   Dev& d = c->d;
   if (!d.dbg) { int rc = dalloc(c, &d.dbg, (size_t)16 * (c->nblk + 8)); if (rc) return rc; }
   HIPCHK(hipMemset(d.dbg, 0, (size_t)16 * (c->nblk + 8) * sizeof(unsigned long long)));
-  DISPATCH_N(c->N, {
+  DISPATCH_N(c->key, {
     if (nblk_max < 0) {
       Dev dd = d; dd.tol_helm = 0.0; dd.tol_relative = 0;
       const StepCoef sc = make_coef(c, 3, 0);
@@ -1273,7 +1319,7 @@ int nsk_bench_kernel(nsk_ctx* c, const char* name, int reps, double* avg_us) {
     const StepCoef sc = make_coef(c, 3, 0);
     const int cyc = 8;
     HIPCHK(hipStreamSynchronize(c->stream));
-    DISPATCH_N(c->N, {
+    DISPATCH_N(c->key, {
       for (int r = 0; r < cyc; ++r)                               // warm
         hipLaunchKernelGGL(k_helm<N>, dim3(c->nblk), dim3(Cfg<N>::NT), 0, c->stream, d, sc, r % cyc, (const double*)d.rloc);
       HIPCHK(hipEventRecord(e0, c->stream));
@@ -1295,7 +1341,7 @@ int nsk_bench_kernel(nsk_ctx* c, const char* name, int reps, double* avg_us) {
 // ---- test hooks -------------------------------------------------------------
 int nsk_test_axhelm(nsk_ctx* c, const double* u, double h1, double h2, double* out) {
   HIPCHK(hipMemcpy(c->wv1, u, c->nloc * sizeof(double), hipMemcpyHostToDevice));
-  DISPATCH_N(c->N, { hipLaunchKernelGGL(k_axhelm_test<N>, dim3(c->nblk), dim3(Cfg<N>::NT), 0, c->stream, c->d, (const double*)c->wv1, h1, h2, c->wv2); });
+  DISPATCH_N(c->key, { hipLaunchKernelGGL(k_axhelm_test<N>, dim3(c->nblk), dim3(Cfg<N>::NT), 0, c->stream, c->d, (const double*)c->wv1, h1, h2, c->wv2); });
   HIPCHK(hipStreamSynchronize(c->stream));
   HIPCHK(hipMemcpy(out, c->wv2, c->nloc * sizeof(double), hipMemcpyDeviceToHost));
   return 0;
@@ -1310,17 +1356,19 @@ int nsk_test_dssum(nsk_ctx* c, const double* u, double* out) {
 }
 
 int nsk_test_opdiv(nsk_ctx* c, const double* u, const double* v, double* out) {
+  if (c->ndim != 2) return fail(NSK_EINVAL, "2-D hook: use nsk_test_op3");
   HIPCHK(hipMemcpy(c->wv1, u, c->nloc * sizeof(double), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(c->wv1 + c->d.cs, v, c->nloc * sizeof(double), hipMemcpyHostToDevice));
-  DISPATCH_N(c->N, { hipLaunchKernelGGL(k_opdiv_test<N>, dim3(c->nblk), dim3(Cfg<N>::NT), 0, c->stream, c->d, (const double*)c->wv1, c->wp1); });
+  DISPATCH_N(c->key, { hipLaunchKernelGGL(k_opdiv_test<N>, dim3(c->nblk), dim3(Cfg<N>::NT), 0, c->stream, c->d, (const double*)c->wv1, c->wp1); });
   HIPCHK(hipStreamSynchronize(c->stream));
   HIPCHK(hipMemcpy(out, c->wp1, c->npr * sizeof(double), hipMemcpyDeviceToHost));
   return 0;
 }
 
 int nsk_test_opgradt(nsk_ctx* c, const double* p, double* ox, double* oy) {
+  if (c->ndim != 2) return fail(NSK_EINVAL, "2-D hook: use nsk_test_op3");
   HIPCHK(hipMemcpy(c->wp1, p, c->npr * sizeof(double), hipMemcpyHostToDevice));
-  DISPATCH_N(c->N, { hipLaunchKernelGGL(k_gradt<N>, dim3(c->nblk), dim3(Cfg<N>::NT), 0, c->stream, c->d, (const double*)c->wp1, c->wv1); });
+  DISPATCH_N(c->key, { hipLaunchKernelGGL(k_gradt<N>, dim3(c->nblk), dim3(Cfg<N>::NT), 0, c->stream, c->d, (const double*)c->wp1, c->wv1); });
   HIPCHK(hipStreamSynchronize(c->stream));
   HIPCHK(hipMemcpy(ox, c->wv1, c->nloc * sizeof(double), hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(oy, c->wv1 + c->d.cs, c->nloc * sizeof(double), hipMemcpyDeviceToHost));
@@ -1328,12 +1376,70 @@ int nsk_test_opgradt(nsk_ctx* c, const double* p, double* ox, double* oy) {
 }
 
 int nsk_test_convect(nsk_ctx* c, int adjoint, const double* u, const double* v, double* ox, double* oy) {
+  if (c->ndim != 2) return fail(NSK_EINVAL, "2-D hook: use nsk_test_op3");
   HIPCHK(hipMemcpy(c->wv1, u, c->nloc * sizeof(double), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(c->wv1 + c->d.cs, v, c->nloc * sizeof(double), hipMemcpyHostToDevice));
-  DISPATCH_N(c->N, { hipLaunchKernelGGL(k_convect<N>, dim3(c->nel), dim3(Cfg<N>::NTD), 0, c->stream, c->d, (const double*)c->wv1, c->wv2, adjoint); });
+  DISPATCH_N(c->key, { hipLaunchKernelGGL(k_convect<N>, dim3(c->nel), dim3(Cfg<N>::NTD), 0, c->stream, c->d, (const double*)c->wv1, c->wv2, adjoint); });
   HIPCHK(hipStreamSynchronize(c->stream));
   HIPCHK(hipMemcpy(ox, c->wv2, c->nloc * sizeof(double), hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(oy, c->wv2 + c->d.cs, c->nloc * sizeof(double), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// 3-D element operators with packed arguments: which = 1: weak divergence ([3*P] -> [P2]); 2: D^T p ([P2] -> [3*P]);
+// 3: convection term, mode a = 0 direct / 1 adjoint / 2 full equations ([3*P] -> [3*P]);
+// 5: Helmholtz solve of BDF order a ([3*P] unassembled rhs -> [3*P]), iteration count in *iters
+int nsk_test_op3(nsk_ctx* c, int which, const double* in, double* out, int a, int* iters) {
+  if (!c || !in || !out) return fail(NSK_EINVAL, "bad argument");
+  if (c->ndim != 3) return fail(NSK_EINVAL, "nsk_test_op3 needs a 3-D context");
+  Dev& d = c->d;
+  const size_t nv = 3 * (size_t)c->nloc;
+  if (which == 1) {
+    HIPCHK(hipMemcpy(c->wv1, in, nv * sizeof(double), hipMemcpyHostToDevice));
+    DISPATCH_N(c->key, { hipLaunchKernelGGL(k_opdiv_test<N>, dim3(c->nblk), dim3(Cfg<N>::NT), 0, c->stream, d, (const double*)c->wv1, c->wp1); });
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(out, c->wp1, c->npr * sizeof(double), hipMemcpyDeviceToHost));
+  } else if (which == 2) {
+    HIPCHK(hipMemcpy(c->wp1, in, c->npr * sizeof(double), hipMemcpyHostToDevice));
+    DISPATCH_N(c->key, { hipLaunchKernelGGL(k_gradt<N>, dim3(c->nblk), dim3(Cfg<N>::NT), 0, c->stream, d, (const double*)c->wp1, c->wv1); });
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(out, c->wv1, nv * sizeof(double), hipMemcpyDeviceToHost));
+  } else if (which == 3) {
+    HIPCHK(hipMemcpy(c->wv1, in, nv * sizeof(double), hipMemcpyHostToDevice));
+    DISPATCH_N(c->key, { hipLaunchKernelGGL(k_convect<N>, dim3(c->nel), dim3(Cfg<N>::NTD), 0, c->stream, d, (const double*)c->wv1, c->wv2, a); });
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(out, c->wv2, nv * sizeof(double), hipMemcpyDeviceToHost));
+  } else if (which == 5) {
+    HIPCHK(hipMemcpy(d.rloc, in, nv * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d.bloc, d.rloc, nv * sizeof(double), hipMemcpyDeviceToDevice));
+    HIPCHK(hipMemset(d.stats, 0, sizeof(Stats)));
+    const StepCoef sc = make_coef(c, a, 0);
+    DISPATCH_N(c->key, {
+      for (int it = 0; it < c->max_helm; ++it)
+        hipLaunchKernelGGL(k_helm<N>, dim3(c->nblk), dim3(Cfg<N>::NT), 0, c->stream, d, sc, it, (const double*)d.rloc);
+    });
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(out, d.hx, nv * sizeof(double), hipMemcpyDeviceToHost));
+    Stats h; HIPCHK(hipMemcpy(&h, d.stats, sizeof(Stats), hipMemcpyDeviceToHost));
+    if (iters) *iters = (int)h.helm_iters;
+  } else if (which == 6 || which == 7) {               // pressure preconditioner: 6 = Schwarz only, 7 = Schwarz + coarse
+    HIPCHK(hipMemcpy(d.V, in, c->npr * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(d.gsc, 0, sizeof(GmresScal)));
+    std::vector<double> part(c->nblk, 0.0);
+    for (long long q = 0; q < c->npr; ++q) part[q / c->MM] += in[q] * in[q];
+    HIPCHK(hipMemcpy(d.gpart, part.data(), c->nblk * sizeof(double), hipMemcpyHostToDevice));
+    DISPATCH_N(c->key, {
+      hipLaunchKernelGGL(k_gmres_update<N>, dim3(c->nblk), dim3(Cfg<N>::NT), 0, c->stream, d, -1, 1.0, 1, 0);   // normalises V[0], fills ec
+      hipLaunchKernelGGL(k_coarse_restrict_csr, dim3(d.coarse_lda / 256), dim3(256), 0, c->stream, d, c->rc_big);
+      hipLaunchKernelGGL(k_coarse_big, dim3((d.nvert + 3) / 4), dim3(256), 0, c->stream, d, (const double*)c->rc_big);
+      hipLaunchKernelGGL(k_schwarz<N>, dim3(c->nblk), dim3(Cfg<N>::NT), 0, c->stream, d, (const double*)d.V, d.Z, which == 7 ? 1 : 0, 0);
+    });
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(out, d.Z, c->npr * sizeof(double), hipMemcpyDeviceToHost));
+    double nrm = 0; for (long long q = 0; q < c->npr; ++q) nrm += in[q] * in[q];
+    nrm = std::sqrt(nrm);
+    for (long long q = 0; q < c->npr; ++q) out[q] *= nrm;     // undo the normalisation of V[0]
+  } else return fail(NSK_EINVAL, "unknown operator");
   return 0;
 }
 
@@ -1347,6 +1453,7 @@ int nsk_test_eapply(nsk_ctx* c, const double* p, double* out) {
 }
 
 int nsk_test_helm_solve(nsk_ctx* c, const double* rx, const double* ry, int order, double* ox, double* oy, int* iters) {
+  if (c->ndim != 2) return fail(NSK_EINVAL, "2-D hook: use nsk_test_op3");
   Dev& d = c->d;
   HIPCHK(hipMemcpy(d.rloc, rx, c->nloc * sizeof(double), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(d.rloc + d.cs, ry, c->nloc * sizeof(double), hipMemcpyHostToDevice));
@@ -1354,7 +1461,7 @@ int nsk_test_helm_solve(nsk_ctx* c, const double* rx, const double* ry, int orde
   HIPCHK(hipMemset(d.stats, 0, sizeof(Stats)));
   const StepCoef sc = make_coef(c, order, 0);
   const int nh = c->max_helm;
-  DISPATCH_N(c->N, {
+  DISPATCH_N(c->key, {
     for (int it = 0; it < nh; ++it)
       hipLaunchKernelGGL(k_helm<N>, dim3(c->nblk), dim3(Cfg<N>::NT), 0, c->stream, d, sc, it, (const double*)d.rloc);
   });
@@ -1381,7 +1488,7 @@ int nsk_test_pres_solve(nsk_ctx* c, const double* g, double* out, int* iters) {
   c->in_test = 0;
   if (rc) return rc;
   sc.h2 = 1.0;
-  DISPATCH_N(c->N, { hipLaunchKernelGGL(k_pres_update<N>, dim3(c->nblk), dim3(Cfg<N>::NT), 0, c->stream, d, sc); });
+  DISPATCH_N(c->key, { hipLaunchKernelGGL(k_pres_update<N>, dim3(c->nblk), dim3(Cfg<N>::NT), 0, c->stream, d, sc); });
   HIPCHK(hipStreamSynchronize(c->stream));
   d.nproj_max = savep;
   HIPCHK(hipMemcpy(out, d.p, c->npr * sizeof(double), hipMemcpyDeviceToHost));

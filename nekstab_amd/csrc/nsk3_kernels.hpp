@@ -1,0 +1,1073 @@
+// HIP kernels (gfx950) of the linearised PnPn-2 time step on hexahedral elements: the 3-D
+// counterparts of nsk_kernels.hpp, same kernel names and launch signatures (namespace nsk::k3),
+// so the host driver (step graphs, adaptive budgets, Krylov algebra) is shared.
+// One workgroup per element, one thread per GLL node (lx1 = 8: 512 threads = 8 wavefronts),
+// tensor contractions in three LDS passes, dssum as the same fused gather.
+#pragma once
+#include "nsk_kernels.hpp"
+
+namespace nsk {
+namespace k3 {
+
+template <int N>
+struct Cfg {
+  static constexpr int NN = N * N * N, M = N - 2, MM = M * M * M, ND = 3 * N / 2, NDD = ND * ND * ND;
+  static constexpr int EPB = 1;
+  static constexpr int NT = ((NN + 63) / 64) * 64;
+  static constexpr int NTD = NT;
+  static constexpr int NNM = N * N * M, NMM = N * M * M;            // intermediate tile sizes GLL <-> Gauss
+};
+
+// ---------------------------------------------------------------------------
+// element-local building blocks (one element per workgroup, LDS tiles [k][j][i])
+// ---------------------------------------------------------------------------
+// D^T G D on NC tiles su[c][NN]; st scratch [NC][3][NN]   [UPSTREAM hmholtz.f axhelm, 3-D branch]
+// g = (G1..G6) = (rr, ss, tt, rs, rt, st)
+template <int N, int NC>
+__device__ inline void axhelm3(const double* sD, const double* sDt, const double* su, double* st, bool act,
+                               int k, int j, int i, const double (&g)[6], double (&out)[NC]) {
+  constexpr int NN = N * N * N;
+  const int t = (k * N + j) * N + i;
+  if (act) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const double* z = su + c * NN;
+      double ur = 0.0, us = 0.0, ut = 0.0;
+#pragma unroll
+      for (int m = 0; m < N; ++m) {
+        ur += sDt[m * N + i] * z[(k * N + j) * N + m];
+        us += sDt[m * N + j] * z[(k * N + m) * N + i];
+        ut += sDt[m * N + k] * z[(m * N + j) * N + i];
+      }
+      st[(c * 3 + 0) * NN + t] = g[0] * ur + g[3] * us + g[4] * ut;
+      st[(c * 3 + 1) * NN + t] = g[3] * ur + g[1] * us + g[5] * ut;
+      st[(c * 3 + 2) * NN + t] = g[4] * ur + g[5] * us + g[2] * ut;
+    }
+  }
+  lds_barrier();
+  if (act) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const double* t1 = st + (c * 3 + 0) * NN;
+      const double* t2 = st + (c * 3 + 1) * NN;
+      const double* t3 = st + (c * 3 + 2) * NN;
+      double au = 0.0;
+#pragma unroll
+      for (int m = 0; m < N; ++m)
+        au += sD[m * N + i] * t1[(k * N + j) * N + m] + sD[m * N + j] * t2[(k * N + m) * N + i] + sD[m * N + k] * t3[(m * N + j) * N + i];
+      out[c] = au;
+    }
+  }
+}
+
+// weak divergence GLL -> Gauss  [UPSTREAM navier1.f opdiv/multd, 3-D]; su = [3][NN]
+// scratch sA [2][NNM], sB [3][NMM]; w2m = [9][npr] metrics (a*3+c) premultiplied by the Gauss weights.
+// Returns the value for Gauss node tid (< MM).
+template <int N>
+__device__ inline double opdiv3(const double* sJ12, const double* sD12, const double* su, double* sA, double* sB,
+                                int tid, int nt, const double (&w2)[9]) {
+  constexpr int NN = N * N * N, M = N - 2, MM = M * M * M, NNM = N * N * M, NMM = N * M * M;
+  double div = 0.0;
+#pragma unroll 1
+  for (int c = 0; c < 3; ++c) {
+    const double* u = su + c * NN;
+    for (int p = tid; p < NNM; p += nt) {            // axis r: [k][j][a]
+      const int a = p % M, kj = p / M;
+      double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+      for (int i = 0; i < N; ++i) { const double x = u[kj * N + i]; s1 += sD12[a * N + i] * x; s2 += sJ12[a * N + i] * x; }
+      sA[p] = s1; sA[NNM + p] = s2;
+    }
+    lds_barrier();
+    for (int p = tid; p < NMM; p += nt) {            // axis s: [k][b][a]
+      const int a = p % M, b = (p / M) % M, k = p / (M * M);
+      double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        const double x1 = sA[(k * N + j) * M + a], x2 = sA[NNM + (k * N + j) * M + a];
+        s1 += sJ12[b * N + j] * x1; s2 += sD12[b * N + j] * x2; s3 += sJ12[b * N + j] * x2;
+      }
+      sB[p] = s1; sB[NMM + p] = s2; sB[2 * NMM + p] = s3;
+    }
+    lds_barrier();
+    if (tid < MM) {                                  // axis t
+      const int ba = tid % (M * M), cc = tid / (M * M);
+      double ur = 0.0, us = 0.0, ut = 0.0;
+#pragma unroll
+      for (int k = 0; k < N; ++k) {
+        ur += sJ12[cc * N + k] * sB[k * M * M + ba];
+        us += sJ12[cc * N + k] * sB[NMM + k * M * M + ba];
+        ut += sD12[cc * N + k] * sB[2 * NMM + k * M * M + ba];
+      }
+      div += w2[0 * 3 + c] * ur + w2[1 * 3 + c] * us + w2[2 * 3 + c] * ut;
+    }
+  }
+  return div;
+}
+
+// D^T p  [UPSTREAM navier1.f opgradt/cdtp, 3-D]; pw = p (x Gauss weights are inside w2) at Gauss node tid.
+// scratch sP [3][MM], sC [3][NMM], sE [2][NNM]
+template <int N>
+__device__ inline void opgradt3(const double* sJ12, const double* sD12, double pval, const double (&w2)[9], double* sP,
+                                double* sC, double* sE, int tid, int nt, bool act, int k, int j, int i, double (&g)[3]) {
+  constexpr int M = N - 2, MM = M * M * M, NNM = N * N * M, NMM = N * M * M;
+#pragma unroll 1
+  for (int c = 0; c < 3; ++c) {
+    if (tid < MM) {
+      sP[tid] = pval * w2[0 * 3 + c];
+      sP[MM + tid] = pval * w2[1 * 3 + c];
+      sP[2 * MM + tid] = pval * w2[2 * 3 + c];
+    }
+    lds_barrier();
+    for (int p = tid; p < NMM; p += nt) {            // axis t: [kk][b][a]
+      const int ba = p % (M * M), kk = p / (M * M);
+      double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+      for (int cc = 0; cc < M; ++cc) {
+        const double jj = sJ12[cc * N + kk], dd = sD12[cc * N + kk];
+        s1 += jj * sP[cc * M * M + ba]; s2 += jj * sP[MM + cc * M * M + ba]; s3 += dd * sP[2 * MM + cc * M * M + ba];
+      }
+      sC[p] = s1; sC[NMM + p] = s2; sC[2 * NMM + p] = s3;
+    }
+    lds_barrier();
+    for (int p = tid; p < NNM; p += nt) {            // axis s: [kk][jj][a]
+      const int a = p % M, jj = (p / M) % N, kk = p / (M * N);
+      double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+      for (int b = 0; b < M; ++b) {
+        const double jw = sJ12[b * N + jj], dw = sD12[b * N + jj];
+        s1 += jw * sC[(kk * M + b) * M + a];
+        s2 += dw * sC[NMM + (kk * M + b) * M + a] + jw * sC[2 * NMM + (kk * M + b) * M + a];
+      }
+      sE[p] = s1; sE[NNM + p] = s2;
+    }
+    lds_barrier();
+    double s = 0.0;
+    if (act) {
+#pragma unroll
+      for (int a = 0; a < M; ++a) s += sD12[a * N + i] * sE[(k * N + j) * M + a] + sJ12[a * N + i] * sE[NNM + (k * N + j) * M + a];
+    }
+    g[c] = s;
+  }
+}
+
+template <int N>
+__device__ inline void load_basis3(const Dev& d, double* sD, double* sDt, double* sJ12, double* sD12, int tid, int nt) {
+  constexpr int M = N - 2;
+  for (int k = tid; k < N * N; k += nt) {
+    if (sD) sD[k] = d.D[k];
+    if (sDt) sDt[(k % N) * N + k / N] = d.D[k];
+  }
+  if (sJ12)
+    for (int k = tid; k < M * N; k += nt) { sJ12[k] = d.J12[k]; sD12[k] = d.D12[k]; }
+}
+
+__device__ inline void load_w2(const Dev& d, long long q, double (&w2)[9]) {
+#pragma unroll
+  for (int a = 0; a < 9; ++a) w2[a] = d.w2m[(size_t)a * d.npr + q];
+}
+
+// interpolation GLL -> dealiasing mesh of one component: in (global, [NN]) -> sf [NDD]; scratch t1 [N*N*ND], t2 [N*ND*ND]
+template <int N>
+__device__ inline void to_fine(const double* sJ, const double* __restrict__ uin, double* sf, double* t1, double* t2,
+                               int tid, int nt) {
+  constexpr int NN = N * N * N, ND = 3 * N / 2;
+  for (int p = tid; p < NN; p += nt) t2[p] = uin[p];
+  lds_barrier();
+  for (int p = tid; p < N * N * ND; p += nt) {       // r: [k][j][a]
+    const int a = p % ND, kj = p / ND;
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) s += sJ[a * N + i] * t2[kj * N + i];
+    t1[p] = s;
+  }
+  lds_barrier();
+  for (int p = tid; p < N * ND * ND; p += nt) {      // s: [k][b][a]
+    const int a = p % ND, b = (p / ND) % ND, k = p / (ND * ND);
+    double s = 0.0;
+#pragma unroll
+    for (int j = 0; j < N; ++j) s += sJ[b * N + j] * t1[(k * N + j) * ND + a];
+    t2[p] = s;
+  }
+  lds_barrier();
+  for (int p = tid; p < ND * ND * ND; p += nt) {     // t: [c][b][a]
+    const int ba = p % (ND * ND), c = p / (ND * ND);
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < N; ++k) s += sJ[c * N + k] * t2[k * ND * ND + ba];
+    sf[p] = s;
+  }
+  lds_barrier();
+}
+
+// transpose of to_fine: sf [NDD] -> value at GLL node (k,j,i) of this thread
+template <int N>
+__device__ inline double from_fine(const double* sJ, const double* sf, double* t1, double* t2, int tid, int nt,
+                                   bool act, int k, int j, int i) {
+  constexpr int ND = 3 * N / 2;
+  for (int p = tid; p < N * ND * ND; p += nt) {      // t: [k][b][a]
+    const int ba = p % (ND * ND), kk = p / (ND * ND);
+    double s = 0.0;
+#pragma unroll
+    for (int c = 0; c < ND; ++c) s += sJ[c * N + kk] * sf[c * ND * ND + ba];
+    t2[p] = s;
+  }
+  lds_barrier();
+  for (int p = tid; p < N * N * ND; p += nt) {       // s: [k][j][a]
+    const int a = p % ND, jj = (p / ND) % N, kk = p / (ND * N);
+    double s = 0.0;
+#pragma unroll
+    for (int b = 0; b < ND; ++b) s += sJ[b * N + jj] * t2[(kk * ND + b) * ND + a];
+    t1[p] = s;
+  }
+  lds_barrier();
+  double s = 0.0;
+  if (act) {
+#pragma unroll
+    for (int a = 0; a < ND; ++a) s += sJ[a * N + i] * t1[(k * N + j) * ND + a];
+  }
+  lds_barrier();
+  return s;
+}
+
+// ---------------------------------------------------------------------------
+// K1: forcing + dealiased convection -> bf (mass weighted)   [UPSTREAM perturb.f advabp /
+// advabp_adjoint, convect.f convect_new / convect_adj; sponge: core/utils.f:172-177]
+//   bfc = [12][nfine]: 0..2 = w_d J (U . grad xi_a);  3+3c+x = w_d J dU_c/dx_x
+//   mtd = [9][nfine]:  a*3+x = w_d J d(xi_a)/d(x_x)          (full equations, mode 2)
+// ---------------------------------------------------------------------------
+template <int N>
+__global__ __launch_bounds__(Cfg<N>::NT) void k_convect(Dev d, const double* __restrict__ uin,
+                                                        double* __restrict__ bf, int adjoint) {
+  using C = Cfg<N>;
+  constexpr int NN = C::NN, ND = C::ND, NDD = C::NDD, NT = C::NT;
+  constexpr int PPT = (NDD + NT - 1) / NT;
+  __shared__ double sJ[ND * N], sDd[ND * ND];
+  __shared__ double sf[3 * NDD], t1[N * N * ND], t2[N * ND * ND];
+  const int tid = threadIdx.x;
+  const long long e = blockIdx.x;
+  const bool act = tid < NN;
+  const int k = tid / (N * N), j = (tid / N) % N, i = tid % N;
+  for (int p = tid; p < ND * N; p += NT) sJ[p] = d.Jd[p];
+  for (int p = tid; p < ND * ND; p += NT) sDd[p] = d.Dd[p];
+  for (int c = 0; c < 3; ++c) to_fine<N>(sJ, uin + c * d.cs + e * NN, sf + c * NDD, t1, t2, tid, NT);
+  double o[PPT][3];
+  const size_t nf = (size_t)d.nfine;
+#pragma unroll
+  for (int r = 0; r < PPT; ++r) {
+    const int p = tid + r * NT;
+    o[r][0] = o[r][1] = o[r][2] = 0.0;
+    if (p < NDD) {
+      const int a = p % ND, b = (p / ND) % ND, cc = p / (ND * ND);
+      double gr[3][3];                                  // gr[comp][axis]
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const double* f = sf + c * NDD;
+        double ur = 0, us = 0, ut = 0;
+#pragma unroll
+        for (int m = 0; m < ND; ++m) {
+          ur += sDd[a * ND + m] * f[(cc * ND + b) * ND + m];
+          us += sDd[b * ND + m] * f[(cc * ND + m) * ND + a];
+          ut += sDd[cc * ND + m] * f[(m * ND + b) * ND + a];
+        }
+        gr[c][0] = ur; gr[c][1] = us; gr[c][2] = ut;
+      }
+      const double uf[3] = {sf[p], sf[NDD + p], sf[2 * NDD + p]};
+      const size_t q = (size_t)e * NDD + p;
+      if (adjoint == 2) {                               // (u.grad) u   [UPSTREAM advab]
+        double ca[3];
+#pragma unroll
+        for (int a2 = 0; a2 < 3; ++a2)
+          ca[a2] = d.mtd[(a2 * 3 + 0) * nf + q] * uf[0] + d.mtd[(a2 * 3 + 1) * nf + q] * uf[1] + d.mtd[(a2 * 3 + 2) * nf + q] * uf[2];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) o[r][c] = ca[0] * gr[c][0] + ca[1] * gr[c][1] + ca[2] * gr[c][2];
+      } else {
+        const double cr = d.bfc[0 * nf + q], cs = d.bfc[1 * nf + q], ct = d.bfc[2 * nf + q];
+        double G[3][3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+          for (int x = 0; x < 3; ++x) G[c][x] = d.bfc[(3 + 3 * c + x) * nf + q];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const double conv = cr * gr[c][0] + cs * gr[c][1] + ct * gr[c][2];          // (U.grad) u'_c
+          if (!adjoint) o[r][c] = conv + uf[0] * G[c][0] + uf[1] * G[c][1] + uf[2] * G[c][2];   // + (u'.grad) U_c
+          else o[r][c] = uf[0] * G[0][c] + uf[1] * G[1][c] + uf[2] * G[2][c] - conv;  // (grad U)^T u' - (U.grad) u'
+        }
+      }
+    }
+  }
+  lds_barrier();
+#pragma unroll
+  for (int r = 0; r < PPT; ++r) {
+    const int p = tid + r * NT;
+    if (p < NDD) { sf[p] = o[r][0]; sf[NDD + p] = o[r][1]; sf[2 * NDD + p] = o[r][2]; }
+  }
+  lds_barrier();
+  const long long l = e * NN + tid;
+  double sb = 0.0;
+  if (act) sb = d.spng[l] * d.bm1[l];
+  for (int c = 0; c < 3; ++c) {
+    const double s = from_fine<N>(sJ, sf + c * NDD, t1, t2, tid, NT, act, k, j, i);
+    if (act) {
+      const double un = uin[c * d.cs + l];
+      if (adjoint == 2) {
+        const double kk = sb * d.nl_spng_str;
+        bf[c * d.cs + l] = ((kk != 0.0) ? kk * (d.spng_vr[c * d.cs + l] - un) : 0.0) - s;
+      } else {
+        bf[c * d.cs + l] = -(sb * un + s);
+      }
+    }
+  }
+}
+
+// base-flow constants of the convection kernel from a state vector (set-up, set_baseflow)
+template <int N>
+__global__ __launch_bounds__(Cfg<N>::NT) void k_baseflow(Dev d, const double* __restrict__ q, double* __restrict__ bfc,
+                                                         double*, double*, double*, double*, double*) {
+  using C = Cfg<N>;
+  constexpr int NN = C::NN, ND = C::ND, NDD = C::NDD, NT = C::NT;
+  __shared__ double sJ[ND * N], sDd[ND * ND];
+  __shared__ double sf[3 * NDD], t1[N * N * ND], t2[N * ND * ND];
+  const int tid = threadIdx.x;
+  const long long e = blockIdx.x;
+  for (int p = tid; p < ND * N; p += NT) sJ[p] = d.Jd[p];
+  for (int p = tid; p < ND * ND; p += NT) sDd[p] = d.Dd[p];
+  for (int c = 0; c < 3; ++c) to_fine<N>(sJ, q + c * d.nloc + e * NN, sf + c * NDD, t1, t2, tid, NT);
+  const size_t nf = (size_t)d.nfine;
+  for (int p = tid; p < NDD; p += NT) {
+    const int a = p % ND, b = (p / ND) % ND, cc = p / (ND * ND);
+    const size_t qq = (size_t)e * NDD + p;
+    double mt[3][3];
+#pragma unroll
+    for (int a2 = 0; a2 < 3; ++a2)
+#pragma unroll
+      for (int x = 0; x < 3; ++x) mt[a2][x] = d.mtd[(a2 * 3 + x) * nf + qq];
+    const double uf[3] = {sf[p], sf[NDD + p], sf[2 * NDD + p]};
+#pragma unroll
+    for (int a2 = 0; a2 < 3; ++a2) bfc[a2 * nf + qq] = mt[a2][0] * uf[0] + mt[a2][1] * uf[1] + mt[a2][2] * uf[2];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const double* f = sf + c * NDD;
+      double ur = 0, us = 0, ut = 0;
+      for (int m = 0; m < ND; ++m) {
+        ur += sDd[a * ND + m] * f[(cc * ND + b) * ND + m];
+        us += sDd[b * ND + m] * f[(cc * ND + m) * ND + a];
+        ut += sDd[cc * ND + m] * f[(m * ND + b) * ND + a];
+      }
+#pragma unroll
+      for (int x = 0; x < 3; ++x) bfc[(3 + 3 * c + x) * nf + qq] = mt[0][x] * ur + mt[1][x] * us + mt[2][x] * ut;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K2: makextp + makebdfp + lagfieldp + extrapprp + cresvipp  [UPSTREAM perturb.f]
+// ---------------------------------------------------------------------------
+template <int N>
+__global__ __launch_bounds__(Cfg<N>::NT) void k_rhs(Dev d, StepCoef sc) {
+  using C = Cfg<N>;
+  constexpr int NN = C::NN, M = C::M, MM = C::MM, NT = C::NT, NM = N * M, NNM = C::NNM, NMM = C::NMM;
+  __shared__ double sD[N * N], sDt[N * N], sJ12[NM], sD12[NM];
+  __shared__ double su[3 * NN], st[9 * NN];
+  double* sP = st; double* sC = st + 3 * MM; double* sE = sC + 3 * NMM;      // opgradt scratch aliases st
+  static_assert(3 * MM + 3 * NMM + 2 * NNM <= 9 * NN, "scratch");
+  const int tid = threadIdx.x;
+  const long long e = blockIdx.x;
+  const bool act = tid < NN;
+  const int k = tid / (N * N), j = (tid / N) % N, i = tid % N;
+  const long long l = e * NN + tid, nl = d.cs;
+  load_basis3<N>(d, sD, sDt, sJ12, sD12, tid, NT);
+  if (d.nproj_max > 0 && blockIdx.x == 0 && tid == 0) {
+    GmresScal* G = d.gsc;
+    if (G->st_pending) {
+      G->st_pending = 0;
+      if (G->st_n > 0.0) {
+        G->pn[G->st_slot] = G->st_n;
+        G->pcnt += 1;
+        G->nproj = (G->pcnt < d.nproj_max) ? G->pcnt : d.nproj_max;
+      } else { G->pcnt = 0; G->nproj = 0; }
+    }
+  }
+  double u[3] = {0, 0, 0}, bfv[3] = {0, 0, 0}, bm = 0, g[6] = {0, 0, 0, 0, 0, 0};
+  if (act) {
+    bm = d.bm1[l];
+    g[0] = d.g1[l]; g[1] = d.g2[l]; g[2] = d.g3[l]; g[3] = d.g4[l]; g[4] = d.g5[l]; g[5] = d.g6[l];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const long long lc = c * nl + l;
+      const double un = d.u[lc];
+      u[c] = un + sc.xg[0] * d.dulag[lc] + sc.xg[1] * d.dulag[3 * nl + lc] + sc.xg[2] * d.dulag[6 * nl + lc];
+      su[c * NN + tid] = u[c];
+      const double bn = d.bf[lc];
+      const double e1 = d.exlag[lc], e2 = d.exlag[3 * nl + lc];
+      double b = sc.ab[0] * bn + sc.ab[1] * e1 + sc.ab[2] * e2;      // makextp
+      d.exlag[3 * nl + lc] = e1;
+      d.exlag[lc] = bn;
+      const double l1 = d.ulag[lc], l2 = d.ulag[3 * nl + lc];
+      b += bm * (sc.bd[1] * un + sc.bd[2] * l1 + sc.bd[3] * l2) * sc.invdt;   // makebdfp
+      d.ulag[3 * nl + lc] = l1;                                      // lagfieldp
+      d.ulag[lc] = un;
+      bfv[c] = b;
+    }
+  }
+  double pe = 0.0, w2[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (tid < MM) {                                                    // extrapprp
+    const long long q = e * MM + tid;
+    const double pn = d.p[q];
+    pe = (sc.k < 3) ? pn : 2.0 * pn - d.plag[q];
+    d.plag[q] = pn;
+    d.pext[q] = pe;
+    load_w2(d, q, w2);
+  }
+  lds_barrier();
+  double gp[3];
+  opgradt3<N>(sJ12, sD12, pe, w2, sP, sC, sE, tid, NT, act, k, j, i, gp);
+  lds_barrier();
+  double au[3];
+  axhelm3<N, 3>(sD, sDt, su, st, act, k, j, i, g, au);
+  if (act) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const double b = bfv[c] + gp[c];                               // rhs of H u* = b
+      d.bloc[c * nl + l] = b;
+      d.rloc[c * nl + l] = b - (d.nu * au[c] + sc.h2 * bm * u[c]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K3: one Jacobi-PCG iteration of H du = dssum(r), three components, single-reduction
+// (Chronopoulos-Gear) form  [UPSTREAM hmholtz.f cggo].
+//   hscal[par*16 + c*4 + {0:gamma,1:alpha,2:done,3:res}], reference norms at hscal[32 + c]
+//   hpart[par][12][nblk]: c*3 + {0:(r,z), 1:(z,Az), 2:(r,r)}, 9 + c: (b,b)
+// ---------------------------------------------------------------------------
+template <int N>
+__global__ __launch_bounds__(Cfg<N>::NT) void k_helm(Dev d, StepCoef sc, int it, const double* rhs) {
+  using C = Cfg<N>;
+  constexpr int NN = C::NN, NT = C::NT;
+  __shared__ double sD[N * N], sDt[N * N];
+  __shared__ double sz[3 * NN], st[9 * NN];
+  __shared__ double sred[12 * 16];
+  const int tid = threadIdx.x;
+  const long long e = blockIdx.x;
+  const bool act = tid < NN;
+  const int k = tid / (N * N), j = (tid / N) % N, i = tid % N;
+  const long long l = e * NN + tid, nl = d.cs;
+  const int par = it & 1, ppar = par ^ 1;
+  double o[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, refn[3] = {0, 0, 0};
+  if (it > 1) {
+#pragma unroll
+    for (int q = 0; q < 12; ++q) o[q] = d.hscal[ppar * 16 + q];
+    refn[0] = d.hscal[32]; refn[1] = d.hscal[33]; refn[2] = d.hscal[34];
+  }
+  double ps[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (it > 0) {
+    const double* part = d.hpart + (size_t)ppar * 12 * d.nblk;
+    for (int b = tid; b < d.nblk; b += NT) {
+#pragma unroll
+      for (int q = 0; q < 12; ++q) ps[q] += part[(size_t)q * d.nblk + b];
+    }
+  }
+  int4 tab = make_int4(0, -1, -1, -1);
+  double bm = 0, g[6] = {0, 0, 0, 0, 0, 0}, mk = 0, mi = 0, di = 0;
+  double rold[3] = {0, 0, 0}, pold[3] = {0, 0, 0}, sold[3] = {0, 0, 0}, xold[3] = {0, 0, 0};
+  if (act) {
+    tab = d.gs_tab[l];
+    bm = d.bm1[l]; mk = d.mask[l]; mi = d.minv[l];
+    g[0] = d.g1[l]; g[1] = d.g2[l]; g[2] = d.g3[l]; g[3] = d.g4[l]; g[4] = d.g5[l]; g[5] = d.g6[l];
+    di = d.dinv[(size_t)(sc.k - 1) * d.nloc + l];
+    if (it > 0) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const long long lc = c * nl + l;
+        rold[c] = d.hr[lc]; pold[c] = d.hp[lc]; sold[c] = d.hs[lc]; xold[c] = d.hx[lc];
+      }
+    }
+  }
+  if (it > 1 && o[2] != 0.0 && o[6] != 0.0 && o[10] != 0.0) {       // all components finished earlier
+    if (blockIdx.x == 0 && tid < 12) d.hscal[par * 16 + tid] = o[tid];
+    return;
+  }
+  GsVals gv[3], gb[3];
+  if (act) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      if (it == 0) { gv[c] = gs_load(rhs + c * nl, tab, l); gb[c] = gs_load(d.bloc + c * nl, tab, l); }
+      else gv[c] = gs_load(d.hwl + ((size_t)ppar * 3 + c) * nl, tab, l);
+    }
+  }
+  double alpha[3] = {0, 0, 0}, beta[3] = {0, 0, 0};
+  bool done[3] = {false, false, false};
+  if (it > 0) {
+    block_reduce<12>(ps, sred, tid, NT);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const double gg = ps[c * 3 + 0], del = ps[c * 3 + 1], rr = ps[c * 3 + 2];
+      const double res = sqrt(rr / d.vol);
+      const double ref = (it == 1) ? sqrt(ps[9 + c] / d.vol) : refn[c];
+      const double tol = d.tol_relative ? d.tol_helm * ref : d.tol_helm;
+      const bool was = (it > 1 && o[c * 4 + 2] != 0.0);
+      done[c] = was || (res <= tol) || !(gg > 0.0);
+      if (!done[c]) {
+        if (it == 1) { beta[c] = 0.0; alpha[c] = gg / del; }
+        else { beta[c] = gg / o[c * 4 + 0]; alpha[c] = gg / (del - beta[c] * gg / o[c * 4 + 1]); }
+      }
+      if (blockIdx.x == 0 && tid == 0) {
+        double* cur = d.hscal + par * 16 + c * 4;
+        cur[0] = gg; cur[1] = alpha[c]; cur[2] = done[c] ? 1.0 : 0.0;
+        cur[3] = was ? o[c * 4 + 3] : res;
+        if (it == 1) d.hscal[32 + c] = ref;
+        if (done[c] && !was) {
+          if (c == 0) atomicAdd((unsigned long long*)&d.stats->helm_iters, (unsigned long long)(it - 1));
+          atomicMax((unsigned long long*)&d.stats->max_helm, (unsigned long long)(it - 1));
+          atomicMax((unsigned long long*)&d.stats->max_helm_k[sc.cls], (unsigned long long)(it - 1));
+        }
+      }
+    }
+    if (done[0] && done[1] && done[2]) return;
+  }
+  for (int q = tid; q < N * N; q += NT) { const double v = d.D[q]; sD[q] = v; sDt[(q % N) * N + q / N] = v; }
+  double r[3] = {0, 0, 0}, z[3] = {0, 0, 0}, bb[3] = {0, 0, 0};
+  if (act) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const long long lc = c * nl + l;
+      if (it == 0) {
+        r[c] = mk * gs_sum(gv[c], rhs + c * nl, d, tab, l);
+        bb[c] = mk * gs_sum(gb[c], d.bloc + c * nl, d, tab, l);
+        d.hx[lc] = 0.0; d.hp[lc] = 0.0; d.hs[lc] = 0.0; d.hr[lc] = r[c];
+      } else if (!done[c]) {
+        const double w = mk * gs_sum(gv[c], d.hwl + ((size_t)ppar * 3 + c) * nl, d, tab, l);
+        const double pn = di * rold[c] + beta[c] * pold[c];
+        const double sn = w + beta[c] * sold[c];
+        d.hp[lc] = pn; d.hs[lc] = sn;
+        d.hx[lc] = xold[c] + alpha[c] * pn;
+        r[c] = rold[c] - alpha[c] * sn;
+        d.hr[lc] = r[c];
+      } else {
+        r[c] = rold[c];
+      }
+      z[c] = di * r[c];
+      sz[c * NN + tid] = z[c];
+    }
+  }
+  lds_barrier();
+  double au[3];
+  axhelm3<N, 3>(sD, sDt, sz, st, act, k, j, i, g, au);
+  double v[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (act) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const double wl = d.nu * au[c] + sc.h2 * bm * z[c];
+      d.hwl[((size_t)par * 3 + c) * nl + l] = wl;
+      v[c * 3 + 0] = r[c] * z[c] * mi;
+      v[c * 3 + 1] = z[c] * wl;
+      v[c * 3 + 2] = r[c] * r[c] * mi;
+      v[9 + c] = bb[c] * bb[c] * mi;
+    }
+  }
+  block_reduce<12>(v, sred, tid, NT);
+  if (tid < 12) d.hpart[((size_t)par * 12 + tid) * d.nblk + blockIdx.x] = v[tid];
+}
+
+// ---------------------------------------------------------------------------
+// K4: u* = u + du ;  g = -D u*  -> V[0], |g|^2 partials; checks the Helmholtz solve  [UPSTREAM incomprp]
+// ---------------------------------------------------------------------------
+template <int N>
+__global__ __launch_bounds__(Cfg<N>::NT) void k_pres_rhs(Dev d, StepCoef sc, int helm_par, int check_helm) {
+  using C = Cfg<N>;
+  constexpr int NN = C::NN, M = C::M, MM = C::MM, NT = C::NT, NM = N * M, NNM = C::NNM, NMM = C::NMM;
+  __shared__ double sJ12[NM], sD12[NM];
+  __shared__ double su[3 * NN], sA[2 * NNM], sB[3 * NMM];
+  __shared__ double sred[12 * 16];
+  const int tid = threadIdx.x;
+  const long long e = blockIdx.x;
+  const bool act = tid < NN;
+  const long long l = e * NN + tid, nl = d.cs;
+  load_basis3<N>(d, nullptr, nullptr, sJ12, sD12, tid, NT);
+  if (check_helm && blockIdx.x == 0) {
+    double s[12];
+    sum_partials<12>(d.hpart + (size_t)helm_par * 12 * d.nblk, d.nblk, s, sred, tid, NT);
+    if (tid == 0) {
+      double worst = 0.0; int bad = 0;
+      for (int c = 0; c < 3; ++c) {
+        const double res = sqrt(s[c * 3 + 2] / d.vol);
+        const double tol = d.tol_relative ? d.tol_helm * d.hscal[32 + c] : d.tol_helm;
+        const bool was = d.hscal[helm_par * 16 + c * 4 + 2] != 0.0;
+        const double rr = was ? d.hscal[helm_par * 16 + c * 4 + 3] : res;
+        worst = fmax(worst, rr);
+        if (!was && !(res <= tol)) bad = 1;
+        if (!was) {
+          if (c == 0) atomicAdd((unsigned long long*)&d.stats->helm_iters, (unsigned long long)check_helm);
+          atomicMax((unsigned long long*)&d.stats->max_helm, (unsigned long long)check_helm);
+          atomicMax((unsigned long long*)&d.stats->max_helm_k[sc.cls], (unsigned long long)check_helm);
+        }
+      }
+      d.stats->last_helm_res = worst;
+      if (bad) atomicAdd((unsigned long long*)&d.stats->unconverged, 1ull);
+    }
+  }
+  if (act) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const long long lc = c * nl + l;
+      const double l1 = d.dulag[lc], l2 = d.dulag[3 * nl + lc], l3 = d.dulag[6 * nl + lc];
+      const double du = sc.xg[0] * l1 + sc.xg[1] * l2 + sc.xg[2] * l3 + d.hx[lc];
+      d.dulag[6 * nl + lc] = l2;
+      d.dulag[3 * nl + lc] = l1;
+      d.dulag[lc] = du;
+      const double us = d.u[lc] + du;
+      d.u[lc] = us;
+      su[c * NN + tid] = us;
+    }
+  }
+  double w2[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const bool pact = tid < MM;
+  const long long q = e * MM + tid;
+  if (pact) load_w2(d, q, w2);
+  lds_barrier();
+  const double div = opdiv3<N>(sJ12, sD12, su, sA, sB, tid, NT, w2);
+  double v[1] = {0.0};
+  double g = 0.0;
+  if (pact) {
+    g = -div;
+    d.V[q] = g;
+    v[0] = g * g;
+  }
+  block_reduce<1>(v, sred, tid, NT);
+  if (tid == 0) d.gpart[blockIdx.x] = v[0];
+  if (!d.has_outflow) {
+    double t[1] = {g};
+    block_reduce<1>(t, sred, tid, NT);
+    if (tid == 0) d.gpart[(size_t)d.nblk + blockIdx.x] = t[0];
+  }
+  if (d.nproj_max > 0) {
+    if (tid == 0) d.ppart[(size_t)MAXPROJ * d.nblk + blockIdx.x] = v[0];
+    const int np = d.gsc->nproj;
+    __shared__ double sdot[MAXPROJ * 16];
+    const int lane = tid & 63, wv = tid >> 6;
+    for (int kk = 0; kk < np; ++kk) {
+      double t = pact ? g * d.PX[(size_t)kk * d.npr + q] : 0.0;
+      t = wave_sum63(t);
+      if (lane == 63) sdot[kk * 16 + wv] = t;
+    }
+    lds_barrier();
+    if (tid < np) {
+      double t = 0.0;
+      for (int ww = 0; ww < NT / 64; ++ww) t += sdot[tid * 16 + ww];
+      d.ppart[(size_t)tid * d.nblk + blockIdx.x] = t;
+    }
+  }
+}
+
+// Second Gram-Schmidt pass of the pressure GMRES.  The hexahedral solves take 20-40 iterations and single-pass
+// classical Gram-Schmidt with the Pythagorean norm loses orthogonality there (measured: residual estimate 1e-8 against
+// a true residual of 5e-2), so here  w' = w - sum_i h_i v_i  is formed and projected once more:
+// gpart2[k] = (w', v_k), k <= j, and gpart2[j+1] = (w', w').   [UPSTREAM navier1.f uzawa_gmres uses modified GS]
+template <int N>
+__global__ __launch_bounds__(Cfg<N>::NT) void k_gmres_reorth(Dev d, int j) {
+  using C = Cfg<N>;
+  constexpr int MM = C::MM, NT = C::NT;
+  __shared__ double sh[MAXMR + 2];
+  __shared__ double sdot[(MAXMR + 2) * 16];
+  const int tid = threadIdx.x;
+  const long long e = blockIdx.x;
+  if (d.gsc->done) return;
+  sum_partials_multi(d.gpart, d.nblk, j + 1, sh, tid, NT);
+  const bool pact = tid < MM;
+  const long long q = e * MM + tid;
+  double w = 0.0;
+  if (pact) {
+    w = d.V[(size_t)(j + 1) * d.ps + q];
+    for (int kk = 0; kk <= j; ++kk) w -= sh[kk] * d.V[(size_t)kk * d.ps + q];
+    d.V[(size_t)(j + 1) * d.ps + q] = w;
+  }
+  const int lane = tid & 63, wv = tid >> 6;
+  for (int kk = 0; kk <= j + 1; ++kk) {
+    double x = 0.0;
+    if (pact) x = w * ((kk <= j) ? d.V[(size_t)kk * d.ps + q] : w);
+    x = wave_sum63(x);
+    if (lane == 63) sdot[kk * 16 + wv] = x;
+  }
+  lds_barrier();
+  if (tid <= j + 1) {
+    double t = 0.0;
+    for (int ww = 0; ww < NT / 64; ++ww) t += sdot[tid * 16 + ww];
+    d.gpart2[(size_t)tid * d.nblk + blockIdx.x] = t;
+  }
+}
+
+// GMRES bookkeeping + next basis vector + element-corner restriction (8 trilinear vertex functions).
+// j >= 0: runs after k_gmres_reorth; Hessenberg column = first-pass + second-pass coefficients.
+template <int N>
+__global__ __launch_bounds__(Cfg<N>::NT) void k_gmres_update(Dev d, int j, double scale, int min_iter, int ord) {
+  using C = Cfg<N>;
+  constexpr int MM = C::MM, NT = C::NT;
+  __shared__ double sv[MM];
+  __shared__ double sh[MAXMR + 2], sc2[MAXMR + 2], scol[MAXMR + 2];
+  const int tid = threadIdx.x;
+  const long long e = blockIdx.x;
+  GmresScal* G = d.gsc;
+  if (j >= 0 && G->done) return;
+  double wnew = 0.0;
+  if (tid < MM) wnew = d.V[(size_t)(j + 1) * d.ps + e * MM + tid];
+  double hn;
+  if (j < 0) {
+    sum_partials_multi(d.gpart, d.nblk, 1, sh, tid, NT);
+    hn = sqrt(sh[0]);
+  } else {
+    sum_partials_multi(d.gpart, d.nblk, j + 1, sh, tid, NT);
+    sum_partials_multi(d.gpart2, d.nblk, j + 2, sc2, tid, NT);
+    double s2 = 0.0;
+    for (int q = 0; q <= j; ++q) s2 += sc2[q] * sc2[q];
+    const double hn2 = sc2[j + 1] - s2;
+    hn = sqrt(hn2 > 0.0 ? hn2 : 0.0);
+  }
+  const double hinv = (hn > 0.0) ? 1.0 / hn : 0.0;
+  if (blockIdx.x == 0 && tid == 0) {
+    if (j < 0) {
+      G->beta0 = hn; G->g[0] = hn; G->nit = 0; G->resid = hn * scale;
+      if (d.nproj_max <= 0) G->gnorm0 = hn;
+      const double tol0 = d.tol_relative ? d.tol_pres * G->gnorm0 * scale : d.tol_pres;
+      const int dn = (!(hn > 0.0) || (min_iter <= 0 && hn * scale <= tol0)) ? 1 : 0;
+      if (dn) d.stats->last_pres_res = hn * scale;
+      G->done = dn;
+    } else {
+      double* col = scol;
+      for (int q = 0; q <= j; ++q) col[q] = sh[q] + sc2[q];
+      col[j + 1] = hn;
+      for (int q = 0; q < j; ++q) {
+        const double cq = G->cs[q], sq = G->sn[q];
+        const double t = cq * col[q] + sq * col[q + 1];
+        col[q + 1] = -sq * col[q] + cq * col[q + 1];
+        col[q] = t;
+      }
+      const double rho = sqrt(col[j] * col[j] + col[j + 1] * col[j + 1]);
+      const double cj = (rho > 0.0) ? col[j] / rho : 1.0, sj = (rho > 0.0) ? col[j + 1] / rho : 0.0;
+      G->cs[j] = cj; G->sn[j] = sj;
+      col[j] = rho;
+      for (int q = 0; q <= j; ++q) G->R[j * MAXMR + q] = col[q];
+      const double gj = G->g[j];
+      G->g[j] = cj * gj;
+      G->g[j + 1] = -sj * gj;
+      G->nit = j + 1;
+      const double res = fabs(sj * gj) * scale;
+      G->resid = res;
+      const double tol = d.tol_relative ? d.tol_pres * G->gnorm0 * scale : d.tol_pres;
+      if ((res <= tol && (j + 1) >= min_iter) || !(hn > 0.0)) {
+        atomicAdd((unsigned long long*)&d.stats->pres_iters, (unsigned long long)(j + 1));
+        atomicMax((unsigned long long*)&d.stats->max_pres, (unsigned long long)(j + 1));
+        atomicMax((unsigned long long*)&d.stats->max_pres_k[ord], (unsigned long long)(j + 1));
+        d.stats->last_pres_res = res;
+        G->done = 1;
+      }
+    }
+  }
+  if (tid < MM) {
+    const long long q = e * MM + tid;
+    double w = wnew;
+    for (int kk = 0; kk <= j; ++kk) w -= sc2[kk] * d.V[(size_t)kk * d.ps + q];
+    w *= hinv;
+    d.V[(size_t)(j + 1) * d.ps + q] = w;
+    sv[tid] = w;
+  }
+  lds_barrier();
+  for (int c = tid >> 6; c < 8; c += NT / 64) {          // one wavefront per corner
+    const int lane = tid & 63;
+    double s = 0.0;
+    for (int kk = lane; kk < MM; kk += 64) s += d.hat[c * MM + kk] * sv[kk];
+    s = wave_sum63(s);
+    if (lane == 63) d.ec[e * 8 + c] = s;
+  }
+}
+
+// z_j = restricted overlapping Schwarz (v_j) + R^T x_c ;  yl = D^T z_j (unassembled)
+// Patch = the element's Gauss nodes plus the adjacent Gauss layer of every face neighbour = an lx1^3 tensor grid
+// (GLL position n <-> patch position n; own Gauss index a <-> position a+1).  The neighbours' layers come through a
+// gather table derived at set-up from the velocity-mesh dssum lists, which resolves their orientation (p_idx).  Local solve by fast diagonalisation:
+// fdS = [nel][3][N*N] generalised eigenvectors S_d[pos][mode] of the 1-D pairs (A_d, M_d), fdL = [nel][3][N]:
+//   z = (S_t x S_s x S_r) diag(1/(lr+ls+lt)) (S_t x S_s x S_r)^T w,  restricted to the element's own nodes.
+template <int N>
+__global__ __launch_bounds__(Cfg<N>::NT) void k_schwarz(Dev d, const double* __restrict__ vin,
+                                                        double* __restrict__ zout, int use_coarse, int check_done) {
+  using C = Cfg<N>;
+  constexpr int NN = C::NN, M = C::M, MM = C::MM, NT = C::NT, NM = N * M, NNM = C::NNM, NMM = C::NMM;
+  __shared__ double sJ12[NM], sD12[NM];
+  __shared__ double sS[3 * N * N], sL[3 * N];
+  __shared__ double sa[NN], sb[NN];
+  __shared__ double sP[3 * MM], sC[3 * NMM], sE[2 * NNM];
+  const int tid = threadIdx.x;
+  const long long e = blockIdx.x;
+  const bool act = tid < NN;
+  const int k = tid / (N * N), j = (tid / N) % N, i = tid % N;
+  if (check_done && d.gsc->done) return;
+  const bool pact = tid < MM;
+  const long long q = e * MM + tid;
+  load_basis3<N>(d, nullptr, nullptr, sJ12, sD12, tid, NT);
+  for (int p = tid; p < 3 * N * N; p += NT) sS[p] = d.fdS[(size_t)e * 3 * N * N + p];
+  for (int p = tid; p < 3 * N; p += NT) sL[p] = d.fdL[(size_t)e * 3 * N + p];
+  double w2[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, zc = 0.0;
+  if (pact) {
+    load_w2(d, q, w2);
+    if (use_coarse) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) zc += d.hat[c * MM + tid] * d.xc[d.evert[e * 8 + c]];
+    }
+  }
+  if (act) {                                          // the patch, one thread per position
+    const int id = d.p_idx[e * NN + tid];
+    sa[tid] = (id >= 0) ? vin[id] : 0.0;
+  }
+  lds_barrier();
+  // forward: S^T along r, s, t
+  if (act) { double s = 0; for (int m = 0; m < N; ++m) s += sS[0 * N * N + m * N + i] * sa[(k * N + j) * N + m]; sb[tid] = s; }
+  lds_barrier();
+  if (act) { double s = 0; for (int m = 0; m < N; ++m) s += sS[1 * N * N + m * N + j] * sb[(k * N + m) * N + i]; sa[tid] = s; }
+  lds_barrier();
+  if (act) {
+    double s = 0; for (int m = 0; m < N; ++m) s += sS[2 * N * N + m * N + k] * sa[(m * N + j) * N + i];
+    const double lam = sL[i] + sL[N + j] + sL[2 * N + k];
+    sb[tid] = (lam > d.fd_eps) ? s / lam : 0.0;
+  }
+  lds_barrier();
+  // back: S along t, s, r
+  if (act) { double s = 0; for (int m = 0; m < N; ++m) s += sS[2 * N * N + k * N + m] * sb[(m * N + j) * N + i]; sa[tid] = s; }
+  lds_barrier();
+  if (act) { double s = 0; for (int m = 0; m < N; ++m) s += sS[1 * N * N + j * N + m] * sa[(k * N + m) * N + i]; sb[tid] = s; }
+  lds_barrier();
+  if (act) { double s = 0; for (int m = 0; m < N; ++m) s += sS[0 * N * N + i * N + m] * sb[(k * N + j) * N + m]; sa[tid] = s; }
+  lds_barrier();
+  double z = 0.0;
+  if (pact) {
+    const int a = tid % M, b = (tid / M) % M, cc = tid / (M * M);
+    z = sa[((cc + 1) * N + (b + 1)) * N + (a + 1)] + zc;       // restriction to the element's own nodes
+    zout[q] = z;
+  }
+  double gp[3];
+  opgradt3<N>(sJ12, sD12, z, w2, sP, sC, sE, tid, NT, act, k, j, i, gp);
+  if (act) {
+    const long long l = e * NN + tid;
+    d.yl[l] = gp[0]; d.yl[d.cs + l] = gp[1]; d.yl[2 * d.cs + l] = gp[2];
+  }
+}
+
+// yl = D^T p for an arbitrary pressure vector
+template <int N>
+__global__ __launch_bounds__(Cfg<N>::NT) void k_gradt(Dev d, const double* __restrict__ pin, double* __restrict__ yl) {
+  using C = Cfg<N>;
+  constexpr int NN = C::NN, M = C::M, MM = C::MM, NT = C::NT, NM = N * M, NNM = C::NNM, NMM = C::NMM;
+  __shared__ double sJ12[NM], sD12[NM];
+  __shared__ double sP[3 * MM], sC[3 * NMM], sE[2 * NNM];
+  const int tid = threadIdx.x;
+  const long long e = blockIdx.x;
+  const bool act = tid < NN;
+  const int k = tid / (N * N), j = (tid / N) % N, i = tid % N;
+  load_basis3<N>(d, nullptr, nullptr, sJ12, sD12, tid, NT);
+  double w2[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, z = 0.0;
+  if (tid < MM) { z = pin[e * MM + tid]; load_w2(d, e * MM + tid, w2); }
+  lds_barrier();
+  double gp[3];
+  opgradt3<N>(sJ12, sD12, z, w2, sP, sC, sE, tid, NT, act, k, j, i, gp);
+  if (act) {
+    const long long l = e * NN + tid;
+    yl[l] = gp[0]; yl[d.cs + l] = gp[1]; yl[2 * d.cs + l] = gp[2];
+  }
+}
+
+// w = D ( B^-1 mask dssum(yl) ) ; optional dots (w, V_i), i <= j, and (w,w)
+template <int N>
+__global__ __launch_bounds__(Cfg<N>::NT) void k_divgs(Dev d, const double* __restrict__ yl,
+                                                      double* __restrict__ wout, int j, int check_done) {
+  using C = Cfg<N>;
+  constexpr int NN = C::NN, M = C::M, MM = C::MM, NT = C::NT, NM = N * M, NNM = C::NNM, NMM = C::NMM;
+  __shared__ double sJ12[NM], sD12[NM];
+  __shared__ double su[3 * NN], sA[2 * NNM], sB[3 * NMM];
+  __shared__ double sdot[(MAXMR + 2) * 16];
+  const int tid = threadIdx.x;
+  const long long e = blockIdx.x;
+  const bool act = tid < NN;
+  if (check_done && d.gsc->done) return;
+  const long long l = e * NN + tid;
+  load_basis3<N>(d, nullptr, nullptr, sJ12, sD12, tid, NT);
+  if (act) {
+    const int4 tab = d.gs_tab[l];
+    const double bi = d.binv[l];
+    GsVals g0 = gs_load(yl, tab, l), g1 = gs_load(yl + d.cs, tab, l), g2 = gs_load(yl + 2 * d.cs, tab, l);
+    su[tid] = bi * gs_sum(g0, yl, d, tab, l);
+    su[NN + tid] = bi * gs_sum(g1, yl + d.cs, d, tab, l);
+    su[2 * NN + tid] = bi * gs_sum(g2, yl + 2 * d.cs, d, tab, l);
+  }
+  const bool pact = tid < MM;
+  const long long q = e * MM + tid;
+  double w2[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (pact) load_w2(d, q, w2);
+  lds_barrier();
+  const double w = opdiv3<N>(sJ12, sD12, su, sA, sB, tid, NT, w2);
+  if (pact) wout[q] = w;
+  if (j >= 0) {
+    const int lane = tid & 63, wv = tid >> 6;
+    for (int kk = 0; kk <= j + 1; ++kk) {
+      double x = 0.0;
+      if (pact) x = w * ((kk <= j) ? d.V[(size_t)kk * d.ps + q] : w);
+      x = wave_sum63(x);
+      if (lane == 63) sdot[kk * 16 + wv] = x;
+    }
+    lds_barrier();
+    constexpr int NW = NT / 64;
+    if (tid <= j + 1) {
+      double t = 0.0;
+#pragma unroll
+      for (int ww = 0; ww < NW; ++ww) t += sdot[tid * 16 + ww];
+      d.gpart[(size_t)tid * d.nblk + blockIdx.x] = t;
+    }
+  }
+}
+
+// after GMRES: dp = h2 * sum_i y_i Z_i (+ projected part) ; p = p* + dp ; yl = D^T dp
+template <int N>
+__global__ __launch_bounds__(Cfg<N>::NT) void k_pres_update(Dev d, StepCoef sc) {
+  using C = Cfg<N>;
+  constexpr int NN = C::NN, M = C::M, MM = C::MM, NT = C::NT, NM = N * M, NNM = C::NNM, NMM = C::NMM;
+  __shared__ double sJ12[NM], sD12[NM];
+  __shared__ double sP[3 * MM], sC[3 * NMM], sE[2 * NNM];
+  __shared__ double sy[MAXMR], sg[MAXMR], sR[MAXMR * MAXMR];
+  const int tid = threadIdx.x;
+  const long long e = blockIdx.x;
+  const bool act = tid < NN;
+  const int k = tid / (N * N), j = (tid / N) % N, i = tid % N;
+  const GmresScal* G = d.gsc;
+  const int nit = G->nit;
+  for (int p = tid; p < nit * nit; p += NT) { const int cc = p / nit, rr = p % nit; sR[cc * MAXMR + rr] = G->R[cc * MAXMR + rr]; }
+  if (tid < nit) sg[tid] = G->g[tid];
+  load_basis3<N>(d, nullptr, nullptr, sJ12, sD12, tid, NT);
+  lds_barrier();
+  if (tid == 0) {
+    for (int q = nit - 1; q >= 0; --q) {
+      double s = sg[q];
+      for (int kk = q + 1; kk < nit; ++kk) s -= sR[kk * MAXMR + q] * sy[kk];
+      sy[q] = s / sR[q * MAXMR + q];
+    }
+  }
+  lds_barrier();
+  double dp = 0.0, w2[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (tid < MM) {
+    const long long q = e * MM + tid;
+    double x = 0.0;
+    for (int kk = 0; kk < nit; ++kk) x += sy[kk] * d.Z[(size_t)kk * d.npr + q];
+    if (d.nproj_max > 0) {
+      d.PD[q] = x;
+      const int np = G->nproj;
+      for (int kk = 0; kk < np; ++kk) x += G->pa[kk] * d.PX[(size_t)kk * d.npr + q];
+    }
+    dp = sc.h2 * x;
+    d.p[q] = d.pext[q] + dp;
+    load_w2(d, q, w2);
+  }
+  lds_barrier();
+  double gp[3];
+  opgradt3<N>(sJ12, sD12, dp, w2, sP, sC, sE, tid, NT, act, k, j, i, gp);
+  if (act) {
+    const long long l = e * NN + tid;
+    d.yl[l] = gp[0]; d.yl[d.cs + l] = gp[1]; d.yl[2 * d.cs + l] = gp[2];
+  }
+  if (blockIdx.x == 0 && tid == 0 && !G->done) atomicAdd((unsigned long long*)&d.stats->unconverged, 1ull);
+}
+
+// velocity correction fused with E*dp for the projection space
+template <int N>
+__global__ __launch_bounds__(Cfg<N>::NT) void k_vel_update_proj(Dev d, StepCoef sc) {
+  using C = Cfg<N>;
+  constexpr int NN = C::NN, M = C::M, MM = C::MM, NT = C::NT, NM = N * M, NNM = C::NNM, NMM = C::NMM;
+  __shared__ double sJ12[NM], sD12[NM];
+  __shared__ double su[3 * NN], sA[2 * NNM], sB[3 * NMM];
+  const int tid = threadIdx.x;
+  const long long e = blockIdx.x;
+  const bool act = tid < NN;
+  const GmresScal* G = d.gsc;
+  load_basis3<N>(d, nullptr, nullptr, sJ12, sD12, tid, NT);
+  if (act) {
+    const long long l = e * NN + tid;
+    const double bi = d.binv[l];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const double v = bi * gs_gather(d.yl + c * d.cs, d, l);
+      d.u[c * d.cs + l] += v / sc.h2;
+      su[c * NN + tid] = v;
+    }
+  }
+  if (G->nit == 0) return;
+  const bool pact = tid < MM;
+  const long long q = e * MM + tid;
+  double w2[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (pact) load_w2(d, q, w2);
+  lds_barrier();
+  const double w = opdiv3<N>(sJ12, sD12, su, sA, sB, tid, NT, w2);
+  const int np = G->nproj;
+  double del = 0.0, edel = 0.0;
+  if (pact) {
+    edel = w / sc.h2;
+    for (int kk = 0; kk < np; ++kk) edel -= G->pa[kk] * d.PEX[(size_t)kk * d.npr + q];
+    del = d.PD[q];
+    d.PED[q] = edel;
+  }
+  __shared__ double sdot[(MAXPROJ + 1) * 16];
+  const int lane = tid & 63, wv = tid >> 6;
+  for (int kk = 0; kk <= np; ++kk) {
+    double t = 0.0;
+    if (pact) t = (kk < np) ? del * d.PEX[(size_t)kk * d.npr + q] : del * edel;
+    t = wave_sum63(t);
+    if (lane == 63) sdot[kk * 16 + wv] = t;
+  }
+  lds_barrier();
+  if (tid <= np) {
+    double t = 0.0;
+    for (int ww = 0; ww < NT / 64; ++ww) t += sdot[tid * 16 + ww];
+    d.ppart[(size_t)tid * d.nblk + blockIdx.x] = t;
+  }
+}
+
+// ---- test kernels ----
+template <int N>
+__global__ __launch_bounds__(Cfg<N>::NT) void k_axhelm_test(Dev d, const double* __restrict__ u, double h1, double h2,
+                                                            double* __restrict__ out) {
+  using C = Cfg<N>;
+  constexpr int NN = C::NN, NT = C::NT;
+  __shared__ double sD[N * N], sDt[N * N];
+  __shared__ double sz[NN], st[3 * NN];
+  const int tid = threadIdx.x;
+  const long long e = blockIdx.x;
+  const bool act = tid < NN;
+  const long long l = e * NN + tid;
+  load_basis3<N>(d, sD, sDt, nullptr, nullptr, tid, NT);
+  double z = 0, g[6] = {0, 0, 0, 0, 0, 0};
+  if (act) {
+    z = u[l]; sz[tid] = z;
+    g[0] = d.g1[l]; g[1] = d.g2[l]; g[2] = d.g3[l]; g[3] = d.g4[l]; g[4] = d.g5[l]; g[5] = d.g6[l];
+  }
+  lds_barrier();
+  double au[1];
+  axhelm3<N, 1>(sD, sDt, sz, st, act, tid / (N * N), (tid / N) % N, tid % N, g, au);
+  if (act) out[l] = h1 * au[0] + h2 * d.bm1[l] * z;
+}
+
+template <int N>
+__global__ __launch_bounds__(Cfg<N>::NT) void k_opdiv_test(Dev d, const double* __restrict__ u, double* __restrict__ out) {
+  using C = Cfg<N>;
+  constexpr int NN = C::NN, M = C::M, MM = C::MM, NT = C::NT, NM = N * M, NNM = C::NNM, NMM = C::NMM;
+  __shared__ double sJ12[NM], sD12[NM];
+  __shared__ double su[3 * NN], sA[2 * NNM], sB[3 * NMM];
+  const int tid = threadIdx.x;
+  const long long e = blockIdx.x;
+  load_basis3<N>(d, nullptr, nullptr, sJ12, sD12, tid, NT);
+  if (tid < NN)
+    for (int c = 0; c < 3; ++c) su[c * NN + tid] = u[c * d.cs + e * NN + tid];
+  double w2[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (tid < MM) load_w2(d, e * MM + tid, w2);
+  lds_barrier();
+  const double w = opdiv3<N>(sJ12, sD12, su, sA, sB, tid, NT, w2);
+  if (tid < MM) out[e * MM + tid] = w;
+}
+
+}  // namespace k3
+}  // namespace nsk

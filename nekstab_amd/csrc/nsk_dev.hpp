@@ -96,6 +96,13 @@ struct Dev {
   // all-reduced totals below instead of the local per-workgroup partials, and the ghost slots
   // behind every velocity-mesh array / GMRES basis vector hold the neighbours' contributions
   int nranks, rank;
+  // hexahedral elements (ndim = 3): the remaining G factors, the nine Gauss-mesh metrics [a*3+c][npr] (x Gauss
+  // weights), base-flow / metric constants on the dealiasing mesh, element-wise fast-diagonalisation factors
+  int ndim;
+  long long nfine;
+  const double *g3, *g5, *g6, *w2m, *bfc, *mtd, *fdS, *fdL;
+  double fd_eps;
+  double* gpart2;                // partial sums of the second Gram-Schmidt pass (3-D GMRES)
   double *htot;                  // [2 parities][8]  Helmholtz sums over all ranks
   double *gtot;                  // [MAXMR + 2]      GMRES sums over all ranks
 };

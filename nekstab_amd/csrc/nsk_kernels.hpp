@@ -18,6 +18,7 @@ __device__ int g_dbg = 0;
 #define NSK_STAMP(i) do { } while (0)
 #endif     // developer ablation switches (bit mask), 0 in production
 
+namespace k2 {
 template <int N>
 struct Cfg {
   static constexpr int NN = N * N, M = N - 2, MM = M * M, ND = 3 * N / 2, NDD = ND * ND;
@@ -25,6 +26,8 @@ struct Cfg {
   static constexpr int NT = ((EPB * NN + 63) / 64) * 64;
   static constexpr int NTD = ((NDD + 63) / 64) * 64;
 };
+}  // namespace k2
+
 
 // Workgroup barrier that orders LDS traffic only: global loads issued earlier stay in
 // flight across it (hipcc's __syncthreads() drains vmcnt as well, which serialises every
@@ -146,6 +149,7 @@ __device__ inline double gs_sum(const GsVals& v, const double* __restrict__ f, c
 // ---------------------------------------------------------------------------
 // element-local building blocks on LDS tiles
 // ---------------------------------------------------------------------------
+namespace k2 {
 // D^T G D on NC component tiles su[c][EPB][NN]  [UPSTREAM hmholtz.f axhelm]
 template <int N, int EPB, int NC>
 __device__ inline void axhelm_tiles(const double* sD, const double* sDt, const double* su,
@@ -752,6 +756,8 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_pres_rhs(Dev d, StepCoef sc, int
   }
 }
 
+}  // namespace k2
+
 // all-Dirichlet / periodic velocity => E has the constant null space: remove the mean of the
 // right-hand side  [UPSTREAM navier1.f ortho]; recomputes the |g|^2 partials
 __global__ __launch_bounds__(256) void k_ortho(Dev d) {
@@ -812,6 +818,7 @@ __global__ __launch_bounds__(256) void k_proj_apply(Dev d) {
 // the Givens / least-squares state and the convergence flag, and all workgroups form
 //   v_{j+1} = (w - sum_i h_i v_i) / h_{j+1,j}      (j = -1: v_0 = g'/|g'|)
 // plus the element-corner restriction ec[e][c] = sum_k hat_c(k) v(e,k) for the coarse solve.
+namespace k2 {
 template <int N>
 __global__ __launch_bounds__(Cfg<N>::NT) void k_gmres_update(Dev d, int j, double scale, int min_iter, int ord) {
   using C = Cfg<N>;
@@ -910,6 +917,14 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_gmres_update(Dev d, int j, doubl
   }
 }
 
+}  // namespace k2
+
+namespace k2 {
+// the quadrilateral solves stay below ~20 iterations: single-pass Gram-Schmidt (the 3-D set re-orthogonalises)
+template <int N>
+__global__ void k_gmres_reorth(Dev, int) {}
+}  // namespace k2
+
 // coarse solve: r_c = gather of element-corner restrictions (padded vertex table);
 // x_c = Aci r_c with one wavefront per CROWS_W rows, lanes striding the (symmetric) row.
 constexpr int CVT = 8;            // table width = max elements around a vertex
@@ -996,6 +1011,7 @@ __global__ __launch_bounds__(256) void k_coarse_big(Dev d, const double* __restr
   if (lane == 63) d.xc[row] = s;
 }
 
+namespace k2 {
 // z_j = RAS(v_j) + R^T x_c ;  yl = D^T z_j  (unassembled velocity-space)
 // patch tables have a fixed stride PS per element: idx[e*PS + k] (-1 padded), inverse [e][k][MM] fp32
 template <int N>
@@ -1261,6 +1277,8 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_vel_update_proj(Dev d, StepCoef 
   }
 }
 
+}  // namespace k2
+
 // absorb the newest solution into the E-orthogonal projection space (slot = pcnt mod nmax):
 //   x_s <- a_s x_s + (delta - sum_{i!=s} c_i/n_i x_i)      [UPSTREAM navier4.f gensolnp / updtseth]
 __global__ __launch_bounds__(256) void k_proj_update(Dev d) {
@@ -1303,8 +1321,7 @@ __global__ void k_vel_update(Dev d, StepCoef sc) {
   const long long l = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (l >= d.nloc) return;
   const double f = d.binv[l] / sc.h2;
-  d.u[l] += f * gs_gather(d.yl, d, l);
-  d.u[d.cs + l] += f * gs_gather(d.yl + d.cs, d, l);
+  for (int c = 0; c < d.ndim; ++c) d.u[c * d.cs + l] += f * gs_gather(d.yl + c * d.cs, d, l);
 }
 
 // ---------------------------------------------------------------------------
@@ -1313,7 +1330,7 @@ __global__ void k_vel_update(Dev d, StepCoef sc) {
 // partial dots of f with nq vectors, bm1s-weighted, velocity only  (krylov_inner_product)
 __global__ __launch_bounds__(256) void k_dots(const double* __restrict__ f, const double* const* __restrict__ Q,
                                               int nq, const double* __restrict__ w, long long nloc,
-                                              double* __restrict__ part, int nblk) {
+                                              double* __restrict__ part, int nblk, int ndim) {
   __shared__ double sred[16];
   const int tid = threadIdx.x;
   for (int k = 0; k < nq; ++k) {
@@ -1321,7 +1338,9 @@ __global__ __launch_bounds__(256) void k_dots(const double* __restrict__ f, cons
     double v[1] = {0.0};
     for (long long l = (long long)blockIdx.x * 256 + tid; l < nloc; l += (long long)nblk * 256) {
       const double ww = w[l];
-      v[0] += ww * (f[l] * q[l] + f[nloc + l] * q[nloc + l]);
+      double t = f[l] * q[l] + f[nloc + l] * q[nloc + l];
+      if (ndim == 3) t += f[2 * nloc + l] * q[2 * nloc + l];
+      v[0] += ww * t;
     }
     block_reduce<1>(v, sred, tid, 256);
     if (tid == 0) part[(size_t)k * nblk + blockIdx.x] = v[0];
@@ -1465,6 +1484,7 @@ __global__ void k_slice_elems(const T* __restrict__ src, T* __restrict__ dst, co
   dst[t] = src[(size_t)elems[t / per] * per + t % per];
 }
 
+namespace k2 {
 // local axhelm for tests
 template <int N>
 __global__ __launch_bounds__(Cfg<N>::NT) void k_axhelm_test(Dev d, const double* __restrict__ u, double h1,
@@ -1486,11 +1506,14 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_axhelm_test(Dev d, const double*
   if (act) out[l] = h1 * au[0] + h2 * d.bm1[l] * z;
 }
 
+}  // namespace k2
+
 __global__ void k_dssum_test(Dev d, const double* __restrict__ u, double* __restrict__ out) {
   const long long l = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (l < d.nloc) out[l] = gs_gather(u, d, l);
 }
 
+namespace k2 {
 template <int N>
 __global__ __launch_bounds__(Cfg<N>::NT) void k_opdiv_test(Dev d, const double* __restrict__ u,
                                                            double* __restrict__ out) {
@@ -1510,6 +1533,8 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_opdiv_test(Dev d, const double* 
   const double w = opdiv_tiles<N, EPB>(sJ12, sD12, su, sA, act, el, nd, d, e);
   if (act && nd < MM) out[e * MM + nd] = w;
 }
+
+}  // namespace k2
 
 // copy probe responses into the block-sparse E storage (setup)
 __global__ void k_collect_probe(const double* __restrict__ w, const int* __restrict__ col_el, int ncol,

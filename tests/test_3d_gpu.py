@@ -1,0 +1,193 @@
+"""Hexahedral (3-D) hot path through the C-ABI against the 3-D oracle (BASELINE configs 4 and 5 are 3-D):
+element kernels, Helmholtz and pressure solves, direct / adjoint / nonlinear steps on small deformed boxes,
+and the z-extruded cylinder against the 2-D GPU path."""
+import numpy as np
+import pytest
+
+from nekstab_amd import mesh3d
+
+pytestmark = pytest.mark.gpu
+
+TOL = dict(tol_helm=1e-12, tol_pres=1e-8, tol_relative=1, max_helm_iter=200, max_pres_iter=48)
+
+
+def _ubf(x, y, z):
+    return np.stack([1.0 - 0.3 * y * y + 0.1 * np.sin(x + z), 0.2 * np.cos(x) * y + 0.1 * z, 0.15 * np.sin(y + 0.5 * z) + 0.05 * x])
+
+
+def _case(lx1, outflow):
+    if outflow:
+        return mesh3d.box_case_3d(3, 2, 2, lx1, lengths=(2.0, 1.0, 0.8), outflow_xmax=True, re=40.0, endtime=0.05,
+                                  ub_func=_ubf, warp=0.06)
+    # closed box (pressure null space, `ortho`): undeformed, so that D^T 1 vanishes exactly on the free nodes and the
+    # discrete E is exactly singular -- on curved elements it is only nearly so (Gauss quadrature of grad(phi_i)) and
+    # a pinned direct solve and an iterative solve of the nearly singular system legitimately differ
+    return mesh3d.box_case_3d(2, 2, 2, lx1, lengths=(1.0, 1.2, 0.9), re=30.0, endtime=0.05, ub_func=_ubf, warp=0.0,
+                              stretch=lambda t: 0.5 * (1.0 - np.cos(np.pi * t)))
+
+
+def _oracle(c, solvers=True):
+    from oracle.linns3d import LinNS3D
+    return LinNS3D(x=c.x, y=c.y, z=c.z, gid=c.gid, nglob=c.nglob, mask=c.mask, ub=c.ub, spng=c.spng, re=c.re,
+                   endtime=c.endtime, has_outflow=c.has_outflow, build_solvers=solvers)
+
+
+def _hip(c, **kw):
+    from nekstab_amd.capi import NekStabHip
+    a = dict(TOL); a.update(kw)
+    return NekStabHip(c, c.meta["vert"], c.meta["nvert"], **a)
+
+
+@pytest.fixture(scope="module", params=[(6, True), (8, True), (6, False)], ids=["lx6-outflow", "lx8-outflow", "lx6-closed"])
+def setup3(request):
+    lx1, outflow = request.param
+    c = _case(lx1, outflow)
+    c.spng = 0.4 * np.clip(c.x - 1.4, 0.0, None) ** 2 if outflow else np.zeros_like(c.x)
+    o = _oracle(c)
+    h = _hip(c)
+    yield c, o, h
+    h.close()
+
+
+def _rel(a, b):
+    return np.abs(np.asarray(a) - np.asarray(b)).max() / np.abs(np.asarray(b)).max()
+
+
+def test_setup_matches(setup3):
+    c, o, h = setup3
+    assert h.nsteps == o.nsteps and abs(h.dt - o.dt) < 1e-15
+    assert h.nvel == c.nel * c.lx1 ** 3 and h.npres == c.nel * (c.lx1 - 2) ** 3 and h.nstate == 3 * h.nvel + h.npres
+
+
+def test_element_operators(setup3):
+    c, o, h = setup3
+    rng = np.random.default_rng(1)
+    u = rng.standard_normal((3,) + c.x.shape)
+    p = rng.standard_normal((c.nel,) + (c.lx1 - 2,) * 3)
+    assert _rel(h.t_axhelm(u[0], 0.7, 1.3), o.axhelm(u[0], 0.7, 1.3)) < 1e-12
+    assert _rel(h.t_dssum(u[1]), o.dssum(u[1])) < 1e-13
+    assert _rel(h.t_op3(1, u), o.opdiv(u)) < 1e-12
+    assert _rel(h.t_op3(2, p), np.stack(o.opgradt(p))) < 1e-12
+    # E = D B^-1 D^T against the oracle's assembled sparse matrix
+    assert _rel(h.t_eapply(p).ravel(), o._Emat @ p.ravel()) < 1e-11
+
+
+def test_convection_terms(setup3):
+    c, o, h = setup3
+    rng = np.random.default_rng(2)
+    u = rng.standard_normal((3,) + c.x.shape)
+    U = o.ub
+    sp = o.spng * o.bm1
+    direct = np.stack([-(sp * u[k] + o.convect(u, U[k]) + o.convect(U, u[k])) for k in range(3)])
+    assert _rel(h.t_op3(3, u, 0), direct) < 1e-12
+    a = o.convect_adj(u, U)
+    adj = np.stack([-(sp * u[k] + a[k] - o.convect(U, u[k])) for k in range(3)])
+    assert _rel(h.t_op3(3, u, 1), adj) < 1e-12
+    nl = np.stack([-o.convect(u, u[k]) for k in range(3)])
+    assert _rel(h.t_op3(3, u, 2), nl) < 1e-12
+
+
+def test_helmholtz_solve(setup3):
+    c, o, h = setup3
+    rng = np.random.default_rng(3)
+    r = rng.standard_normal((3,) + c.x.shape)
+    out, iters = h.t_op3(5, r, 3)
+    h2 = (11.0 / 6.0) / o.dt
+    ref = np.stack([o.helm_solve(r[k], o.nu, h2) for k in range(3)])
+    assert _rel(out, ref) < 1e-9
+    assert 0 < iters < 200
+
+
+def test_pressure_solve(setup3):
+    c, o, h = setup3
+    rng = np.random.default_rng(4)
+    g = rng.standard_normal((c.nel,) + (c.lx1 - 2,) * 3)
+    if not c.has_outflow:
+        g -= g.mean()
+    x, iters = h.t_pres_solve(g)
+    ref = o.E_solve(g)
+    if not c.has_outflow:
+        x = x - x.mean()
+    assert _rel(x, ref) < 1e-6, iters
+    assert 0 < iters <= 48
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_steps_match_oracle(setup3, mode):
+    c, o, h = setup3
+    x, y, z = c.x, c.y, c.z
+    q = [np.sin(1.3 * x + z) * np.cos(2.0 * y) * c.mask, np.cos(0.7 * x + 0.2) * np.sin(3.0 * y - z) * c.mask,
+         np.sin(x + y) * np.cos(2.0 * z) * c.mask]
+    m = c.lx1 - 2
+    p = np.zeros((c.nel, m, m, m))
+    nst = 5
+    ref = o.matvec((q[0], q[1], q[2], p), adjoint=bool(mode), nsteps=nst)
+    v0, v1 = h.alloc(2)
+    h.upload3(v0, q[0], q[1], q[2], p)
+    keep = h.nsteps
+    h.set_nsteps(nst)
+    h.matvec(v1, v0, mode)
+    h.set_nsteps(keep)
+    out = h.download3(v1)
+    sc = max(np.abs(ref[k]).max() for k in range(3))
+    for k in range(3):
+        assert np.abs(out[k] - ref[k]).max() < 1e-7 * sc
+    pr, po = ref[3], out[3]
+    if not c.has_outflow:
+        pr, po = pr - pr.mean(), po - po.mean()
+    assert np.abs(po - pr).max() < 1e-4 * max(np.abs(pr).max(), 1e-30)
+    st = h.stats()
+    assert st["unconverged"] == 0
+    h.free([v0, v1])
+
+
+def test_krylov_algebra_3d(setup3):
+    c, o, h = setup3
+    rng = np.random.default_rng(5)
+    a = [rng.standard_normal(c.x.shape) for _ in range(3)]
+    b = [rng.standard_normal(c.x.shape) for _ in range(3)]
+    m = c.lx1 - 2
+    pa, pb = rng.standard_normal((c.nel, m, m, m)), rng.standard_normal((c.nel, m, m, m))
+    va, vb = h.alloc(2)
+    h.upload3(va, *a, pa); h.upload3(vb, *b, pb)
+    assert abs(h.dot(va, vb) - o.inner(a, b)) < 1e-12 * abs(o.inner(a, a))
+    h.axpy(va, -0.5, vb)
+    out = h.download3(va)
+    assert np.abs(out[2] - (a[2] - 0.5 * b[2])).max() < 1e-14 and np.abs(out[3] - (pa - 0.5 * pb)).max() < 1e-14
+    h.free([va, vb])
+
+
+def test_extruded_cylinder_matches_2d():
+    """z-invariant perturbation on the z-extruded cylinder mesh (the reference's own geometry): the hexahedral
+    path must reproduce the quadrilateral path plane by plane."""
+    import os
+    from nekstab_amd import mesh
+    from nekstab_amd.capi import NekStabHip
+    here = os.path.dirname(os.path.abspath(__file__))
+    c2 = mesh.load_case_npz(os.path.join(here, "golden", "cylinder_case.npz"), 6)
+    modes = np.load(os.path.join(here, "golden", "cylinder_modes.npz"))
+    c3 = mesh3d.extrude_case(c2, 2, 1.0, periodic=True)
+    prod = dict(tol_helm=1e-11, tol_pres=1e-4, tol_relative=1, max_helm_iter=150, max_pres_iter=48, nproj=8)
+    h2 = NekStabHip(c2, c2.meta["vert"], c2.meta["nvert"], **prod)
+    h3 = _hip(c3, **prod)
+    try:
+        assert h3.nsteps == h2.nsteps
+        u, v = modes["dRe_u"][0].astype(np.float64) * c2.mask, modes["dRe_u"][1].astype(np.float64) * c2.mask
+        nst = 6
+        a0, a1 = h2.alloc(2)
+        h2.upload(a0, u, v, np.zeros(h2.npres)); h2.set_nsteps(nst); h2.matvec(a1, a0, 0)
+        r2 = h2.download(a1)
+        b0, b1 = h3.alloc(2)
+        h3.upload3(b0, mesh3d.extrude_field(u, 2), mesh3d.extrude_field(v, 2), np.zeros(h3.nvel), np.zeros(h3.npres))
+        h3.set_nsteps(nst); h3.matvec(b1, b0, 0)
+        r3 = h3.download3(b1)
+        sc = np.abs(r2[0]).max()
+        for k in range(6):
+            for layer in range(2):
+                e = slice(layer * c2.nel, (layer + 1) * c2.nel)
+                assert np.abs(r3[0][e, k] - r2[0]).max() < 1e-7 * sc
+                assert np.abs(r3[1][e, k] - r2[1]).max() < 1e-7 * sc
+        assert np.abs(r3[2]).max() < 1e-7 * sc
+        assert h3.stats()["unconverged"] == 0
+    finally:
+        h2.close(); h3.close()
