@@ -627,13 +627,20 @@ static int build(nsk_ctx* c, const nsk_case& cs) {
 // ---------------------------------------------------------------------------
 // one nek_advance() in perturbation mode
 // ---------------------------------------------------------------------------
+// hexahedral contexts: one workgroup sums each row of per-workgroup partials (Dev::use_tot)
+static inline void tot_rows(nsk_ctx* c, const double* part, int rows, double* tot) {
+  if (c->d.use_tot) hipLaunchKernelGGL(k_tot2, dim3(rows), dim3(256), 0, c->stream, part, c->nblk, tot);
+}
+
 static int pres_solve_launch(nsk_ctx* c, double h2, int ord, int np) {
   Dev& d = c->d;
   const double scale = 1.0 / (h2 * std::sqrt(d.vol));
   DISPATCH_N(c->key, {
     constexpr int NT = Cfg<N>::NT;
-    if (!d.has_outflow && !c->in_test) hipLaunchKernelGGL(k_ortho, dim3(c->nblk), dim3(256), 0, c->stream, d);
-    if (d.nproj_max > 0 && !c->in_test) hipLaunchKernelGGL(k_proj_apply, dim3(c->nblk), dim3(256), 0, c->stream, d);
+    tot_rows(c, d.gpart, d.has_outflow ? 1 : 2, d.gtot);
+    if (d.nproj_max > 0 && !c->in_test) tot_rows(c, d.ppart, MAXPROJ + 1, d.ptot);
+    if (!d.has_outflow && !c->in_test) { hipLaunchKernelGGL(k_ortho, dim3(c->nblk), dim3(256), 0, c->stream, d); tot_rows(c, d.gpart, 1, d.gtot); }
+    if (d.nproj_max > 0 && !c->in_test) { hipLaunchKernelGGL(k_proj_apply, dim3(c->nblk), dim3(256), 0, c->stream, d); tot_rows(c, d.gpart, 1, d.gtot); }
     hipLaunchKernelGGL(k_gmres_update<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, -1, scale, c->min_pres, ord);
     for (int j = 0; j < np; ++j) {
       if (c->ndim == 3) {
@@ -647,7 +654,11 @@ static int pres_solve_launch(nsk_ctx* c, double h2, int ord, int np) {
       }
       hipLaunchKernelGGL(k_schwarz<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, (const double*)(d.V + (size_t)j * d.ps), d.Z + (size_t)j * d.npr, 1, 1);
       hipLaunchKernelGGL(k_divgs<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, (const double*)d.yl, d.V + (size_t)(j + 1) * d.ps, j, 1);
-      if (c->ndim == 3) hipLaunchKernelGGL(k_gmres_reorth<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, j);
+      if (c->ndim == 3) {
+        tot_rows(c, d.gpart, j + 2, d.gtot);
+        hipLaunchKernelGGL(k_gmres_reorth<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, j);
+        tot_rows(c, d.gpart2, j + 2, d.gtot2);
+      }
       hipLaunchKernelGGL(k_gmres_update<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, j, scale, c->min_pres, ord);
     }
   });
@@ -662,8 +673,10 @@ static int step(nsk_ctx* c, int istep, int adjoint) {
     constexpr int NT = Cfg<N>::NT;
     hipLaunchKernelGGL(k_convect<N>, dim3(c->nel), dim3(Cfg<N>::NTD), 0, c->stream, d, (const double*)d.u, d.bf, adjoint);
     hipLaunchKernelGGL(k_rhs<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, sc);
-    for (int it = 0; it < nh; ++it)
+    for (int it = 0; it < nh; ++it) {
       hipLaunchKernelGGL(k_helm<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, sc, it, (const double*)d.rloc);
+      tot_rows(c, d.hpart + (size_t)(it & 1) * 12 * c->nblk, 12, d.htot + (it & 1) * 16);
+    }
     hipLaunchKernelGGL(k_pres_rhs<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, sc, (nh - 1) & 1, nh - 1);
   });
   int rc = pres_solve_launch(c, sc.h2, sc.cls, c->cur_pres[sc.cls]);
@@ -675,6 +688,7 @@ static int step(nsk_ctx* c, int istep, int adjoint) {
     DISPATCH_N(c->key, {
       hipLaunchKernelGGL(k_vel_update_proj<N>, dim3(c->nblk), dim3(Cfg<N>::NT), 0, c->stream, d, sc);
     });
+    tot_rows(c, d.ppart, MAXPROJ + 1, d.ptot);
     hipLaunchKernelGGL(k_proj_update, dim3(c->nblk), dim3(256), 0, c->stream, d);
   } else {
     hipLaunchKernelGGL(k_vel_update, dim3((unsigned)((d.nloc + 255) / 256)), dim3(256), 0, c->stream, d, sc);
@@ -1415,8 +1429,10 @@ int nsk_test_op3(nsk_ctx* c, int which, const double* in, double* out, int a, in
     HIPCHK(hipMemset(d.stats, 0, sizeof(Stats)));
     const StepCoef sc = make_coef(c, a, 0);
     DISPATCH_N(c->key, {
-      for (int it = 0; it < c->max_helm; ++it)
+      for (int it = 0; it < c->max_helm; ++it) {
         hipLaunchKernelGGL(k_helm<N>, dim3(c->nblk), dim3(Cfg<N>::NT), 0, c->stream, d, sc, it, (const double*)d.rloc);
+        tot_rows(c, d.hpart + (size_t)(it & 1) * 12 * c->nblk, 12, d.htot + (it & 1) * 16);
+      }
     });
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipMemcpy(out, d.hx, nv * sizeof(double), hipMemcpyDeviceToHost));
@@ -1429,6 +1445,7 @@ int nsk_test_op3(nsk_ctx* c, int which, const double* in, double* out, int a, in
     for (long long q = 0; q < c->npr; ++q) part[q / c->MM] += in[q] * in[q];
     HIPCHK(hipMemcpy(d.gpart, part.data(), c->nblk * sizeof(double), hipMemcpyHostToDevice));
     DISPATCH_N(c->key, {
+      tot_rows(c, d.gpart, 1, d.gtot);
       hipLaunchKernelGGL(k_gmres_update<N>, dim3(c->nblk), dim3(Cfg<N>::NT), 0, c->stream, d, -1, 1.0, 1, 0);   // normalises V[0], fills ec
       hipLaunchKernelGGL(k_coarse_restrict_csr, dim3(d.coarse_lda / 256), dim3(256), 0, c->stream, d, c->rc_big);
       hipLaunchKernelGGL(k_coarse_big, dim3((d.nvert + 3) / 4), dim3(256), 0, c->stream, d, (const double*)c->rc_big);

@@ -438,74 +438,35 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_rhs(Dev d, StepCoef sc) {
 
 // ---------------------------------------------------------------------------
 // K3: one Jacobi-PCG iteration of H du = dssum(r), three components, single-reduction
-// (Chronopoulos-Gear) form  [UPSTREAM hmholtz.f cggo].
+// (Chronopoulos-Gear) form  [UPSTREAM hmholtz.f cggo].  The components are processed one after the
+// other (one tile set in LDS, low register count => several workgroups per CU: this kernel is HBM-bound
+// on 3-D meshes).  Sums of the previous launch come from htot (k_tot2), never from the per-workgroup partials.
 //   hscal[par*16 + c*4 + {0:gamma,1:alpha,2:done,3:res}], reference norms at hscal[32 + c]
-//   hpart[par][12][nblk]: c*3 + {0:(r,z), 1:(z,Az), 2:(r,r)}, 9 + c: (b,b)
+//   hpart[par][12][nblk] / htot[par*16 + .]: c*3 + {0:(r,z), 1:(z,Az), 2:(r,r)}, 9 + c: (b,b)
 // ---------------------------------------------------------------------------
 template <int N>
-__global__ __launch_bounds__(Cfg<N>::NT) void k_helm(Dev d, StepCoef sc, int it, const double* rhs) {
+__global__ __launch_bounds__(Cfg<N>::NT, 4) void k_helm(Dev d, StepCoef sc, int it, const double* rhs) {
   using C = Cfg<N>;
   constexpr int NN = C::NN, NT = C::NT;
   __shared__ double sD[N * N], sDt[N * N];
-  __shared__ double sz[3 * NN], st[9 * NN];
-  __shared__ double sred[12 * 16];
+  __shared__ double sz[NN], st[3 * NN];
+  __shared__ double sred[4 * 16];
   const int tid = threadIdx.x;
   const long long e = blockIdx.x;
   const bool act = tid < NN;
   const int k = tid / (N * N), j = (tid / N) % N, i = tid % N;
   const long long l = e * NN + tid, nl = d.cs;
   const int par = it & 1, ppar = par ^ 1;
-  double o[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, refn[3] = {0, 0, 0};
-  if (it > 1) {
-#pragma unroll
-    for (int q = 0; q < 12; ++q) o[q] = d.hscal[ppar * 16 + q];
-    refn[0] = d.hscal[32]; refn[1] = d.hscal[33]; refn[2] = d.hscal[34];
-  }
-  double ps[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  if (it > 0) {
-    const double* part = d.hpart + (size_t)ppar * 12 * d.nblk;
-    for (int b = tid; b < d.nblk; b += NT) {
-#pragma unroll
-      for (int q = 0; q < 12; ++q) ps[q] += part[(size_t)q * d.nblk + b];
-    }
-  }
-  int4 tab = make_int4(0, -1, -1, -1);
-  double bm = 0, g[6] = {0, 0, 0, 0, 0, 0}, mk = 0, mi = 0, di = 0;
-  double rold[3] = {0, 0, 0}, pold[3] = {0, 0, 0}, sold[3] = {0, 0, 0}, xold[3] = {0, 0, 0};
-  if (act) {
-    tab = d.gs_tab[l];
-    bm = d.bm1[l]; mk = d.mask[l]; mi = d.minv[l];
-    g[0] = d.g1[l]; g[1] = d.g2[l]; g[2] = d.g3[l]; g[3] = d.g4[l]; g[4] = d.g5[l]; g[5] = d.g6[l];
-    di = d.dinv[(size_t)(sc.k - 1) * d.nloc + l];
-    if (it > 0) {
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const long long lc = c * nl + l;
-        rold[c] = d.hr[lc]; pold[c] = d.hp[lc]; sold[c] = d.hs[lc]; xold[c] = d.hx[lc];
-      }
-    }
-  }
-  if (it > 1 && o[2] != 0.0 && o[6] != 0.0 && o[10] != 0.0) {       // all components finished earlier
-    if (blockIdx.x == 0 && tid < 12) d.hscal[par * 16 + tid] = o[tid];
-    return;
-  }
-  GsVals gv[3], gb[3];
-  if (act) {
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      if (it == 0) { gv[c] = gs_load(rhs + c * nl, tab, l); gb[c] = gs_load(d.bloc + c * nl, tab, l); }
-      else gv[c] = gs_load(d.hwl + ((size_t)ppar * 3 + c) * nl, tab, l);
-    }
-  }
   double alpha[3] = {0, 0, 0}, beta[3] = {0, 0, 0};
   bool done[3] = {false, false, false};
   if (it > 0) {
-    block_reduce<12>(ps, sred, tid, NT);
+    const double* ps = d.htot + ppar * 16;
+    const double* o = d.hscal + ppar * 16;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const double gg = ps[c * 3 + 0], del = ps[c * 3 + 1], rr = ps[c * 3 + 2];
       const double res = sqrt(rr / d.vol);
-      const double ref = (it == 1) ? sqrt(ps[9 + c] / d.vol) : refn[c];
+      const double ref = (it == 1) ? sqrt(ps[9 + c] / d.vol) : d.hscal[32 + c];
       const double tol = d.tol_relative ? d.tol_helm * ref : d.tol_helm;
       const bool was = (it > 1 && o[c * 4 + 2] != 0.0);
       done[c] = was || (res <= tol) || !(gg > 0.0);
@@ -515,8 +476,8 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_helm(Dev d, StepCoef sc, int it,
       }
       if (blockIdx.x == 0 && tid == 0) {
         double* cur = d.hscal + par * 16 + c * 4;
-        cur[0] = gg; cur[1] = alpha[c]; cur[2] = done[c] ? 1.0 : 0.0;
-        cur[3] = was ? o[c * 4 + 3] : res;
+        const double keep = was ? o[c * 4 + 3] : res;
+        cur[0] = gg; cur[1] = alpha[c]; cur[2] = done[c] ? 1.0 : 0.0; cur[3] = keep;
         if (it == 1) d.hscal[32 + c] = ref;
         if (done[c] && !was) {
           if (c == 0) atomicAdd((unsigned long long*)&d.stats->helm_iters, (unsigned long long)(it - 1));
@@ -528,47 +489,54 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_helm(Dev d, StepCoef sc, int it,
     if (done[0] && done[1] && done[2]) return;
   }
   for (int q = tid; q < N * N; q += NT) { const double v = d.D[q]; sD[q] = v; sDt[(q % N) * N + q / N] = v; }
-  double r[3] = {0, 0, 0}, z[3] = {0, 0, 0}, bb[3] = {0, 0, 0};
+  int4 tab = make_int4(0, -1, -1, -1);
+  double bm = 0, g[6] = {0, 0, 0, 0, 0, 0}, mk = 0, mi = 0, di = 0;
   if (act) {
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const long long lc = c * nl + l;
+    tab = d.gs_tab[l];
+    bm = d.bm1[l]; mk = d.mask[l]; mi = d.minv[l];
+    g[0] = d.g1[l]; g[1] = d.g2[l]; g[2] = d.g3[l]; g[3] = d.g4[l]; g[4] = d.g5[l]; g[5] = d.g6[l];
+    di = d.dinv[(size_t)(sc.k - 1) * d.nloc + l];
+  }
+#pragma unroll 1
+  for (int c = 0; c < 3; ++c) {
+    const long long lc = c * nl + l;
+    double r = 0.0, z = 0.0, bb = 0.0;
+    if (act) {
       if (it == 0) {
-        r[c] = mk * gs_sum(gv[c], rhs + c * nl, d, tab, l);
-        bb[c] = mk * gs_sum(gb[c], d.bloc + c * nl, d, tab, l);
-        d.hx[lc] = 0.0; d.hp[lc] = 0.0; d.hs[lc] = 0.0; d.hr[lc] = r[c];
+        const GsVals gv = gs_load(rhs + c * nl, tab, l), gb = gs_load(d.bloc + c * nl, tab, l);
+        r = mk * gs_sum(gv, rhs + c * nl, d, tab, l);
+        bb = mk * gs_sum(gb, d.bloc + c * nl, d, tab, l);
+        d.hx[lc] = 0.0; d.hp[lc] = 0.0; d.hs[lc] = 0.0; d.hr[lc] = r;
       } else if (!done[c]) {
-        const double w = mk * gs_sum(gv[c], d.hwl + ((size_t)ppar * 3 + c) * nl, d, tab, l);
-        const double pn = di * rold[c] + beta[c] * pold[c];
-        const double sn = w + beta[c] * sold[c];
+        const double* wl = d.hwl + ((size_t)ppar * 3 + c) * nl;
+        const GsVals gv = gs_load(wl, tab, l);
+        const double rold = d.hr[lc], pold = d.hp[lc], sold = d.hs[lc], xold = d.hx[lc];
+        const double w = mk * gs_sum(gv, wl, d, tab, l);
+        const double pn = di * rold + beta[c] * pold;
+        const double sn = w + beta[c] * sold;
         d.hp[lc] = pn; d.hs[lc] = sn;
-        d.hx[lc] = xold[c] + alpha[c] * pn;
-        r[c] = rold[c] - alpha[c] * sn;
-        d.hr[lc] = r[c];
+        d.hx[lc] = xold + alpha[c] * pn;
+        r = rold - alpha[c] * sn;
+        d.hr[lc] = r;
       } else {
-        r[c] = rold[c];
+        r = d.hr[lc];
       }
-      z[c] = di * r[c];
-      sz[c * NN + tid] = z[c];
+      z = di * r;
+      sz[tid] = z;
     }
-  }
-  lds_barrier();
-  double au[3];
-  axhelm3<N, 3>(sD, sDt, sz, st, act, k, j, i, g, au);
-  double v[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  if (act) {
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const double wl = d.nu * au[c] + sc.h2 * bm * z[c];
+    lds_barrier();
+    double au[1];
+    axhelm3<N, 1>(sD, sDt, sz, st, act, k, j, i, g, au);
+    double v[4] = {0, 0, 0, 0};
+    if (act) {
+      const double wl = d.nu * au[0] + sc.h2 * bm * z;
       d.hwl[((size_t)par * 3 + c) * nl + l] = wl;
-      v[c * 3 + 0] = r[c] * z[c] * mi;
-      v[c * 3 + 1] = z[c] * wl;
-      v[c * 3 + 2] = r[c] * r[c] * mi;
-      v[9 + c] = bb[c] * bb[c] * mi;
+      v[0] = r * z * mi; v[1] = z * wl; v[2] = r * r * mi; v[3] = bb * bb * mi;
     }
+    block_reduce<4>(v, sred, tid, NT);
+    if (tid < 3) d.hpart[((size_t)par * 12 + c * 3 + tid) * d.nblk + blockIdx.x] = v[tid];
+    if (tid == 3) d.hpart[((size_t)par * 12 + 9 + c) * d.nblk + blockIdx.x] = v[3];
   }
-  block_reduce<12>(v, sred, tid, NT);
-  if (tid < 12) d.hpart[((size_t)par * 12 + tid) * d.nblk + blockIdx.x] = v[tid];
 }
 
 // ---------------------------------------------------------------------------
@@ -587,8 +555,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_pres_rhs(Dev d, StepCoef sc, int
   const long long l = e * NN + tid, nl = d.cs;
   load_basis3<N>(d, nullptr, nullptr, sJ12, sD12, tid, NT);
   if (check_helm && blockIdx.x == 0) {
-    double s[12];
-    sum_partials<12>(d.hpart + (size_t)helm_par * 12 * d.nblk, d.nblk, s, sred, tid, NT);
+    const double* s = d.htot + helm_par * 16;
     if (tid == 0) {
       double worst = 0.0; int bad = 0;
       for (int c = 0; c < 3; ++c) {
@@ -674,7 +641,8 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_gmres_reorth(Dev d, int j) {
   const int tid = threadIdx.x;
   const long long e = blockIdx.x;
   if (d.gsc->done) return;
-  sum_partials_multi(d.gpart, d.nblk, j + 1, sh, tid, NT);
+  if (tid <= j) sh[tid] = d.gtot[tid];
+  lds_barrier();
   const bool pact = tid < MM;
   const long long q = e * MM + tid;
   double w = 0.0;
@@ -714,11 +682,11 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_gmres_update(Dev d, int j, doubl
   if (tid < MM) wnew = d.V[(size_t)(j + 1) * d.ps + e * MM + tid];
   double hn;
   if (j < 0) {
-    sum_partials_multi(d.gpart, d.nblk, 1, sh, tid, NT);
-    hn = sqrt(sh[0]);
+    hn = sqrt(d.gtot[0]);
   } else {
-    sum_partials_multi(d.gpart, d.nblk, j + 1, sh, tid, NT);
-    sum_partials_multi(d.gpart2, d.nblk, j + 2, sc2, tid, NT);
+    if (tid <= j) sh[tid] = d.gtot[tid];
+    if (tid <= j + 1) sc2[tid] = d.gtot2[tid];
+    lds_barrier();
     double s2 = 0.0;
     for (int q = 0; q <= j; ++q) s2 += sc2[q] * sc2[q];
     const double hn2 = sc2[j + 1] - s2;

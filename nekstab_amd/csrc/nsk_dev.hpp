@@ -103,6 +103,10 @@ struct Dev {
   const double *g3, *g5, *g6, *w2m, *bfc, *mtd, *fdS, *fdL;
   double fd_eps;
   double* gpart2;                // partial sums of the second Gram-Schmidt pass (3-D GMRES)
+  // hexahedral meshes have one workgroup per element (10^3-10^5 of them): every set of per-workgroup partials is
+  // summed once by k_tot2 into these totals instead of being re-summed by every consumer workgroup (O(nblk^2))
+  int use_tot;
+  double *gtot2, *ptot;
   double *htot;                  // [2 parities][8]  Helmholtz sums over all ranks
   double *gtot;                  // [MAXMR + 2]      GMRES sums over all ranks
 };

@@ -764,7 +764,7 @@ __global__ __launch_bounds__(256) void k_ortho(Dev d) {
   __shared__ double sred[16];
   const int tid = threadIdx.x;
   double sm[1];
-  if (d.nranks > 1) sm[0] = d.gtot[1];
+  if (d.nranks > 1 || d.use_tot) sm[0] = d.gtot[1];
   else sum_partials<1>(d.gpart + d.nblk, d.nblk, sm, sred, tid, 256);
   const double mean = sm[0] / (double)d.npr_glob;
   double v[1] = {0.0};
@@ -785,11 +785,17 @@ __global__ __launch_bounds__(256) void k_proj_apply(Dev d) {
   const int tid = threadIdx.x;
   GmresScal* G = d.gsc;
   const int np = G->nproj;
-  sum_partials_multi(d.ppart, d.nblk, np, sh, tid, 256);
-  if (blockIdx.x == 0) {
-    double gg[1];
-    sum_partials<1>(d.ppart + (size_t)MAXPROJ * d.nblk, d.nblk, gg, sred, tid, 256);
-    if (tid == 0) G->gnorm0 = sqrt(gg[0]);
+  if (d.use_tot) {
+    if (tid < np) sh[tid] = d.ptot[tid];
+    if (blockIdx.x == 0 && tid == 0) G->gnorm0 = sqrt(d.ptot[MAXPROJ]);
+    __syncthreads();
+  } else {
+    sum_partials_multi(d.ppart, d.nblk, np, sh, tid, 256);
+    if (blockIdx.x == 0) {
+      double gg[1];
+      sum_partials<1>(d.ppart + (size_t)MAXPROJ * d.nblk, d.nblk, gg, sred, tid, 256);
+      if (tid == 0) G->gnorm0 = sqrt(gg[0]);
+    }
   }
   if (tid < np) sh[tid] = sh[tid] / G->pn[tid];
   __syncthreads();
@@ -1289,7 +1295,8 @@ __global__ __launch_bounds__(256) void k_proj_update(Dev d) {
   if (G->nit == 0) return;
   const int np = G->nproj, nmax = d.nproj_max;
   const int s = G->pcnt % nmax;
-  sum_partials_multi(d.ppart, d.nblk, np + 1, sh, tid, 256);
+  if (d.use_tot) { if (tid <= np) sh[tid] = d.ptot[tid]; __syncthreads(); }
+  else sum_partials_multi(d.ppart, d.nblk, np + 1, sh, tid, 256);
   const double as = (s < np) ? G->pa[s] : 0.0;
   if (tid < np) cf[tid] = (tid == s) ? 0.0 : sh[tid] / G->pn[tid];
   __syncthreads();
@@ -1459,6 +1466,15 @@ __global__ __launch_bounds__(256) void k_tot(const double* __restrict__ part, in
   __shared__ double sh[MAXMR + 8];
   sum_partials_multi(part, nblk, nv, sh, threadIdx.x, 256);
   if ((int)threadIdx.x < nv) tot[threadIdx.x] = sh[threadIdx.x];
+}
+// one workgroup per row of per-workgroup partials: tot[q] = sum_k part[q][k]  (fixed order)
+__global__ __launch_bounds__(256) void k_tot2(const double* __restrict__ part, int nblk, double* __restrict__ tot) {
+  __shared__ double sred[16];
+  const int q = blockIdx.x, tid = threadIdx.x;
+  double v[1] = {0.0};
+  for (int k = tid; k < nblk; k += 256) v[0] += part[(size_t)q * nblk + k];
+  block_reduce<1>(v, sred, tid, 256);
+  if (tid == 0) tot[q] = v[0];
 }
 // loop-back all-reduce for virtual ranks living in one process: every buffer <- sum of all (rank order)
 __global__ void k_loop_allreduce(double* const* __restrict__ bufs, int nr, int n) {
