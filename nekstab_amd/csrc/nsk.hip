@@ -1334,11 +1334,15 @@ int nsk_bench_kernel(nsk_ctx* c, const char* name, int reps, double* avg_us) {
     const int cyc = 8;
     HIPCHK(hipStreamSynchronize(c->stream));
     DISPATCH_N(c->key, {
-      for (int r = 0; r < cyc; ++r)                               // warm
+      for (int r = 0; r < cyc; ++r) {                             // warm
         hipLaunchKernelGGL(k_helm<N>, dim3(c->nblk), dim3(Cfg<N>::NT), 0, c->stream, d, sc, r % cyc, (const double*)d.rloc);
+        tot_rows(c, d.hpart + (size_t)(r & 1) * 12 * c->nblk, 12, d.htot + (r & 1) * 16);
+      }
       HIPCHK(hipEventRecord(e0, c->stream));
-      for (int r = 0; r < reps; ++r)
+      for (int r = 0; r < reps; ++r) {
         hipLaunchKernelGGL(k_helm<N>, dim3(c->nblk), dim3(Cfg<N>::NT), 0, c->stream, d, sc, r % cyc, (const double*)d.rloc);
+        tot_rows(c, d.hpart + (size_t)(r & 1) * 12 * c->nblk, 12, d.htot + (r & 1) * 16);   // hexahedra only (a few us, included)
+      }
       HIPCHK(hipEventRecord(e1, c->stream));
     });
   } else {

@@ -22,3 +22,4 @@ for rep in range(2):
     t0 = time.time(); h3.matvec(b1, b0, 0); dt = time.time() - t0
     st = h3.stats()
     print("lx1 %d E %d pts/field %d: %.2f ms/step helm/step %.1f pres/step %.1f" % (lx1, c3.nel, h3.nvel, 1e3 * dt / nst, st["helm_iters"] / nst, st["pres_iters"] / nst), flush=True)
+    print(st, flush=True)

@@ -51,7 +51,17 @@ def main():
     np.savez_compressed(OUT + "/cylinder_upo.npz", u=fl.u[:, :, 0], p=fl.p[:, 0], period=fl.time,
                         spectre_Hd=nekio.read_spectre(REF + "/stability/direct_Floquet/Spectre_Hd.dat"),
                         spectre_Ha=nekio.read_spectre(REF + "/stability/adjoint_Floquet/Spectre_Ha.dat"))
-    for f in ("cylinder_case.npz", "cylinder_spectre.npz", "cylinder_modes.npz"):
+    # lid-driven cavity (examples/lid_driven): mesh, vertex ids, committed base flow.  usrdat2 rescales y to
+    # [0, uparam(10)]; the committed field was written with aspect ratio 1.2 (its own coordinate block says so)
+    ld = os.path.dirname(os.path.dirname(REF)) + "/lid_driven/"
+    cm = nekio.read_re2(ld + "cav.re2")
+    cv, _ = nekio.read_ma2(ld + "cav.ma2")
+    cf = nekio.read_fld(ld + "BF_cav0.f00001")
+    cm.yc = (cm.yc + 0.5) * 1.2
+    np.savez_compressed(OUT + "/cavity_case.npz", xc=cm.xc, yc=cm.yc,
+                        bc_ef=np.array([[b[0], b[1]] for b in cm.bcs], dtype=np.int32), bc_code=np.array([b[3] for b in cm.bcs]),
+                        vlex=cv.astype(np.int32), bf_u=cf.u[:, :, 0], bf_p=cf.p[:, 0])
+    for f in ("cylinder_case.npz", "cylinder_spectre.npz", "cylinder_modes.npz", "cavity_case.npz"):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
 

@@ -257,3 +257,76 @@ def test_nonlinear_map_and_relinearisation_3d():
             assert np.abs(g2[k] - r2[k]).max() < 1e-7 * sc
     finally:
         h.close()
+
+
+def _cavity_2d(re):
+    import os
+    from nekstab_amd import mesh, nekio
+    from nekstab_amd.quadrature import gauss_legendre, gauss_lobatto_legendre, interp_matrix
+    here = os.path.dirname(os.path.abspath(__file__))
+    z = np.load(os.path.join(here, "golden", "cavity_case.npz"))
+    bcs = [(int(a), int(b), np.zeros(5), str(cd)) for (a, b), cd in zip(z["bc_ef"], z["bc_code"])]
+    m = nekio.Re2Mesh(2, z["xc"].shape[0], z["xc"], z["yc"], None, [], bcs)
+    c2 = mesh.build_case_2d(m, z["vlex"].astype(np.int64), z["bf_u"].astype(np.float64), 6, re=re, endtime=1.0, spng_str=0.0)
+    J = interp_matrix(gauss_lobatto_legendre(6)[0], gauss_legendre(4)[0])
+    return c2, J @ z["bf_p"].astype(np.float64) @ J.T
+
+
+def test_lid_driven_cavity_baseflow_is_a_fixed_point_2d_and_3d():
+    """Reference data pin for the closed-cavity (pressure null space) nonlinear path: the committed base flow of
+    examples/lid_driven (BF_cav0.f00001: 100 elements, lx1=6, y rescaled to [0,1.2], header istep = 697) is a fixed
+    point of Phi_T at Re = 3600 (viscosity = -3600, cav.par:31) and at no other Reynolds number; its z-extrusion is
+    the same fixed point of the hexahedral map."""
+    from nekstab_amd.capi import NekStabHip
+    kw = dict(tol_helm=1e-12, tol_pres=1e-6, tol_relative=1, nproj=0, max_helm_iter=150, max_pres_iter=48)
+    res = {}
+    for re in (3600.0, 4000.0):
+        c2, p2 = _cavity_2d(re)
+        h = NekStabHip(c2, c2.meta["vert"], c2.meta["nvert"], **kw)
+        assert h.nsteps == 696                      # file header: istep = nsteps + 1 = 697  (third dt-rule pin)
+        q, f = h.alloc(2)
+        h.upload(q, c2.ub[0], c2.ub[1], p2)
+        h.nonlinear_map(f, q, subtract_q=True)
+        res[re] = h.norm(f) ** 2
+        h.close()
+    assert res[3600.0] < 2e-9 and res[4000.0] > 1e-6, res
+    c2, p2 = _cavity_2d(3600.0)
+    c3 = mesh3d.extrude_case(c2, 2, 0.4, periodic=True)
+    h = NekStabHip(c3, c3.meta["vert"], c3.meta["nvert"], **kw)
+    try:
+        q, f = h.alloc(2)
+        h.upload3(q, mesh3d.extrude_field(c2.ub[0], 2), mesh3d.extrude_field(c2.ub[1], 2), np.zeros(c3.x.shape),
+                  mesh3d.extrude_pressure(p2, 2))
+        h.nonlinear_map(f, q, subtract_q=True)
+        r3 = h.norm(f) ** 2 / 0.4                   # the 3-D norm integrates over the span
+        assert abs(r3 - res[3600.0]) < 1e-3 * res[3600.0], (r3, res)
+        assert h.stats()["unconverged"] == 0
+    finally:
+        h.close()
+
+
+def test_newton_krylov_3d_box():
+    """Newton-Krylov (core/newton_krylov.f:5-296 restated in newton.py) on a hexahedral context: lid-driven box,
+    spanwise periodic, Re = 50; the converged state must be a fixed point of the 3-D oracle's map as well."""
+    from nekstab_amd import newton
+    lid = lambda x, y, z: np.stack([np.where(np.isclose(y, 1.0), (1.0 - (2 * x - 1.0) ** 2) ** 2 * (1.0 + 0.3 * np.sin(2 * np.pi * z / 0.6)), 0.0),
+                                    0.0 * x, 0.0 * x])
+    c = mesh3d.box_case_3d(3, 3, 2, 6, lengths=(1.0, 1.0, 0.6), periodic=(False, False, True), re=50.0, endtime=0.5, ub_func=lid)
+    h = _hip(c, tol_pres=1e-7)
+    try:
+        m = c.lx1 - 2
+        q = h.alloc(1)[0]
+        h.upload3(q, c.ub[0], c.ub[1], c.ub[2], np.zeros((c.nel, m, m, m)))
+        its, hist = newton.newton_krylov(h, q, k_dim=30, tol=1e-12, maxiter_newton=8)
+        assert hist[-1] < 1e-12 and its <= 8, hist
+        out = h.download3(q)
+        assert np.abs(out[2]).max() > 1e-4          # genuinely three-dimensional
+        o = _oracle(c)
+        o.ub = np.stack(out[:3]); o.dt, o.nsteps = o.timestep_rule()
+        assert o.nsteps == h.nsteps
+        ref = o.nonlinear_map(out)
+        sc = max(np.abs(out[k]).max() for k in range(3))
+        for k in range(3):
+            assert np.abs(ref[k] - out[k]).max() < 5e-6 * sc
+    finally:
+        h.close()
