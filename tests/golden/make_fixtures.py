@@ -53,7 +53,7 @@ def main():
                         spectre_Ha=nekio.read_spectre(REF + "/stability/adjoint_Floquet/Spectre_Ha.dat"))
     # lid-driven cavity (examples/lid_driven): mesh, vertex ids, committed base flow.  usrdat2 rescales y to
     # [0, uparam(10)]; the committed field was written with aspect ratio 1.2 (its own coordinate block says so)
-    ld = os.path.dirname(os.path.dirname(REF)) + "/lid_driven/"
+    ld = os.path.dirname(REF) + "/lid_driven/"
     cm = nekio.read_re2(ld + "cav.re2")
     cv, _ = nekio.read_ma2(ld + "cav.ma2")
     cf = nekio.read_fld(ld + "BF_cav0.f00001")
