@@ -226,7 +226,7 @@ static int build(nsk_ctx* c, const nsk_case& cs) {
   d.tol_helm = cs.tol_helm > 0 ? cs.tol_helm : 1e-9;
   d.tol_pres = cs.tol_pres > 0 ? cs.tol_pres : 1e-7;
   d.tol_relative = cs.tol_relative; d.max_mr = c->max_pres; d.has_outflow = cs.has_outflow;
-  d.nproj_max = cs.has_outflow ? std::min(cs.nproj, MAXPROJ) : 0;   // projection space needs a non-singular E (todo)
+  d.nproj_max = cs.has_outflow ? std::min(cs.nproj, MAXPROJ) : 0;   // with the pressure null space the projected solves stagnate (measured): off
 
   // ---- bases
   std::vector<double> z1, w1, z2, w2, zd, wd;

@@ -37,7 +37,7 @@ def _endian(tag_bytes: bytes) -> str:
 def read_re2(path: str) -> Re2Mesh:
     with open(path, "rb") as f:
         hdr = f.read(80).decode("ascii")
-        if not hdr.startswith("#v002"):
+        if not (hdr.startswith("#v002") or hdr.startswith("#v003")):     # both: 8-byte reals; v003 = same record layout
             raise ValueError(f"unsupported re2 version: {hdr[:5]!r}")
         toks = hdr.split()
         nel, ndim = int(toks[1]), int(toks[2])

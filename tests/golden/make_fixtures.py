@@ -61,7 +61,24 @@ def main():
     np.savez_compressed(OUT + "/cavity_case.npz", xc=cm.xc, yc=cm.yc,
                         bc_ef=np.array([[b[0], b[1]] for b in cm.bcs], dtype=np.int32), bc_code=np.array([b[3] for b in cm.bcs]),
                         vlex=cv.astype(np.int32), bf_u=cf.u[:, :, 0], bf_p=cf.p[:, 0])
-    for f in ("cylinder_case.npz", "cylinder_spectre.npz", "cylinder_modes.npz", "cavity_case.npz"):
+    # backward-facing step, transient growth at T = 1 (examples/back_fstep/transient_growth): gmsh-made .re2 (v003,
+    # 'MSH' boundary records carrying a boundary id; bfs.usr:usrdat2 maps 4 -> 'v', 2 -> 'v', 3 -> 'W'), base flow,
+    # the optimal perturbation pRe and its response ore = M pRe written by outpost_ks (core/eigensolvers.f:645-652)
+    bd = os.path.dirname(REF) + "/back_fstep/transient_growth/"
+    bm = nekio.read_re2(bd + "bfs.re2")
+    idmap = {4: "v", 2: "v", 3: "W"}
+    bm.bcs = [(e, f, prm, idmap[int(prm[4])]) for (e, f, prm, _c) in bm.bcs]
+    bv, _ = nekio.read_ma2(bd + "bfs.ma2")
+    bb = nekio.read_fld(bd + "BF_bfs0.f00001")
+    mesh.save_case_npz(OUT + "/backstep_case.npz", bm, bv, bb.u[:, :, 0].astype(np.float32), bb.p[:, 0].astype(np.float32))
+    tg = {}
+    for key, name in (("pRe", "pRebfs0.f00001"), ("pIm", "pImbfs0.f00001"), ("ore", "orebfs0.f00001")):
+        f = nekio.read_fld(bd + name)
+        tg[key + "_u"] = f.u[:, :, 0].astype(np.float32)
+        tg[key + "_p"] = f.p[:, 0].astype(np.float32)
+        tg[key + "_istep"] = f.istep
+    np.savez_compressed(OUT + "/backstep_tg.npz", **tg)
+    for f in ("cylinder_case.npz", "cylinder_spectre.npz", "cylinder_modes.npz", "cavity_case.npz", "backstep_case.npz", "backstep_tg.npz"):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
 
