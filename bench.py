@@ -81,7 +81,7 @@ def main():
 
     case = mesh.load_case_npz(os.path.join(ROOT, "tests", "golden", "cylinder_case.npz"), a.lx1)
     h = NekStabHip(case, case.meta["vert"], case.meta["nvert"], tol_helm=a.tol_helm, tol_pres=a.tol_pres,
-                   tol_relative=1, schwarz_layers=2, max_helm_iter=100, max_pres_iter=48, nproj=8)
+                   tol_relative=1, schwarz_layers=2, max_helm_iter=100, max_pres_iter=48, nproj=16)
     k_dim = a.steps
     qx, qy = seed.add_noise(case)
     full = h

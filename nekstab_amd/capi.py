@@ -106,7 +106,7 @@ def load_library(path: str | None = None):
     global _LIB
     if _LIB is not None and path is None:
         return _LIB
-    p = path or LIB_PATH
+    p = path or os.environ.get("NSK_LIB") or LIB_PATH      # NSK_LIB: diagnostic builds (stamps, experiments)
     if not os.path.exists(p):
         raise FileNotFoundError(
             f"{p} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -44,6 +44,7 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
     case 12: { using namespace nsk::k2; constexpr int N = 12; __VA_ARGS__; } break;             \
     case 106: { using namespace nsk::k3; constexpr int N = 6; __VA_ARGS__; } break;             \
     case 108: { using namespace nsk::k3; constexpr int N = 8; __VA_ARGS__; } break;             \
+    case 110: { using namespace nsk::k3; constexpr int N = 10; __VA_ARGS__; } break;           \
     default: return fail(NSK_EINVAL, "unsupported lx1");                                        \
   }
 

@@ -236,6 +236,21 @@ __device__ inline double from_fine(const double* sJ, const double* sf, double* t
 //   bfc = [12][nfine]: 0..2 = w_d J (U . grad xi_a);  3+3c+x = w_d J dU_c/dx_x
 //   mtd = [9][nfine]:  a*3+x = w_d J d(xi_a)/d(x_x)          (full equations, mode 2)
 // ---------------------------------------------------------------------------
+// One component at a time lives on the dealiasing mesh (sf = 1 x lxd^3: 27 KB at lx1 = 10), the pointwise products
+// are accumulated in registers across the component loop.
+template <int N>
+__device__ inline void fine_grad(const double* sDd, const double* f, int a, int b, int cc, double (&g)[3]) {
+  constexpr int ND = 3 * N / 2;
+  double ur = 0, us = 0, ut = 0;
+#pragma unroll
+  for (int m = 0; m < ND; ++m) {
+    ur += sDd[a * ND + m] * f[(cc * ND + b) * ND + m];
+    us += sDd[b * ND + m] * f[(cc * ND + m) * ND + a];
+    ut += sDd[cc * ND + m] * f[(m * ND + b) * ND + a];
+  }
+  g[0] = ur; g[1] = us; g[2] = ut;
+}
+
 template <int N>
 __global__ __launch_bounds__(Cfg<N>::NT) void k_convect(Dev d, const double* __restrict__ uin,
                                                         double* __restrict__ bf, int adjoint) {
@@ -243,72 +258,76 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_convect(Dev d, const double* __r
   constexpr int NN = C::NN, ND = C::ND, NDD = C::NDD, NT = C::NT;
   constexpr int PPT = (NDD + NT - 1) / NT;
   __shared__ double sJ[ND * N], sDd[ND * ND];
-  __shared__ double sf[3 * NDD], t1[N * N * ND], t2[N * ND * ND];
+  __shared__ double sf[NDD], t1[N * N * ND], t2[N * ND * ND];
   const int tid = threadIdx.x;
   const long long e = blockIdx.x;
   const bool act = tid < NN;
   const int k = tid / (N * N), j = (tid / N) % N, i = tid % N;
   for (int p = tid; p < ND * N; p += NT) sJ[p] = d.Jd[p];
   for (int p = tid; p < ND * ND; p += NT) sDd[p] = d.Dd[p];
-  for (int c = 0; c < 3; ++c) to_fine<N>(sJ, uin + c * d.cs + e * NN, sf + c * NDD, t1, t2, tid, NT);
-  double o[PPT][3];
   const size_t nf = (size_t)d.nfine;
+  double o[PPT][3], ca[PPT][3];
 #pragma unroll
-  for (int r = 0; r < PPT; ++r) {
-    const int p = tid + r * NT;
-    o[r][0] = o[r][1] = o[r][2] = 0.0;
-    if (p < NDD) {
-      const int a = p % ND, b = (p / ND) % ND, cc = p / (ND * ND);
-      double gr[3][3];                                  // gr[comp][axis]
+  for (int r = 0; r < PPT; ++r) { o[r][0] = o[r][1] = o[r][2] = 0.0; ca[r][0] = ca[r][1] = ca[r][2] = 0.0; }
+  if (adjoint == 2) {                                  // full equations: convecting field c_a = w_d J (u . grad xi_a)
+#pragma unroll 1
+    for (int c = 0; c < 3; ++c) {
+      to_fine<N>(sJ, uin + c * d.cs + e * NN, sf, t1, t2, tid, NT);
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const double* f = sf + c * NDD;
-        double ur = 0, us = 0, ut = 0;
+      for (int r = 0; r < PPT; ++r) {
+        const int p = tid + r * NT;
+        if (p < NDD) {
+          const size_t q = (size_t)e * NDD + p;
+          const double uf = sf[p];
 #pragma unroll
-        for (int m = 0; m < ND; ++m) {
-          ur += sDd[a * ND + m] * f[(cc * ND + b) * ND + m];
-          us += sDd[b * ND + m] * f[(cc * ND + m) * ND + a];
-          ut += sDd[cc * ND + m] * f[(m * ND + b) * ND + a];
+          for (int a2 = 0; a2 < 3; ++a2) ca[r][a2] += d.mtd[(a2 * 3 + c) * nf + q] * uf;
         }
-        gr[c][0] = ur; gr[c][1] = us; gr[c][2] = ut;
       }
-      const double uf[3] = {sf[p], sf[NDD + p], sf[2 * NDD + p]};
-      const size_t q = (size_t)e * NDD + p;
-      if (adjoint == 2) {                               // (u.grad) u   [UPSTREAM advab]
-        double ca[3];
+      lds_barrier();
+    }
+  }
+#pragma unroll 1
+  for (int c = 0; c < 3; ++c) {
+    to_fine<N>(sJ, uin + c * d.cs + e * NN, sf, t1, t2, tid, NT);
 #pragma unroll
-        for (int a2 = 0; a2 < 3; ++a2)
-          ca[a2] = d.mtd[(a2 * 3 + 0) * nf + q] * uf[0] + d.mtd[(a2 * 3 + 1) * nf + q] * uf[1] + d.mtd[(a2 * 3 + 2) * nf + q] * uf[2];
+    for (int r = 0; r < PPT; ++r) {
+      const int p = tid + r * NT;
+      if (p < NDD) {
+        const int a = p % ND, b = (p / ND) % ND, cc = p / (ND * ND);
+        double g[3];
+        fine_grad<N>(sDd, sf, a, b, cc, g);
+        const double uf = sf[p];
+        const size_t q = (size_t)e * NDD + p;
+        if (adjoint == 2) {                             // (u.grad) u_c   [UPSTREAM advab]
+          const double v = ca[r][0] * g[0] + ca[r][1] * g[1] + ca[r][2] * g[2];
+          if (c == 0) o[r][0] = v; else if (c == 1) o[r][1] = v; else o[r][2] = v;
+        } else {
+          const double conv = d.bfc[0 * nf + q] * g[0] + d.bfc[1 * nf + q] * g[1] + d.bfc[2 * nf + q] * g[2];   // (U.grad) u'_c
+          const double sg = adjoint ? -conv : conv;
+          if (c == 0) o[r][0] += sg; else if (c == 1) o[r][1] += sg; else o[r][2] += sg;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) o[r][c] = ca[0] * gr[c][0] + ca[1] * gr[c][1] + ca[2] * gr[c][2];
-      } else {
-        const double cr = d.bfc[0 * nf + q], cs = d.bfc[1 * nf + q], ct = d.bfc[2 * nf + q];
-        double G[3][3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-#pragma unroll
-          for (int x = 0; x < 3; ++x) G[c][x] = d.bfc[(3 + 3 * c + x) * nf + q];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          const double conv = cr * gr[c][0] + cs * gr[c][1] + ct * gr[c][2];          // (U.grad) u'_c
-          if (!adjoint) o[r][c] = conv + uf[0] * G[c][0] + uf[1] * G[c][1] + uf[2] * G[c][2];   // + (u'.grad) U_c
-          else o[r][c] = uf[0] * G[0][c] + uf[1] * G[1][c] + uf[2] * G[2][c] - conv;  // (grad U)^T u' - (U.grad) u'
+          for (int x = 0; x < 3; ++x) {
+            // direct:  + u'_c dU_x/dx_c   (u'.grad) U ;   adjoint:  + u'_c dU_c/dx_x   (grad U)^T u'
+            const double G = adjoint ? d.bfc[(3 + 3 * c + x) * nf + q] : d.bfc[(3 + 3 * x + c) * nf + q];
+            o[r][x] += uf * G;
+          }
         }
       }
     }
+    lds_barrier();
   }
-  lds_barrier();
-#pragma unroll
-  for (int r = 0; r < PPT; ++r) {
-    const int p = tid + r * NT;
-    if (p < NDD) { sf[p] = o[r][0]; sf[NDD + p] = o[r][1]; sf[2 * NDD + p] = o[r][2]; }
-  }
-  lds_barrier();
   const long long l = e * NN + tid;
   double sb = 0.0;
   if (act) sb = d.spng[l] * d.bm1[l];
+#pragma unroll
   for (int c = 0; c < 3; ++c) {
-    const double s = from_fine<N>(sJ, sf + c * NDD, t1, t2, tid, NT, act, k, j, i);
+#pragma unroll
+    for (int r = 0; r < PPT; ++r) {
+      const int p = tid + r * NT;
+      if (p < NDD) sf[p] = o[r][c];
+    }
+    lds_barrier();
+    const double s = from_fine<N>(sJ, sf, t1, t2, tid, NT, act, k, j, i);
     if (act) {
       const double un = uin[c * d.cs + l];
       if (adjoint == 2) {
@@ -328,36 +347,35 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_baseflow(Dev d, const double* __
   using C = Cfg<N>;
   constexpr int NN = C::NN, ND = C::ND, NDD = C::NDD, NT = C::NT;
   __shared__ double sJ[ND * N], sDd[ND * ND];
-  __shared__ double sf[3 * NDD], t1[N * N * ND], t2[N * ND * ND];
+  __shared__ double sf[NDD], t1[N * N * ND], t2[N * ND * ND];
   const int tid = threadIdx.x;
   const long long e = blockIdx.x;
   for (int p = tid; p < ND * N; p += NT) sJ[p] = d.Jd[p];
   for (int p = tid; p < ND * ND; p += NT) sDd[p] = d.Dd[p];
-  for (int c = 0; c < 3; ++c) to_fine<N>(sJ, q + c * d.nloc + e * NN, sf + c * NDD, t1, t2, tid, NT);
   const size_t nf = (size_t)d.nfine;
-  for (int p = tid; p < NDD; p += NT) {
-    const int a = p % ND, b = (p / ND) % ND, cc = p / (ND * ND);
-    const size_t qq = (size_t)e * NDD + p;
-    double mt[3][3];
+#pragma unroll 1
+  for (int c = 0; c < 3; ++c) {
+    to_fine<N>(sJ, q + c * d.nloc + e * NN, sf, t1, t2, tid, NT);
+    for (int p = tid; p < NDD; p += NT) {
+      const int a = p % ND, b = (p / ND) % ND, cc = p / (ND * ND);
+      const size_t qq = (size_t)e * NDD + p;
+      double mt[3][3];
 #pragma unroll
-    for (int a2 = 0; a2 < 3; ++a2)
+      for (int a2 = 0; a2 < 3; ++a2)
 #pragma unroll
-      for (int x = 0; x < 3; ++x) mt[a2][x] = d.mtd[(a2 * 3 + x) * nf + qq];
-    const double uf[3] = {sf[p], sf[NDD + p], sf[2 * NDD + p]};
+        for (int x = 0; x < 3; ++x) mt[a2][x] = d.mtd[(a2 * 3 + x) * nf + qq];
+      const double uf = sf[p];
 #pragma unroll
-    for (int a2 = 0; a2 < 3; ++a2) bfc[a2 * nf + qq] = mt[a2][0] * uf[0] + mt[a2][1] * uf[1] + mt[a2][2] * uf[2];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const double* f = sf + c * NDD;
-      double ur = 0, us = 0, ut = 0;
-      for (int m = 0; m < ND; ++m) {
-        ur += sDd[a * ND + m] * f[(cc * ND + b) * ND + m];
-        us += sDd[b * ND + m] * f[(cc * ND + m) * ND + a];
-        ut += sDd[cc * ND + m] * f[(m * ND + b) * ND + a];
+      for (int a2 = 0; a2 < 3; ++a2) {
+        const double v = mt[a2][c] * uf;
+        bfc[a2 * nf + qq] = (c == 0) ? v : bfc[a2 * nf + qq] + v;
       }
+      double g[3];
+      fine_grad<N>(sDd, sf, a, b, cc, g);
 #pragma unroll
-      for (int x = 0; x < 3; ++x) bfc[(3 + 3 * c + x) * nf + qq] = mt[0][x] * ur + mt[1][x] * us + mt[2][x] * ut;
+      for (int x = 0; x < 3; ++x) bfc[(3 + 3 * c + x) * nf + qq] = mt[0][x] * g[0] + mt[1][x] * g[1] + mt[2][x] * g[2];
     }
+    lds_barrier();
   }
 }
 
@@ -368,10 +386,11 @@ template <int N>
 __global__ __launch_bounds__(Cfg<N>::NT) void k_rhs(Dev d, StepCoef sc) {
   using C = Cfg<N>;
   constexpr int NN = C::NN, M = C::M, MM = C::MM, NT = C::NT, NM = N * M, NNM = C::NNM, NMM = C::NMM;
+  constexpr int RG = (3 * MM + 3 * NMM + 2 * NNM) > 4 * NN ? (3 * MM + 3 * NMM + 2 * NNM) : 4 * NN;
   __shared__ double sD[N * N], sDt[N * N], sJ12[NM], sD12[NM];
-  __shared__ double su[3 * NN], st[9 * NN];
-  double* sP = st; double* sC = st + 3 * MM; double* sE = sC + 3 * NMM;      // opgradt scratch aliases st
-  static_assert(3 * MM + 3 * NMM + 2 * NNM <= 9 * NN, "scratch");
+  __shared__ double reg[RG];                                                 // D^T p scratch, then the axhelm tiles
+  double* sP = reg; double* sC = reg + 3 * MM; double* sE = sC + 3 * NMM;
+  double* su = reg; double* st = reg + NN;
   const int tid = threadIdx.x;
   const long long e = blockIdx.x;
   const bool act = tid < NN;
@@ -398,7 +417,6 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_rhs(Dev d, StepCoef sc) {
       const long long lc = c * nl + l;
       const double un = d.u[lc];
       u[c] = un + sc.xg[0] * d.dulag[lc] + sc.xg[1] * d.dulag[3 * nl + lc] + sc.xg[2] * d.dulag[6 * nl + lc];
-      su[c * NN + tid] = u[c];
       const double bn = d.bf[lc];
       const double e1 = d.exlag[lc], e2 = d.exlag[3 * nl + lc];
       double b = sc.ab[0] * bn + sc.ab[1] * e1 + sc.ab[2] * e2;      // makextp
@@ -423,15 +441,17 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_rhs(Dev d, StepCoef sc) {
   lds_barrier();
   double gp[3];
   opgradt3<N>(sJ12, sD12, pe, w2, sP, sC, sE, tid, NT, act, k, j, i, gp);
-  lds_barrier();
-  double au[3];
-  axhelm3<N, 3>(sD, sDt, su, st, act, k, j, i, g, au);
-  if (act) {
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
+  for (int c = 0; c < 3; ++c) {
+    lds_barrier();
+    if (act) su[tid] = u[c];
+    lds_barrier();
+    double au[1];
+    axhelm3<N, 1>(sD, sDt, su, st, act, k, j, i, g, au);
+    if (act) {
       const double b = bfv[c] + gp[c];                               // rhs of H u* = b
       d.bloc[c * nl + l] = b;
-      d.rloc[c * nl + l] = b - (d.nu * au[c] + sc.h2 * bm * u[c]);
+      d.rloc[c * nl + l] = b - (d.nu * au[0] + sc.h2 * bm * u[c]);
     }
   }
 }

@@ -19,6 +19,11 @@ __device__ int g_dbg = 0;
 #endif     // developer ablation switches (bit mask), 0 in production
 
 namespace k2 {
+#ifdef NSK_NT_STORES
+#define NSK_ST(p, v) __builtin_nontemporal_store((v), (p))
+#else
+#define NSK_ST(p, v) (*(p) = (v))
+#endif
 template <int N>
 struct Cfg {
   static constexpr int NN = N * N, M = N - 2, MM = M * M, ND = 3 * N / 2, NDD = ND * ND;
@@ -632,10 +637,10 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_helm(Dev d, StepCoef sc, int it,
         const double w = mk * gs_sum(gv[c], d.hwl + ((size_t)ppar * 2 + c) * nl, d, tab, l);
         const double pn = di * rold[c] + beta[c] * pold[c];
         const double sn = w + beta[c] * sold[c];
-        d.hp[lc] = pn; d.hs[lc] = sn;
-        d.hx[lc] = xold[c] + alpha[c] * pn;
+        NSK_ST(d.hp + lc, pn); NSK_ST(d.hs + lc, sn);
+        NSK_ST(d.hx + lc, xold[c] + alpha[c] * pn);
         r[c] = rold[c] - alpha[c] * sn;
-        d.hr[lc] = r[c];
+        NSK_ST(d.hr + lc, r[c]);
       } else {
         r[c] = rold[c];
       }
@@ -653,7 +658,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_helm(Dev d, StepCoef sc, int it,
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       const double wl = d.nu * au[c] + sc.h2 * bm * z[c];
-      d.hwl[((size_t)par * 2 + c) * nl + l] = wl;
+      NSK_ST(d.hwl + ((size_t)par * 2 + c) * nl + l, wl);
       v[c * 3 + 0] = r[c] * z[c] * mi;
       v[c * 3 + 1] = z[c] * wl;
       v[c * 3 + 2] = r[c] * r[c] * mi;
@@ -768,11 +773,10 @@ __global__ __launch_bounds__(256) void k_ortho(Dev d) {
   else sum_partials<1>(d.gpart + d.nblk, d.nblk, sm, sred, tid, 256);
   const double mean = sm[0] / (double)d.npr_glob;
   double v[1] = {0.0};
-  const long long q = (long long)blockIdx.x * 256 + tid;
-  if (q < d.npr) {
+  for (long long q = (long long)blockIdx.x * 256 + tid; q < d.npr; q += (long long)gridDim.x * 256) {
     const double g = d.V[q] - mean;
     d.V[q] = g;
-    v[0] = g * g;
+    v[0] += g * g;
   }
   block_reduce<1>(v, sred, tid, 256);
   if (tid == 0) d.gpart[blockIdx.x] = v[0];
@@ -801,12 +805,11 @@ __global__ __launch_bounds__(256) void k_proj_apply(Dev d) {
   __syncthreads();
   if (blockIdx.x == 0 && tid < np) G->pa[tid] = sh[tid];
   double v[1] = {0.0};
-  const long long q = (long long)blockIdx.x * 256 + tid;
-  if (q < d.npr) {
+  for (long long q = (long long)blockIdx.x * 256 + tid; q < d.npr; q += (long long)gridDim.x * 256) {
     double g = d.V[q];
     for (int k = 0; k < np; ++k) g -= sh[k] * d.PEX[(size_t)k * d.npr + q];
     d.V[q] = g;
-    v[0] = g * g;
+    v[0] += g * g;
   }
   block_reduce<1>(v, sred, tid, 256);
   if (tid == 0) d.gpart[blockIdx.x] = v[0];
@@ -1300,8 +1303,7 @@ __global__ __launch_bounds__(256) void k_proj_update(Dev d) {
   const double as = (s < np) ? G->pa[s] : 0.0;
   if (tid < np) cf[tid] = (tid == s) ? 0.0 : sh[tid] / G->pn[tid];
   __syncthreads();
-  const long long q = (long long)blockIdx.x * 256 + tid;
-  if (q < d.npr) {
+  for (long long q = (long long)blockIdx.x * 256 + tid; q < d.npr; q += (long long)gridDim.x * 256) {
     double x = d.PD[q], ex = d.PED[q];
     for (int k = 0; k < np; ++k) {
       if (k == s) continue;

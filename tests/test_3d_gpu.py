@@ -38,7 +38,8 @@ def _hip(c, **kw):
     return NekStabHip(c, c.meta["vert"], c.meta["nvert"], **a)
 
 
-@pytest.fixture(scope="module", params=[(6, True), (8, True), (6, False)], ids=["lx6-outflow", "lx8-outflow", "lx6-closed"])
+@pytest.fixture(scope="module", params=[(6, True), (8, True), (6, False), (10, True)],
+                ids=["lx6-outflow", "lx8-outflow", "lx6-closed", "lx10-outflow"])
 def setup3(request):
     lx1, outflow = request.param
     c = _case(lx1, outflow)
