@@ -32,6 +32,7 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=16, help="oracle time steps in the CPU sample")
     ap.add_argument("--tol-helm", type=float, default=1e-11)
     ap.add_argument("--tol-pres", type=float, default=1e-1)
+    ap.add_argument("--nproj", type=int, default=8, help="pressure projection space (residualProj)")
     return ap.parse_args()
 
 
@@ -81,7 +82,7 @@ def main():
 
     case = mesh.load_case_npz(os.path.join(ROOT, "tests", "golden", "cylinder_case.npz"), a.lx1)
     h = NekStabHip(case, case.meta["vert"], case.meta["nvert"], tol_helm=a.tol_helm, tol_pres=a.tol_pres,
-                   tol_relative=1, schwarz_layers=2, max_helm_iter=100, max_pres_iter=48, nproj=16)
+                   tol_relative=1, schwarz_layers=2, max_helm_iter=100, max_pres_iter=48, nproj=a.nproj)
     k_dim = a.steps
     qx, qy = seed.add_noise(case)
     full = h
