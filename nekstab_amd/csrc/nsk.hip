@@ -51,6 +51,7 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 struct nsk_ctx {
   int N = 0, NN = 0, M = 0, MM = 0, ND = 0, NDD = 0, EPB = 0, NT = 0, NTD = 0;
   int ndim = 2, key = 0;                // key selects the kernel set (DISPATCH_N)
+  int hrows = 8, hstride = 8;           // rows of Helmholtz partials per parity / stride of their totals (3-D: 12 / 16)
   int nel = 0, nblk = 0, nvert = 0;
   long long nloc = 0, npr = 0, nstate = 0;
   double dt = 0, re = 0, endtime = 0;
@@ -616,6 +617,12 @@ static int build(nsk_ctx* c, const nsk_case& cs) {
     c->h_pidx = p_idx; c->PS = PS;
     if ((rc = dupload(c, &d.p_idx, p_idx)) || (rc = dupload(c, &d.p_inv, p_inv))) return rc;
   }
+  // many workgroups (lx1 = 12 has one element per workgroup: config 3 has 7984): sum every row of partials once
+  // (k_tot2) instead of in every consumer workgroup, which is O(nblk^2)
+  if (c->nblk > 1024 || std::getenv("NSK_USE_TOT")) {
+    d.use_tot = 1;
+    if ((rc = dalloc(c, &d.htot, 32)) || (rc = dalloc(c, &d.gtot, MAXMR + 8)) || (rc = dalloc(c, &d.ptot, MAXPROJ + 2))) return rc;
+  }
   for (int k = 0; k < 6; ++k) { c->cur_helm[k] = c->max_helm; c->cur_pres[k] = c->max_pres; }
   if (const char* g = std::getenv("NSK_USE_GRAPH")) c->use_graph = std::atoi(g);
   if (const char* g = std::getenv("NSK_DEBUG")) c->debug = std::atoi(g);
@@ -655,6 +662,7 @@ static int pres_solve_launch(nsk_ctx* c, double h2, int ord, int np) {
       }
       hipLaunchKernelGGL(k_schwarz<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, (const double*)(d.V + (size_t)j * d.ps), d.Z + (size_t)j * d.npr, 1, 1);
       hipLaunchKernelGGL(k_divgs<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, (const double*)d.yl, d.V + (size_t)(j + 1) * d.ps, j, 1);
+      if (c->ndim != 3) tot_rows(c, d.gpart, j + 2, d.gtot);
       if (c->ndim == 3) {
         tot_rows(c, d.gpart, j + 2, d.gtot);
         hipLaunchKernelGGL(k_gmres_reorth<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, j);
@@ -676,7 +684,7 @@ static int step(nsk_ctx* c, int istep, int adjoint) {
     hipLaunchKernelGGL(k_rhs<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, sc);
     for (int it = 0; it < nh; ++it) {
       hipLaunchKernelGGL(k_helm<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, sc, it, (const double*)d.rloc);
-      tot_rows(c, d.hpart + (size_t)(it & 1) * 12 * c->nblk, 12, d.htot + (it & 1) * 16);
+      tot_rows(c, d.hpart + (size_t)(it & 1) * c->hrows * c->nblk, c->hrows, d.htot + (it & 1) * c->hstride);
     }
     hipLaunchKernelGGL(k_pres_rhs<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, sc, (nh - 1) & 1, nh - 1);
   });
@@ -1337,12 +1345,12 @@ int nsk_bench_kernel(nsk_ctx* c, const char* name, int reps, double* avg_us) {
     DISPATCH_N(c->key, {
       for (int r = 0; r < cyc; ++r) {                             // warm
         hipLaunchKernelGGL(k_helm<N>, dim3(c->nblk), dim3(Cfg<N>::NT), 0, c->stream, d, sc, r % cyc, (const double*)d.rloc);
-        tot_rows(c, d.hpart + (size_t)(r & 1) * 12 * c->nblk, 12, d.htot + (r & 1) * 16);
+        tot_rows(c, d.hpart + (size_t)(r & 1) * c->hrows * c->nblk, c->hrows, d.htot + (r & 1) * c->hstride);
       }
       HIPCHK(hipEventRecord(e0, c->stream));
       for (int r = 0; r < reps; ++r) {
         hipLaunchKernelGGL(k_helm<N>, dim3(c->nblk), dim3(Cfg<N>::NT), 0, c->stream, d, sc, r % cyc, (const double*)d.rloc);
-        tot_rows(c, d.hpart + (size_t)(r & 1) * 12 * c->nblk, 12, d.htot + (r & 1) * 16);   // hexahedra only (a few us, included)
+        tot_rows(c, d.hpart + (size_t)(r & 1) * c->hrows * c->nblk, c->hrows, d.htot + (r & 1) * c->hstride);   // use_tot contexts only (a few us, included)
       }
       HIPCHK(hipEventRecord(e1, c->stream));
     });
@@ -1436,7 +1444,7 @@ int nsk_test_op3(nsk_ctx* c, int which, const double* in, double* out, int a, in
     DISPATCH_N(c->key, {
       for (int it = 0; it < c->max_helm; ++it) {
         hipLaunchKernelGGL(k_helm<N>, dim3(c->nblk), dim3(Cfg<N>::NT), 0, c->stream, d, sc, it, (const double*)d.rloc);
-        tot_rows(c, d.hpart + (size_t)(it & 1) * 12 * c->nblk, 12, d.htot + (it & 1) * 16);
+        tot_rows(c, d.hpart + (size_t)(it & 1) * c->hrows * c->nblk, c->hrows, d.htot + (it & 1) * c->hstride);
       }
     });
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -1484,8 +1492,10 @@ int nsk_test_helm_solve(nsk_ctx* c, const double* rx, const double* ry, int orde
   const StepCoef sc = make_coef(c, order, 0);
   const int nh = c->max_helm;
   DISPATCH_N(c->key, {
-    for (int it = 0; it < nh; ++it)
+    for (int it = 0; it < nh; ++it) {
       hipLaunchKernelGGL(k_helm<N>, dim3(c->nblk), dim3(Cfg<N>::NT), 0, c->stream, d, sc, it, (const double*)d.rloc);
+      tot_rows(c, d.hpart + (size_t)(it & 1) * c->hrows * c->nblk, c->hrows, d.htot + (it & 1) * c->hstride);
+    }
   });
   HIPCHK(hipStreamSynchronize(c->stream));
   HIPCHK(hipMemcpy(ox, d.hx, c->nloc * sizeof(double), hipMemcpyDeviceToHost));

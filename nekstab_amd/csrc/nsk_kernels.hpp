@@ -548,7 +548,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_helm(Dev d, StepCoef sc, int it,
   }
   double ps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (it > 0) {
-    if (d.nranks > 1) {                 // all-reduced totals (k_tot + all-reduce ran after the previous launch)
+    if (d.nranks > 1 || d.use_tot) {    // totals: all-reduced over ranks, or summed once by k_tot2 (many workgroups)
 #pragma unroll
       for (int q = 0; q < 8; ++q) ps[q] = (tid == 0) ? d.htot[ppar * 8 + q] : 0.0;
     } else {
@@ -689,7 +689,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_pres_rhs(Dev d, StepCoef sc, int
   load_basis<N, EPB>(d, nullptr, nullptr, sJ12, sD12, tid, NT);
   if (check_helm && blockIdx.x == 0) {       // last partials -> final residual of the velocity solve
     double s[8];
-    if (d.nranks > 1) {
+    if (d.nranks > 1 || d.use_tot) {
 #pragma unroll
       for (int q = 0; q < 8; ++q) s[q] = d.htot[helm_par * 8 + q];
     } else {
@@ -846,7 +846,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_gmres_update(Dev d, int j, doubl
   double wnew = 0.0;
   if (act && nd < MM) wnew = d.V[(size_t)(j + 1) * d.ps + e * MM + nd];
   const int nv = (j < 0) ? 1 : j + 2;
-  if (d.nranks > 1) {
+  if (d.nranks > 1 || d.use_tot) {
     if (tid < nv) sh[tid] = d.gtot[tid];
     lds_barrier();
   } else {
