@@ -31,18 +31,34 @@ def kry_name(session, i):
     return "KRY%s0.f%05d" % (session, i)
 
 
-def write_krylov_vector(be, case, v, path, time=0.0, wdsize=8):
+def state_to_fields(be, case, v):
+    """Device state -> (x, u, p on mesh 1) in the field-file layout (ndim, nel, nz, ny, nx); 2-D and 3-D."""
     J21, _ = _maps(case)
+    if getattr(case, "ndim", 2) == 3:
+        vx, vy, vz, pr = be.download3(v)
+        p1 = np.einsum("ci,bj,ak,ekji->ecba", J21, J21, J21, pr, optimize=True)      # map21 along r, s, t
+        return np.stack([case.x, case.y, case.z]), np.stack([vx, vy, vz]), p1
     vx, vy, pr = be.download(v)
-    x = np.stack([case.x, case.y])[:, :, None]
-    nekio.write_fld(path, x=x, u=np.stack([vx, vy])[:, :, None], p=(J21 @ pr @ J21.T)[:, None], time=time,
-                    istep=be.nsteps + 1, wdsize=wdsize)
+    return np.stack([case.x, case.y])[:, :, None], np.stack([vx, vy])[:, :, None], (J21 @ pr @ J21.T)[:, None]
+
+
+def fields_to_state(be, case, v, f):
+    """Field file (``nekio.NekField``) -> device state (pressure back to mesh 2: map12)."""
+    _, J12 = _maps(case)
+    if getattr(case, "ndim", 2) == 3:
+        p2 = np.einsum("ci,bj,ak,ekji->ecba", J12, J12, J12, f.p, optimize=True)
+        be.upload3(v, f.u[0], f.u[1], f.u[2], p2)
+    else:
+        be.upload(v, f.u[0, :, 0], f.u[1, :, 0], J12 @ f.p[:, 0] @ J12.T)
+
+
+def write_krylov_vector(be, case, v, path, time=0.0, wdsize=8):
+    x, u, p1 = state_to_fields(be, case, v)
+    nekio.write_fld(path, x=x, u=u, p=p1, time=time, istep=be.nsteps + 1, wdsize=wdsize)
 
 
 def read_krylov_vector(be, case, v, path):
-    _, J12 = _maps(case)
-    f = nekio.read_fld(path)
-    be.upload(v, f.u[0, :, 0], f.u[1, :, 0], J12 @ f.p[:, 0] @ J12.T)
+    fields_to_state(be, case, v, nekio.read_fld(path))
 
 
 def arnoldi_checkpoint(be, case, Q, H, k, outdir, *, session="1cyl", evop="d", sampling_period=1.0, wdsize=8):

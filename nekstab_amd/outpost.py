@@ -14,8 +14,8 @@ import os
 import numpy as np
 
 from . import nekio
+from .checkpoint import state_to_fields
 from .krylov import assemble_mode, log_transform
-from .quadrature import gauss_legendre, gauss_lobatto_legendre, interp_matrix
 
 
 def outpost_ks(be, res, case, outdir, *, evop="d", sampling_period=1.0, eigen_tol=1e-6, maxmodes=20,
@@ -26,9 +26,6 @@ def outpost_ks(be, res, case, outdir, *, evop="d", sampling_period=1.0, eigen_to
     nekio.write_spectre(os.path.join(outdir, f"Spectre_H{evop}.dat"), res.vals, res.residual)
     nekio.write_spectre(os.path.join(outdir, f"Spectre_NS{evop}.dat"), lam, res.residual)
     conv = []
-    n, m = case.lx1, case.lx1 - 2
-    J21 = interp_matrix(gauss_legendre(m)[0], gauss_lobatto_legendre(n)[0])     # pressure -> mesh 1 for output (map21)
-    x = np.stack([case.x, case.y])[:, :, None]
     re, im = be.alloc(2)
     written = []
     for i in range(k):
@@ -37,11 +34,9 @@ def outpost_ks(be, res, case, outdir, *, evop="d", sampling_period=1.0, eigen_to
             assemble_mode(be, res, i, re, im)
             idx = len(conv)
             for tag, v in (("Re", re), ("Im", im)):
-                vx, vy, pr = be.download(v)
-                p1 = J21 @ pr @ J21.T
+                x, u, p1 = state_to_fields(be, case, v)          # pressure -> mesh 1 for output (map21); 2-D and 3-D
                 f = os.path.join(outdir, "%s%s%s0.f%05d" % (evop, tag, session, idx))
-                nekio.write_fld(f, x=x, u=np.stack([vx, vy])[:, :, None], p=p1[:, None], time=float(i + 1),
-                                istep=be.nsteps + 1, wdsize=wdsize)
+                nekio.write_fld(f, x=x, u=u, p=p1, time=float(i + 1), istep=be.nsteps + 1, wdsize=wdsize)
                 written.append(f)
     nekio.write_spectre(os.path.join(outdir, f"Spectre_NS{evop}_conv.dat"), np.array(conv))
     be.free([re, im])

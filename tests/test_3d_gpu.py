@@ -331,3 +331,32 @@ def test_newton_krylov_3d_box():
             assert np.abs(ref[k] - out[k]).max() < 5e-6 * sc
     finally:
         h.close()
+
+
+def test_field_files_and_checkpoint_3d(tmp_path):
+    """Krylov vectors / eigenmodes of a hexahedral run in the reference's field-file format (3-D #std files, pressure
+    on mesh 1) and back (core/eigensolvers.f:802-905, core/IO.f:15-60)."""
+    from nekstab_amd import checkpoint, nekio
+    c = _case(6, True)
+    h = _hip(c)
+    try:
+        rng = np.random.default_rng(7)
+        m = c.lx1 - 2
+        a = [rng.standard_normal(c.x.shape) * c.mask for _ in range(3)]
+        J12 = checkpoint._maps(c)[1]
+        p1 = np.sin(c.x + 2 * c.y - c.z)                           # a mesh-1 pressure that mesh 2 represents
+        p2 = np.einsum("ci,bj,ak,ekji->ecba", J12, J12, J12, p1, optimize=True)
+        v, w = h.alloc(2)
+        h.upload3(v, *a, p2)
+        path = str(tmp_path / checkpoint.kry_name("box", 3))
+        checkpoint.write_krylov_vector(h, c, v, path, time=2.0)
+        f = nekio.read_fld(path)
+        assert (f.nx, f.ny, f.nz, f.nel) == (6, 6, 6, c.nel) and f.u.shape == (3, c.nel, 6, 6, 6) and f.istep == h.nsteps + 1
+        assert np.abs(f.x[2] - c.z).max() == 0.0
+        checkpoint.read_krylov_vector(h, c, w, path)
+        out = h.download3(w)
+        for k in range(3):
+            assert np.abs(out[k] - a[k]).max() == 0.0
+        assert np.abs(out[3] - p2).max() < 1e-12 * np.abs(p2).max()   # mesh 2 -> 1 -> 2 is the identity on P_{lx2-1}
+    finally:
+        h.close()
