@@ -820,7 +820,6 @@ extern "C" {
 // Cut the shard of `rank` (part[e] = owner of global element e) out of a full-mesh context.
 int nsk_shard_create(nsk_ctx* parent, const int* part, int rank, int nranks, nsk_ctx** out) {
   if (!parent || !part || !out) return fail(NSK_EINVAL, "bad argument");
-  if (parent->ndim != 2) return fail(NSK_EINVAL, "element sharding: 2-D only in this build");
   return shard_create(parent, part, rank, nranks, out);
 }
 
@@ -879,7 +878,7 @@ int nsk_group_test(nsk_ctx** shards, int n, int which, const double* const* in, 
     for (int r = 0; r < n; ++r) HIPCHK(hipMemcpyAsync(G[r]->wp1, in[r], G[r]->npr * sizeof(double), hipMemcpyHostToDevice, G[r]->stream));
     DISPATCH_N(G[0]->key, {
       for (nsk_ctx* c : G) hipLaunchKernelGGL(k_gradt<N>, dim3(c->nblk), dim3(Cfg<N>::NT), 0, c->stream, c->d, (const double*)c->wp1, c->d.yl);
-      if ((rc = xchg_vel(G, &Dev::yl, 0, 2))) return rc;
+      if ((rc = xchg_vel(G, &Dev::yl, 0, G[0]->ndim))) return rc;
       for (nsk_ctx* c : G) hipLaunchKernelGGL(k_divgs<N>, dim3(c->nblk), dim3(Cfg<N>::NT), 0, c->stream, c->d, (const double*)c->d.yl, c->wp2, -1, 0);
     });
     for (int r = 0; r < n; ++r) HIPCHK(hipMemcpyAsync(out[r], G[r]->wp2, G[r]->npr * sizeof(double), hipMemcpyDeviceToHost, G[r]->stream));

@@ -18,8 +18,8 @@ from .capi import NekStabHip, NskError, _dp
 def partition_rcb(case, nranks: int) -> np.ndarray:
     """Recursive coordinate bisection of element centroids -> owner rank per element.
     (The reference partitions with the .ma2 RSB tree; any partition of whole elements works.)"""
-    cx = case.x.mean(axis=(1, 2))
-    cy = case.y.mean(axis=(1, 2))
+    ax = tuple(range(1, case.x.ndim))
+    cen = [case.x.mean(axis=ax), case.y.mean(axis=ax)] + ([case.z.mean(axis=ax)] if getattr(case, "ndim", 2) == 3 else [])
     part = np.zeros(case.nel, dtype=np.int32)
 
     def rec(idx, r0, nr):
@@ -27,8 +27,7 @@ def partition_rcb(case, nranks: int) -> np.ndarray:
             part[idx] = r0
             return
         nl = nr // 2
-        span_x, span_y = np.ptp(cx[idx]), np.ptp(cy[idx])
-        key = cx[idx] if span_x >= span_y else cy[idx]
+        key = max(cen, key=lambda a: np.ptp(a[idx]))[idx]          # split along the longest extent
         order = idx[np.argsort(key, kind="stable")]
         cut = len(order) * nl // nr
         rec(order[:cut], r0, nl)
@@ -82,6 +81,23 @@ class ShardGroup:
         for r, c in enumerate(self.ctx):
             arr = (C.c_void_p * len(vecs))(*[v.parts[r].value for v in vecs])
             self._chk(self.lib.nsk_vec_free(c, len(vecs), arr))
+
+    def upload3(self, v, vx, vy, vz, pr):
+        for r, c in enumerate(self.ctx):
+            e = self.elems[r]
+            a, b, w, p = (np.ascontiguousarray(f[e], dtype=np.float64) for f in (vx, vy, vz, pr))
+            self._chk(self.lib.nsk_vec_upload3(c, v.parts[r], a.ctypes.data_as(_dp), b.ctypes.data_as(_dp), w.ctypes.data_as(_dp), p.ctypes.data_as(_dp)))
+
+    def download3(self, v):
+        n, m = self.lx1, self.lx2
+        out = [np.empty((self.nel, n, n, n)) for _ in range(3)] + [np.empty((self.nel, m, m, m))]
+        for r, c in enumerate(self.ctx):
+            e = self.elems[r]
+            loc = [np.empty((len(e), n, n, n)) for _ in range(3)] + [np.empty((len(e), m, m, m))]
+            self._chk(self.lib.nsk_vec_download3(c, v.parts[r], *[a.ctypes.data_as(_dp) for a in loc]))
+            for o, a in zip(out, loc):
+                o[e] = a
+        return tuple(out)
 
     def upload(self, v, vx, vy, pr):
         for r, c in enumerate(self.ctx):

@@ -105,3 +105,48 @@ def test_rccl_transport_single_rank_plumbing(hip6, case6, oracle6_nosolve, modes
         assert np.abs(x - y).max() <= 1e-12 * np.abs(y).max()
     s.free([a, b]); s.close()
     hip6.free([vq, vf]); hip6.set_nsteps(100)
+
+
+@pytest.mark.parametrize("nranks", [2, 3])
+def test_sharded_hexahedral_matvec_equals_single_rank(nranks):
+    """Element sharding of a hexahedral context (BASELINE configs 4 and 5 are 3-D on 8 GPUs): dssum halo of three
+    velocity components, halo of the Schwarz patch layers (face, edge and corner neighbours on other ranks),
+    all-reduced totals of both Gram-Schmidt passes and of the coarse restriction; virtual ranks on one GPU."""
+    from nekstab_amd import mesh3d
+    from nekstab_amd.capi import NekStabHip
+    from nekstab_amd.sharded import ShardGroup, partition_rcb
+    ubf = lambda x, y, z: np.stack([1.0 - 0.3 * y * y + 0.1 * np.sin(x + z), 0.2 * np.cos(x) * y + 0.1 * z, 0.15 * np.sin(y + 0.5 * z)])
+    c = mesh3d.box_case_3d(4, 3, 2, 6, lengths=(2.0, 1.0, 0.8), outflow_xmax=True, re=40.0, endtime=0.05, ub_func=ubf, warp=0.05)
+    h = NekStabHip(c, c.meta["vert"], c.meta["nvert"], tol_helm=1e-12, tol_pres=1e-7, tol_relative=1, max_helm_iter=200,
+                   max_pres_iter=48)
+    try:
+        x, y, z = c.x, c.y, c.z
+        q = [np.sin(1.3 * x + z) * np.cos(2.0 * y) * c.mask, np.cos(0.7 * x + 0.2) * np.sin(3.0 * y - z) * c.mask,
+             np.sin(x + y) * np.cos(2.0 * z) * c.mask, np.zeros((c.nel, 4, 4, 4))]
+        h.set_nsteps(4)
+        vq, vf = h.alloc(2)
+        h.upload3(vq, *q)
+        h.matvec(vf, vq, 0)
+        ref = h.download3(vf)
+        part = partition_rcb(c, nranks)
+        assert sorted(np.unique(part)) == list(range(nranks))
+        g = ShardGroup(h, c, nranks, part)
+        rng = np.random.default_rng(0)
+        u = rng.standard_normal(c.x.shape)
+        assert np.abs(g.group_test(0, u) - h.t_dssum(u)).max() < 1e-12 * 8
+        p = rng.standard_normal((c.nel, 4, 4, 4))
+        er = h.t_eapply(p)
+        assert np.abs(g.group_test(1, p) - er).max() < 1e-12 * np.abs(er).max()
+        g.set_nsteps(4)
+        sq, sf = g.alloc(2)
+        g.upload3(sq, *q)
+        assert abs(g.dot(sq, sq) - h.dot(vq, vq)) < 1e-12 * h.dot(vq, vq)
+        g.matvec(sf, sq, 0)
+        got = g.download3(sf)
+        sc = max(np.abs(ref[k]).max() for k in range(3))
+        for k in range(3):
+            assert np.abs(got[k] - ref[k]).max() < 1e-8 * sc
+        assert np.abs(got[3] - ref[3]).max() < 1e-4 * np.abs(ref[3]).max()
+        g.free([sq, sf]); g.close()
+    finally:
+        h.close()
