@@ -52,6 +52,12 @@ struct nsk_ctx {
   int N = 0, NN = 0, M = 0, MM = 0, ND = 0, NDD = 0, EPB = 0, NT = 0, NTD = 0;
   int ndim = 2, key = 0;                // key selects the kernel set (DISPATCH_N)
   int hrows = 8, hstride = 8;           // rows of Helmholtz partials per parity / stride of their totals (3-D: 12 / 16)
+  // large coarse spaces: sparse operator + Chebyshev-Jacobi polynomial instead of the dense inverse
+  int coarse_iter = 0, cheb_deg = 0;
+  double cheb_theta = 0, cheb_delta = 0;
+  const int *cA_rp = nullptr, *cA_ci = nullptr;
+  const double *cA_va = nullptr, *cA_dinv = nullptr;
+  double *cw_d0 = nullptr, *cw_d1 = nullptr, *cw_r = nullptr;
   int nel = 0, nblk = 0, nvert = 0;
   long long nloc = 0, npr = 0, nstate = 0;
   double dt = 0, re = 0, endtime = 0;
@@ -653,7 +659,8 @@ static int pres_solve_launch(nsk_ctx* c, double h2, int ord, int np) {
     for (int j = 0; j < np; ++j) {
       if (c->ndim == 3) {
         hipLaunchKernelGGL(k_coarse_restrict_csr, dim3(d.coarse_lda / 256), dim3(256), 0, c->stream, d, c->rc_big);
-        hipLaunchKernelGGL(k_coarse_big, dim3((d.nvert + 3) / 4), dim3(256), 0, c->stream, d, (const double*)c->rc_big);
+        if (c->coarse_iter) { int rc2 = coarse_iterative(c, c->rc_big); if (rc2) return rc2; }
+        else hipLaunchKernelGGL(k_coarse_big, dim3((d.nvert + 3) / 4), dim3(256), 0, c->stream, d, (const double*)c->rc_big);
       } else if (d.coarse_lda <= 3072) {
         hipLaunchKernelGGL(k_coarse, dim3((d.nvert + 4 * CROWS_W - 1) / (4 * CROWS_W)), dim3(256), d.coarse_lda * sizeof(double), c->stream, d);
       } else {
@@ -1460,7 +1467,8 @@ int nsk_test_op3(nsk_ctx* c, int which, const double* in, double* out, int a, in
       tot_rows(c, d.gpart, 1, d.gtot);
       hipLaunchKernelGGL(k_gmres_update<N>, dim3(c->nblk), dim3(Cfg<N>::NT), 0, c->stream, d, -1, 1.0, 1, 0);   // normalises V[0], fills ec
       hipLaunchKernelGGL(k_coarse_restrict_csr, dim3(d.coarse_lda / 256), dim3(256), 0, c->stream, d, c->rc_big);
-      hipLaunchKernelGGL(k_coarse_big, dim3((d.nvert + 3) / 4), dim3(256), 0, c->stream, d, (const double*)c->rc_big);
+      if (c->coarse_iter) { int rc2 = coarse_iterative(c, c->rc_big); if (rc2) return rc2; }
+      else hipLaunchKernelGGL(k_coarse_big, dim3((d.nvert + 3) / 4), dim3(256), 0, c->stream, d, (const double*)c->rc_big);
       hipLaunchKernelGGL(k_schwarz<N>, dim3(c->nblk), dim3(Cfg<N>::NT), 0, c->stream, d, (const double*)d.V, d.Z, which == 7 ? 1 : 0, 0);
     });
     HIPCHK(hipStreamSynchronize(c->stream));
