@@ -388,3 +388,25 @@ def test_arnoldi_on_extruded_cylinder_finds_the_reference_eigenvalue(spectre):
         assert abs(mu - complex(ref[0], abs(ref[1]))) < 5e-6, mu
     finally:
         h.close()
+
+
+def test_chebyshev_coarse_solve_matches_dense_inverse(monkeypatch):
+    """Large coarse spaces (configs 4 and 5: 5e4-1e5 vertices) use a sparse A_c with a fixed-degree Chebyshev-Jacobi
+    polynomial instead of the dense inverse; forced here on a small mesh it must give the same pressure solution and
+    (nearly) the same GMRES iteration count."""
+    c = _case(6, True)
+    o = _oracle(c)
+    rng = np.random.default_rng(4)
+    g = rng.standard_normal((c.nel, 4, 4, 4))
+    ref = o.E_solve(g)
+    h = _hip(c)
+    x0, it0 = h.t_pres_solve(g)
+    h.close()
+    monkeypatch.setenv("NSK_COARSE_ITER", "1")
+    h = _hip(c)
+    try:
+        x1, it1 = h.t_pres_solve(g)
+        assert _rel(x1, ref) < 1e-6 and _rel(x0, ref) < 1e-6
+        assert 0 < it1 <= it0 + 3, (it0, it1)
+    finally:
+        h.close()
