@@ -132,7 +132,8 @@ def main():
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "r01_pmc_fetch_write_per_kernel.json")
     if os.path.exists(pmc) and a.lx1 == 8:
-        rec = json.load(open(pmc)).get("void nsk::k_helm<8>")
+        tab = json.load(open(pmc))
+        rec = tab.get("void nsk::k2::k_helm<8>") or tab.get("void nsk::k_helm<8>")
         if rec:
             traffic = (2.0 * rec["fetch_kb_p90"] + rec["write_kb_p90"]) * 1024.0
     out = {
