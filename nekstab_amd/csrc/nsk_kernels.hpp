@@ -1463,12 +1463,6 @@ __global__ void k_phalo_pack(const double* __restrict__ v, const int* __restrict
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k < n) sendbuf[k] = v[idx[k]];
 }
-// rank-level totals of nv arrays of per-workgroup partials (fixed order), one workgroup
-__global__ __launch_bounds__(256) void k_tot(const double* __restrict__ part, int nblk, int nv, double* __restrict__ tot) {
-  __shared__ double sh[MAXMR + 8];
-  sum_partials_multi(part, nblk, nv, sh, threadIdx.x, 256);
-  if ((int)threadIdx.x < nv) tot[threadIdx.x] = sh[threadIdx.x];
-}
 // one workgroup per row of per-workgroup partials: tot[q] = sum_k part[q][k]  (fixed order)
 __global__ __launch_bounds__(256) void k_tot2(const double* __restrict__ part, int nblk, double* __restrict__ tot) {
   __shared__ double sred[16];
@@ -1479,13 +1473,6 @@ __global__ __launch_bounds__(256) void k_tot2(const double* __restrict__ part, i
   if (tid == 0) tot[q] = v[0];
 }
 // loop-back all-reduce for virtual ranks living in one process: every buffer <- sum of all (rank order)
-__global__ void k_loop_allreduce(double* const* __restrict__ bufs, int nr, int n) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= n) return;
-  double s = 0.0;
-  for (int r = 0; r < nr; ++r) s += bufs[r][k];
-  for (int r = 0; r < nr; ++r) bufs[r][k] = s;
-}
 struct LoopPack { double* p[16]; };
 __global__ void k_loop_allreduce_pack(LoopPack pk, int nr, int n) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
