@@ -222,7 +222,8 @@ class ShardRank:
         self.nsteps, self.dt = full.nsteps, full.dt
         self.lx1, self.lx2 = full.lx1, full.lx2
         self.nel = len(self.elems)
-        self.npres, self.nvel = self.nel * self.lx2 ** 2, self.nel * self.lx1 ** 2
+        self.ndim = int(getattr(case, "ndim", 2))
+        self.npres, self.nvel = self.nel * self.lx2 ** self.ndim, self.nel * self.lx1 ** self.ndim
         self.ctx = C.c_void_p()
         self._chk(self.lib.nsk_shard_create(full.ctx, self.part.ctypes.data_as(C.POINTER(C.c_int)), rank, nranks, C.byref(self.ctx)))
         if unique_id is not None:
@@ -260,6 +261,17 @@ class ShardRank:
         """vx, vy, pr: full-mesh arrays; this rank keeps its own elements."""
         a, b, p = (np.ascontiguousarray(f[self.elems], dtype=np.float64) for f in (vx, vy, pr))
         self._chk(self.lib.nsk_vec_upload(self.ctx, v, a.ctypes.data_as(_dp), b.ctypes.data_as(_dp), p.ctypes.data_as(_dp)))
+
+    def upload3(self, v, vx, vy, vz, pr):
+        """hexahedral contexts: full-mesh arrays, this rank keeps its own elements."""
+        a, b, w, p = (np.ascontiguousarray(f[self.elems], dtype=np.float64) for f in (vx, vy, vz, pr))
+        self._chk(self.lib.nsk_vec_upload3(self.ctx, v, a.ctypes.data_as(_dp), b.ctypes.data_as(_dp), w.ctypes.data_as(_dp), p.ctypes.data_as(_dp)))
+
+    def download3_local(self, v):
+        n, m = self.lx1, self.lx2
+        loc = [np.empty((self.nel, n, n, n)) for _ in range(3)] + [np.empty((self.nel, m, m, m))]
+        self._chk(self.lib.nsk_vec_download3(self.ctx, v, *[a.ctypes.data_as(_dp) for a in loc]))
+        return tuple(loc)
 
     def download_local(self, v):
         n, m = self.lx1, self.lx2
