@@ -81,3 +81,33 @@ def test_reference_baseflow_is_fixed_point_of_nonlinear_map():
     f = o.nonlinear_map(q)
     d = [f[0] - q[0], f[1] - q[1]]
     assert o.inner(d, d) < 5e-11
+
+
+def test_oracle_pins_on_the_other_reference_geometries():
+    """dt rule, geometry and the sponge-masked inner product of the oracle on the reference's two other 2-D examples:
+    backward-facing step (transient growth, field headers istep = 173, unit-norm optimal perturbation, gain = |ore|^2)
+    and lid-driven cavity (base-flow header istep = 697)."""
+    import os
+    from nekstab_amd import mesh, nekio
+    from oracle.linns import LinNS2D
+    here = os.path.dirname(os.path.abspath(__file__))
+    c = mesh.load_case_npz(os.path.join(here, "golden", "backstep_case.npz"), 6, re=500.0, endtime=1.0, xlspg=5.0, xrspg=10.0, spng_str=2.0)
+    o = LinNS2D(x=c.x, y=c.y, gid=c.gid, nglob=c.nglob, mask=c.mask, ub=c.ub, spng=c.spng, re=c.re, endtime=c.endtime,
+                has_outflow=c.has_outflow, build_solvers=False)
+    tg = np.load(os.path.join(here, "golden", "backstep_tg.npz"))
+    assert o.nsteps == 172 and int(tg["pRe_istep"]) == 173 and int(tg["ore_istep"]) == 173
+    w = o.bm1s()
+    n2 = lambda a: float(np.sum(w * (a[0].astype(float) ** 2 + a[1].astype(float) ** 2)))
+    assert abs(n2(tg["pRe_u"]) - 1.0) < 1e-7                     # core/eigensolvers.f:619-627
+    assert abs(n2(tg["ore_u"]) - 3.2370) < 1e-3                  # optimal energy gain G(T=1) of the committed response
+    assert not c.has_outflow and c.spng.max() == 1.0
+    z = np.load(os.path.join(here, "golden", "cavity_case.npz"))
+    bcs = [(int(a), int(b), np.zeros(5), str(cd)) for (a, b), cd in zip(z["bc_ef"], z["bc_code"])]
+    m = nekio.Re2Mesh(2, z["xc"].shape[0], z["xc"], z["yc"], None, [], bcs)
+    c2 = mesh.build_case_2d(m, z["vlex"].astype(np.int64), z["bf_u"].astype(np.float64), 6, re=3600.0, endtime=1.0, spng_str=0.0)
+    o2 = LinNS2D(x=c2.x, y=c2.y, gid=c2.gid, nglob=c2.nglob, mask=c2.mask, ub=c2.ub, spng=c2.spng, re=c2.re, endtime=c2.endtime,
+                 has_outflow=c2.has_outflow, build_solvers=False)
+    assert o2.nsteps == 696                                      # BF_cav0.f00001 header: istep = 697
+    assert abs(o2.bm1.sum() - 1.2) < 1e-12                       # [-0.5,0.5] x [0,1.2]
+    lid = np.isclose(c2.y, 1.2) & (np.abs(c2.x) < 0.499)
+    assert np.all(c2.ub[0][lid] == 1.0) and np.all(c2.mask[lid] == 0.0)
