@@ -30,8 +30,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--shard", action="store_true", help="N>1: element-shard ONE eigenproblem over the ranks (RCCL halos) instead of replicas")
     ap.add_argument("--cpu-steps", type=int, default=16, help="oracle time steps in the CPU sample")
-    ap.add_argument("--tol-helm", type=float, default=1e-11)
-    ap.add_argument("--tol-pres", type=float, default=1e-1)
+    ap.add_argument("--tol-helm", type=float, default=1e-10)
+    ap.add_argument("--tol-pres", type=float, default=2e-1)
     ap.add_argument("--nproj", type=int, default=8, help="pressure projection space (residualProj)")
     return ap.parse_args()
 
@@ -119,6 +119,12 @@ def main():
         t = torch.tensor([elapsed], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # leading Ritz pair of the timed factorisation.  The reference's only lx1 = 8 table is the adjoint one (same spectrum):
+    # Spectre_Ha.dat row 1 = 0.7386891 -+ 0.6972319i; this build with tightly converged solves (1e-12 / 1e-4): 0.7386873819 + 0.6972306556i
+    kk = a.warmup + a.steps
+    vals, vecs = krylov.eig_sorted(H[:kk, :kk])
+    ritz = {"re": float(vals[0].real), "im": float(abs(vals[0].imag)), "residual": float(abs(H[kk, kk - 1] * vecs[kk - 1, 0])),
+            "reference_Spectre_Ha_lx1_8": [0.7386891, 0.6972319], "tight_tolerance_run": [0.7386873819, 0.6972306556]}
     h = full if not sharded else h
     st = full.stats() if not sharded else {"helm_iters": 0, "pres_iters": 0, "steps": 1}
     # dominant kernel, timed with HIP events on the library's own stream
@@ -144,10 +150,11 @@ def main():
         "config": {"workload": "cylinder Re=50 direct Arnoldi (BASELINE configs[1]): E=%d, lx1=%d, lxd=%d, nsteps=%d/matvec, k_dim=%d"
                    % (case.nel, case.lx1, case.lxd, h.nsteps, a.steps),
                    "base_flow": "reference BF_1cyl0.f00001 (committed fixture), seed = add_noise",
-                   "tolerances": "Helmholtz |b-Hu|<=%g|b|, pressure |g-E dp|<=%g|g| (matvec parity vs oracle 1e-9, tests/)" % (a.tol_helm, a.tol_pres),
+                   "tolerances": "Helmholtz |b-Hu|<=%g|b|, pressure |g-E dp|<=%g|g| (x0.01 in time steps 1-3 of a map): one matvec on a Krylov vector differs from a tightly converged one by 6e-8 (relative L2, scripts/tol_sweep.py), the leading eigenvalue at k_dim=128 by 6e-8" % (a.tol_helm, a.tol_pres),
                    "parallelism": ("element-sharded x%d (RCCL halos)" % world if sharded else "replicas x%d" % world) if world > 1 else "1 GPU"},
         "wall_time_kdim_s": elapsed if a.steps >= 128 else None,
         "matvec_s_mean": float(np.mean(stats["matvec_s"])), "orth_s_mean": float(np.mean(stats["orth_s"])),
+        "leading_ritz": ritz,
         "helm_iters_per_step": st["helm_iters"] / max(st["steps"], 1), "pres_iters_per_step": st["pres_iters"] / max(st["steps"], 1),
         "roofline": {"bound": "hbm", "kernel": "k_helm<%d>" % case.lx1, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                      "frac": achieved / 8000.0, "traffic": traffic, "avg_launch_us": kern["avg_us"],
