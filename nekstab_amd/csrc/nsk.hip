@@ -647,9 +647,14 @@ static inline void tot_rows(nsk_ctx* c, const double* part, int rows, double* to
   if (c->d.use_tot) hipLaunchKernelGGL(k_tot2, dim3(rows), dim3(256), 0, c->stream, part, c->nblk, tot);
 }
 
+// tolerance of the early time steps of a map: tightened, but never below 1e-4 (what 48 GMRES iterations deliver on every mesh)
+static inline double early_tol(const Dev& d, double mul) {
+  return d.tol_relative ? std::max(d.tol_pres * mul, std::min(d.tol_pres, 1e-4)) : d.tol_pres;
+}
+
 static int pres_solve_launch(nsk_ctx* c, double h2, int ord, int np, double tol_mul = 1.0) {
   Dev d = c->d;                                            // by value: the early steps of a map run with a tighter tolerance
-  if (d.tol_relative) d.tol_pres = std::max(d.tol_pres * tol_mul, std::min(d.tol_pres, 1e-6));   // single-pass GMRES: not below 1e-6
+  d.tol_pres = early_tol(d, tol_mul);
   const double scale = 1.0 / (h2 * std::sqrt(d.vol));
   DISPATCH_N(c->key, {
     constexpr int NT = Cfg<N>::NT;
