@@ -235,3 +235,20 @@ def test_checkpoint_restart(hip6, case6, tmp_path):
     assert np.abs(H2 - H).max() < 1e-8 * np.abs(H).max()
     hip6.free(Q + Q2)
     hip6.set_nsteps(100)
+
+
+def test_bench_tolerances_reproduce_the_reference_eigenvalue(hip6, case6, spectre):
+    """The tolerances bench.py runs with (Helmholtz 1e-10, pressure 2e-1, x0.01 in the first three steps of a map:
+    DESIGN.md section 1) reproduce row 1 of the reference's Spectre_Hd.dat to its seven digits."""
+    from nekstab_amd import krylov, seed
+    hip6.set_tolerances(1e-10, 2e-1, 1)
+    qx, qy = seed.add_noise(case6)
+    v = hip6.alloc(1)[0]
+    hip6.upload(v, qx, qy, np.zeros(hip6.npres))
+    res = krylov.krylov_schur(hip6, v, 170, schur_tgt=0)
+    ref = spectre["Hd"][0]
+    mu = res.vals[0] if res.vals[0].imag > 0 else res.vals[1]
+    assert res.residual[0] < 1e-7
+    assert abs(mu - complex(ref[0], abs(ref[1]))) < 2e-7, mu
+    hip6.free(res.Q + [v])
+    hip6.set_tolerances(1e-13, 1e-13, 1)
