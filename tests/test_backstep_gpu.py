@@ -101,5 +101,13 @@ def test_hexahedral_path_on_the_extruded_step(bfs):
                 assert np.abs(out[1][e, k] - ore[1]).max() < 2e-6 * sc
         assert np.abs(out[2]).max() < 1e-7 * sc
         assert abs(h3.norm(f) ** 2 - 3.2370) < 1e-3  # span 1.0: same energy gain
+        # config 4 is an *adjoint* run: direct-adjoint composition on hexahedra, M^T M pRe = G pRe
+        from nekstab_amd.capi import NSK_DIRECT_ADJOINT
+        g = h3.alloc(1)[0]
+        h3.matvec(g, q, NSK_DIRECT_ADJOINT)
+        lam = h3.dot(q, g) / h3.dot(q, q)
+        assert abs(lam - 3.2370) < 2e-3, lam
+        h3.axpy(g, -lam, q)
+        assert h3.norm(g) < 3e-3 * lam
     finally:
         h3.close()
