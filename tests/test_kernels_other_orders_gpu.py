@@ -73,3 +73,46 @@ def test_full_steps_other_orders(lx1, modes):
     mu_abs = abs(0.7387113 + 0.6972442j)
     assert abs(e1 / e0 - mu_abs ** (2 * 6 * h.dt)) < 2e-3
     h.close()
+
+
+def test_refined_mesh_config3_paths(modes):
+    """BASELINE config 3's mesh (every element split 2x2, E = 7984): exercises the streaming coarse solve (8k vertices)
+    and, with more than 1024 workgroups, the summed-once totals path of the quadrilateral kernels.  Operators against
+    the oracle on the refined mesh; a few whole time steps on the reference's eigenmode."""
+    from nekstab_amd import mesh
+    from nekstab_amd.capi import NekStabHip
+    from tests.conftest import GOLDEN, make_oracle
+    c0 = mesh.load_case_npz(os.path.join(GOLDEN, "cylinder_case.npz"), 6)
+    case = mesh.refine_case_2x2(c0)
+    assert case.nel == 4 * c0.nel
+    o = make_oracle(case, build_solvers=False)
+    kw = dict(tol_helm=1e-11, tol_pres=1e-4, tol_relative=1, nproj=8, max_helm_iter=150, max_pres_iter=48)
+    h = NekStabHip(case, case.meta["vert"], case.meta["nvert"], **kw)
+    try:
+        rng = np.random.default_rng(0)
+        u = np.sin(0.7 * case.x) * np.cos(0.5 * case.y) + 0.1 * rng.standard_normal(case.x.shape)
+        p = rng.standard_normal((case.nel, 4, 4))
+        assert rel(h.t_axhelm(u, 0.02, 300.0), o.axhelm(u, 0.02, 300.0)) < 1e-12
+        assert rel(h.t_dssum(u), o.dssum(u)) < 1e-13
+        wx, wy = o.opgradt(p)
+        fac = o.binvm1 * o.mask
+        assert rel(h.t_eapply(p), o.opdiv(fac * o.dssum(wx * o.mask), fac * o.dssum(wy * o.mask))) < 1e-12
+        # a few whole time steps (all solver kernels of these paths) on the reference's eigenmode: converged, and the
+        # energy follows the eigenvalue (|mu|^(2 t / T)), as in test_full_steps_other_orders
+        m = modes["dRe_u"].astype(np.float64)
+        cm = mesh.refine_case_2x2(mesh.Case(**{**c0.__dict__, "ub": m}))
+        nst = 6
+        b0, b1 = h.alloc(2)
+        h.upload(b0, cm.ub[0] * case.mask, cm.ub[1] * case.mask, np.zeros(h.npres))
+        e0 = h.dot(b0, b0)
+        h.set_nsteps(nst); h.matvec(b1, b0, 0)
+        e1 = h.dot(b1, b1)
+        assert h.stats()["unconverged"] == 0
+        mu_abs = abs(0.7387113 + 0.6972442j)
+        assert abs(e1 / e0 - mu_abs ** (2 * nst * h.dt)) < 2e-3
+        r1 = h.download(b1)
+        div = h.t_opdiv(r1[0], r1[1])
+        div0 = h.t_opdiv(cm.ub[0] + 0.01 * case.x * case.mask, cm.ub[1])
+        assert np.abs(div).max() < 1e-5 * np.abs(div0).max()
+    finally:
+        h.close()
