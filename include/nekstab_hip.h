@@ -81,7 +81,11 @@ int nsk_get_info(nsk_ctx* ctx, double* dt, int* nsteps, long long* nstate,
                  long long* nvel, long long* npres);
 int nsk_set_nsteps(nsk_ctx* ctx, int nsteps);   /* test hook: shorten the map (dt unchanged) */
 int nsk_set_tolerances(nsk_ctx* ctx, double tol_helm, double tol_pres, int relative);
-int nsk_set_option(nsk_ctx* ctx, const char* name, double value);   /* "use_graph", "min_pres_iter", ... */
+/* run-time switches: "use_graph" (hipGraph replay of the step classes, default 1), "min_pres_iter",
+ * "helm_guess" (extrapolated Helmholtz initial guess, default 1), "early_pres_mul" (pressure tolerance factor of
+ * time steps 1-3 of every map, default 0.01: they project out the divergence of the input vector),
+ * "budget_helm" / "budget_pres" (launch budgets), "dbg" (developer ablation mask) */
+int nsk_set_option(nsk_ctx* ctx, const char* name, double value);
 
 /* allocate(Q(k_dim+1)) (core/eigensolvers.f:170) */
 int nsk_vec_alloc(nsk_ctx* ctx, int n, nsk_vec* out);
