@@ -9,6 +9,45 @@
 namespace nsk {
 namespace k3 {
 
+// Workgroup -> element map.  Workgroups are handed to the 8 XCDs round-robin (blockIdx % 8), each XCD
+// with its own L2; consecutive elements are almost always face neighbours (97 % of the r-faces of the
+// reference's cylinder mesh are e, e+1), and the dssum gather reads the neighbours' face nodes.  Giving
+// every XCD one contiguous run of elements makes those reads hit the L2 that streams the neighbour's
+// own tile at about the same time, instead of fetching the same lines again from memory.
+__device__ inline long long xcd_element(unsigned b, unsigned n) {
+  const unsigned x = b & 7u, q = b >> 3, base = n >> 3, rem = n & 7u;
+  return (long long)(x * base + (x < rem ? x : rem) + q);
+}
+
+// Nodes of valence 5..8 (hexahedral vertices) do not fit the 4-wide gather table.  Their index lists
+// are the same for every component and iteration, so a launch stages them once in LDS (8 ints per
+// thread, private to the thread: no barrier) and every later gather issues its value loads at once
+// instead of walking offsets -> indices -> values.  Same left-to-right sum as gs_csr.
+__device__ inline void gs_wide_stage(const Dev& d, const int4 tab, long long l, int* sw) {
+  if (tab.x >= 0) return;
+  const int o0 = d.gs_off[l], o1 = d.gs_off[l + 1];
+  if (o1 - o0 > 8) { sw[0] = -2; return; }
+  int id[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) id[q] = (o0 + q < o1) ? d.gs_idx[o0 + q] : -1;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) sw[q] = id[q];
+}
+__device__ inline double gs_wide_sum(const double* __restrict__ f, const Dev& d, long long l, const int* sw) {
+  int id[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) id[q] = sw[q];
+  if (id[0] == -2) return gs_csr(f, d, l);
+  double v[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) v[q] = (id[q] >= 0) ? f[id[q]] : 0.0;
+  double s = 0.0;
+#pragma unroll
+  for (int q = 0; q < 8; ++q)
+    if (id[q] >= 0) s += v[q];
+  return s;
+}
+
 template <int N>
 struct Cfg {
   static constexpr int NN = N * N * N, M = N - 2, MM = M * M * M, ND = 3 * N / 2, NDD = ND * ND * ND;
@@ -464,6 +503,14 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_rhs(Dev d, StepCoef sc) {
 //   hscal[par*16 + c*4 + {0:gamma,1:alpha,2:done,3:res}], reference norms at hscal[32 + c]
 //   hpart[par][12][nblk] / htot[par*16 + .]: c*3 + {0:(r,z), 1:(z,Az), 2:(r,r)}, 9 + c: (b,b)
 // ---------------------------------------------------------------------------
+// a wave-uniform double moved to scalar registers
+__device__ inline double uniform_f64(double v) {
+  union { double d; int i[2]; } u;
+  u.d = v;
+  u.i[0] = __builtin_amdgcn_readfirstlane(u.i[0]);
+  u.i[1] = __builtin_amdgcn_readfirstlane(u.i[1]);
+  return u.d;
+}
 template <int N>
 __global__ __launch_bounds__(Cfg<N>::NT, 4) void k_helm(Dev d, StepCoef sc, int it, const double* rhs) {
   using C = Cfg<N>;
@@ -471,8 +518,9 @@ __global__ __launch_bounds__(Cfg<N>::NT, 4) void k_helm(Dev d, StepCoef sc, int 
   __shared__ double sD[N * N], sDt[N * N];
   __shared__ double sz[NN], st[3 * NN];
   __shared__ double sred[4 * 16];
+  __shared__ int sW[NT * 8];
   const int tid = threadIdx.x;
-  const long long e = blockIdx.x;
+  const long long e = xcd_element(blockIdx.x, gridDim.x);
   const bool act = tid < NN;
   const int k = tid / (N * N), j = (tid / N) % N, i = tid % N;
   const long long l = e * NN + tid, nl = d.cs;
@@ -507,6 +555,9 @@ __global__ __launch_bounds__(Cfg<N>::NT, 4) void k_helm(Dev d, StepCoef sc, int 
       }
     }
     if (done[0] && done[1] && done[2]) return;
+    // wave-uniform CG scalars go to scalar registers (126 VGPRs, no spills => two workgroups per CU)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { alpha[c] = uniform_f64(alpha[c]); beta[c] = uniform_f64(beta[c]); done[c] = __builtin_amdgcn_readfirstlane((int)done[c]) != 0; }
   }
   for (int q = tid; q < N * N; q += NT) { const double v = d.D[q]; sD[q] = v; sDt[(q % N) * N + q / N] = v; }
   int4 tab = make_int4(0, -1, -1, -1);
@@ -516,6 +567,7 @@ __global__ __launch_bounds__(Cfg<N>::NT, 4) void k_helm(Dev d, StepCoef sc, int 
     bm = d.bm1[l]; mk = d.mask[l]; mi = d.minv[l];
     g[0] = d.g1[l]; g[1] = d.g2[l]; g[2] = d.g3[l]; g[3] = d.g4[l]; g[4] = d.g5[l]; g[5] = d.g6[l];
     di = d.dinv[(size_t)(sc.k - 1) * d.nloc + l];
+    gs_wide_stage(d, tab, l, sW + tid * 8);
   }
 #pragma unroll 1
   for (int c = 0; c < 3; ++c) {
@@ -524,14 +576,14 @@ __global__ __launch_bounds__(Cfg<N>::NT, 4) void k_helm(Dev d, StepCoef sc, int 
     if (act) {
       if (it == 0) {
         const GsVals gv = gs_load(rhs + c * nl, tab, l), gb = gs_load(d.bloc + c * nl, tab, l);
-        r = mk * gs_sum(gv, rhs + c * nl, d, tab, l);
-        bb = mk * gs_sum(gb, d.bloc + c * nl, d, tab, l);
+        r = mk * (tab.x < 0 ? gs_wide_sum(rhs + c * nl, d, l, sW + tid * 8) : gs_sum(gv, rhs + c * nl, d, tab, l));
+        bb = mk * (tab.x < 0 ? gs_wide_sum(d.bloc + c * nl, d, l, sW + tid * 8) : gs_sum(gb, d.bloc + c * nl, d, tab, l));
         d.hx[lc] = 0.0; d.hp[lc] = 0.0; d.hs[lc] = 0.0; d.hr[lc] = r;
       } else if (!done[c]) {
         const double* wl = d.hwl + ((size_t)ppar * 3 + c) * nl;
         const GsVals gv = gs_load(wl, tab, l);
         const double rold = d.hr[lc], pold = d.hp[lc], sold = d.hs[lc], xold = d.hx[lc];
-        const double w = mk * gs_sum(gv, wl, d, tab, l);
+        const double w = mk * (tab.x < 0 ? gs_wide_sum(wl, d, l, sW + tid * 8) : gs_sum(gv, wl, d, tab, l));
         const double pn = di * rold + beta[c] * pold;
         const double sn = w + beta[c] * sold;
         d.hp[lc] = pn; d.hs[lc] = sn;
@@ -553,9 +605,19 @@ __global__ __launch_bounds__(Cfg<N>::NT, 4) void k_helm(Dev d, StepCoef sc, int 
       d.hwl[((size_t)par * 3 + c) * nl + l] = wl;
       v[0] = r * z * mi; v[1] = z * wl; v[2] = r * r * mi; v[3] = bb * bb * mi;
     }
-    block_reduce<4>(v, sred, tid, NT);
-    if (tid < 3) d.hpart[((size_t)par * 12 + c * 3 + tid) * d.nblk + blockIdx.x] = v[tid];
-    if (tid == 3) d.hpart[((size_t)par * 12 + 9 + c) * d.nblk + blockIdx.x] = v[3];
+    // workgroup sums: wave sums to LDS, rows added (fixed order) by the four threads that store them;
+    // sred is rewritten only after the next component's barriers
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const double x = wave_sum63(v[q]);
+      if ((tid & 63) == 63) sred[q * 16 + (tid >> 6)] = x;
+    }
+    lds_barrier();
+    if (tid < 4) {
+      double s = 0.0;
+      for (int w = 0; w < NT / 64; ++w) s += sred[tid * 16 + w];
+      d.hpart[((size_t)par * 12 + (tid < 3 ? c * 3 + tid : 9 + c)) * d.nblk + e] = s;
+    }
   }
 }
 

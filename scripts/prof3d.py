@@ -12,7 +12,7 @@ c2 = mesh.load_case_npz(os.path.join(ROOT, "tests/golden/cylinder_case.npz"), lx
 modes = np.load(os.path.join(ROOT, "tests/golden/cylinder_modes.npz"))
 c3 = mesh3d.extrude_case(c2, nz, 0.5 * nz, periodic=True)
 u = mesh.interp_field_2d(modes["dRe_u"].astype(np.float64), lx1) * c2.mask
-h3 = NekStabHip(c3, c3.meta["vert"], c3.meta["nvert"], tol_helm=1e-11, tol_pres=1e-1, tol_relative=1, max_helm_iter=150, max_pres_iter=48, nproj=8)
+h3 = NekStabHip(c3, c3.meta["vert"], c3.meta["nvert"], tol_helm=1e-10, tol_pres=2e-1, tol_relative=1, max_helm_iter=150, max_pres_iter=48, nproj=8)
 b0, b1 = h3.alloc(2)
 rng = np.random.default_rng(0)
 w = 1e-3 * rng.standard_normal(c3.x.shape) * c3.mask
