@@ -64,6 +64,7 @@ struct nsk_ctx {
   int nsteps = 0;
   int max_helm = 60, max_pres = 40, min_pres = 0, layers = 1;
   int cur_helm[6] = {0, 0, 0, 0, 0, 0}, cur_pres[6] = {0, 0, 0, 0, 0, 0};       // adaptive launch budgets per BDF order
+  int bh_helm[6][8] = {}, bh_pres[6][8] = {}, bh_n = 0;                         // iteration maxima of the last maps (budgets_update)
   int use_graph = 1;
   int in_test = 0;
   int helm_guess = 1;
@@ -631,6 +632,7 @@ static int build(nsk_ctx* c, const nsk_case& cs) {
     if ((rc = dalloc(c, &d.htot, 32)) || (rc = dalloc(c, &d.gtot, MAXMR + 8)) || (rc = dalloc(c, &d.ptot, MAXPROJ + 2))) return rc;
   }
   for (int k = 0; k < 6; ++k) { c->cur_helm[k] = c->max_helm; c->cur_pres[k] = c->max_pres; }
+  c->bh_n = 0;
   if (const char* g = std::getenv("NSK_USE_GRAPH")) c->use_graph = std::atoi(g);
   if (const char* g = std::getenv("NSK_DEBUG")) c->debug = std::atoi(g);
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -777,6 +779,31 @@ static int run_map(nsk_ctx* c, int adjoint, double* f, const double* q) {
   return 0;
 }
 
+// Launch budgets of the step classes from the iteration maxima of the maps run so far.  The maxima of one
+// class move by +-3 between consecutive Krylov vectors; budgets that follow the last map alone are cut after a
+// cheap map, the next map runs out of launches and is redone as a whole (measured on cfg 2: 29 redone maps and
+// 449 graph re-captures in 130 maps).  So: a window of the last BW maps; grow at once; shrink to the window
+// maximum + head-room only when the window is full, or when the budget is more than twice what the window asks
+// for (start-up budgets, doubled budgets after a redone map).
+constexpr int BW = 8, BHEAD = 3;
+static void budgets_update(nsk_ctx* c, const Stats& h) {
+  const int slot = c->bh_n % BW;
+  for (int k = 0; k < 6; ++k) { c->bh_helm[k][slot] = (int)h.max_helm_k[k]; c->bh_pres[k][slot] = (int)h.max_pres_k[k]; }
+  c->bh_n++;
+  const int nv = std::min(c->bh_n, BW);
+  for (int k = 0; k < 6; ++k) {
+    if (CLS_ISTEP[k] > c->nsteps) break;
+    int mh = 0, mp = 0;
+    for (int i = 0; i < nv; ++i) { mh = std::max(mh, c->bh_helm[k][i]); mp = std::max(mp, c->bh_pres[k][i]); }
+    // the classes of time steps 1..6 hold one to three steps per map and their counts vary most (pressure
+    // solves of steps 2-3: 4 to 23 iterations): spare launches there cost microseconds, a redone map 0.1 s
+    const int xh = k <= 3 ? std::max(4, mh / 2) : (k == 4 ? 1 : 0), xp = k <= 3 ? std::max(4, mp) : (k == 4 ? 1 : 0);
+    const int th = std::min(c->max_helm, mh + BHEAD + xh), tp = std::min(c->max_pres, mp + BHEAD + xp);
+    if (th > c->cur_helm[k] || (nv == BW ? th < c->cur_helm[k] - 1 : c->cur_helm[k] > 2 * th)) c->cur_helm[k] = th;
+    if (tp > c->cur_pres[k] || (nv == BW ? tp < c->cur_pres[k] - 1 : c->cur_pres[k] > 2 * tp)) c->cur_pres[k] = tp;
+  }
+}
+
 // run one map with the adaptive launch budgets: every inner solve early-exits on its
 // own convergence flag; a solve that runs out of launched iterations is counted on the
 // device and the whole map is redone with larger budgets.
@@ -800,16 +827,15 @@ static int run_map_adaptive(nsk_ctx* c, int adjoint, double* f, const double* q)
       c->hstats.max_helm_k[k] = std::max(c->hstats.max_helm_k[k], h.max_helm_k[k]);
       c->hstats.max_pres_k[k] = std::max(c->hstats.max_pres_k[k], h.max_pres_k[k]);
     }
+    if (c->debug >= 2) {
+      fprintf(stderr, "map: unconverged %llu | helm max/budget", (unsigned long long)h.unconverged);
+      for (int k = 0; k < 6; ++k) fprintf(stderr, " %llu/%d", (unsigned long long)h.max_helm_k[k], c->cur_helm[k]);
+      fprintf(stderr, " | pres max/budget");
+      for (int k = 0; k < 6; ++k) fprintf(stderr, " %llu/%d", (unsigned long long)h.max_pres_k[k], c->cur_pres[k]);
+      fprintf(stderr, "\n");
+    }
     if (h.unconverged == 0) {
-      for (int k = 0; k < 6; ++k) {
-        if (CLS_ISTEP[k] > c->nsteps) break;
-        // grow at once (with head-room), shrink only when clearly oversized: every change re-captures a graph
-        const int nh = (int)h.max_helm_k[k] + 2, npp = (int)h.max_pres_k[k] + 2;
-        if (nh > c->cur_helm[k]) c->cur_helm[k] = std::min(c->max_helm, nh + 1);
-        else if (nh < c->cur_helm[k] - 4) c->cur_helm[k] = std::min(c->max_helm, nh + 1);
-        if (npp > c->cur_pres[k]) c->cur_pres[k] = std::min(c->max_pres, npp + 1);
-        else if (npp < c->cur_pres[k] - 4) c->cur_pres[k] = std::min(c->max_pres, npp + 1);
-      }
+      budgets_update(c, h);
       return 0;
     }
     bool capped = true;
@@ -977,6 +1003,7 @@ int nsk_set_tolerances(nsk_ctx* c, double th, double tp, int relative) {
   c->d.tol_helm = th; c->d.tol_pres = tp; c->d.tol_relative = relative;
   for (auto& a : c->graphs) for (auto& g : a) g.nh = -1;   // Dev is captured by value: re-capture
   for (int k = 0; k < 6; ++k) { c->cur_helm[k] = c->max_helm; c->cur_pres[k] = c->max_pres; }
+  c->bh_n = 0;
   return 0;
 }
 
@@ -987,6 +1014,7 @@ int nsk_set_option(nsk_ctx* c, const char* name, double value) {
   else if (n == "min_pres_iter") c->min_pres = (int)value;
   else if (n == "helm_guess") c->helm_guess = (int)value;
   else if (n == "early_pres_mul") c->early_pres_mul = value;
+  else if (n == "proj_reset") c->d.proj_reset = (int)value;
   else if (n == "dbg") { int v = (int)value; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), &v, sizeof(int))); }
   else if (n == "budget_helm") { for (int k = 0; k < 6; ++k) c->cur_helm[k] = std::min(c->max_helm, std::max(1, (int)value)); }
   else if (n == "budget_pres") { for (int k = 0; k < 6; ++k) c->cur_pres[k] = std::min(c->max_pres, std::max(1, (int)value)); }
@@ -1165,6 +1193,7 @@ int nsk_set_orbit(nsk_ctx* c, nsk_vec q0v, double spng_str, nsk_vec end) {
   if (!d.bstep && (rc = dalloc(c, &d.bstep, 4))) return rc;
   for (auto& a : c->graphs) for (auto& g : a) g.nh = -1;
   for (int k = 0; k < 6; ++k) { c->cur_helm[k] = c->max_helm; c->cur_pres[k] = c->max_pres; }
+  c->bh_n = 0;
   HIPCHK(hipMemsetAsync(d.stats, 0, sizeof(Stats), c->stream));
   HIPCHK(hipMemcpyAsync(d.u, q0, d.nloc * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(d.u + d.cs, q0 + d.nloc, d.nloc * sizeof(double), hipMemcpyDeviceToDevice, c->stream));

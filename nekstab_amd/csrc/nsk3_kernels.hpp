@@ -446,6 +446,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_rhs(Dev d, StepCoef sc) {
         G->nproj = (G->pcnt < d.nproj_max) ? G->pcnt : d.nproj_max;
       } else { G->pcnt = 0; G->nproj = 0; }
     }
+    if (d.proj_reset && sc.cls == 0) { G->pcnt = 0; G->nproj = 0; }
   }
   double u[3] = {0, 0, 0}, bfv[3] = {0, 0, 0}, bm = 0, g[6] = {0, 0, 0, 0, 0, 0};
   if (act) {

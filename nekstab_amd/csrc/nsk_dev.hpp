@@ -55,6 +55,7 @@ struct Dev {
   long long npr_glob;            // pressure dofs over all ranks
   double nu, dt, vol, tol_helm, tol_pres;
   int tol_relative, max_mr, has_outflow, nproj_max;
+  int proj_reset;                // 1: every map starts with an empty pressure projection space
   // bases
   const double *D, *J12, *D12, *Jd, *Dd, *hat;
   // per GLL node

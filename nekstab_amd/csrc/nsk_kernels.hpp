@@ -480,6 +480,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_rhs(Dev d, StepCoef sc) {
         G->pcnt = 0; G->nproj = 0;
       }
     }
+    if (d.proj_reset && sc.cls == 0) { G->pcnt = 0; G->nproj = 0; }      // first step of a map: the space of the last map is stale
   }
   double u[2] = {0, 0}, bfv[2] = {0, 0}, bm = 0, g1 = 0, g2 = 0, g4 = 0;
   if (act) {
