@@ -63,15 +63,15 @@ struct nsk_ctx {
   double dt = 0, re = 0, endtime = 0;
   int nsteps = 0;
   int max_helm = 60, max_pres = 40, min_pres = 0, layers = 1;
-  int cur_helm[6] = {0, 0, 0, 0, 0, 0}, cur_pres[6] = {0, 0, 0, 0, 0, 0};       // adaptive launch budgets per BDF order
-  int bh_helm[6][8] = {}, bh_pres[6][8] = {}, bh_n = 0;                         // iteration maxima of the last maps (budgets_update)
+  int cur_helm[NCLS] = {}, cur_pres[NCLS] = {};       // adaptive launch budgets per BDF order
+  int bh_helm[NCLS][8] = {}, bh_pres[NCLS][8] = {}, bh_n = 0;                         // iteration maxima of the last maps (budgets_update)
   int use_graph = 1;
   int in_test = 0;
   int helm_guess = 1;
   double early_pres_mul = 1e-2;         // pressure tolerance factor of time steps 1-3 of every map
   long long recaptures = 0, retries = 0;
   int debug = 0;
-  struct StepGraph { hipGraphExec_t exec = nullptr; int nh = -1, np = -1; } graphs[3][6];
+  struct StepGraph { hipGraphExec_t exec = nullptr; int nh = -1, np = -1; } graphs[3][NCLS];
   double* scratch = nullptr;            // one state vector
   double* rc_big = nullptr;             // coarse restriction for nvert > 3072
   Dev d{};
@@ -146,7 +146,7 @@ static StepCoef make_coef(const nsk_ctx* c, int istep, int adjoint) {
   static const double XG[4][3] = {{0, 0, 0}, {1, 0, 0}, {2, -1, 0}, {3, -3, 1}};
   const int gi = !g ? 0 : std::min(istep, 4) - 1;
   for (int q = 0; q < 3; ++q) s.xg[q] = XG[gi][q];
-  s.cls = istep <= 3 ? istep - 1 : (istep <= 6 ? 3 : (istep <= 16 ? 4 : 5));
+  s.cls = step_class(istep);
   return s;
 }
 
@@ -416,7 +416,7 @@ static int build(nsk_ctx* c, const nsk_case& cs) {
     std::vector<double> dAs = dssum_h(dA), bs = dssum_h(bm1);
     c->h_dAs = dAs; c->h_bs = bs; c->h_mask = mask;
     const double bd0[3] = {1.0, 1.5, 11.0 / 6.0};
-    for (int k = 0; k < 6; ++k)
+    for (int k = 0; k < 3; ++k)
       for (long long l = 0; l < nloc; ++l) dinv[(size_t)k * nloc + l] = mask[l] / (d.nu * dAs[l] + bd0[k] / c->dt * bs[l]);
   }
 
@@ -631,7 +631,7 @@ static int build(nsk_ctx* c, const nsk_case& cs) {
     d.use_tot = 1;
     if ((rc = dalloc(c, &d.htot, 32)) || (rc = dalloc(c, &d.gtot, MAXMR + 8)) || (rc = dalloc(c, &d.ptot, MAXPROJ + 2))) return rc;
   }
-  for (int k = 0; k < 6; ++k) { c->cur_helm[k] = c->max_helm; c->cur_pres[k] = c->max_pres; }
+  for (int k = 0; k < NCLS; ++k) { c->cur_helm[k] = c->max_helm; c->cur_pres[k] = c->max_pres; }
   c->bh_n = 0;
   if (const char* g = std::getenv("NSK_USE_GRAPH")) c->use_graph = std::atoi(g);
   if (const char* g = std::getenv("NSK_DEBUG")) c->debug = std::atoi(g);
@@ -723,8 +723,7 @@ static int step(nsk_ctx* c, int istep, int adjoint) {
   return 0;
 }
 
-static const int CLS_ISTEP[6] = {1, 2, 3, 4, 7, 17};    // a representative step of every class
-static inline int step_class(int istep) { return istep <= 3 ? istep - 1 : (istep <= 6 ? 3 : (istep <= 16 ? 4 : 5)); }
+static const int CLS_ISTEP[NCLS] = {1, 2, 3, 4, 7, 17};    // first step of every class
 
 static int ensure_graph(nsk_ctx* c, int cls, int adjoint) {
   nsk_ctx::StepGraph& g = c->graphs[adjoint][cls];
@@ -746,7 +745,7 @@ static int ensure_graph(nsk_ctx* c, int cls, int adjoint) {
 static int run_map(nsk_ctx* c, int adjoint, double* f, const double* q) {
   Dev& d = c->d;
   if (c->use_graph)
-    for (int k = 0; k < 6; ++k) { int rc = ensure_graph(c, k, adjoint); if (rc) return rc; }
+    for (int k = 0; k < NCLS; ++k) { int rc = ensure_graph(c, k, adjoint); if (rc) return rc; }
   for (int cc = 0; cc < c->ndim; ++cc)
     HIPCHK(hipMemcpyAsync(d.u + cc * d.cs, q + cc * d.nloc, d.nloc * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(d.p, q + c->ndim * d.nloc, d.npr * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
@@ -788,10 +787,10 @@ static int run_map(nsk_ctx* c, int adjoint, double* f, const double* q) {
 constexpr int BW = 8, BHEAD = 3;
 static void budgets_update(nsk_ctx* c, const Stats& h) {
   const int slot = c->bh_n % BW;
-  for (int k = 0; k < 6; ++k) { c->bh_helm[k][slot] = (int)h.max_helm_k[k]; c->bh_pres[k][slot] = (int)h.max_pres_k[k]; }
+  for (int k = 0; k < NCLS; ++k) { c->bh_helm[k][slot] = (int)h.max_helm_k[k]; c->bh_pres[k][slot] = (int)h.max_pres_k[k]; }
   c->bh_n++;
   const int nv = std::min(c->bh_n, BW);
-  for (int k = 0; k < 6; ++k) {
+  for (int k = 0; k < NCLS; ++k) {
     if (CLS_ISTEP[k] > c->nsteps) break;
     int mh = 0, mp = 0;
     for (int i = 0; i < nv; ++i) { mh = std::max(mh, c->bh_helm[k][i]); mp = std::max(mp, c->bh_pres[k][i]); }
@@ -823,15 +822,15 @@ static int run_map_adaptive(nsk_ctx* c, int adjoint, double* f, const double* q)
     c->hstats.helm_iters += h.helm_iters; c->hstats.pres_iters += h.pres_iters; c->hstats.steps += c->nsteps;
     c->hstats.max_helm = std::max(c->hstats.max_helm, h.max_helm); c->hstats.max_pres = std::max(c->hstats.max_pres, h.max_pres);
     c->hstats.last_helm_res = h.last_helm_res; c->hstats.last_pres_res = h.last_pres_res;
-    for (int k = 0; k < 6; ++k) {
+    for (int k = 0; k < NCLS; ++k) {
       c->hstats.max_helm_k[k] = std::max(c->hstats.max_helm_k[k], h.max_helm_k[k]);
       c->hstats.max_pres_k[k] = std::max(c->hstats.max_pres_k[k], h.max_pres_k[k]);
     }
     if (c->debug >= 2) {
       fprintf(stderr, "map: unconverged %llu | helm max/budget", (unsigned long long)h.unconverged);
-      for (int k = 0; k < 6; ++k) fprintf(stderr, " %llu/%d", (unsigned long long)h.max_helm_k[k], c->cur_helm[k]);
+      for (int k = 0; k < NCLS; ++k) fprintf(stderr, " %llu/%d", (unsigned long long)h.max_helm_k[k], c->cur_helm[k]);
       fprintf(stderr, " | pres max/budget");
-      for (int k = 0; k < 6; ++k) fprintf(stderr, " %llu/%d", (unsigned long long)h.max_pres_k[k], c->cur_pres[k]);
+      for (int k = 0; k < NCLS; ++k) fprintf(stderr, " %llu/%d", (unsigned long long)h.max_pres_k[k], c->cur_pres[k]);
       fprintf(stderr, "\n");
     }
     if (h.unconverged == 0) {
@@ -839,13 +838,13 @@ static int run_map_adaptive(nsk_ctx* c, int adjoint, double* f, const double* q)
       return 0;
     }
     bool capped = true;
-    for (int k = 0; k < 6; ++k) capped = capped && c->cur_helm[k] >= c->max_helm && c->cur_pres[k] >= c->max_pres;
+    for (int k = 0; k < NCLS; ++k) capped = capped && c->cur_helm[k] >= c->max_helm && c->cur_pres[k] >= c->max_pres;
     if (capped) {
       c->hstats.unconverged += h.unconverged;
       return fail(NSK_ENOCONV, "inner solve hit its iteration cap (" + std::to_string(h.unconverged) + " solves)");
     }
     c->retries++;
-    for (int k = 0; k < 6; ++k) {
+    for (int k = 0; k < NCLS; ++k) {
       c->cur_helm[k] = std::min(c->max_helm, 2 * c->cur_helm[k] + 4);
       c->cur_pres[k] = std::min(c->max_pres, 2 * c->cur_pres[k] + 4);
     }
@@ -1002,7 +1001,7 @@ int nsk_set_tolerances(nsk_ctx* c, double th, double tp, int relative) {
   if (!c) return fail(NSK_EINVAL, "null ctx");
   c->d.tol_helm = th; c->d.tol_pres = tp; c->d.tol_relative = relative;
   for (auto& a : c->graphs) for (auto& g : a) g.nh = -1;   // Dev is captured by value: re-capture
-  for (int k = 0; k < 6; ++k) { c->cur_helm[k] = c->max_helm; c->cur_pres[k] = c->max_pres; }
+  for (int k = 0; k < NCLS; ++k) { c->cur_helm[k] = c->max_helm; c->cur_pres[k] = c->max_pres; }
   c->bh_n = 0;
   return 0;
 }
@@ -1016,8 +1015,8 @@ int nsk_set_option(nsk_ctx* c, const char* name, double value) {
   else if (n == "early_pres_mul") c->early_pres_mul = value;
   else if (n == "proj_reset") c->d.proj_reset = (int)value;
   else if (n == "dbg") { int v = (int)value; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), &v, sizeof(int))); }
-  else if (n == "budget_helm") { for (int k = 0; k < 6; ++k) c->cur_helm[k] = std::min(c->max_helm, std::max(1, (int)value)); }
-  else if (n == "budget_pres") { for (int k = 0; k < 6; ++k) c->cur_pres[k] = std::min(c->max_pres, std::max(1, (int)value)); }
+  else if (n == "budget_helm") { for (int k = 0; k < NCLS; ++k) c->cur_helm[k] = std::min(c->max_helm, std::max(1, (int)value)); }
+  else if (n == "budget_pres") { for (int k = 0; k < NCLS; ++k) c->cur_pres[k] = std::min(c->max_pres, std::max(1, (int)value)); }
   else return fail(NSK_EINVAL, "unknown option " + n);
   for (auto& a : c->graphs) for (auto& g : a) g.nh = -1;
   return 0;
@@ -1192,7 +1191,7 @@ int nsk_set_orbit(nsk_ctx* c, nsk_vec q0v, double spng_str, nsk_vec end) {
   d.spng_vr = vr; d.nl_spng_str = spng_str;
   if (!d.bstep && (rc = dalloc(c, &d.bstep, 4))) return rc;
   for (auto& a : c->graphs) for (auto& g : a) g.nh = -1;
-  for (int k = 0; k < 6; ++k) { c->cur_helm[k] = c->max_helm; c->cur_pres[k] = c->max_pres; }
+  for (int k = 0; k < NCLS; ++k) { c->cur_helm[k] = c->max_helm; c->cur_pres[k] = c->max_pres; }
   c->bh_n = 0;
   HIPCHK(hipMemsetAsync(d.stats, 0, sizeof(Stats), c->stream));
   HIPCHK(hipMemcpyAsync(d.u, q0, d.nloc * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
