@@ -1483,7 +1483,16 @@ __global__ __launch_bounds__(256) void k_tot2(const double* __restrict__ part, i
   __shared__ double sred[16];
   const int q = blockIdx.x, tid = threadIdx.x;
   double v[1] = {0.0};
-  for (int k = tid; k < nblk; k += 256) v[0] += part[(size_t)q * nblk + k];
+  const double* row = part + (size_t)q * nblk;
+  int k = tid;
+  for (; k + 7 * 256 < nblk; k += 8 * 256) {          // eight loads in flight, added in the same order as a plain loop
+    double a[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] = row[k + u * 256];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[0] += a[u];
+  }
+  for (; k < nblk; k += 256) v[0] += row[k];
   block_reduce<1>(v, sred, tid, 256);
   if (tid == 0) tot[q] = v[0];
 }
