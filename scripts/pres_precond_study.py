@@ -113,3 +113,31 @@ if os.environ.get("SPECTRUM"):
         print("coarse weight", om, gmres_counts(rhs["noise"], Mw, tols))
     # local part alone and coarse alone, to see who limits
     print("local only", gmres_counts(rhs["noise"], M_loc, tols))
+
+if os.environ.get("MIDLEVEL"):
+    # enriched coarse spaces (exact Galerkin solves): continuous piecewise-bilinear functions on every element cut
+    # into s x s cells (s = 2, 3), i.e. the vertex space refined
+    for s_ in (2, 3):
+        # node coordinates in the reference element: k/s ; global numbering through rounded physical coordinates
+        tt = np.linspace(-1, 1, s_ + 1)
+        # 1-D hats on the refined grid evaluated at the Gauss points
+        hh = np.zeros((s_ + 1, m))
+        for k in range(s_ + 1):
+            e_k = np.zeros(s_ + 1); e_k[k] = 1.0
+            hh[k] = np.interp(z2, tt, e_k)
+        # physical coordinates of the refined nodes (bilinear map of the element vertices is enough for numbering)
+        from oracle.linns import interp_mat
+        Jv = interp_mat(o.z1, tt)
+        xn = np.einsum("ja,eab,ib->eji", Jv, c.x, Jv); yn = np.einsum("ja,eab,ib->eji", Jv, c.y, Jv)
+        key = np.round(np.stack([xn, yn], -1) * 1e6).astype(np.int64).reshape(-1, 2)
+        _, gidn = np.unique(key, axis=0, return_inverse=True)
+        gidn = gidn.reshape(nel, s_ + 1, s_ + 1); nn_ = gidn.max() + 1
+        vals = np.einsum("jb,ia->jiba", hh, hh).reshape((s_ + 1) ** 2, MM)            # [node (j,i)] x [gauss (b,a)]
+        rows = (np.arange(nel)[:, None, None] * MM + np.arange(MM)[None, None, :]).repeat((s_ + 1) ** 2, 1).ravel()
+        cols = gidn.reshape(nel, -1)[:, :, None].repeat(MM, 2).ravel()
+        R2 = sp.coo_matrix((np.tile(vals, (nel, 1, 1)).ravel(), (rows, cols)), shape=(o.npr, nn_)).tocsr()
+        A2 = (R2.T @ E @ R2).tocsc()
+        lu2 = spla.splu(A2)
+        M2 = lambda r: M_loc(r) + R2 @ lu2.solve(R2.T @ r)
+        for name, b in rhs.items():
+            print("refined vertex space s=%d (%d dofs) + patches: %-20s %s" % (s_, nn_, name, gmres_counts(b, M2, tols)), flush=True)
