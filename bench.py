@@ -32,6 +32,7 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=16, help="oracle time steps in the CPU sample")
     ap.add_argument("--tol-helm", type=float, default=1e-10)
     ap.add_argument("--tol-pres", type=float, default=2e-1)
+    ap.add_argument("--pres-floor", type=float, default=0.0, help="absolute floor of the relative pressure tolerance (scaled residual units)")
     ap.add_argument("--proj-reset", type=int, default=0, help="1: every map starts with an empty pressure projection space")
     ap.add_argument("--nproj", type=int, default=8, help="pressure projection space (residualProj)")
     return ap.parse_args()
@@ -85,6 +86,8 @@ def main():
     h = NekStabHip(case, case.meta["vert"], case.meta["nvert"], tol_helm=a.tol_helm, tol_pres=a.tol_pres,
                    tol_relative=1, schwarz_layers=2, max_helm_iter=100, max_pres_iter=48, nproj=a.nproj)
     h.set_option("proj_reset", a.proj_reset)
+    if a.pres_floor > 0:
+        h.set_option("pres_floor", a.pres_floor)
     k_dim = a.steps
     qx, qy = seed.add_noise(case)
     full = h

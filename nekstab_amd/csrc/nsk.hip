@@ -1014,6 +1014,7 @@ int nsk_set_option(nsk_ctx* c, const char* name, double value) {
   else if (n == "helm_guess") c->helm_guess = (int)value;
   else if (n == "early_pres_mul") c->early_pres_mul = value;
   else if (n == "proj_reset") c->d.proj_reset = (int)value;
+  else if (n == "pres_floor") c->d.tol_pres_floor = value;
   else if (n == "dbg") { int v = (int)value; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), &v, sizeof(int))); }
   else if (n == "budget_helm") { for (int k = 0; k < NCLS; ++k) c->cur_helm[k] = std::min(c->max_helm, std::max(1, (int)value)); }
   else if (n == "budget_pres") { for (int k = 0; k < NCLS; ++k) c->cur_pres[k] = std::min(c->max_pres, std::max(1, (int)value)); }

@@ -780,7 +780,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_gmres_update(Dev d, int j, doubl
     if (j < 0) {
       G->beta0 = hn; G->g[0] = hn; G->nit = 0; G->resid = hn * scale;
       if (d.nproj_max <= 0) G->gnorm0 = hn;
-      const double tol0 = d.tol_relative ? d.tol_pres * G->gnorm0 * scale : d.tol_pres;
+      const double tol0 = d.tol_relative ? fmax(d.tol_pres * G->gnorm0 * scale, d.tol_pres_floor) : d.tol_pres;
       const int dn = (!(hn > 0.0) || (min_iter <= 0 && hn * scale <= tol0)) ? 1 : 0;
       if (dn) d.stats->last_pres_res = hn * scale;
       G->done = dn;
@@ -805,7 +805,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_gmres_update(Dev d, int j, doubl
       G->nit = j + 1;
       const double res = fabs(sj * gj) * scale;
       G->resid = res;
-      const double tol = d.tol_relative ? d.tol_pres * G->gnorm0 * scale : d.tol_pres;
+      const double tol = d.tol_relative ? fmax(d.tol_pres * G->gnorm0 * scale, d.tol_pres_floor) : d.tol_pres;
       if ((res <= tol && (j + 1) >= min_iter) || !(hn > 0.0)) {
         atomicAdd((unsigned long long*)&d.stats->pres_iters, (unsigned long long)(j + 1));
         atomicMax((unsigned long long*)&d.stats->max_pres, (unsigned long long)(j + 1));
