@@ -798,8 +798,12 @@ static void budgets_update(nsk_ctx* c, const Stats& h) {
     // solves of steps 2-3: 4 to 23 iterations): spare launches there cost microseconds, a redone map 0.1 s
     const int xh = k <= 3 ? std::max(4, mh / 2) : (k == 4 ? 1 : 0), xp = k <= 3 ? std::max(4, mp) : (k == 4 ? 1 : 0);
     const int th = std::min(c->max_helm, mh + BHEAD + xh), tp = std::min(c->max_pres, mp + BHEAD + xp);
-    if (th > c->cur_helm[k] || (nv == BW ? th < c->cur_helm[k] - 1 : c->cur_helm[k] > 2 * th)) c->cur_helm[k] = th;
-    if (tp > c->cur_pres[k] || (nv == BW ? tp < c->cur_pres[k] - 1 : c->cur_pres[k] > 2 * tp)) c->cur_pres[k] = tp;
+    // before the window is full only the long classes are cut (their spare launches are what costs); the classes of
+    // steps 1-6 keep what they have: the second Krylov vector of a run can need 34 pressure iterations where the
+    // noise seed needed 4
+    const bool early = nv < BW && k >= 4;
+    if (th > c->cur_helm[k] || (nv == BW ? th < c->cur_helm[k] - 1 : (early && c->cur_helm[k] > 2 * th))) c->cur_helm[k] = th;
+    if (tp > c->cur_pres[k] || (nv == BW ? tp < c->cur_pres[k] - 1 : (early && c->cur_pres[k] > 2 * tp))) c->cur_pres[k] = tp;
   }
 }
 

@@ -9,7 +9,7 @@ lx1 = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 c0 = mesh.load_case_npz(os.path.join(ROOT, "tests/golden/cylinder_case.npz"), lx1)
 case = mesh.refine_case_2x2(c0)
 t0 = time.time()
-h = NekStabHip(case, case.meta["vert"], case.meta["nvert"], tol_helm=1e-11, tol_pres=1e-1, tol_relative=1, nproj=8,
+h = NekStabHip(case, case.meta["vert"], case.meta["nvert"], tol_helm=1e-10, tol_pres=2e-1, tol_relative=1, nproj=8,
                schwarz_layers=2, max_helm_iter=150, max_pres_iter=48)
 print("E=%d lx1=%d points/field=%d init %.1fs dt=%g nsteps=%d" % (case.nel, lx1, h.nvel, time.time() - t0, h.dt, h.nsteps), flush=True)
 qx, qy = seed.add_noise(case)
