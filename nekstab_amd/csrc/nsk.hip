@@ -645,8 +645,8 @@ static int build(nsk_ctx* c, const nsk_case& cs) {
 // one nek_advance() in perturbation mode
 // ---------------------------------------------------------------------------
 // hexahedral contexts: one workgroup sums each row of per-workgroup partials (Dev::use_tot)
-static inline void tot_rows(nsk_ctx* c, const double* part, int rows, double* tot) {
-  if (c->d.use_tot) hipLaunchKernelGGL(k_tot2, dim3(rows), dim3(256), 0, c->stream, part, c->nblk, tot);
+static inline void tot_rows(nsk_ctx* c, const double* part, int rows, double* tot, const int* gate = nullptr) {
+  if (c->d.use_tot) hipLaunchKernelGGL(k_tot2, dim3(rows), dim3(256), 0, c->stream, part, c->nblk, tot, gate);
 }
 
 // tolerance of the early time steps of a map: tightened, but never below 1e-4 (what 48 GMRES iterations deliver on every mesh)
@@ -678,11 +678,11 @@ static int pres_solve_launch(nsk_ctx* c, double h2, int ord, int np, double tol_
       }
       hipLaunchKernelGGL(k_schwarz<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, (const double*)(d.V + (size_t)j * d.ps), d.Z + (size_t)j * d.npr, 1, 1);
       hipLaunchKernelGGL(k_divgs<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, (const double*)d.yl, d.V + (size_t)(j + 1) * d.ps, j, 1);
-      if (c->ndim != 3) tot_rows(c, d.gpart, j + 2, d.gtot);
+      if (c->ndim != 3) tot_rows(c, d.gpart, j + 2, d.gtot, &d.gsc->done);
       if (c->ndim == 3) {
-        tot_rows(c, d.gpart, j + 2, d.gtot);
+        tot_rows(c, d.gpart, j + 2, d.gtot, &d.gsc->done);
         hipLaunchKernelGGL(k_gmres_reorth<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, j);
-        tot_rows(c, d.gpart2, j + 2, d.gtot2);
+        tot_rows(c, d.gpart2, j + 2, d.gtot2, &d.gsc->done);
       }
       hipLaunchKernelGGL(k_gmres_update<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, j, scale, c->min_pres, ord);
     }
@@ -797,7 +797,9 @@ static void budgets_update(nsk_ctx* c, const Stats& h) {
     // the classes of time steps 1..6 hold one to three steps per map and their counts vary most (pressure
     // solves of steps 2-3: 4 to 23 iterations): spare launches there cost microseconds, a redone map 0.1 s
     const int xh = k <= 3 ? std::max(4, mh / 2) : (k == 4 ? 1 : 0), xp = k <= 3 ? std::max(4, mp) : (k == 4 ? 1 : 0);
-    const int th = std::min(c->max_helm, mh + BHEAD + xh), tp = std::min(c->max_pres, mp + BHEAD + xp);
+    // the first maps of a run differ most from one another (noise seed, empty projection space): wider margin
+    const int sh = nv < 4 ? std::max(2, mh / 4) : 0, sp = nv < 4 ? std::max(4, mp) : 0;
+    const int th = std::min(c->max_helm, mh + BHEAD + xh + sh), tp = std::min(c->max_pres, mp + BHEAD + xp + sp);
     // before the window is full only the long classes are cut (their spare launches are what costs); the classes of
     // steps 1-6 keep what they have: the second Krylov vector of a run can need 34 pressure iterations where the
     // noise seed needed 4

@@ -1479,9 +1479,10 @@ __global__ void k_phalo_pack(const double* __restrict__ v, const int* __restrict
   if (k < n) sendbuf[k] = v[idx[k]];
 }
 // one workgroup per row of per-workgroup partials: tot[q] = sum_k part[q][k]  (fixed order)
-__global__ __launch_bounds__(256) void k_tot2(const double* __restrict__ part, int nblk, double* __restrict__ tot) {
+__global__ __launch_bounds__(256) void k_tot2(const double* __restrict__ part, int nblk, double* __restrict__ tot, const int* gate) {
   __shared__ double sred[16];
   const int q = blockIdx.x, tid = threadIdx.x;
+  if (gate && *gate) return;                     // GMRES rows of a solve that has converged
   double v[1] = {0.0};
   const double* row = part + (size_t)q * nblk;
   int k = tid;

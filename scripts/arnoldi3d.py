@@ -12,7 +12,7 @@ kdim = int(sys.argv[3]) if len(sys.argv) > 3 else 80
 c2 = mesh.load_case_npz(os.path.join(ROOT, "tests/golden/cylinder_case.npz"), lx1)
 c3 = mesh3d.extrude_case(c2, nz, 1.0 * nz, periodic=True)
 h = NekStabHip(c3, c3.meta["vert"], c3.meta["nvert"], tol_helm=1e-10, tol_pres=2e-1, tol_relative=1, nproj=8, max_helm_iter=150, max_pres_iter=48)
-h.set_option("proj_reset", int(os.environ.get("PROJ_RESET", "0")))
+if "PROJ_RESET" in os.environ: h.set_option("proj_reset", int(os.environ["PROJ_RESET"]))
 qx, qy = seed.add_noise(c2)
 rng = np.random.default_rng(1)
 zz = c3.z
