@@ -84,7 +84,7 @@ int nsk_set_tolerances(nsk_ctx* ctx, double tol_helm, double tol_pres, int relat
 /* run-time switches: "use_graph" (hipGraph replay of the step classes, default 1), "min_pres_iter",
  * "helm_guess" (extrapolated Helmholtz initial guess, default 1), "early_pres_mul" (pressure tolerance factor of
  * time steps 1-3 of every map, default 0.01: they project out the divergence of the input vector),
- * "proj_reset" (1: every map starts with an empty pressure projection space; default 0: the space carries over),
+ * "proj_reset" (1: every map starts with an empty pressure projection space: default on hexahedra; 0: the space carries over: default on quadrilaterals),
  * "pres_floor" (absolute floor under the relative pressure tolerance, in the scaled units of nsk_stats.last_pres_res; 0 = off),
  * "budget_helm" / "budget_pres" (launch budgets), "dbg" (developer ablation mask) */
 int nsk_set_option(nsk_ctx* ctx, const char* name, double value);
