@@ -81,7 +81,8 @@ int nsk_get_info(nsk_ctx* ctx, double* dt, int* nsteps, long long* nstate,
                  long long* nvel, long long* npres);
 int nsk_set_nsteps(nsk_ctx* ctx, int nsteps);   /* test hook: shorten the map (dt unchanged) */
 int nsk_set_tolerances(nsk_ctx* ctx, double tol_helm, double tol_pres, int relative);
-/* run-time switches: "use_graph" (hipGraph replay of the step classes, default 1), "min_pres_iter",
+/* run-time switches: "use_graph" (hipGraph replay of the step classes, default 1), "min_pres_iter" (at least this many
+ * GMRES iterations per pressure solve, default 0), "pres_cap" (at most this many in time steps >= 4, default 0 = none),
  * "helm_guess" (extrapolated Helmholtz initial guess, default 1), "early_pres_mul" (pressure tolerance factor of
  * time steps 1-3 of every map, default 0.01: they project out the divergence of the input vector),
  * "proj_reset" (1: every map starts with an empty pressure projection space: default on hexahedra; 0: the space carries over: default on quadrilaterals),

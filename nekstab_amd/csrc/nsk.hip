@@ -62,7 +62,7 @@ struct nsk_ctx {
   long long nloc = 0, npr = 0, nstate = 0;
   double dt = 0, re = 0, endtime = 0;
   int nsteps = 0;
-  int max_helm = 60, max_pres = 40, min_pres = 0, layers = 1;
+  int max_helm = 60, max_pres = 40, min_pres = 0, pres_cap = 0, layers = 1;
   int cur_helm[NCLS] = {}, cur_pres[NCLS] = {};       // adaptive launch budgets per BDF order
   int bh_helm[NCLS][8] = {}, bh_pres[NCLS][8] = {}, bh_n = 0;                         // iteration maxima of the last maps (budgets_update)
   int use_graph = 1;
@@ -657,6 +657,8 @@ static inline double early_tol(const Dev& d, double mul) {
 static int pres_solve_launch(nsk_ctx* c, double h2, int ord, int np, double tol_mul = 1.0) {
   Dev d = c->d;                                            // by value: the early steps of a map run with a tighter tolerance
   d.tol_pres = early_tol(d, tol_mul);
+  // time steps >= 4: optionally a bounded solve (min_pres_iter .. pres_cap iterations): nothing is launched beyond the cap
+  if (c->pres_cap > 0 && ord >= 3 && !c->in_test) { d.pres_cap = std::max(c->pres_cap, c->min_pres); np = std::min(np, d.pres_cap); }
   const double scale = 1.0 / (h2 * std::sqrt(d.vol));
   DISPATCH_N(c->key, {
     constexpr int NT = Cfg<N>::NT;
@@ -1017,6 +1019,7 @@ int nsk_set_option(nsk_ctx* c, const char* name, double value) {
   const std::string n(name);
   if (n == "use_graph") c->use_graph = (int)value;
   else if (n == "min_pres_iter") c->min_pres = (int)value;
+  else if (n == "pres_cap") c->pres_cap = (int)value;
   else if (n == "helm_guess") c->helm_guess = (int)value;
   else if (n == "early_pres_mul") c->early_pres_mul = value;
   else if (n == "proj_reset") c->d.proj_reset = (int)value;

@@ -64,6 +64,7 @@ struct Dev {
   double nu, dt, vol, tol_helm, tol_pres;
   int tol_relative, max_mr, has_outflow, nproj_max;
   int proj_reset;                // 1: every map starts with an empty pressure projection space
+  int pres_cap;                  // > 0: a pressure solve stops after this many GMRES iterations whatever its residual (set per launch)
   double tol_pres_floor;         // relative pressure tolerance never asks for less than this (units of GmresScal::resid); 0 = off
   // bases
   const double *D, *J12, *D12, *Jd, *Dd, *hat;

@@ -912,7 +912,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_gmres_update(Dev d, int j, doubl
       const double res = fabs(sj * gj) * scale;
       G->resid = res;
       const double tol = d.tol_relative ? fmax(d.tol_pres * G->gnorm0 * scale, d.tol_pres_floor) : d.tol_pres;
-      if ((res <= tol && (j + 1) >= min_iter) || !(hn > 0.0)) {
+      if ((res <= tol && (j + 1) >= min_iter) || !(hn > 0.0) || (d.pres_cap > 0 && (j + 1) >= d.pres_cap)) {
         atomicAdd((unsigned long long*)&d.stats->pres_iters, (unsigned long long)(j + 1));
         atomicMax((unsigned long long*)&d.stats->max_pres, (unsigned long long)(j + 1));
         atomicMax((unsigned long long*)&d.stats->max_pres_k[ord], (unsigned long long)(j + 1));
