@@ -145,6 +145,11 @@ typedef struct {
   long long max_helm_iter, max_pres_iter;   /* worst single solve */
   long long budget_helm, budget_pres;       /* iterations currently launched per solve */
   long long recaptures, retries;            /* graph re-captures / maps redone with larger budgets (since init) */
+  long long capped_solves;                  /* pressure solves ended by "pres_cap" above their tolerance (last matvec) */
+  double worst_cap_ratio;                   /* largest residual / tolerance among them */
+  long long total_capped_solves;            /* the same two since nsk_init */
+  double total_worst_cap_ratio;
+  long long total_helm_iters, total_pres_iters, total_steps;   /* since nsk_init: what bytes_per_matvec is computed from */
 } nsk_stats;
 int nsk_get_stats(nsk_ctx* ctx, nsk_stats* s);
 

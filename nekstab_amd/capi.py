@@ -39,7 +39,10 @@ class NskStats(C.Structure):
                 ("unconverged", C.c_longlong), ("last_helm_res", C.c_double), ("last_pres_res", C.c_double),
                 ("max_helm_iter", C.c_longlong), ("max_pres_iter", C.c_longlong),
                 ("budget_helm", C.c_longlong), ("budget_pres", C.c_longlong),
-                ("recaptures", C.c_longlong), ("retries", C.c_longlong)]
+                ("recaptures", C.c_longlong), ("retries", C.c_longlong),
+                ("capped_solves", C.c_longlong), ("worst_cap_ratio", C.c_double),
+                ("total_capped_solves", C.c_longlong), ("total_worst_cap_ratio", C.c_double),
+                ("total_helm_iters", C.c_longlong), ("total_pres_iters", C.c_longlong), ("total_steps", C.c_longlong)]
 
 
 # every symbol include/nekstab_hip.h declares: (restype, argtypes)
@@ -271,6 +274,10 @@ class NekStabHip:
         yi = np.ascontiguousarray(np.imag(y), dtype=np.float64)
         arr = (C.c_void_p * k)(*[v.value for v in Q])
         self._chk(self.lib.nsk_basis_gemv(self.ctx, arr, k, _p(yr), _p(yi) if im is not None else None, re, im))
+
+    def seed_noise(self, v):
+        """add_noise (core/utils.f:344-408) on the device."""
+        self._chk(self.lib.nsk_seed_noise(self.ctx, v))
 
     def set_nsteps(self, n):
         self._chk(self.lib.nsk_set_nsteps(self.ctx, n))

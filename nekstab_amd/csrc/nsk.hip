@@ -70,9 +70,13 @@ struct nsk_ctx {
   int helm_guess = 1;
   double early_pres_mul = 1e-2;         // pressure tolerance factor of time steps 1-3 of every map
   long long recaptures = 0, retries = 0;
+  // since init (nsk_stats: the per-matvec fields are reset by every nsk_matvec, these are not)
+  long long tot_capped = 0, tot_helm_iters = 0, tot_pres_iters = 0, tot_steps = 0;
+  double tot_worst_cap = 0.0;
   int debug = 0;
   struct StepGraph { hipGraphExec_t exec = nullptr; int nh = -1, np = -1; } graphs[3][NCLS];
   double* scratch = nullptr;            // one state vector
+  const double* xyz = nullptr;          // GLL coordinates [ndim][nloc] (nsk_seed_noise)
   double* rc_big = nullptr;             // coarse restriction for nvert > 3072
   Dev d{};
   Stats hstats{};
@@ -430,6 +434,11 @@ static int build(nsk_ctx* c, const nsk_case& cs) {
       (rc = dupload(c, &d.gs_idx, gs_idx)) || (rc = dupload(c, &d.rxd, rxdA)) || (rc = dupload(c, &d.ryd, rydA)) ||
       (rc = dupload(c, &d.sxd, sxdA)) || (rc = dupload(c, &d.syd, sydA))) return rc;
   d.nl_spng_str = 0.0; d.spng_vr = nullptr; d.bstep = nullptr; d.bf_stride = 0;
+  {
+    std::vector<double> xy((size_t)2 * nloc);
+    std::copy(cs.x, cs.x + nloc, xy.begin()); std::copy(cs.y, cs.y + nloc, xy.begin() + nloc);
+    if ((rc = dupload(c, &c->xyz, xy))) return rc;
+  }
 
   // ---- state + solver work arrays
   if ((rc = dalloc(c, &d.u, 2 * d.cs)) || (rc = dalloc(c, &d.p, npr)) || (rc = dalloc(c, &d.plag, npr)) ||
@@ -654,11 +663,13 @@ static inline double early_tol(const Dev& d, double mul) {
   return d.tol_relative ? std::max(d.tol_pres * mul, std::min(d.tol_pres, 1e-4)) : d.tol_pres;
 }
 
-static int pres_solve_launch(nsk_ctx* c, double h2, int ord, int np, double tol_mul = 1.0) {
+static int pres_solve_launch(nsk_ctx* c, double h2, int ord, int np, double tol_mul = 1.0, bool allow_cap = false) {
   Dev d = c->d;                                            // by value: the early steps of a map run with a tighter tolerance
   d.tol_pres = early_tol(d, tol_mul);
   // time steps >= 4: optionally a bounded solve (min_pres_iter .. pres_cap iterations): nothing is launched beyond the cap
-  if (c->pres_cap > 0 && ord >= 3 && !c->in_test) { d.pres_cap = std::max(c->pres_cap, c->min_pres); np = std::min(np, d.pres_cap); }
+  if (c->pres_cap > 0 && ord >= 3 && allow_cap && c->ndim == 2) {   // validated on quadrilateral linearised maps only
+    d.pres_cap = std::max(c->pres_cap, c->min_pres); np = std::min(np, d.pres_cap);
+  }
   const double scale = 1.0 / (h2 * std::sqrt(d.vol));
   DISPATCH_N(c->key, {
     constexpr int NT = Cfg<N>::NT;
@@ -708,7 +719,7 @@ static int step(nsk_ctx* c, int istep, int adjoint) {
   });
   // The first steps of a map project out whatever divergence the input vector has (a noise seed is far from
   // solenoidal): an error there survives to the end of the map, so those solves are converged further.
-  int rc = pres_solve_launch(c, sc.h2, sc.cls, c->cur_pres[sc.cls], istep <= 3 ? c->early_pres_mul : 1.0);
+  int rc = pres_solve_launch(c, sc.h2, sc.cls, c->cur_pres[sc.cls], istep <= 3 ? c->early_pres_mul : 1.0, adjoint != 2);
   if (rc) return rc;
   DISPATCH_N(c->key, {
     hipLaunchKernelGGL(k_pres_update<N>, dim3(c->nblk), dim3(Cfg<N>::NT), 0, c->stream, d, sc);
@@ -830,6 +841,9 @@ static int run_map_adaptive(nsk_ctx* c, int adjoint, double* f, const double* q)
     c->hstats.helm_iters += h.helm_iters; c->hstats.pres_iters += h.pres_iters; c->hstats.steps += c->nsteps;
     c->hstats.max_helm = std::max(c->hstats.max_helm, h.max_helm); c->hstats.max_pres = std::max(c->hstats.max_pres, h.max_pres);
     c->hstats.last_helm_res = h.last_helm_res; c->hstats.last_pres_res = h.last_pres_res;
+    c->hstats.capped_solves += h.capped_solves; c->hstats.worst_cap_ratio = std::max(c->hstats.worst_cap_ratio, h.worst_cap_ratio);
+    c->tot_capped += h.capped_solves; c->tot_worst_cap = std::max(c->tot_worst_cap, h.worst_cap_ratio);
+    c->tot_helm_iters += h.helm_iters; c->tot_pres_iters += h.pres_iters; c->tot_steps += c->nsteps;
     for (int k = 0; k < NCLS; ++k) {
       c->hstats.max_helm_k[k] = std::max(c->hstats.max_helm_k[k], h.max_helm_k[k]);
       c->hstats.max_pres_k[k] = std::max(c->hstats.max_pres_k[k], h.max_pres_k[k]);
@@ -1019,7 +1033,10 @@ int nsk_set_option(nsk_ctx* c, const char* name, double value) {
   const std::string n(name);
   if (n == "use_graph") c->use_graph = (int)value;
   else if (n == "min_pres_iter") c->min_pres = (int)value;
-  else if (n == "pres_cap") c->pres_cap = (int)value;
+  else if (n == "pres_cap") {
+    if (value > 0 && c->ndim != 2) return fail(NSK_EINVAL, "pres_cap is validated on quadrilateral linearised maps only (DESIGN.md section 1)");
+    c->pres_cap = (int)value;
+  }
   else if (n == "helm_guess") c->helm_guess = (int)value;
   else if (n == "early_pres_mul") c->early_pres_mul = value;
   else if (n == "proj_reset") c->d.proj_reset = (int)value;
@@ -1109,6 +1126,9 @@ int nsk_get_stats(nsk_ctx* c, nsk_stats* s) {
   s->max_helm_iter = h.max_helm; s->max_pres_iter = h.max_pres;
   s->budget_helm = c->cur_helm[5]; s->budget_pres = c->cur_pres[5];
   s->recaptures = c->recaptures; s->retries = c->retries;
+  s->capped_solves = h.capped_solves; s->worst_cap_ratio = h.worst_cap_ratio;
+  s->total_capped_solves = c->tot_capped; s->total_worst_cap_ratio = c->tot_worst_cap;
+  s->total_helm_iters = c->tot_helm_iters; s->total_pres_iters = c->tot_pres_iters; s->total_steps = c->tot_steps;
   return 0;
 }
 
@@ -1358,8 +1378,16 @@ int nsk_basis_gemv(nsk_ctx* c, const nsk_vec* Q, int k, const double* y_re, cons
 }
 
 int nsk_seed_noise(nsk_ctx* c, nsk_vec v) {
-  (void)c; (void)v;
-  return fail(NSK_EINVAL, "nsk_seed_noise: build the seed on the host (nekstab_amd.seed) and upload it");
+  if (!c || !v) return fail(NSK_EINVAL, "bad argument");
+  if (c->parent) return fail(NSK_EINVAL, "nsk_seed_noise: seed the full-mesh context and scatter (shards do not hold the global element ids)");
+  if (!c->xyz) return fail(NSK_EINVAL, "context holds no coordinates");
+  double* q = (double*)v;
+  const unsigned grid = (unsigned)((c->nloc + 255) / 256);
+  HIPCHK(hipMemsetAsync(q, 0, c->nstate * sizeof(double), c->stream));                // pressure (and scalars): zero
+  hipLaunchKernelGGL(k_seed_rand, dim3(grid), dim3(256), 0, c->stream, (const double*)c->xyz, c->nloc, c->ndim, c->N, q);
+  hipLaunchKernelGGL(k_seed_avg, dim3(grid), dim3(256), 0, c->stream, c->d, (const double*)q, c->scratch, 0);
+  hipLaunchKernelGGL(k_seed_avg, dim3(grid), dim3(256), 0, c->stream, c->d, (const double*)c->scratch, q, 1);
+  return 0;
 }
 
 // diagnostic (NSK_STAMPS build): run `reps` full pressure iterations' k_divgs and dump the stamps

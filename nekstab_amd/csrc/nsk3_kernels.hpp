@@ -811,6 +811,10 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_gmres_update(Dev d, int j, doubl
         atomicMax((unsigned long long*)&d.stats->max_pres, (unsigned long long)(j + 1));
         atomicMax((unsigned long long*)&d.stats->max_pres_k[ord], (unsigned long long)(j + 1));
         d.stats->last_pres_res = res;
+        if (!(res <= tol) && hn > 0.0) {           // ended by the cap, not by its tolerance: counted, never silent
+          d.stats->capped_solves += 1;
+          if (res / tol > d.stats->worst_cap_ratio) d.stats->worst_cap_ratio = res / tol;
+        }
         G->done = 1;
       }
     }

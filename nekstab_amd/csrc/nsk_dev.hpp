@@ -53,6 +53,8 @@ struct Stats {
   long long max_helm, max_pres;
   long long max_helm_k[NCLS], max_pres_k[NCLS];   // per step class (separate graphs, separate budgets)
   double last_helm_res, last_pres_res;
+  long long capped_solves;                        // pressure solves ended by `pres_cap` above their tolerance
+  double worst_cap_ratio;                         // largest residual / tolerance among them
 };
 
 struct Dev {

@@ -917,6 +917,10 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_gmres_update(Dev d, int j, doubl
         atomicMax((unsigned long long*)&d.stats->max_pres, (unsigned long long)(j + 1));
         atomicMax((unsigned long long*)&d.stats->max_pres_k[ord], (unsigned long long)(j + 1));
         d.stats->last_pres_res = res;
+        if (!(res <= tol) && hn > 0.0) {           // ended by the cap, not by its tolerance: counted, never silent
+          d.stats->capped_solves += 1;
+          if (res / tol > d.stats->worst_cap_ratio) d.stats->worst_cap_ratio = res / tol;
+        }
         G->done = 1;
       }
     }
@@ -1400,6 +1404,47 @@ __global__ void k_axpby(double* __restrict__ y, double a, const double* __restri
 __global__ void k_scale_rsqrt(double* __restrict__ y, const double* __restrict__ nrm2, long long n) {
   const long long l = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (l < n) y[l] *= 1.0 / sqrt(*nrm2);
+}
+
+// add_noise seed (core/utils.f:344-408) with mth_rand (:457-469): one thread per GLL node.  The chain
+// 1e3 sin(1e3 sin(r)) amplifies a last-bit difference in r by 1e6, so the operations follow the host mirror
+// (nekstab_amd/seed.py) one by one and fused multiply-adds are off: both then differ by the rounding of sin/cos only.
+__global__ void k_seed_rand(const double* __restrict__ xyz, long long nloc, int ndim, int N, double* __restrict__ out) {
+#pragma clang fp contract(off)
+  const long long l = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= nloc) return;
+  const int per = (ndim == 3) ? N * N * N : N * N;
+  const double ieg = (double)(l / per + 1);                        // LGLEL: global element id, 1-based
+  const int nd = (int)(l % per);
+  const double ix = (double)(nd % N + 1), iy = (double)((nd / N) % N + 1), iz = (double)(nd / (N * N) + 1);
+  const double x = xyz[l], y = xyz[nloc + l], z = (ndim == 3) ? xyz[2 * nloc + l] : 0.0;
+  const double FC[3][3] = {{3.0e4, -1.5e3, 0.5e5}, {2.3e4, 2.3e3, -2.0e5}, {2.0e4, 1.0e3, 1.0e5}};
+  for (int c = 0; c < ndim; ++c) {
+    const double t0 = x * sin(y);
+    const double t1 = FC[c][0] * (ieg + t0);
+    const double t2 = (FC[c][1] * ix) * iy;
+    const double t3 = FC[c][2] * ix;
+    double r = (t1 + t2) + t3;
+    if (ndim == 3) {
+      const double u0 = z * sin(r);
+      const double u1 = FC[c][0] * (ieg + u0);
+      const double u2 = (FC[c][1] * iz) * ix;
+      const double u3 = FC[c][2] * iz;
+      r = (u1 + u2) + u3;
+    }
+    r = 1.0e3 * sin(r);
+    r = 1.0e3 * sin(r);
+    out[(size_t)c * nloc + l] = cos(r);
+  }
+}
+// face averaging of add_noise: pass 0: t = (dssum(q) / mult) / mult ; pass 1: q = mask * dssum(t)   (opdssum, opcolv(vmult), dsavg, bcdirvc)
+__global__ void k_seed_avg(Dev d, const double* __restrict__ in, double* __restrict__ out, int pass) {
+  const long long l = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= d.nloc) return;
+  for (int c = 0; c < d.ndim; ++c) {
+    const double s = gs_gather(in + (size_t)c * d.nloc, d, l);
+    out[(size_t)c * d.nloc + l] = pass ? d.mask[l] * s : (s * d.minv[l]) * d.minv[l];
+  }
 }
 
 // out_c = sum_k Q_k * Z[k][c]  for c < nc   (basis rotation / mode assembly)

@@ -1,27 +1,39 @@
 """nekStab's deterministic pseudo-noise seed, restated on the host
 (``add_noise`` + ``mth_rand``, core/utils.f:344-408, :457-469): per-node value from
-(i, j, global element id, coordinates), then dssum / multiplicity average and the
-Dirichlet mask. Used once per run; not on the device path."""
+(i, j, k, global element id, coordinates), then dssum / multiplicity average and the
+Dirichlet mask.  The device version is ``nsk_seed_noise`` (same operation order, no fused
+multiply-adds); this one is the host mirror the tests compare it with."""
 from __future__ import annotations
 
 import numpy as np
 
+# fcoeff triples of add_noise (core/utils.f:372-381): qx, qy, qz
+FCOEFF = ((3.0e4, -1.5e3, 0.5e5), (2.3e4, 2.3e3, -2.0e5), (2.0e4, 1.0e3, 1.0e5))
 
-def _mth_rand(ix, iy, ieg, x, y, fc):
-    r = fc[0] * (ieg + x * np.sin(y)) + fc[1] * ix * iy + fc[2] * ix
+
+def _mth_rand(ix, iy, iz, ieg, xl, fc):
+    """core/utils.f:457-469; ``xl`` = (x, y) or (x, y, z)."""
+    r = fc[0] * (ieg + xl[0] * np.sin(xl[1])) + fc[1] * ix * iy + fc[2] * ix
+    if len(xl) == 3:                                   # IF3D branch (:463)
+        r = fc[0] * (ieg + xl[2] * np.sin(r)) + fc[1] * iz * ix + fc[2] * iz
     r = 1.0e3 * np.sin(r)
     r = 1.0e3 * np.sin(r)
     return np.cos(r)
 
 
 def add_noise(case):
-    """Returns (qx, qy) shaped (nel, lx1, lx1)."""
+    """Returns (qx, qy) shaped (nel, lx1, lx1), or (qx, qy, qz) shaped (nel, lx1, lx1, lx1) for hexahedra."""
     n = case.lx1
-    ix = np.arange(1, n + 1)[None, None, :] * np.ones((1, n, 1))
-    iy = np.arange(1, n + 1)[None, :, None] * np.ones((1, 1, n))
-    ieg = np.arange(1, case.nel + 1)[:, None, None]
-    qx = _mth_rand(ix, iy, ieg, case.x, case.y, (3.0e4, -1.5e3, 0.5e5))
-    qy = _mth_rand(ix, iy, ieg, case.x, case.y, (2.3e4, 2.3e3, -2.0e5))
+    nd = int(getattr(case, "ndim", 2))
+    ieg = np.arange(1, case.nel + 1).reshape((case.nel,) + (1,) * nd)
+    one = np.ones((1,) + (n,) * nd)
+    idx = np.arange(1, n + 1, dtype=np.float64)
+    if nd == 2:
+        ix, iy, iz = idx[None, None, :] * one, idx[None, :, None] * one, None
+        xl = (case.x, case.y)
+    else:
+        ix, iy, iz = idx[None, None, None, :] * one, idx[None, None, :, None] * one, idx[None, :, None, None] * one
+        xl = (case.x, case.y, case.z)
     g = case.gid.ravel()
     mult = np.bincount(g, minlength=case.nglob)[case.gid]
 
@@ -29,8 +41,9 @@ def add_noise(case):
         return np.bincount(g, weights=f.ravel(), minlength=case.nglob)[case.gid]
 
     out = []
-    for q in (qx, qy):
+    for c in range(nd):
+        q = _mth_rand(ix, iy, iz, ieg, xl, FCOEFF[c])
         q = dssum(q) / mult            # opdssum + opcolv(vmult)
         q = dssum(q / mult)            # dsavg
         out.append(q * case.mask)      # bcdirvc
-    return out[0], out[1]
+    return tuple(out)

@@ -111,7 +111,7 @@ class LinNS2D:
     PnPn-2 spectral elements, BDFk/EXTk with per-matvec order ramp, 2-D."""
 
     def __init__(self, *, x, y, gid, nglob, mask, ub, spng, re, endtime, cfl=0.5,
-                 lxd=None, has_outflow=True, build_solvers=True):
+                 lxd=None, has_outflow=True, build_solvers=True, factorize_pressure=True):
         self.nel, self.n = x.shape[0], x.shape[-1]
         n = self.n
         self.m = n - 2
@@ -164,6 +164,7 @@ class LinNS2D:
         self.npr = self.nel * self.m * self.m
         self._helm = {}
         self._E = None
+        self._factorize_pressure = factorize_pressure     # False: assemble E only (oracle/cpu_port.py needs the matrix, not its LU)
         if build_solvers:
             self._build_pressure_solver()
 
@@ -284,6 +285,8 @@ class LinNS2D:
         Wg = sp.diags(binv_g * self.gmask)
         E = sum(G @ Wg @ G.T for G in Gs).tocsc()       # D B^-1 D^T (without 1/h2)
         self._Emat = E
+        if not self._factorize_pressure:
+            return
         if self.has_outflow:
             self._E = spla.splu(E)
         else:

@@ -123,3 +123,48 @@ def test_partition_rcb(case6, nranks):
         return int(np.sum((owners & (owners - 1)) != 0))
     rng = np.random.default_rng(0)
     assert interface_nodes(p) < 0.2 * interface_nodes(rng.permutation(p))
+
+
+def test_spectre_info_manifest(tmp_path, case6):
+    """Spectre_<op>.info (core/eigensolvers.f:664-717): same keys, order and edit descriptors as the reference."""
+    from types import SimpleNamespace
+    from nekstab_amd import outpost
+    be = SimpleNamespace(nsteps=100, dt=0.01)
+    res = SimpleNamespace(H=np.zeros((201, 200)), schur_cnt=3)
+    f = str(tmp_path / "Spectre_d.info")
+    outpost.write_info(f, be, case6, res, evop="d", sampling_period=1.0, eigen_tol=1e-6, schur_tgt=2, schur_del=0.1,
+                       outposted=10, uparam=[3.1, 0, 0, 5.0, 5.0, 1.7], tol_pres=1e-7, tol_vel=1e-9, nranks=4)
+    lines = open(f).read().splitlines()
+    assert lines[2] == "[mesh]" and lines[3] == "lx1=             " + "%16d" % 6
+    assert lines[5] == "tot elemts=      " + "%16d" % 1996 and lines[8] == "e/rank=          " + "%16d" % 499
+    assert lines[9] == "[userParams]" and lines[10] == "uparam01=        " + "  3.100000000000"
+    assert lines[20] == "[solver]" and lines[23] == "dt=              " + "  0.1000000E-01"       # (A,E15.7)
+    assert lines[25] == "residualTol PRE= " + "   0.1000E-06"                                      # (A,E13.4)
+    assert lines[27] == "[eigensolver]" and lines[29] == "k_dim=           " + "%16d" % 200
+    assert lines[-1] == "outposted=       " + "%16d" % 10 and len(lines) == 35
+    info = outpost.read_info(f)
+    assert int(info["schur iterations"]) == 3 and float(info["Re"]) == 50.0 and int(info["nsteps"]) == 100
+
+
+def test_seed_hexahedral_branch():
+    """mth_rand's IF3D branch (core/utils.f:463) in the host mirror: deterministic, single-valued on shared nodes,
+    masked, and different from the planar formula."""
+    from types import SimpleNamespace
+    from nekstab_amd import seed
+    n, nel = 4, 2
+    z1 = np.linspace(0.0, 1.0, n)
+    x = np.zeros((nel, n, n, n)); y = np.zeros_like(x); z = np.zeros_like(x)
+    for e in range(nel):
+        x[e] = e + z1[None, None, :]; y[e] = z1[None, :, None]; z[e] = z1[:, None, None]
+    key = np.round(x * 3).astype(np.int64) * 100 + np.round(y * 3).astype(np.int64) * 10 + np.round(z * 3).astype(np.int64)
+    _, gid = np.unique(key, return_inverse=True)
+    gid = gid.reshape(x.shape)
+    mask = np.ones_like(x); mask[x == 0.0] = 0.0
+    c = SimpleNamespace(ndim=3, nel=nel, lx1=n, x=x, y=y, z=z, gid=gid, nglob=int(gid.max()) + 1, mask=mask)
+    a = seed.add_noise(c); b = seed.add_noise(c)
+    assert len(a) == 3 and all(np.array_equal(p, q) for p, q in zip(a, b))
+    g = np.zeros(c.nglob); g[gid.ravel()] = a[2].ravel()
+    assert np.array_equal(g[gid], a[2]) and np.all(a[0][mask == 0] == 0)
+    r2 = seed._mth_rand(1.0, 2.0, None, 1.0, (0.3, 0.4), seed.FCOEFF[0])
+    r3 = seed._mth_rand(1.0, 2.0, 3.0, 1.0, (0.3, 0.4, 0.5), seed.FCOEFF[0])
+    assert abs(r2) <= 1 and abs(r3) <= 1 and r2 != r3

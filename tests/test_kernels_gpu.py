@@ -90,3 +90,30 @@ def test_pres_solve(hip6, oracle6, fields):
     ref = o.E_solve(g)
     print("pressure iterations", it)
     assert rel(x, ref) < 1e-7
+
+
+def test_seed_noise_on_device(hip6, case6):
+    """nsk_seed_noise = add_noise + mth_rand (core/utils.f:344-408, :457-469) on the device against the host mirror.
+    mth_rand is chaotic by construction: r ~ 6e7 has an ulp of 7e-9 and cos(1e3 sin(1e3 sin(r))) turns one ulp of r into
+    7e-3, one ulp of the first sine into 1e-10.  The device's and numpy's sin differ in the last bit for some arguments,
+    so the two versions cannot agree bit for bit; with the same operation order and fused multiply-adds off they agree
+    to 1e-8 on all but a few per cent of the nodes (those where sin(y) differs by an ulp and r rounds the other way)."""
+    from nekstab_amd import seed
+    qx, qy = seed.add_noise(case6)
+    v, v2 = hip6.alloc(2)
+    hip6.seed_noise(v)
+    hip6.seed_noise(v2)
+    gx, gy, gp = hip6.download(v)
+    hx, hy, _ = hip6.download(v2)
+    assert np.array_equal(gx, hx) and np.array_equal(gy, hy)                   # deterministic
+    for g, q in ((gx, qx), (gy, qy)):
+        d = np.abs(g - q)
+        frac = float(np.mean(d > 1e-8))
+        print("seed: nodes off by more than 1e-8: %.3f %%, max diff %.2e, median %.1e" % (100 * frac, d.max(), np.median(d)))
+        assert frac < 0.05 and np.median(d) < 1e-9
+        assert np.abs(g).max() <= 1.0 + 1e-12 and np.abs(g).max() > 0.5
+        gl = np.zeros(case6.nglob); gl[case6.gid.ravel()] = g.ravel()
+        assert np.array_equal(gl[case6.gid], g)                                 # single-valued on shared nodes (dsavg)
+        assert np.all(g[case6.mask == 0] == 0.0)                                # bcdirvc
+    assert np.all(gp == 0.0)
+    hip6.free([v, v2])

@@ -111,3 +111,27 @@ def test_oracle_pins_on_the_other_reference_geometries():
     assert abs(o2.bm1.sum() - 1.2) < 1e-12                       # [-0.5,0.5] x [0,1.2]
     lid = np.isclose(c2.y, 1.2) & (np.abs(c2.x) < 0.499)
     assert np.all(c2.ub[0][lid] == 1.0) and np.all(c2.mask[lid] == 0.0)
+
+
+def test_cpu_port_matches_oracle(case6, oracle6, modes):
+    """oracle/cpu_step.c (C + OpenMP, iterative solves: what bench.py times as cpu_baseline) against the numpy oracle
+    (sparse direct solves) on the reference's eigenmode: two independent restatements of the same step."""
+    from oracle.cpu_port import CpuPort
+    o = oracle6
+    cp = CpuPort(o, case6.meta["vert"], case6.meta["nvert"], tol_helm=1e-13, tol_pres=1e-13, tol_relative=0)
+    u = modes["dRe_u"].astype(np.float64)
+    q = (u[0], u[1], o.J12 @ modes["dRe_p"].astype(np.float64) @ o.J12.T)
+    f = cp.matvec(q, nsteps=4)
+    ref = o.matvec(q, nsteps=4)
+    num = sum(np.sum(o.bm1 * (a - b) ** 2) for a, b in zip(f[:2], ref[:2]))
+    den = sum(np.sum(o.bm1 * b ** 2) for b in ref[:2])
+    assert np.sqrt(num / den) < 2e-9, np.sqrt(num / den)
+    assert np.abs(f[2] - ref[2]).max() / np.abs(ref[2]).max() < 1e-5
+    assert cp.stats["unconverged"] == 0 and cp.stats["steps"] == 4
+    # thread count does not change the answer beyond reduction-order rounding
+    cp.set_threads(1)
+    f1 = cp.matvec(q, nsteps=2)
+    cp.set_threads(cp.max_threads())
+    cp.set_threads(4)
+    f4 = cp.matvec(q, nsteps=2)
+    assert max(np.abs(a - b).max() for a, b in zip(f1[:2], f4[:2])) < 1e-12
