@@ -87,7 +87,9 @@ int nsk_set_tolerances(nsk_ctx* ctx, double tol_helm, double tol_pres, int relat
  * time steps 1-3 of every map, default 0.01: they project out the divergence of the input vector),
  * "proj_reset" (1: every map starts with an empty pressure projection space: default on hexahedra; 0: the space carries over: default on quadrilaterals),
  * "pres_floor" (absolute floor under the relative pressure tolerance, in the scaled units of nsk_stats.last_pres_res; 0 = off),
- * "budget_helm" / "budget_pres" (launch budgets), "dbg" (developer ablation mask) */
+ * "budget_helm" / "budget_pres" (launch budgets), "fused" (persistent velocity solve: right-hand side, all CG iterations and
+ * the pressure right-hand side in one launch with device-side grid barriers; default 0: not faster on config 2),
+ * "dbg" (developer ablation mask) */
 int nsk_set_option(nsk_ctx* ctx, const char* name, double value);
 
 /* allocate(Q(k_dim+1)) (core/eigensolvers.f:170) */
@@ -164,6 +166,13 @@ int nsk_shard_create(nsk_ctx* parent, const int* part, int rank, int nranks, nsk
 int nsk_group_matvec(nsk_ctx** shards, int n, int mode, nsk_vec* f, nsk_vec* q);
 /* RCCL transport, one process per GPU: rank 0 creates the id, everybody calls init on its shard;
  * afterwards nsk_group_matvec(&shard, 1, ...) exchanges halos / all-reduces over xGMI. */
+/* Host-staged transport for ranks in separate processes WITHOUT RCCL (any host message layer: MPI, torch.distributed gloo;
+ * what lets several ranks share one GPU in the tests): the library packs on the device, copies to pinned host buffers and
+ * calls back.  exchange: send[k] / recv[k] hold counts[k] doubles for peer peers[k] (both directions have the same count);
+ * allreduce: sum buf[0..n) over all ranks in place.  Return 0 on success. */
+typedef int (*nsk_exchange_fn)(void* user, int npeers, const int* peers, const int* counts, const double* const* send, double* const* recv);
+typedef int (*nsk_allreduce_fn)(void* user, double* buf, int n);
+int nsk_comm_init_host(nsk_ctx* shard, nsk_exchange_fn exchange, nsk_allreduce_fn allreduce, void* user);
 int nsk_comm_unique_id(unsigned char* out128);
 int nsk_comm_init_rccl(nsk_ctx* shard, const unsigned char* id128);
 int nsk_allreduce_host(nsk_ctx* shard, double* buf, int n);

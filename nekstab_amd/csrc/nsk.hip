@@ -21,6 +21,7 @@
 #include "../../include/nekstab_hip.h"
 #include "nsk_basis.hpp"
 #include "nsk_kernels.hpp"
+#include "nsk_persist.hpp"
 #include "nsk3_kernels.hpp"
 
 using namespace nsk;
@@ -66,6 +67,8 @@ struct nsk_ctx {
   int cur_helm[NCLS] = {}, cur_pres[NCLS] = {};       // adaptive launch budgets per BDF order
   int bh_helm[NCLS][8] = {}, bh_pres[NCLS][8] = {}, bh_n = 0;                         // iteration maxima of the last maps (budgets_update)
   int use_graph = 1;
+  int fused = 0;                        // persistent velocity solve (k_helm_fused): one launch per time step instead of one per CG iteration
+  unsigned* sync = nullptr;             // grid-barrier counters of the persistent kernels
   int in_test = 0;
   int helm_guess = 1;
   double early_pres_mul = 1e-2;         // pressure tolerance factor of time steps 1-3 of every map
@@ -108,6 +111,9 @@ struct nsk_ctx {
   double *psend = nullptr, *precv = nullptr;
   double* rc_part = nullptr;                            // coarse restriction (all vertices), summed over ranks
   void* comm = nullptr;                                 // ncclComm_t when ranks are real processes
+  // host-staged transport (nsk_comm_init_host): ranks in separate processes without RCCL, e.g. several ranks on one GPU
+  nsk_exchange_fn host_xchg = nullptr; nsk_allreduce_fn host_allred = nullptr; void* host_user = nullptr;
+  double *hs_send = nullptr, *hs_recv = nullptr; size_t hs_cap = 0;
   // ---- time-periodic base flow (Floquet)
   double* orbit[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   const double* steady[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -213,6 +219,7 @@ __global__ void k_gj_update(double* __restrict__ A, int n, int k, const double* 
 // ---------------------------------------------------------------------------
 // nsk_init
 // ---------------------------------------------------------------------------
+static int fused_possible(nsk_ctx* c);
 static int build(nsk_ctx* c, const nsk_case& cs) {
   const int N = cs.lx1, NN = N * N, M = N - 2, MM = M * M, ND = cs.lxd > 0 ? cs.lxd : 3 * N / 2, NDD = ND * ND;
   if (cs.ndim != 2) return fail(NSK_EINVAL, "build(): ndim must be 2");
@@ -642,6 +649,11 @@ static int build(nsk_ctx* c, const nsk_case& cs) {
   }
   for (int k = 0; k < NCLS; ++k) { c->cur_helm[k] = c->max_helm; c->cur_pres[k] = c->max_pres; }
   c->bh_n = 0;
+  if ((rc = dalloc(c, &c->sync, SYNC_WORDS))) return rc;
+  // persistent velocity solve: available where the grid is resident, OFF by default -- measured on config 2 it is not faster
+  // than the launch-per-iteration form (13.6 vs 13.5 us per CG iteration: DESIGN.md section 5); option "fused" / NSK_FUSED=1
+  c->fused = 0;
+  if (const char* g = std::getenv("NSK_FUSED")) c->fused = std::atoi(g) && fused_possible(c);
   if (const char* g = std::getenv("NSK_USE_GRAPH")) c->use_graph = std::atoi(g);
   if (const char* g = std::getenv("NSK_DEBUG")) c->debug = std::atoi(g);
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -703,6 +715,33 @@ static int pres_solve_launch(nsk_ctx* c, double h2, int ord, int np, double tol_
   return 0;
 }
 
+// ---- persistent velocity solve (nsk_persist.hpp): only the quadrilateral kernel set has it
+namespace nsk { namespace k3 { template <int N> __global__ void k_helm_fused(Dev, StepCoef, int, unsigned*) {} } }
+template <int N>
+static void launch_fused(nsk_ctx* c, const StepCoef& sc, int max_it = -1, const Dev* dd = nullptr) {
+  if (c->ndim != 2) return;
+  hipLaunchKernelGGL(nsk::k2::k_helm_fused<N>, dim3(c->nblk), dim3(nsk::k2::Cfg<N>::NT), 0, c->stream, dd ? *dd : c->d, sc,
+                     max_it < 0 ? c->max_helm : max_it, c->sync);
+}
+// Can every workgroup of the grid be resident at once?  (grid barrier => all or nothing.)  The occupancy query can be
+// one block per CU high at 81..112 SGPRs (MI355X_MICROARCH.md, residency), so one block per CU of margin is kept.
+static int fused_possible(nsk_ctx* c) {
+  if (c->ndim != 2 || c->parent || c->d.use_tot || c->d.nranks > 1) return 0;
+  int ncu = 0, dev = 0, per = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+  hipError_t e = hipErrorUnknown;
+  switch (c->N) {
+    case 6: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, nsk::k2::k_helm_fused<6>, nsk::k2::Cfg<6>::NT, 0); break;
+    case 8: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, nsk::k2::k_helm_fused<8>, nsk::k2::Cfg<8>::NT, 0); break;
+    case 10: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, nsk::k2::k_helm_fused<10>, nsk::k2::Cfg<10>::NT, 0); break;
+    case 12: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, nsk::k2::k_helm_fused<12>, nsk::k2::Cfg<12>::NT, 0); break;
+    default: return 0;
+  }
+  if (e != hipSuccess || per < 2 || ncu < 1) return 0;
+  const int need = (c->nblk + ncu - 1) / ncu;
+  return need <= std::min(per, 5);      // 5: what ~110 SGPRs admit (floor(800 / 128) = 6) minus one
+}
+
 static int step(nsk_ctx* c, int istep, int adjoint) {
   Dev& d = c->d;
   const StepCoef sc = make_coef(c, istep, adjoint);
@@ -710,12 +749,18 @@ static int step(nsk_ctx* c, int istep, int adjoint) {
   DISPATCH_N(c->key, {
     constexpr int NT = Cfg<N>::NT;
     hipLaunchKernelGGL(k_convect<N>, dim3(c->nel), dim3(Cfg<N>::NTD), 0, c->stream, d, (const double*)d.u, d.bf, adjoint);
-    hipLaunchKernelGGL(k_rhs<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, sc);
-    for (int it = 0; it < nh; ++it) {
-      hipLaunchKernelGGL(k_helm<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, sc, it, (const double*)d.rloc);
-      tot_rows(c, d.hpart + (size_t)(it & 1) * c->hrows * c->nblk, c->hrows, d.htot + (it & 1) * c->hstride);
+    if (c->fused) {
+      // persistent velocity solve: rhs + every CG iteration + pressure right-hand side in one launch
+      HIPCHK(hipMemsetAsync(c->sync, 0, SYNC_WORDS * sizeof(unsigned), c->stream));
+      launch_fused<N>(c, sc);
+    } else {
+      hipLaunchKernelGGL(k_rhs<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, sc);
+      for (int it = 0; it < nh; ++it) {
+        hipLaunchKernelGGL(k_helm<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, sc, it, (const double*)d.rloc);
+        tot_rows(c, d.hpart + (size_t)(it & 1) * c->hrows * c->nblk, c->hrows, d.htot + (it & 1) * c->hstride);
+      }
+      hipLaunchKernelGGL(k_pres_rhs<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, sc, (nh - 1) & 1, nh - 1);
     }
-    hipLaunchKernelGGL(k_pres_rhs<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, sc, (nh - 1) & 1, nh - 1);
   });
   // The first steps of a map project out whatever divergence the input vector has (a noise seed is far from
   // solenoidal): an error there survives to the end of the map, so those solves are converged further.
@@ -817,7 +862,7 @@ static void budgets_update(nsk_ctx* c, const Stats& h) {
     // steps 1-6 keep what they have: the second Krylov vector of a run can need 34 pressure iterations where the
     // noise seed needed 4
     const bool early = nv < BW && k >= 4;
-    if (th > c->cur_helm[k] || (nv == BW ? th < c->cur_helm[k] - 1 : (early && c->cur_helm[k] > 2 * th))) c->cur_helm[k] = th;
+    if (!c->fused && (th > c->cur_helm[k] || (nv == BW ? th < c->cur_helm[k] - 1 : (early && c->cur_helm[k] > 2 * th)))) c->cur_helm[k] = th;   // fused: the solve ends on the device
     if (tp > c->cur_pres[k] || (nv == BW ? tp < c->cur_pres[k] - 1 : (early && c->cur_pres[k] > 2 * tp))) c->cur_pres[k] = tp;
   }
 }
@@ -855,6 +900,7 @@ static int run_map_adaptive(nsk_ctx* c, int adjoint, double* f, const double* q)
       for (int k = 0; k < NCLS; ++k) fprintf(stderr, " %llu/%d", (unsigned long long)h.max_pres_k[k], c->cur_pres[k]);
       fprintf(stderr, "\n");
     }
+    if (h.sync_timeouts) return fail(NSK_EHIP, "grid barrier of the persistent velocity solve timed out (workgroups not co-resident?): set option fused = 0");
     if (h.unconverged == 0) {
       budgets_update(c, h);
       return 0;
@@ -903,6 +949,11 @@ int nsk_comm_unique_id(unsigned char* out128) {
   std::memcpy(out128, id.internal, 128);
   return 0;
 }
+int nsk_comm_init_host(nsk_ctx* shard, nsk_exchange_fn xchg, nsk_allreduce_fn allred, void* user) {
+  if (!shard || !xchg || !allred || !shard->parent) return fail(NSK_EINVAL, "needs a shard context and both callbacks");
+  shard->host_xchg = xchg; shard->host_allred = allred; shard->host_user = user;
+  return 0;
+}
 int nsk_comm_init_rccl(nsk_ctx* shard, const unsigned char* id128) {
   if (!shard || !id128 || !shard->parent) return fail(NSK_EINVAL, "needs a shard context");
   if (!rccl_rt::load()) return fail(NSK_EHIP, "librccl not found");
@@ -916,6 +967,10 @@ int nsk_comm_init_rccl(nsk_ctx* shard, const unsigned char* id128) {
 // sum a small host array over the ranks (Krylov inner products), through the device
 int nsk_allreduce_host(nsk_ctx* shard, double* buf, int n) {
   if (!shard || !buf || n < 1 || n > 1024) return fail(NSK_EINVAL, "bad argument");
+  if (shard->host_allred) {
+    if (shard->host_allred(shard->host_user, buf, n) != 0) return fail(NSK_EHIP, "host all-reduce callback failed");
+    return 0;
+  }
   if (!shard->comm) return 0;                                   // single process: nothing to do
   HIPCHK(hipMemcpyAsync(shard->kout, buf, n * sizeof(double), hipMemcpyHostToDevice, shard->stream));
   if (rccl_rt::AllReduce(shard->kout, shard->kout, n, rccl_rt::kDouble, rccl_rt::kSum, shard->comm, shard->stream) != 0)
@@ -997,6 +1052,8 @@ int nsk_finalize(nsk_ctx* c) {
   for (auto& a : c->graphs) for (auto& g : a) if (g.exec) (void)hipGraphExecDestroy(g.exec);
   for (void* p : c->allocs) (void)hipFree(p);
   if (c->hpin) (void)hipHostFree(c->hpin);
+  if (c->hs_send) (void)hipHostFree(c->hs_send);
+  if (c->hs_recv) (void)hipHostFree(c->hs_recv);
   if (c->comm && rccl_rt::CommDestroy) (void)rccl_rt::CommDestroy(c->comm);
   if (c->stream && !c->parent) (void)hipStreamDestroy(c->stream);      // shards share the parent's stream
   delete c;
@@ -1038,6 +1095,11 @@ int nsk_set_option(nsk_ctx* c, const char* name, double value) {
     c->pres_cap = (int)value;
   }
   else if (n == "helm_guess") c->helm_guess = (int)value;
+  else if (n == "fused") {
+    if (value != 0 && !fused_possible(c)) return fail(NSK_EINVAL, "persistent velocity solve not available for this context (needs a quadrilateral single-rank context whose workgroups are all resident)");
+    c->fused = value != 0;
+    for (int k = 0; k < NCLS; ++k) c->cur_helm[k] = c->max_helm;
+  }
   else if (n == "early_pres_mul") c->early_pres_mul = value;
   else if (n == "proj_reset") c->d.proj_reset = (int)value;
   else if (n == "pres_floor") c->d.tol_pres_floor = value;
@@ -1434,6 +1496,20 @@ int nsk_bench_kernel(nsk_ctx* c, const char* name, int reps, double* avg_us) {
         hipLaunchKernelGGL(k_helm<N>, dim3(c->nblk), dim3(Cfg<N>::NT), 0, c->stream, d, sc, r % cyc, (const double*)d.rloc);
         tot_rows(c, d.hpart + (size_t)(r & 1) * c->hrows * c->nblk, c->hrows, d.htot + (r & 1) * c->hstride);   // use_tot contexts only (a few us, included)
       }
+      HIPCHK(hipEventRecord(e1, c->stream));
+    });
+  } else if (n == "helm_fused" || n == "helm_fused0") {
+    // persistent velocity solve with 8 (or 0) CG iterations per launch, never converging: the difference of the two
+    // is the cost of 8 iterations (axhelm + updates + one grid barrier each)
+    if (!c->fused) return fail(NSK_EINVAL, "persistent velocity solve not enabled in this context");
+    d.tol_helm = 0.0; d.tol_relative = 0;
+    const StepCoef sc = make_coef(c, 3, 0);
+    const int its = (n == "helm_fused") ? 8 : 0;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    DISPATCH_N(c->key, {
+      for (int r = 0; r < 4; ++r) { HIPCHK(hipMemsetAsync(c->sync, 0, SYNC_WORDS * sizeof(unsigned), c->stream)); launch_fused<N>(c, sc, its, &d); }
+      HIPCHK(hipEventRecord(e0, c->stream));
+      for (int r = 0; r < reps; ++r) { HIPCHK(hipMemsetAsync(c->sync, 0, SYNC_WORDS * sizeof(unsigned), c->stream)); launch_fused<N>(c, sc, its, &d); }
       HIPCHK(hipEventRecord(e1, c->stream));
     });
   } else {

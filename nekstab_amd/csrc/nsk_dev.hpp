@@ -55,6 +55,7 @@ struct Stats {
   double last_helm_res, last_pres_res;
   long long capped_solves;                        // pressure solves ended by `pres_cap` above their tolerance
   double worst_cap_ratio;                         // largest residual / tolerance among them
+  long long sync_timeouts;                        // grid barriers of the persistent kernels that gave up (never in a healthy run)
 };
 
 struct Dev {

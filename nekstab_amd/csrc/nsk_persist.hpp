@@ -1,0 +1,348 @@
+// Persistent velocity solve of one time step (quadrilaterals): ONE launch runs
+//   K2  makextp + makebdfp + lagfieldp + extrapprp + cresvipp          (was k_rhs)
+//   K3  the whole Jacobi-PCG solve of H du = dssum(r), both components   (was one k_helm launch per iteration)
+//   K4  u* = u + du, g = -D u*, projection dots                          (was k_pres_rhs)
+// with the CG state (x, r, p, s, geometry factors, Jacobi diagonal, gather table) in registers for the whole
+// solve and a device-side grid barrier per CG iteration instead of a kernel boundary.  What crosses workgroups per
+// iteration is only the unassembled A z of the element-boundary nodes (dssum as a gather from the neighbours' tiles)
+// and 8 dot-product partials per workgroup; both are published write-through (sc1 stores) and read after one
+// agent-scope acquire (cdna_hip_programming.md, Guideline 16, recipe R1).  The solve ends on the device: no launch is
+// spent on iterations that find the solve converged (17 % of a config-2 step with the launch-per-iteration form).
+//
+// Arithmetic, summation orders and convergence rule are those of k_rhs / k_helm / k_pres_rhs, so the two forms give
+// bit-identical fields (tests/test_persistent_gpu.py).  Requires every workgroup of the grid to be resident at once
+// (checked on the host against the occupancy query with a margin); every spin is bounded and a time-out is
+// reported through Stats::sync_timeouts.
+#pragma once
+#include "nsk_kernels.hpp"
+
+namespace nsk {
+
+constexpr int SYNC_GROUPS = 8;                 // arrival counters, one 128-B line each, blocks sharded by blockIdx % 8
+constexpr int SYNC_WORDS = (2 * SYNC_GROUPS + 2) * 32;      // cnt[8] | top | fail | gen[8], every word on a line of its own
+constexpr unsigned SYNC_SPIN_LIMIT = 400000u;  // polls (~1 us each with s_sleep) before a barrier gives up
+#ifndef NSK_BARRIER_ACQUIRE
+#define NSK_BARRIER_ACQUIRE 1                  // 0 (experiment only): measured WRONG on MI355X at 2 workgroups per CU, the acquire stays
+#endif
+
+__device__ inline void st_sc1(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// Loads of bytes another workgroup wrote in this launch: PLAIN loads behind the barrier's agent-scope acquire.  Measured on
+// MI355X (tests/test_persistent_gpu.py): 8-byte sc1 loads (`global_load_dwordx2 sc1`) return stale values here, with or
+// without the acquire -- the form is outside the table of MI355X_MICROARCH.md (section visibility) -- while plain loads
+// behind the acquire reproduce the launch-per-iteration results bit for bit.
+#ifdef NSK_XLD_SC1
+__device__ inline double ld_sc1(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#else
+__device__ inline double ld_sc1(const double* p) { return *p; }
+#endif
+__device__ inline GsVals gs_load_x(const double* f, const int4 t, long long l) {
+  GsVals v;
+  v.a = ld_sc1(f + (t.x >= 0 ? t.x : l));
+  v.b = (t.y >= 0) ? ld_sc1(f + t.y) : 0.0;
+  v.c = (t.z >= 0) ? ld_sc1(f + t.z) : 0.0;
+  v.d = (t.w >= 0) ? ld_sc1(f + t.w) : 0.0;
+  return v;
+}
+__device__ inline double gs_csr_x(const double* f, const Dev& d, long long l) {
+  const int o0 = d.gs_off[l], o1 = d.gs_off[l + 1];
+  double s = 0.0;
+  for (int k0 = o0; k0 < o1; k0 += 8) {
+    int id[8];
+    double v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) id[q] = (k0 + q < o1) ? d.gs_idx[k0 + q] : -1;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = (id[q] >= 0) ? ld_sc1(f + id[q]) : 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      if (id[q] >= 0) s += v[q];
+  }
+  return s;
+}
+__device__ inline double gs_sum_x(const GsVals& v, const double* f, const Dev& d, const int4 t, long long l) {
+  if (t.x < 0) return gs_csr_x(f, d, l);
+  return ((v.a + v.b) + v.c) + v.d;
+}
+
+// Grid barrier for a fully resident grid, two levels (blocks grouped by blockIdx % 8: with round-robin placement one
+// group = one XCD; only speed depends on that).  Payload stores before it must be sc1 (write-through): every storing
+// wave drains them, the workgroup meets, one lane arrives on its group's counter.  The last arriver of a group is the
+// group's leader for this epoch: it arrives on the top counter, polls it, and then releases its group through the group's
+// generation word; everybody else polls that word only (62 pollers per line instead of 499 on one).  One agent-scope
+// acquire per workgroup, after which plain loads may read the other workgroups' bytes.
+// `epoch` = 1, 2, ... counts barriers within the launch (all words are zeroed by a memset node before it).
+__device__ inline bool grid_barrier(unsigned* sync, unsigned epoch, int nblk, int* s_fail) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (g_dbg & 1) return true;                   // timing ablation only (results are wrong): no grid barrier
+  if (threadIdx.x == 0 && !*s_fail) {
+    const int g = blockIdx.x % SYNC_GROUPS;
+    const unsigned gsize = (unsigned)((nblk - g + SYNC_GROUPS - 1) / SYNC_GROUPS);
+    const unsigned ngroups = (unsigned)(nblk < SYNC_GROUPS ? nblk : SYNC_GROUPS);
+    unsigned* top = sync + SYNC_GROUPS * 32;
+    unsigned* failw = top + 32;
+    unsigned* gen = sync + (SYNC_GROUPS + 2 + g) * 32;
+    const unsigned old = __hip_atomic_fetch_add(sync + g * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool leader = (old + 1u == epoch * gsize);
+    if (leader) __hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned* word = leader ? top : gen;
+    const unsigned want = leader ? epoch * ngroups : epoch;
+    unsigned spins = 0;
+    bool bad = false;
+    while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > SYNC_SPIN_LIMIT || ((spins & 255u) == 0u && __hip_atomic_load(failw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) { bad = true; break; }
+    }
+    if (bad) {
+      __hip_atomic_store(failw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // tell everybody; stop waiting for good
+      *s_fail = 1;
+    }
+    if (leader) __hip_atomic_store(gen, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // release the group (also after a time-out)
+#if NSK_BARRIER_ACQUIRE
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  }
+  __syncthreads();
+  return *s_fail == 0;
+}
+
+namespace k2 {
+
+template <int N>
+__global__ __launch_bounds__(Cfg<N>::NT, 2) void k_helm_fused(Dev d, StepCoef sc, int max_it, unsigned* sync) {
+  using C = Cfg<N>;
+  constexpr int NN = C::NN, M = C::M, MM = C::MM, EPB = C::EPB, NT = C::NT, NM = N * M;
+  __shared__ double sD[NN], sDt[NN], sJ12[NM], sD12[NM];
+  __shared__ double sz[2 * EPB * NN], st1[2 * EPB * NN], st2[2 * EPB * NN];
+  __shared__ double sP[4 * EPB * MM], sB[4 * EPB * NM];
+  __shared__ double sred[8 * 16];
+  __shared__ int s_fail;
+  const int tid = threadIdx.x, el = tid / NN, nd = tid % NN;
+  const long long e = (long long)blockIdx.x * EPB + el;
+  const bool act = (el < EPB) && (e < d.nel);
+  const int j = nd / N, i = nd % N;
+  const long long l = e * NN + nd, nl = d.cs;
+  if (tid == 0) s_fail = 0;
+  load_basis<N, EPB>(d, sD, sDt, sJ12, sD12, tid, NT);
+
+  // ================= K2 (k_rhs) =================
+  if (d.bf_stride && sc.adjoint != 2 && blockIdx.x == 0 && tid == 0) *d.bstep += 1;
+  if (d.nproj_max > 0 && blockIdx.x == 0 && tid == 0) {
+    GmresScal* G = d.gsc;
+    if (G->st_pending) {
+      G->st_pending = 0;
+      if (G->st_n > 0.0) {
+        G->pn[G->st_slot] = G->st_n;
+        G->pcnt += 1;
+        G->nproj = (G->pcnt < d.nproj_max) ? G->pcnt : d.nproj_max;
+      } else {
+        G->pcnt = 0; G->nproj = 0;
+      }
+    }
+    if (d.proj_reset && sc.cls == 0) { G->pcnt = 0; G->nproj = 0; }
+  }
+  int4 tab = make_int4(0, -1, -1, -1);
+  double bm = 0, g1 = 0, g2 = 0, g4 = 0, mk = 0, mi = 0, di = 0;
+  double un[2] = {0, 0}, du0[2] = {0, 0};
+  {
+    double u[2] = {0, 0}, bfv[2] = {0, 0};
+    if (act) {
+      tab = d.gs_tab[l];
+      bm = d.bm1[l]; g1 = d.g1[l]; g2 = d.g2[l]; g4 = d.g4[l]; mk = d.mask[l]; mi = d.minv[l];
+      di = d.dinv[(size_t)(sc.k - 1) * d.nloc + l];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const long long lc = c * nl + l;
+        un[c] = d.u[lc];
+        const double l1 = d.dulag[lc], l2 = d.dulag[2 * nl + lc], l3 = d.dulag[4 * nl + lc];
+        du0[c] = sc.xg[0] * l1 + sc.xg[1] * l2 + sc.xg[2] * l3;                 // extrapolated guess of the increment
+        d.dulag[4 * nl + lc] = l2; d.dulag[2 * nl + lc] = l1;                  // (slot 0 <- du at the end of the solve)
+        u[c] = un[c] + sc.xg[0] * l1 + sc.xg[1] * l2 + sc.xg[2] * l3;           // u^n + du0, summed as k_rhs does
+        sz[(c * EPB + el) * NN + nd] = u[c];
+        const double bn = d.bf[lc];
+        const double e1 = d.exlag[lc], e2 = d.exlag[2 * nl + lc];
+        double b = sc.ab[0] * bn + sc.ab[1] * e1 + sc.ab[2] * e2;              // makextp
+        d.exlag[2 * nl + lc] = e1;
+        d.exlag[lc] = bn;
+        const double v1 = d.ulag[lc], v2 = d.ulag[2 * nl + lc];
+        b += bm * (sc.bd[1] * un[c] + sc.bd[2] * v1 + sc.bd[3] * v2) * sc.invdt;   // makebdfp
+        d.ulag[2 * nl + lc] = v1;                                               // lagfieldp
+        d.ulag[lc] = un[c];
+        bfv[c] = b;
+      }
+      if (nd < MM) {                                                            // extrapprp
+        const long long q = e * MM + nd;
+        const double pn = d.p[q];
+        const double pe = (sc.k < 3) ? pn : 2.0 * pn - d.plag[q];
+        d.plag[q] = pn;
+        d.pext[q] = pe;
+        sP[(0 * EPB + el) * MM + nd] = pe * d.w2rx[q];
+        sP[(1 * EPB + el) * MM + nd] = pe * d.w2sx[q];
+        sP[(2 * EPB + el) * MM + nd] = pe * d.w2ry[q];
+        sP[(3 * EPB + el) * MM + nd] = pe * d.w2sy[q];
+      }
+    }
+    __syncthreads();
+    double gx, gy;
+    opgradt_tiles<N, EPB>(sJ12, sD12, sP, sB, act, el, nd, gx, gy);
+    double au[2];
+    axhelm_tiles<N, EPB, 2>(sD, sDt, sz, st1, st2, act, el, j, i, g1, g2, g4, au);
+    if (act) {
+      const double bx = bfv[0] + gx, by = bfv[1] + gy;                          // rhs of H u* = b
+      st_sc1(d.bloc + l, bx);
+      st_sc1(d.bloc + nl + l, by);
+      st_sc1(d.rloc + l, bx - (d.nu * au[0] + sc.h2 * bm * u[0]));
+      st_sc1(d.rloc + nl + l, by - (d.nu * au[1] + sc.h2 * bm * u[1]));
+    }
+  }
+  unsigned epoch = 1;
+  bool ok = grid_barrier(sync, epoch++, d.nblk, &s_fail);
+
+  // ================= K3 (k_helm, all iterations) =================
+  double r[2] = {0, 0}, p[2] = {0, 0}, s[2] = {0, 0}, x[2] = {0, 0};
+  double gprev[2] = {0, 0}, aprev[2] = {0, 0}, refn[2] = {0, 0}, resrec[2] = {0, 0};
+  bool fin[2] = {false, false};
+  int used = 0;
+  bool unconv = false;
+  for (int it = 0; ok; ++it) {
+    const int par = it & 1, ppar = par ^ 1;
+    double alpha[2] = {0, 0}, beta[2] = {0, 0};
+    bool done[2] = {false, false};
+    GsVals gv[2], gb[2];
+    if (act) {                                                                  // gathers first: they only need the table
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        if (it == 0) { gv[c] = gs_load_x(d.rloc + c * nl, tab, l); gb[c] = gs_load_x(d.bloc + c * nl, tab, l); }
+        else gv[c] = gs_load_x(d.hwl + ((size_t)ppar * 2 + c) * nl, tab, l);
+      }
+    }
+    if (it > 0) {
+      double ps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      const double* part = d.hpart + (size_t)ppar * 8 * d.nblk;
+      if (!(g_dbg & 2))                          // (timing ablation: no partial-sum loads)
+      for (int k = tid; k < d.nblk; k += NT) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) ps[q] += ld_sc1(part + (size_t)q * d.nblk + k);
+      }
+      block_reduce<8>(ps, sred, tid, NT);
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const double g = ps[c * 3 + 0], del = ps[c * 3 + 1], rr = ps[c * 3 + 2];
+        const double res = sqrt(rr / d.vol);
+        if (it == 1) refn[c] = sqrt(ps[6 + c] / d.vol);                        // ||b||: H u* = b
+        const double tol = d.tol_relative ? d.tol_helm * refn[c] : d.tol_helm;
+        const bool was = fin[c];
+        done[c] = was || (res <= tol) || !(g > 0.0);
+        if (!done[c]) {
+          if (it == 1) { beta[c] = 0.0; alpha[c] = g / del; }
+          else { beta[c] = g / gprev[c]; alpha[c] = g / (del - beta[c] * g / aprev[c]); }
+        }
+        gprev[c] = g; aprev[c] = alpha[c];
+        if (!was) resrec[c] = res;
+        fin[c] = done[c];
+      }
+      if (done[0] && done[1]) { used = it - 1; break; }
+      if (it >= max_it) { used = it - 1; unconv = true; break; }
+    }
+    double zz[2] = {0, 0}, bb[2] = {0, 0};
+    if (act) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        if (it == 0) {
+          r[c] = mk * gs_sum_x(gv[c], d.rloc + c * nl, d, tab, l);
+          bb[c] = mk * gs_sum_x(gb[c], d.bloc + c * nl, d, tab, l);
+        } else if (!done[c]) {
+          const double w = mk * gs_sum_x(gv[c], d.hwl + ((size_t)ppar * 2 + c) * nl, d, tab, l);
+          const double pn = di * r[c] + beta[c] * p[c];
+          const double sn = w + beta[c] * s[c];
+          p[c] = pn; s[c] = sn;
+          x[c] = x[c] + alpha[c] * pn;
+          r[c] = r[c] - alpha[c] * sn;
+        }
+        zz[c] = di * r[c];
+        sz[(c * EPB + el) * NN + nd] = zz[c];
+      }
+    }
+    lds_barrier();
+    double au[2];
+    axhelm_tiles<N, EPB, 2>(sD, sDt, sz, st1, st2, act, el, j, i, g1, g2, g4, au);
+    double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (act) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const double wl = d.nu * au[c] + sc.h2 * bm * zz[c];
+        st_sc1(d.hwl + ((size_t)par * 2 + c) * nl + l, wl);
+        v[c * 3 + 0] = r[c] * zz[c] * mi;
+        v[c * 3 + 1] = zz[c] * wl;
+        v[c * 3 + 2] = r[c] * r[c] * mi;
+        v[6 + c] = bb[c] * bb[c] * mi;
+      }
+    }
+    block_reduce<8>(v, sred, tid, NT);
+    if (tid < 8) st_sc1(d.hpart + ((size_t)par * 8 + tid) * d.nblk + blockIdx.x, v[tid]);
+    ok = grid_barrier(sync, epoch++, d.nblk, &s_fail);
+  }
+  if (blockIdx.x == 0 && tid == 0) {
+    if (!ok) atomicAdd((unsigned long long*)&d.stats->sync_timeouts, 1ull);
+    else {
+      atomicAdd((unsigned long long*)&d.stats->helm_iters, (unsigned long long)used);
+      atomicMax((unsigned long long*)&d.stats->max_helm, (unsigned long long)used);
+      atomicMax((unsigned long long*)&d.stats->max_helm_k[sc.cls], (unsigned long long)used);
+      d.stats->last_helm_res = fmax(resrec[0], resrec[1]);
+      if (unconv) atomicAdd((unsigned long long*)&d.stats->unconverged, 1ull);
+    }
+  }
+  if (!ok) return;
+
+  // ================= K4 (k_pres_rhs) =================
+  if (act) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const long long lc = c * nl + l;
+      const double du = du0[c] + x[c];                                          // guess + CG correction
+      d.dulag[lc] = du;
+      const double us = un[c] + du;
+      d.u[lc] = us;
+      sz[(c * EPB + el) * NN + nd] = us;
+    }
+  }
+  __syncthreads();
+  const double div = opdiv_tiles<N, EPB>(sJ12, sD12, sz, sB, act, el, nd, d, e);
+  double v1[1] = {0.0};
+  double g = 0.0;
+  const bool pact = act && nd < MM;
+  if (pact) {
+    g = -div;
+    d.V[e * MM + nd] = g;
+    v1[0] = g * g;
+  }
+  block_reduce<1>(v1, sred, tid, NT);
+  if (tid == 0) d.gpart[blockIdx.x] = v1[0];
+  if (!d.has_outflow) {
+    double t[1] = {g};
+    block_reduce<1>(t, sred, tid, NT);
+    if (tid == 0) d.gpart[(size_t)d.nblk + blockIdx.x] = t[0];
+  }
+  if (d.nproj_max > 0) {
+    if (tid == 0) d.ppart[(size_t)MAXPROJ * d.nblk + blockIdx.x] = v1[0];
+    const int np = d.gsc->nproj;
+    double* sdot = sP;                                                          // [MAXPROJ * 4] <= 4 * EPB * MM doubles
+    const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll 4
+    for (int k = 0; k < np; ++k) {
+      double t = pact ? g * d.PX[(size_t)k * d.npr + e * MM + nd] : 0.0;
+      t = wave_sum63(t);
+      if (lane == 63) sdot[k * 4 + wv] = t;
+    }
+    lds_barrier();
+    if (tid < np) {
+      double t = 0.0;
+      for (int ww = 0; ww < NT / 64; ++ww) t += sdot[tid * 4 + ww];
+      d.ppart[(size_t)tid * d.nblk + blockIdx.x] = t;
+    }
+  }
+}
+
+}  // namespace k2
+}  // namespace nsk

@@ -1,0 +1,63 @@
+"""Algorithmic-byte accounting of one matvec: every distinct input array once and every output array
+once per kernel invocation, fp64 = 8 B, fp32 = 4 B, indices 4 B, irrespective of cache residency, summed over the
+invocations actually executed (iteration counts are run-time data, read from ``nsk_get_stats``).
+
+    bytes_per_matvec = nsteps * [K1 + K2 + K4 + n_helm * d * K3 + n_pres * (precond + E + GMRES) + K10 + projection]
+                       + Krylov projection at Arnoldi step j
+
+``d`` = number of velocity components.  The per-kernel entries below are what DESIGN.md section 5 tabulates; they are
+the *compulsory* traffic of the launch-per-kernel formulation, so a kernel that keeps state in registers across iterations
+(the persistent velocity solve) moves fewer bytes than its algorithmic figure -- which is the point of it.
+"""
+from __future__ import annotations
+
+
+def per_step_bytes(*, nel, lx1, ndim=2, nvert=0, coarse_lda=0, patch_stride=0, nproj=0, helm_iters=0.0, pres_iters=0.0):
+    """Algorithmic bytes of ONE time step, by kernel family.  ``helm_iters`` / ``pres_iters``: mean iterations per step
+    (both velocity components advance together in one CG iteration)."""
+    d = ndim
+    N, M, ND = lx1, lx1 - 2, 3 * lx1 // 2
+    P, P2, Pd = nel * N ** d, nel * M ** d, nel * ND ** d
+    f = 8.0
+    nmet2 = d * d                       # Gauss-mesh metrics per pressure point
+    out = {}
+    # K1 convection + sponge: u' (d), spng, bm1, bf out (d) on P; base-flow constants on the dealiasing mesh: 2-D 6, 3-D 12
+    out["K1 convect"] = f * (P * (2 * d + 2) + Pd * (6 if d == 2 else 12))
+    # K2 rhs: u (d), dulag (3d), bf (d), exlag rw (2d + 2d), ulag rw (2d + 2d), bm1, G factors (3 | 6); p, plag rw, pext, metrics on P2; rloc, bloc out (2d)
+    ng = 3 if d == 2 else 6
+    out["K2 rhs"] = f * (P * (d + 3 * d + d + 4 * d + 4 * d + 1 + ng + 2 * d) + P2 * (4 + nmet2))
+    # K3+K4+K5 one CG iteration of one component: SURVEY 8(d) table: 148 B/pt (2-D), 172 B/pt (3-D)
+    out["K3 helm iteration (x n_helm x d)"] = (148.0 if d == 2 else 172.0) * P * d * helm_iters
+    # K4' pressure rhs: hx (d), dulag rw (3d + 3d), u rw (2d); metrics, V0 out, PX reads on P2
+    out["K4 pres_rhs"] = f * (P * (d + 6 * d + 2 * d) + P2 * (nmet2 + 1 + nproj))
+    # per GMRES iteration (mean basis index j ~ (n-1)/2)
+    jbar = max(pres_iters - 1.0, 0.0) / 2.0
+    coarse = 4.0 * nvert * coarse_lda + f * (nel * 2 ** d + 2 * nvert)                      # fp32 dense inverse + restriction + x_c
+    schwarz = 4.0 * nel * patch_stride * M ** d + 4.0 * nel * patch_stride + f * nel * patch_stride + f * P2 * (1 + nmet2) + f * P * d
+    if d == 3:                                                                              # fast-diagonalisation patches: 3 N^2 + 3 N factors per element
+        schwarz = f * nel * (3 * N * N + 3 * N) + f * nel * N ** 3 + f * P2 * (1 + nmet2) + f * P * d
+        coarse = 0.0                                                                        # sparse / polynomial coarse solve: not counted (problem dependent)
+    divgs = f * (P * (d + 1) + 2.0 * P) + f * P2 * (nmet2 + 1 + (jbar + 1))                # yl gather (d), binv, 16-B table; metrics, w out, V_0..j for the dots
+    gupd = f * P2 * (jbar + 3)                                                              # V_0..j, V_{j+1} read + write
+    out["K6 coarse (x n_pres)"] = coarse * pres_iters
+    out["K6 schwarz (x n_pres)"] = schwarz * pres_iters
+    out["K7 divgs (x n_pres)"] = divgs * pres_iters
+    out["K7 gmres_update (x n_pres)"] = gupd * (pres_iters + 1.0)
+    # K10 pressure / velocity update + projection space
+    out["K10 pres_update"] = f * (P2 * (pres_iters + nproj + 3 + nmet2) + P * d)
+    out["K10 vel_update(+proj)"] = f * (P * (d + 1 + 2 * d + 2.0) + P2 * (nmet2 + 2 + 2 * nproj))
+    out["projection apply/update"] = f * P2 * (2 + nproj + 4 * nproj + 2) if nproj else 0.0
+    return out
+
+
+def krylov_bytes(nstate, j):
+    """Two-pass classical Gram-Schmidt at Arnoldi step j: read Q(1:j) for the dots, again for the update,
+    f read + write, per pass."""
+    return 2.0 * (2.0 * j + 2.0) * nstate * 8.0
+
+
+def matvec_bytes(stats_total, nsteps, **geom):
+    """Bytes of one matvec from the accumulated solver statistics (``total_*`` fields of nsk_get_stats)."""
+    steps = max(stats_total["total_steps"], 1)
+    per = per_step_bytes(helm_iters=stats_total["total_helm_iters"] / steps, pres_iters=stats_total["total_pres_iters"] / steps, **geom)
+    return nsteps * sum(per.values()), per

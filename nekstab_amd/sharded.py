@@ -331,3 +331,70 @@ class ShardRank:
         Zc = np.asfortranarray(Z, dtype=np.float64)
         arr = (C.c_void_p * k)(*[v.value for v in Q])
         self._chk(self.lib.nsk_basis_gemm(self.ctx, arr, k, Zc.ctypes.data_as(_dp), Zc.shape[0]))
+
+
+class HostTransport:
+    """Host-staged transport for ``nsk_comm_init_host`` over ``torch.distributed`` point-to-point messages and all-reduce
+    (any backend that moves CPU tensors, e.g. gloo): what lets several ranks share ONE GPU, so that the exchange protocol
+    of the sharded time stepper (pack / unpack tables, message order, reductions) is proven across processes without a
+    second GPU.  The C library packs on the device, stages through pinned host memory and calls these two functions."""
+
+    XF = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(_dp), C.POINTER(_dp))
+    AF = C.CFUNCTYPE(C.c_int, C.c_void_p, _dp, C.c_int)
+
+    def __init__(self, dist):
+        self.dist = dist
+        self.n_exchange = self.n_allreduce = 0
+        self.xf = HostTransport.XF(self._exchange)
+        self.af = HostTransport.AF(self._allreduce)
+
+    def exchange(self, peers, send):
+        """send[k] (1-D float64 array) goes to rank peers[k]; returns what each peer sent back (same lengths)."""
+        import torch
+        reqs, recv = [], []
+        for p, sbuf in zip(peers, send):
+            t = torch.from_numpy(np.ascontiguousarray(sbuf, dtype=np.float64).copy())
+            r = torch.empty(t.numel(), dtype=torch.float64)
+            reqs.append(self.dist.isend(t, int(p)))
+            reqs.append(self.dist.irecv(r, int(p)))
+            recv.append(r)
+        for q in reqs:
+            q.wait()
+        self.n_exchange += 1
+        return [r.numpy() for r in recv]
+
+    def allreduce(self, buf):
+        import torch
+        t = torch.from_numpy(buf)
+        self.dist.all_reduce(t)
+        self.n_allreduce += 1
+        return buf
+
+    def _exchange(self, user, npeers, peers, counts, send, recv):
+        try:
+            ps = [peers[k] for k in range(npeers)]
+            out = self.exchange(ps, [np.ctypeslib.as_array(send[k], shape=(counts[k],)) for k in range(npeers)])
+            for k in range(npeers):
+                np.ctypeslib.as_array(recv[k], shape=(counts[k],))[:] = out[k]
+            return 0
+        except Exception as e:      # an exception must not unwind through the C frames
+            print("HostTransport.exchange failed:", repr(e), flush=True)
+            return -1
+
+    def _allreduce(self, user, buf, n):
+        try:
+            self.allreduce(np.ctypeslib.as_array(buf, shape=(n,)))
+            return 0
+        except Exception as e:
+            print("HostTransport.allreduce failed:", repr(e), flush=True)
+            return -1
+
+
+def attach_host_transport(shard: "ShardRank", dist):
+    """Route the halos and reductions of a ShardRank through ``dist`` (host-staged) instead of RCCL."""
+    tr = HostTransport(dist)
+    rc = shard.lib.nsk_comm_init_host(shard.ctx, C.cast(tr.xf, C.c_void_p), C.cast(tr.af, C.c_void_p), None)
+    if rc != 0:
+        raise NskError(rc, shard.lib.nsk_last_error().decode())
+    shard._transport = tr          # keep the callbacks alive
+    return tr

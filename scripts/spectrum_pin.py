@@ -38,6 +38,19 @@ SETTINGS = {
     "m7": (1e-10, 5e-2, 1, 8, {"min_pres_iter": 2}),
     "m8": (1e-11, 3e-2, 1, 8, {"min_pres_iter": 2}),
     "m9": (1e-12, 1e-3, 1, 8, {"min_pres_iter": 2}),
+    "h12p1": (1e-12, 1e-1, 1, 8, {"min_pres_iter": 2}),
+    "h12p2": (1e-12, 2e-1, 1, 8, {"min_pres_iter": 2}),
+    "h12p3": (1e-12, 3e-1, 1, 8, {"min_pres_iter": 2}),
+    "h13p1": (1e-13, 1e-1, 1, 8, {"min_pres_iter": 2}),
+    "h12p1c6": (1e-12, 1e-1, 1, 8, {"min_pres_iter": 2, "pres_cap": 6}),
+    "h12p1np": (1e-12, 1e-1, 1, 0, {"min_pres_iter": 2}),
+    "h11p1": (1e-11, 1e-1, 1, 8, {"min_pres_iter": 2}),
+    "h11p1n16": (1e-11, 1e-1, 1, 16, {"min_pres_iter": 2}),
+    "h11p1n24": (1e-11, 1e-1, 1, 24, {"min_pres_iter": 2}),
+    "h11p1n32": (1e-11, 1e-1, 1, 32, {"min_pres_iter": 2}),
+    "h11p2n20": (1e-11, 2e-1, 1, 20, {"min_pres_iter": 2}),
+    "h11p1n20m1": (1e-11, 1e-1, 1, 20, {"min_pres_iter": 1}),
+    "h12p1n20": (1e-12, 1e-1, 1, 20, {"min_pres_iter": 2}),
 }
 
 

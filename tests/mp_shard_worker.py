@@ -1,0 +1,66 @@
+"""Worker of tests/test_multiprocess_gpu.py: one rank of an element-sharded matvec whose ranks are separate PROCESSES
+sharing one GPU; halos and reductions travel through torch.distributed (gloo) on the host."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    from nekstab_amd import mesh
+    from nekstab_amd.capi import NekStabHip
+    from nekstab_amd.sharded import ShardRank, attach_host_transport, partition_rcb
+    from nekstab_amd.quadrature import gauss_legendre, gauss_lobatto_legendre, interp_matrix
+    nsteps = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+    case = mesh.load_case_npz(os.path.join(ROOT, "tests", "golden", "cylinder_case.npz"), 6)
+    modes = np.load(os.path.join(ROOT, "tests", "golden", "cylinder_modes.npz"))
+    J = interp_matrix(gauss_lobatto_legendre(6)[0], gauss_legendre(4)[0])
+    u = modes["dRe_u"].astype(np.float64)
+    q = (u[0], u[1], J @ modes["dRe_p"].astype(np.float64) @ J.T)
+    full = NekStabHip(case, case.meta["vert"], case.meta["nvert"], tol_helm=1e-12, tol_pres=1e-6, tol_relative=1,
+                      schwarz_layers=2, max_helm_iter=120, max_pres_iter=48)
+    part = partition_rcb(case, world)
+    sh = ShardRank(full, case, rank, world, None, part)
+    tr = attach_host_transport(sh, dist)
+    sh.set_nsteps(nsteps)
+    vq, vf = sh.alloc(2)
+    sh.upload(vq, *q)
+    n2 = sh.dot(vq, vq)                          # all-reduced inner product
+    sh.matvec(vf, vq, 0)
+    loc = sh.download_local(vf)
+    gathered = [None] * world
+    dist.gather_object((sh.elems, loc), gathered if rank == 0 else None, dst=0)
+    ok = True
+    if rank == 0:
+        full.set_nsteps(nsteps)
+        a, b = full.alloc(2)
+        full.upload(a, *q)
+        full.matvec(b, a, 0)
+        ref = full.download(b)
+        got = [np.empty_like(r) for r in ref]
+        for elems, l in gathered:
+            for g, x in zip(got, l):
+                g[elems] = x
+        scale = max(np.abs(ref[0]).max(), np.abs(ref[1]).max())
+        err = max(np.abs(g - r).max() for g, r in zip(got[:2], ref[:2])) / scale
+        perr = np.abs(got[2] - ref[2]).max() / np.abs(ref[2]).max()
+        dn = abs(n2 - full.dot(a, a)) / full.dot(a, a)
+        print("MPSHARD world %d nsteps %d: velocity rel diff %.3e pressure %.3e norm %.1e exchanges %d allreduces %d"
+              % (world, nsteps, err, perr, dn, tr.n_exchange, tr.n_allreduce), flush=True)
+        ok = err < 1e-9 and perr < 1e-5 and dn < 1e-12 and tr.n_exchange > 0
+    flag = torch.tensor([1.0 if ok else 0.0])
+    dist.broadcast(flag, 0)
+    sh.close(); full.close()
+    dist.destroy_process_group()
+    sys.exit(0 if flag.item() == 1.0 else 1)
+
+
+if __name__ == "__main__":
+    main()

@@ -87,23 +87,49 @@ def test_seed_is_deterministic_and_continuous(case6):
     assert np.all(a[0][case6.mask == 0] == 0)
 
 
-def test_two_rank_gloo_timing_reduction(tmp_path):
-    """bench.py's N>1 protocol (barrier, max-over-ranks time, aggregate = sum of units / max time)
-    on two CPU processes with gloo."""
+def test_two_rank_gloo_host_transport_and_timing(tmp_path):
+    """The N>1 host protocol on two CPU processes (gloo): the product's host-staged halo transport
+    (nekstab_amd.sharded.HostTransport: per-peer exchange + all-reduce, what nsk_comm_init_host calls back into) and
+    bench.py's timing reduction (barrier, max-over-ranks time, aggregate = sum of units / max time)."""
     script = tmp_path / "w.py"
     script.write_text(
-        "import os, time, torch, torch.distributed as dist\n"
+        "import sys, time, numpy as np, torch, torch.distributed as dist\n"
+        "sys.path.insert(0, %r)\n"
+        "from nekstab_amd.sharded import HostTransport\n"
         "dist.init_process_group('gloo')\n"
-        "r = dist.get_rank(); dist.barrier(); t0 = time.perf_counter(); time.sleep(0.05 * (r + 1)); dist.barrier()\n"
+        "r = dist.get_rank(); tr = HostTransport(dist)\n"
+        "got = tr.exchange([1 - r], [np.arange(5, dtype=np.float64) + 10 * r])\n"
+        "assert np.array_equal(got[0], np.arange(5) + 10 * (1 - r))\n"
+        "# through the ctypes callbacks, as the C library calls them\n"
+        "import ctypes as C\n"
+        "send = (np.ones(3) * (r + 1)); recv = np.zeros(3); dp = C.POINTER(C.c_double)\n"
+        "peers = (C.c_int * 1)(1 - r); cnt = (C.c_int * 1)(3)\n"
+        "sp = (dp * 1)(send.ctypes.data_as(dp)); rp = (dp * 1)(recv.ctypes.data_as(dp))\n"
+        "assert tr.xf(None, 1, peers, cnt, sp, rp) == 0 and np.all(recv == 2 - r)\n"
+        "buf = np.array([1.0 + r, 2.0]); assert tr.af(None, buf.ctypes.data_as(dp), 2) == 0 and np.all(buf == [3.0, 4.0])\n"
+        "dist.barrier(); t0 = time.perf_counter(); time.sleep(0.05 * (r + 1)); dist.barrier()\n"
         "t = torch.tensor([0.05 * (r + 1)], dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX)\n"
         "units = torch.tensor([10.0]); dist.all_reduce(units)\n"
         "assert abs(t.item() - 0.1) < 1e-12 and units.item() == 20.0\n"
-        "print('ok', r)\n")
+        "print('ok', r)\n" % ROOT)
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
                           "--master-addr", "127.0.0.1", "--master-port", "29611", str(script)],
                          capture_output=True, text=True, timeout=300)
-    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-2000:]
     assert out.stdout.count("ok") == 2
+
+
+def test_bench_spawns_its_ranks(tmp_path):
+    """`python bench.py --gpus N` without a launcher starts N child processes with RANK / WORLD_SIZE set (checked without
+    a GPU: the children stop at 'needs a GPU'), and a launcher / --gpus mismatch is an error."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the GPU runs")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and out.stderr.count("bench.py needs a GPU") == 2, out.stderr[-1500:]
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode != 0 and "launcher started 1 ranks" in out.stderr
 
 
 @pytest.mark.parametrize("nranks", [2, 3, 8])

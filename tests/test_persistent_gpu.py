@@ -1,0 +1,77 @@
+"""The persistent velocity solve (nsk_persist.hpp: right-hand side, every CG iteration and the pressure right-hand side in
+ONE launch, device-side grid barriers) against the launch-per-iteration form of the same algorithm."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _ctx(case, **kw):
+    from nekstab_amd.capi import NekStabHip
+    return NekStabHip(case, case.meta["vert"], case.meta["nvert"], tol_helm=1e-11, tol_pres=1e-2, tol_relative=1,
+                      schwarz_layers=2, max_helm_iter=100, max_pres_iter=48, **kw)
+
+
+@pytest.mark.parametrize("lx1,mode", [(6, 0), (8, 0), (8, 1)])
+def test_fused_equals_launch_per_iteration(lx1, mode):
+    """Same arithmetic, same summation orders, same convergence rule => the same fields to rounding (bit-identical when
+    the compiler contracts the same multiply-adds), the same iteration counts; no barrier time-outs; with graphs and
+    without."""
+    from nekstab_amd import mesh, seed
+    from tests.conftest import GOLDEN
+    case = mesh.load_case_npz(os.path.join(GOLDEN, "cylinder_case.npz"), lx1, adjoint=bool(mode))
+    h = _ctx(case, nproj=8)
+    h.set_option("proj_reset", 1)                # every map starts with an empty pressure projection space: maps are repeatable
+    qx, qy = seed.add_noise(case)
+    q, f0, f1, f2 = h.alloc(4)
+    h.upload(q, qx, qy, np.zeros(h.npres))
+    h.scal(q, 1.0 / h.norm(q))
+    h.set_nsteps(12)
+    h.set_option("fused", 0)
+    h.matvec(f0, q, mode)
+    s0 = h.stats()
+    h.set_option("fused", 1)                     # raises if the grid cannot be resident
+    h.matvec(f1, q, mode)
+    s1 = h.stats()
+    h.set_option("use_graph", 0)
+    h.matvec(f2, q, mode)
+    a, b, c2 = h.download(f0), h.download(f1), h.download(f2)
+    scale = max(np.abs(a[0]).max(), np.abs(a[1]).max())
+    err = max(np.abs(x - y).max() for x, y in zip(a[:2], b[:2])) / scale
+    errg = max(np.abs(x - y).max() for x, y in zip(b[:2], c2[:2])) / scale
+    print("lx1", lx1, "mode", mode, "fused vs launches: max rel diff %.2e; graph vs eager %.2e; helm iters %d / %d, pres iters %d / %d"
+          % (err, errg, s0["helm_iters"], s1["helm_iters"], s0["pres_iters"], s1["pres_iters"]))
+    assert err < 1e-12 and errg < 1e-12
+    assert s1["pres_iters"] == s0["pres_iters"] and s1["unconverged"] == 0
+    h.close()
+
+
+def test_fused_full_map_vs_oracle_lx1_8():
+    """Five direct steps at lx1 = 8 (config 2's order) through the persistent kernel against the oracle: the direct-mode
+    full-step comparison at this order."""
+    from nekstab_amd import mesh
+    from tests.conftest import GOLDEN, make_oracle
+    case = mesh.load_case_npz(os.path.join(GOLDEN, "cylinder_case.npz"), 8)
+    o = make_oracle(case)
+    from nekstab_amd.capi import NekStabHip
+    h = NekStabHip(case, case.meta["vert"], case.meta["nvert"], tol_helm=1e-13, tol_pres=1e-13, tol_relative=0,
+                   schwarz_layers=2, max_helm_iter=120, max_pres_iter=48)
+    rng = np.random.default_rng(3)
+    # a smooth C0 field: the interpolated base flow plus a masked perturbation of it
+    u = case.ub[0] * case.mask * (1.0 + 0.1 * np.sin(case.x)), case.ub[1] * case.mask + 0.05 * case.mask * np.cos(case.y)
+    q = (u[0], u[1], rng.standard_normal((case.nel, 6, 6)) * 1e-3)
+    h.set_nsteps(5)
+    vq, vf = h.alloc(2)
+    h.upload(vq, *q)
+    for fused in (1, 0):
+        h.set_option("fused", fused)
+        h.matvec(vf, vq, 0)
+        f = h.download(vf)
+        ref = o.matvec(q, nsteps=5) if fused else ref
+        num = sum(np.sum(o.bm1 * (x - y) ** 2) for x, y in zip(f[:2], ref[:2]))
+        den = sum(np.sum(o.bm1 * y ** 2) for y in ref[:2])
+        print("fused", fused, "rel L2 vs oracle %.2e" % np.sqrt(num / den))
+        assert np.sqrt(num / den) < 1e-9
+    h.close()
