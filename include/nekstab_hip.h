@@ -89,6 +89,7 @@ int nsk_set_tolerances(nsk_ctx* ctx, double tol_helm, double tol_pres, int relat
  * "pres_floor" (absolute floor under the relative pressure tolerance, in the scaled units of nsk_stats.last_pres_res; 0 = off),
  * "budget_helm" / "budget_pres" (launch budgets), "fused" (persistent velocity solve: right-hand side, all CG iterations and
  * the pressure right-hand side in one launch with device-side grid barriers; default 0: not faster on config 2),
+ * "mfma_convect" (hexahedra, lx1 = 8: convection contractions on v_mfma_f64_16x16x4_f64, default 1),
  * "dbg" (developer ablation mask) */
 int nsk_set_option(nsk_ctx* ctx, const char* name, double value);
 
@@ -197,7 +198,8 @@ int nsk_test_eapply(nsk_ctx* ctx, const double* p, double* out);   /* D B^-1 D^T
 int nsk_test_helm_solve(nsk_ctx* ctx, const double* rx, const double* ry, int order,
                         double* ox, double* oy, int* iters);
 int nsk_test_pres_solve(nsk_ctx* ctx, const double* g, double* out, int* iters);
-/* 3-D element operators, packed arrays: which = 1 weak divergence, 2 D^T p, 3 convection (a = mode), 5 Helmholtz solve (a = order) */
+/* 3-D element operators, packed arrays: which = 1 weak divergence, 2 D^T p, 3 convection (a = mode), 5 Helmholtz solve (a = order),
+ * 8 convection on the matrix cores (lx1 = 8) */
 int nsk_test_op3(nsk_ctx* ctx, int which, const double* in, double* out, int a, int* iters);
 
 #ifdef __cplusplus

