@@ -25,7 +25,19 @@ constexpr unsigned SYNC_SPIN_LIMIT = 400000u;  // polls (~1 us each with s_sleep
 #define NSK_BARRIER_ACQUIRE 1                  // 0 (experiment only): measured WRONG on MI355X at 2 workgroups per CU, the acquire stays
 #endif
 
+// Publishing form.  1 (default): the architecturally defined one -- plain stores, every storing wave drains, the workgroup
+// meets, ONE lane executes an agent-scope RELEASE fence (buffer_wbl2 sc1) before it arrives; consumers: agent-scope ACQUIRE
+// + plain loads.  0: write-through (sc1) stores and no release fence (Guideline 16, R1): faster by ~1 us per barrier, but
+// measured on MI355X with two workgroups per CU it is NOT reliable here (scripts/fused_stress.py: a solve that stagnates
+// on stale values in 1 of ~10 maps at lx1 = 8), so it is an experiment switch only.
+#ifndef NSK_PUBLISH_RELEASE
+#define NSK_PUBLISH_RELEASE 1
+#endif
+#if NSK_PUBLISH_RELEASE
+__device__ inline void st_sc1(double* p, double v) { *p = v; }
+#else
 __device__ inline void st_sc1(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#endif
 // Loads of bytes another workgroup wrote in this launch: PLAIN loads behind the barrier's agent-scope acquire.  Measured on
 // MI355X (tests/test_persistent_gpu.py): 8-byte sc1 loads (`global_load_dwordx2 sc1`) return stale values here, with or
 // without the acquire -- the form is outside the table of MI355X_MICROARCH.md (section visibility) -- while plain loads
@@ -76,6 +88,10 @@ __device__ inline bool grid_barrier(unsigned* sync, unsigned epoch, int nblk, in
   __syncthreads();
   if (g_dbg & 1) return true;                   // timing ablation only (results are wrong): no grid barrier
   if (threadIdx.x == 0 && !*s_fail) {
+#if NSK_PUBLISH_RELEASE
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // after the fence, always (ROCm 7.2 can drop the fence's own wait: Guideline 16, pitfall 12)
+#endif
     const int g = blockIdx.x % SYNC_GROUPS;
     const unsigned gsize = (unsigned)((nblk - g + SYNC_GROUPS - 1) / SYNC_GROUPS);
     const unsigned ngroups = (unsigned)(nblk < SYNC_GROUPS ? nblk : SYNC_GROUPS);
