@@ -16,6 +16,7 @@
 #include <map>
 #include <utility>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/nekstab_hip.h"

@@ -80,3 +80,46 @@ def test_config4_backstep_extruded_E50100_adjoint():
     assert d_out < 0.2 * d_in                              # a 1e-2 pressure tolerance per step, input with O(1) divergence in w
     assert 0.5 < nf < 2.0
     h.close()
+
+
+def test_config5_lid_driven_cube_E99452_lx1_10():
+    """lid-driven cube, 46 x 46 x 47 = 99 452 hexahedra with wall clustering as examples/lid_driven/cav.box, lx1 = 10
+    (lxd = 15): 99.5 M points per field, 349 M unknowns (2.8 GB per state vector), ~150 GB of device memory on ONE GPU;
+    closed domain (singular pressure operator), Chebyshev coarse solve on 103 823 vertices.  Full equations (the Newton-
+    Krylov map of config 5) and the linearised map, three time steps each."""
+    from nekstab_amd import mesh3d
+    from nekstab_amd.capi import NekStabHip
+    stretch = lambda xi: 0.5 * (1.0 - np.cos(np.pi * xi))              # Chebyshev-like wall clustering
+    lid = lambda x, y, z: np.stack([(1.0 - (2.0 * x - 1.0) ** 2) ** 2 * (1.0 - (2.0 * z - 1.0) ** 2) ** 2 * (y > 1.0 - 1e-12), 0 * x, 0 * x])
+    t0 = time.perf_counter()
+    c = mesh3d.box_case_3d(46, 46, 47, 10, lengths=(1.0, 1.0, 1.0), re=1000.0, endtime=0.02, stretch=stretch, ub_func=lid)
+    # a smooth divergence-free-ish interior base flow (one big vortex in x-y) so that the CFL rule sees a real velocity
+    X, Y, Z = c.x, c.y, c.z
+    sx, sy, sz = np.sin(np.pi * X), np.sin(np.pi * Y), np.sin(np.pi * Z)
+    c.ub[0] = sx ** 2 * np.sin(2 * np.pi * Y) * sz ** 2 * c.mask
+    c.ub[1] = -np.sin(2 * np.pi * X) * sy ** 2 * sz ** 2 * c.mask
+    del X, Y, Z, sx, sy, sz
+    assert c.nel == 99452
+    tm = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    h = NekStabHip(c, c.meta["vert"], c.meta["nvert"], tol_helm=1e-9, tol_pres=1e-2, tol_relative=1, max_helm_iter=150, max_pres_iter=48)
+    setup = time.perf_counter() - t0
+    assert h.nvel == 99452 * 1000 and h.nstate == 3 * h.nvel + h.npres
+    q, f = h.alloc(2)
+    rng = np.random.default_rng(2)
+    w = 1e-2 * rng.standard_normal(c.x.shape) * c.mask
+    h.upload3(q, c.ub[0] + w, c.ub[1] - w, w, np.zeros(h.npres))
+    del w
+    n0 = h.norm(q)
+    nst = 3
+    h.set_nsteps(nst)
+    out = {}
+    for name, run in (("linearised", lambda: h.matvec(f, q, 0)), ("full equations", lambda: h.nonlinear_map(f, q))):
+        run()
+        t0 = time.perf_counter(); run(); nf = h.norm(f); dt = time.perf_counter() - t0
+        st = h.stats()
+        out[name] = (1e3 * dt / nst, st["helm_iters"] / nst, st["pres_iters"] / nst, nf)
+        assert st["unconverged"] == 0 and np.isfinite(nf) and 0.5 * n0 < nf < 2.0 * n0
+    print("config 5: E %d lx1 10, %d points/field, state %.2f GB, mesh %.0f s, set-up %.0f s; " % (c.nel, h.nvel, 8e-9 * h.nstate, tm, setup) +
+          "; ".join("%s %.0f ms per time step (%.1f Helmholtz + %.1f pressure iterations)" % (k, v[0], v[1], v[2]) for k, v in out.items()))
+    h.close()

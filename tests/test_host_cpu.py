@@ -194,3 +194,16 @@ def test_seed_hexahedral_branch():
     r2 = seed._mth_rand(1.0, 2.0, None, 1.0, (0.3, 0.4), seed.FCOEFF[0])
     r3 = seed._mth_rand(1.0, 2.0, 3.0, 1.0, (0.3, 0.4, 0.5), seed.FCOEFF[0])
     assert abs(r2) <= 1 and abs(r3) <= 1 and r2 != r3
+
+
+def test_scripts_compile():
+    """scripts/ holds the measurement drivers DESIGN.md cites (scripts/README.md): keep them syntactically alive."""
+    import py_compile
+    sdir = os.path.join(ROOT, "scripts")
+    names = [f for f in os.listdir(sdir) if f.endswith(".py")]
+    assert len(names) >= 15
+    for f in names:
+        py_compile.compile(os.path.join(sdir, f), doraise=True)
+    listed = open(os.path.join(sdir, "README.md")).read()
+    for f in names:
+        assert f in listed, f + " is not described in scripts/README.md"
