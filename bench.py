@@ -28,6 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 K_DIM = 128
+WATCHDOG_S = 1500          # N > 1 only
 
 
 def parse():
@@ -164,6 +165,17 @@ def main():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     dist = None
     if world > 1:
+        # watchdog: a multi-rank run that stalls (an exchange that never completes) must not hang the caller for ever
+        import signal
+
+        def _stalled(signum, frame):
+            print("bench.py rank %d: no result after %d s: giving up" % (rank, WATCHDOG_S), file=sys.stderr, flush=True)
+            if rank == 0:
+                print(json.dumps({"metric": "Arnoldi matvecs/sec + wall-time to k_dim=128 eigenpairs, cylinder Re=50", "value": None, "unit": "matvecs/s",
+                                  "n_gpus": world, "error": "multi-rank run stalled for %d s (watchdog)" % WATCHDOG_S}), flush=True)
+            os._exit(3)
+        signal.signal(signal.SIGALRM, _stalled)
+        signal.alarm(WATCHDOG_S)
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", 0))

@@ -69,6 +69,7 @@ struct nsk_ctx {
   int cur_helm[NCLS] = {}, cur_pres[NCLS] = {};       // adaptive launch budgets per BDF order
   int bh_helm[NCLS][8] = {}, bh_pres[NCLS][8] = {}, bh_n = 0;                         // iteration maxima of the last maps (budgets_update)
   int use_graph = 1;
+  int gmres_cycle = MAXMR;              // pressure GMRES restarts after this many iterations (option "gmres_cycle": tests use short cycles)
   int mfma_convect = 1;                 // hexahedra, lx1 = 8: convection kernel with the contractions on the fp64 matrix cores (nsk3_mfma.hpp)
   int fused = 0;                        // persistent velocity solve (k_helm_fused): one launch per time step instead of one per CG iteration
   unsigned* sync = nullptr;             // grid-barrier counters of the persistent kernels
@@ -239,7 +240,7 @@ static int build(nsk_ctx* c, const nsk_case& cs) {
   c->re = cs.re; c->endtime = cs.endtime;
   c->layers = std::max(1, std::min(cs.schwarz_layers > 0 ? cs.schwarz_layers : 1, std::min(4, M)));
   if (cs.max_helm_iter > 0) c->max_helm = cs.max_helm_iter;
-  if (cs.max_pres_iter > 0) c->max_pres = std::min(cs.max_pres_iter, MAXMR);
+  if (cs.max_pres_iter > 0) c->max_pres = std::min(cs.max_pres_iter, 4 * MAXMR);     // beyond MAXMR: restarted GMRES cycles
   const long long nloc = c->nloc, npr = c->npr;
   HIPCHK(hipStreamCreate(&c->stream));
   Dev& d = c->d;
@@ -249,7 +250,7 @@ static int build(nsk_ctx* c, const nsk_case& cs) {
   c->h_gid.assign(cs.gid, cs.gid + nloc);
   d.tol_helm = cs.tol_helm > 0 ? cs.tol_helm : 1e-9;
   d.tol_pres = cs.tol_pres > 0 ? cs.tol_pres : 1e-7;
-  d.tol_relative = cs.tol_relative; d.max_mr = c->max_pres; d.has_outflow = cs.has_outflow;
+  d.tol_relative = cs.tol_relative; d.max_mr = std::min(c->max_pres, MAXMR); d.has_outflow = cs.has_outflow;
   d.nproj_max = cs.has_outflow ? std::min(cs.nproj, MAXPROJ) : 0;   // with the pressure null space the projected solves stagnate (measured): off
 
   // ---- bases
@@ -464,6 +465,7 @@ static int build(nsk_ctx* c, const nsk_case& cs) {
   if (d.nproj_max > 0)
     if ((rc = dalloc(c, &d.PX, (size_t)d.nproj_max * npr)) || (rc = dalloc(c, &d.PEX, (size_t)d.nproj_max * npr)) ||
         (rc = dalloc(c, &d.PD, npr)) || (rc = dalloc(c, &d.PED, npr)) || (rc = dalloc(c, &d.ppart, (size_t)(MAXPROJ + 2) * c->nblk))) return rc;
+  if ((rc = dalloc(c, &d.xacc, npr))) return rc;
   c->kblk = 256;
   if ((rc = dalloc(c, &c->kpart, (size_t)c->kblk * 1024)) || (rc = dalloc(c, &c->kout, 1024)) || (rc = dalloc(c, &c->kptr, 1024))) return rc;
   HIPCHK(hipHostMalloc((void**)&c->hpin, 4096 * sizeof(double)));
@@ -693,7 +695,13 @@ static int pres_solve_launch(nsk_ctx* c, double h2, int ord, int np, double tol_
     if (!d.has_outflow && !c->in_test) { hipLaunchKernelGGL(k_ortho, dim3(c->nblk), dim3(256), 0, c->stream, d); tot_rows(c, d.gpart, 1, d.gtot); }
     if (d.nproj_max > 0 && !c->in_test) { hipLaunchKernelGGL(k_proj_apply, dim3(c->nblk), dim3(256), 0, c->stream, d); tot_rows(c, d.gpart, 1, d.gtot); }
     hipLaunchKernelGGL(k_gmres_update<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, -1, scale, c->min_pres, ord);
-    for (int j = 0; j < np; ++j) {
+    for (int jt = 0; jt < np; ++jt) {
+      const int j = jt % c->gmres_cycle;                 // index inside the current GMRES cycle
+      if (jt > 0 && j == 0) {                            // cycle full and not converged: restart on the residual
+        hipLaunchKernelGGL(k_gmres_restart, dim3(c->nblk), dim3(256), 0, c->stream, d, c->gmres_cycle);
+        tot_rows(c, d.gpart, 1, d.gtot, &d.gsc->done);
+        hipLaunchKernelGGL(k_gmres_update<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, -2, scale, c->min_pres, ord);
+      }
       if (c->ndim == 3) {
         hipLaunchKernelGGL(k_coarse_restrict_csr, dim3(d.coarse_lda / 256), dim3(256), 0, c->stream, d, c->rc_big);
         if (c->coarse_iter) { int rc2 = coarse_iterative(c, c->rc_big); if (rc2) return rc2; }
@@ -1102,6 +1110,7 @@ int nsk_set_option(nsk_ctx* c, const char* name, double value) {
   }
   else if (n == "helm_guess") c->helm_guess = (int)value;
   else if (n == "mfma_convect") c->mfma_convect = (int)value;
+  else if (n == "gmres_cycle") c->gmres_cycle = std::max(2, std::min((int)value, MAXMR));
   else if (n == "fused") {
     if (value != 0 && !fused_possible(c)) return fail(NSK_EINVAL, "persistent velocity solve not available for this context (needs a quadrilateral single-rank context whose workgroups are all resident)");
     c->fused = value != 0;
@@ -1386,6 +1395,14 @@ int nsk_zero(nsk_ctx* c, nsk_vec p) {
   return 0;
 }
 
+// Rank-sharded contexts: the inner products are sums over ranks (`glsc3`, core/krylov_subspace.f:37-43).  The coefficients stay
+// on the device: rank-local dots -> all-reduce of the j-vector on the stream (RCCL, or the host-staged transport) -> projection.
+static int dots_allreduce(nsk_ctx* c, int n) {
+  if (!c->parent || (!c->comm && !c->host_allred)) return 0;
+  std::vector<nsk_ctx*> G(1, c);
+  return allreduce_ptr(G, &nsk_ctx::kout, n);
+}
+
 int nsk_orth(nsk_ctx* c, nsk_vec fv, const nsk_vec* Q, int j, double* h, double* beta) {
   if (!c || !fv || (j > 0 && !Q) || !h || !beta) return fail(NSK_EINVAL, "bad argument");
   double* f = (double*)fv;
@@ -1394,6 +1411,7 @@ int nsk_orth(nsk_ctx* c, nsk_vec fv, const nsk_vec* Q, int j, double* h, double*
   for (int ps = 0; ps < 2 && j > 0; ++ps) {        // two projection passes (re-orthogonalisation)
     int rc = dots_to_device(c, f, Q, j);
     if (rc) return rc;
+    if ((rc = dots_allreduce(c, j))) return rc;
     hipLaunchKernelGGL(k_project_out, dim3((unsigned)((c->nstate + 255) / 256)), dim3(256), 0, c->stream, f, (const double* const*)c->kptr, j, (const double*)c->kout, c->nstate);
     HIPCHK(hipMemcpyAsync(pass.data(), c->kout, j * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -1402,6 +1420,7 @@ int nsk_orth(nsk_ctx* c, nsk_vec fv, const nsk_vec* Q, int j, double* h, double*
   nsk_vec self = fv;
   int rc = dots_to_device(c, f, &self, 1);
   if (rc) return rc;
+  if ((rc = dots_allreduce(c, 1))) return rc;
   hipLaunchKernelGGL(k_scale_rsqrt, dim3((unsigned)((c->nstate + 255) / 256)), dim3(256), 0, c->stream, f, (const double*)c->kout, c->nstate);
   double n2 = 0;
   HIPCHK(hipMemcpyAsync(&n2, c->kout, sizeof(double), hipMemcpyDeviceToHost, c->stream));

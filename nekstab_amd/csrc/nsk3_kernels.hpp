@@ -760,7 +760,9 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_gmres_update(Dev d, int j, doubl
   const int tid = threadIdx.x;
   const long long e = blockIdx.x;
   GmresScal* G = d.gsc;
-  if (j >= 0 && G->done) return;
+  const bool restart = (j == -2);               // open the next GMRES cycle on the residual k_gmres_restart left in V[0]
+  if (restart) j = -1;
+  if ((j >= 0 || restart) && G->done) return;
   double wnew = 0.0;
   if (tid < MM) wnew = d.V[(size_t)(j + 1) * d.ps + e * MM + tid];
   double hn;
@@ -777,8 +779,12 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_gmres_update(Dev d, int j, doubl
   }
   const double hinv = (hn > 0.0) ? 1.0 / hn : 0.0;
   if (blockIdx.x == 0 && tid == 0) {
-    if (j < 0) {
+    if (restart) {
+      G->nit_prev += G->nit;
       G->beta0 = hn; G->g[0] = hn; G->nit = 0; G->resid = hn * scale;
+      if (!(hn > 0.0)) G->done = 1;
+    } else if (j < 0) {
+      G->beta0 = hn; G->g[0] = hn; G->nit = 0; G->nit_prev = 0; G->resid = hn * scale;
       if (d.nproj_max <= 0) G->gnorm0 = hn;
       const double tol0 = d.tol_relative ? fmax(d.tol_pres * G->gnorm0 * scale, d.tol_pres_floor) : d.tol_pres;
       const int dn = (!(hn > 0.0) || (min_iter <= 0 && hn * scale <= tol0)) ? 1 : 0;
@@ -807,9 +813,9 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_gmres_update(Dev d, int j, doubl
       G->resid = res;
       const double tol = d.tol_relative ? fmax(d.tol_pres * G->gnorm0 * scale, d.tol_pres_floor) : d.tol_pres;
       if ((res <= tol && (j + 1) >= min_iter) || !(hn > 0.0) || (d.pres_cap > 0 && (j + 1) >= d.pres_cap)) {
-        atomicAdd((unsigned long long*)&d.stats->pres_iters, (unsigned long long)(j + 1));
-        atomicMax((unsigned long long*)&d.stats->max_pres, (unsigned long long)(j + 1));
-        atomicMax((unsigned long long*)&d.stats->max_pres_k[ord], (unsigned long long)(j + 1));
+        atomicAdd((unsigned long long*)&d.stats->pres_iters, (unsigned long long)(G->nit_prev + j + 1));
+        atomicMax((unsigned long long*)&d.stats->max_pres, (unsigned long long)(G->nit_prev + j + 1));
+        atomicMax((unsigned long long*)&d.stats->max_pres_k[ord], (unsigned long long)(G->nit_prev + j + 1));
         d.stats->last_pres_res = res;
         if (!(res <= tol) && hn > 0.0) {           // ended by the cap, not by its tolerance: counted, never silent
           d.stats->capped_solves += 1;
@@ -1008,7 +1014,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_pres_update(Dev d, StepCoef sc) 
   double dp = 0.0, w2[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   if (tid < MM) {
     const long long q = e * MM + tid;
-    double x = 0.0;
+    double x = (G->nit_prev > 0) ? d.xacc[q] : 0.0;  // completed GMRES cycles of a restarted solve
     for (int kk = 0; kk < nit; ++kk) x += sy[kk] * d.Z[(size_t)kk * d.npr + q];
     if (d.nproj_max > 0) {
       d.PD[q] = x;

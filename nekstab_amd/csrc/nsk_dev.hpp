@@ -38,6 +38,7 @@ struct GmresScal {               // device-resident small state of one pressure 
   int done;
   int nit;
   int nproj;                     // vectors currently in the projection space
+  int nit_prev;                  // iterations of the completed GMRES cycles of this solve (restarts)
 };
 
 // Step classes: one captured hipGraph and one launch budget each.  Time steps 1, 2, 3 differ in BDF/EXT order and
@@ -91,6 +92,7 @@ struct Dev {
   double *hx, *hr, *hp, *hs, *hwl, *hpart, *hscal;
   // pressure GMRES
   double *V, *Z, *yl, *ec, *xc, *gpart;
+  double *xacc;                  // solution accumulated over the completed GMRES cycles (restarted solves)
   GmresScal* gsc;
   // projection onto previous pressure solutions (E-orthonormal)
   double *PX, *PEX, *PD, *PED, *ppart;

@@ -854,7 +854,9 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_gmres_update(Dev d, int j, doubl
   const long long e = (long long)blockIdx.x * EPB + el;
   const bool act = (el < EPB) && (e < d.nel);
   GmresScal* G = d.gsc;
-  if (j >= 0 && G->done) return;
+  const bool restart = (j == -2);               // open the next GMRES cycle on the residual k_gmres_restart left in V[0]
+  if (restart) j = -1;
+  if ((j >= 0 || restart) && G->done) return;
   double hatv[(4 * MM + NT - 1) / NT];
 #pragma unroll
   for (int r = 0; r < (4 * MM + NT - 1) / NT; ++r) hatv[r] = (tid + r * NT < 4 * MM) ? d.hat[tid + r * NT] : 0.0;
@@ -884,8 +886,12 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_gmres_update(Dev d, int j, doubl
     lds_barrier();
   }
   if (blockIdx.x == 0 && tid == 0) {
-    if (j < 0) {
+    if (restart) {
+      G->nit_prev += G->nit;
       G->beta0 = hn; G->g[0] = hn; G->nit = 0; G->resid = hn * scale;
+      if (!(hn > 0.0)) G->done = 1;
+    } else if (j < 0) {
+      G->beta0 = hn; G->g[0] = hn; G->nit = 0; G->nit_prev = 0; G->resid = hn * scale;
       if (d.nproj_max <= 0) G->gnorm0 = hn;
       const double tol0 = d.tol_relative ? fmax(d.tol_pres * G->gnorm0 * scale, d.tol_pres_floor) : d.tol_pres;
       const int dn = (!(hn > 0.0) || (min_iter <= 0 && hn * scale <= tol0)) ? 1 : 0;
@@ -913,9 +919,9 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_gmres_update(Dev d, int j, doubl
       G->resid = res;
       const double tol = d.tol_relative ? fmax(d.tol_pres * G->gnorm0 * scale, d.tol_pres_floor) : d.tol_pres;
       if ((res <= tol && (j + 1) >= min_iter) || !(hn > 0.0) || (d.pres_cap > 0 && (j + 1) >= d.pres_cap)) {
-        atomicAdd((unsigned long long*)&d.stats->pres_iters, (unsigned long long)(j + 1));
-        atomicMax((unsigned long long*)&d.stats->max_pres, (unsigned long long)(j + 1));
-        atomicMax((unsigned long long*)&d.stats->max_pres_k[ord], (unsigned long long)(j + 1));
+        atomicAdd((unsigned long long*)&d.stats->pres_iters, (unsigned long long)(G->nit_prev + j + 1));
+        atomicMax((unsigned long long*)&d.stats->max_pres, (unsigned long long)(G->nit_prev + j + 1));
+        atomicMax((unsigned long long*)&d.stats->max_pres_k[ord], (unsigned long long)(G->nit_prev + j + 1));
         d.stats->last_pres_res = res;
         if (!(res <= tol) && hn > 0.0) {           // ended by the cap, not by its tolerance: counted, never silent
           d.stats->capped_solves += 1;
@@ -946,6 +952,50 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_gmres_update(Dev d, int j, doubl
 }
 
 }  // namespace k2
+
+// GMRES restart (Nek5000 restarts at lgmres = 30; here the cycle is MAXMR = 48): after m iterations without convergence
+//   xacc (+)= Z y,   r = V_{m+1} s  with  s = Omega_0^T ... Omega_{m-1}^T (g_m e_{m+1})   (the residual in the Krylov basis),
+// r overwrites V[0] and its |r|^2 partials go to gpart row 0; k_gmres_update(j = -2) then normalises it and opens the next
+// cycle.  Same launch shape as k_proj_apply (d.nblk workgroups, grid-stride), works for both kernel sets.
+__global__ __launch_bounds__(256) void k_gmres_restart(Dev d, int m) {
+  __shared__ double sy[MAXMR], sg[MAXMR + 1], ss[MAXMR + 1], scs[MAXMR], ssn[MAXMR], sR[MAXMR * MAXMR];
+  __shared__ double sred[16];
+  const GmresScal* G = d.gsc;
+  if (G->done) return;
+  const int tid = threadIdx.x;
+  for (int p = tid; p < m * m; p += 256) { const int cc = p / m, rr = p % m; sR[cc * MAXMR + rr] = G->R[cc * MAXMR + rr]; }
+  if (tid <= m) sg[tid] = G->g[tid];
+  if (tid < m) { scs[tid] = G->cs[tid]; ssn[tid] = G->sn[tid]; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int q = m - 1; q >= 0; --q) {
+      double s = sg[q];
+      for (int k = q + 1; k < m; ++k) s -= sR[k * MAXMR + q] * sy[k];
+      sy[q] = s / sR[q * MAXMR + q];
+    }
+    for (int i = 0; i < m; ++i) ss[i] = 0.0;
+    ss[m] = sg[m];
+    for (int i = m - 1; i >= 0; --i) {
+      const double a = ss[i], b = ss[i + 1];
+      ss[i] = scs[i] * a - ssn[i] * b;
+      ss[i + 1] = ssn[i] * a + scs[i] * b;
+    }
+  }
+  __syncthreads();
+  const bool first = (G->nit_prev == 0);
+  double v[1] = {0.0};
+  for (long long q = (long long)blockIdx.x * 256 + tid; q < d.npr; q += (long long)gridDim.x * 256) {
+    double x = 0.0;
+    for (int k = 0; k < m; ++k) x += sy[k] * d.Z[(size_t)k * d.npr + q];
+    d.xacc[q] = first ? x : d.xacc[q] + x;
+    double r = 0.0;
+    for (int i = 0; i <= m; ++i) r += ss[i] * d.V[(size_t)i * d.ps + q];
+    d.V[q] = r;
+    v[0] += r * r;
+  }
+  block_reduce<1>(v, sred, tid, 256);
+  if (tid == 0) d.gpart[blockIdx.x] = v[0];
+}
 
 namespace k2 {
 // the quadrilateral solves stay below ~20 iterations: single-pass Gram-Schmidt (the 3-D set re-orthogonalises)
@@ -1226,7 +1276,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_pres_update(Dev d, StepCoef sc) 
   lds_barrier();
   if (act && nd < MM) {
     const long long q = e * MM + nd;
-    double x = 0.0;
+    double x = (G->nit_prev > 0) ? d.xacc[q] : 0.0;  // completed GMRES cycles of a restarted solve
     for (int k = 0; k < nit; ++k) x += sy[k] * d.Z[(size_t)k * d.npr + q];
     if (d.nproj_max > 0) {
       d.PD[q] = x;                                   // GMRES correction delta

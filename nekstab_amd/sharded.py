@@ -314,17 +314,14 @@ class ShardRank:
         self._chk(self.lib.nsk_zero(self.ctx, p))
 
     def orth(self, f, Q):
-        h = np.zeros(len(Q))
-        for _ in range(2):
-            if not Q:
-                break
-            cpass = self._dots(f, Q)
-            arr = (C.c_void_p * len(Q))(*[v.value for v in Q])
-            self._chk(self.lib.nsk_project_out(self.ctx, f, arr, len(Q), cpass.ctypes.data_as(_dp)))
-            h += cpass
-        beta = self.norm(f)
-        self.scal(f, 1.0 / beta)
-        return h, beta
+        """update_hessenberg_matrix on sharded vectors: one library call; the two projection passes and the normalisation
+        run on the device, the coefficient vectors are all-reduced over the ranks on the stream (RCCL or host-staged)."""
+        j = len(Q)
+        arr = (C.c_void_p * max(j, 1))(*[v.value for v in Q])
+        h = np.zeros(max(j, 1))
+        beta = C.c_double()
+        self._chk(self.lib.nsk_orth(self.ctx, f, arr, j, h.ctypes.data_as(_dp), C.byref(beta)))
+        return h[:j].copy(), beta.value
 
     def basis_gemm(self, Q, Z):
         k = len(Q)

@@ -34,6 +34,15 @@ def main():
     sh.upload(vq, *q)
     n2 = sh.dot(vq, vq)                          # all-reduced inner product
     sh.matvec(vf, vq, 0)
+    # update_hessenberg_matrix across processes: orthogonalise M q against q (coefficient all-reduced on the stream)
+    vg = sh.alloc(1)[0]
+    sh.copy(vg, vf)
+    hq, bq = sh.orth(vg, [vq] if False else [])          # norm only
+    sh.copy(vg, vf)
+    sh.scal(vq, 1.0 / np.sqrt(n2))
+    h1, b1 = sh.orth(vg, [vq])
+    sh.scal(vq, np.sqrt(n2))
+    orth_res = abs(sh.dot(vg, vq)) / np.sqrt(n2)
     loc = sh.download_local(vf)
     gathered = [None] * world
     dist.gather_object((sh.elems, loc), gathered if rank == 0 else None, dst=0)
@@ -52,9 +61,15 @@ def main():
         err = max(np.abs(g - r).max() for g, r in zip(got[:2], ref[:2])) / scale
         perr = np.abs(got[2] - ref[2]).max() / np.abs(ref[2]).max()
         dn = abs(n2 - full.dot(a, a)) / full.dot(a, a)
-        print("MPSHARD world %d nsteps %d: velocity rel diff %.3e pressure %.3e norm %.1e exchanges %d allreduces %d"
-              % (world, nsteps, err, perr, dn, tr.n_exchange, tr.n_allreduce), flush=True)
-        ok = err < 1e-9 and perr < 1e-5 and dn < 1e-12 and tr.n_exchange > 0
+        # the same orthogonalisation on the single-rank context
+        g1 = full.alloc(1)[0]
+        full.copy(g1, b)
+        full.scal(a, 1.0 / full.norm(a))
+        h0, b0 = full.orth(g1, [a])
+        do = max(abs(h1[0] - h0[0]) / abs(h0[0]), abs(b1 - b0) / b0)
+        print("MPSHARD world %d nsteps %d: velocity rel diff %.3e pressure %.3e norm %.1e orth %.1e (residual %.1e) exchanges %d allreduces %d"
+              % (world, nsteps, err, perr, dn, do, orth_res, tr.n_exchange, tr.n_allreduce), flush=True)
+        ok = err < 1e-9 and perr < 1e-5 and dn < 1e-12 and tr.n_exchange > 0 and do < 1e-9 and orth_res < 1e-12
     flag = torch.tensor([1.0 if ok else 0.0])
     dist.broadcast(flag, 0)
     sh.close(); full.close()

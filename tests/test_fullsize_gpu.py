@@ -102,7 +102,9 @@ def test_config5_lid_driven_cube_E99452_lx1_10():
     assert c.nel == 99452
     tm = time.perf_counter() - t0
     t0 = time.perf_counter()
-    h = NekStabHip(c, c.meta["vert"], c.meta["nvert"], tol_helm=1e-9, tol_pres=1e-2, tol_relative=1, max_helm_iter=150, max_pres_iter=48)
+    # cav.box's Chebyshev clustering at 46 elements per direction means cell-size ratios of 29: the pressure GMRES needs ~50
+    # iterations per step here, i.e. a restart (cycle of 48: k_gmres_restart)
+    h = NekStabHip(c, c.meta["vert"], c.meta["nvert"], tol_helm=1e-9, tol_pres=1e-2, tol_relative=1, max_helm_iter=200, max_pres_iter=192)
     setup = time.perf_counter() - t0
     assert h.nvel == 99452 * 1000 and h.nstate == 3 * h.nvel + h.npres
     q, f = h.alloc(2)

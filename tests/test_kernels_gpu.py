@@ -117,3 +117,24 @@ def test_seed_noise_on_device(hip6, case6):
         assert np.all(g[case6.mask == 0] == 0.0)                                # bcdirvc
     assert np.all(gp == 0.0)
     hip6.free([v, v2])
+
+
+def test_pressure_gmres_restart(oracle6, case6):
+    """Restarted GMRES (k_gmres_restart; Nek5000 restarts at lgmres = 30): with cycles of 8 iterations the pressure solve
+    reaches the same solution as the un-restarted one (and as the oracle's direct solve), in more iterations."""
+    from nekstab_amd.capi import NekStabHip
+    h = NekStabHip(case6, case6.meta["vert"], case6.meta["nvert"], tol_helm=1e-12, tol_pres=1e-5, tol_relative=1,
+                   schwarz_layers=2, max_helm_iter=120, max_pres_iter=160)
+    rng = np.random.default_rng(11)
+    g = rng.standard_normal((case6.nel, 4, 4))
+    ref = oracle6.E_solve(g)
+    x0, it0 = h.t_pres_solve(g)
+    h.set_option("gmres_cycle", 8)
+    x1, it1 = h.t_pres_solve(g)
+    print("un-restarted %d iterations, cycles of 8: %d iterations" % (it0, it1))
+    assert 8 < it0 <= 48 and it1 > it0
+    sc = np.abs(ref).max()
+    e0, e1 = np.abs(x0 - ref).max() / sc, np.abs(x1 - ref).max() / sc
+    print("error vs direct solve: %.1e un-restarted, %.1e restarted" % (e0, e1))
+    assert e0 < 1e-3 and e1 < 1e-3
+    h.close()
