@@ -89,6 +89,7 @@ int nsk_set_tolerances(nsk_ctx* ctx, double tol_helm, double tol_pres, int relat
  * "pres_floor" (absolute floor under the relative pressure tolerance, in the scaled units of nsk_stats.last_pres_res; 0 = off),
  * "budget_helm" / "budget_pres" (launch budgets), "fused" (persistent velocity solve: right-hand side, all CG iterations and
  * the pressure right-hand side in one launch with device-side grid barriers; default 0: not faster on config 2),
+ * "endtime" (the sampling period T = param(10); used by the next nsk_set_baseflow / nsk_set_orbit),
  * "gmres_cycle" (the pressure GMRES restarts after this many iterations, default and maximum 48; `max_pres_iter` may be up to 4 x 48),
  * "mfma_convect" (hexahedra, lx1 = 8: convection contractions on v_mfma_f64_16x16x4_f64, default 1),
  * "dbg" (developer ablation mask) */

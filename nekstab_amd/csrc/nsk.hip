@@ -1110,6 +1110,10 @@ int nsk_set_option(nsk_ctx* c, const char* name, double value) {
   }
   else if (n == "helm_guess") c->helm_guess = (int)value;
   else if (n == "mfma_convect") c->mfma_convect = (int)value;
+  else if (n == "endtime") {                     // param(10): the sampling period T (Newton for periodic orbits changes it every iteration)
+    if (!(value > 0.0)) return fail(NSK_EINVAL, "endtime must be positive");
+    c->endtime = value;                          // takes effect at the next nsk_set_baseflow / nsk_set_orbit (dt, nsteps from the CFL rule)
+  }
   else if (n == "gmres_cycle") c->gmres_cycle = std::max(2, std::min((int)value, MAXMR));
   else if (n == "fused") {
     if (value != 0 && !fused_possible(c)) return fail(NSK_EINVAL, "persistent velocity solve not available for this context (needs a quadrilateral single-rank context whose workgroups are all resident)");

@@ -4,7 +4,9 @@
     initialize_gmres_vector    core/newton_krylov.f:305-328
     nonlinear_forward_map      core/newton_krylov.f:336-378   (-> nsk_nonlinear_map on the device)
     newton_linearized_map      core/matvec.f:381-428          (-> nsk_matvec mode NSK_NEWTON)
-over the device backend (steady fixed points, uparam(1) = 2; the UPO variants are not built)."""
+over the device backend: steady fixed points (uparam(1) = 2) and unstable periodic orbits (uparam(1) = 2.1: the Krylov
+vector carries the period as its ``time`` component, core/krylov_subspace.f:12, :46-48, and the linearised map is bordered
+with the time derivatives at the two ends of the orbit, core/matvec.f:402-418, :434-475)."""
 from __future__ import annotations
 
 import numpy as np
@@ -72,3 +74,110 @@ def newton_krylov(be, q, k_dim=100, tol=1e-11, maxiter_newton=100, log=None):
         be.axpy(q, -1.0, dq)                             # krylov_sub2(q, dq)
     be.free([f, dq])
     return i, hist
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Newton for unstable periodic orbits (uparam(1) = 2.1)
+# ----------------------------------------------------------------------------------------------------------------------
+class BVec:
+    """krylov_vector with its ``time`` component (core/krylov_subspace.f:7-15)."""
+    def __init__(self, v, t=0.0):
+        self.v, self.t = v, float(t)
+
+
+class BorderedBackend:
+    """The vector interface of krylov.py / ts_gmres on bordered vectors: velocity-pressure state on the device + the period
+    on the host.  ``matvec`` is newton_linearized_map's UPO branch (core/matvec.f:398-418):
+        f      = (exp(LT) - I) q + bvec(fc_nwt) * q%time
+        f%time = < bvec(ic_nwt), q >
+    with bvec(state) = (one full-equation time step from state - state) / dt (compute_bvec, core/matvec.f:434-475)."""
+
+    def __init__(self, be):
+        self.be = be
+        self.bvec, self.btvec = be.alloc(2)
+
+    def close(self):
+        self.be.free([self.bvec, self.btvec])
+
+    def time_derivative(self, out, state):
+        """compute_bvec: a single first-order step of the full equations from ``state`` approximates d(state)/dt."""
+        be = self.be
+        ns = be.nsteps
+        be.set_nsteps(1)
+        be.nonlinear_map(out, state, subtract_q=True)
+        be.set_nsteps(ns)
+        be.scal(out, 1.0 / be.dt)
+
+    # ---- vector interface
+    def alloc(self, n=1):
+        return [BVec(v) for v in self.be.alloc(n)]
+
+    def free(self, vs):
+        self.be.free([b.v for b in vs])
+
+    def copy(self, dst, src):
+        self.be.copy(dst.v, src.v); dst.t = src.t
+
+    def zero(self, p):
+        self.be.zero(p.v); p.t = 0.0
+
+    def scal(self, p, a):
+        self.be.scal(p.v, a); p.t *= a
+
+    def axpy(self, p, a, q):
+        self.be.axpy(p.v, a, q.v); p.t += a * q.t
+
+    def dot(self, p, q):
+        return self.be.dot(p.v, q.v) + p.t * q.t             # core/krylov_subspace.f:46-48
+
+    def norm(self, p):
+        return float(np.sqrt(self.dot(p, p)))
+
+    def orth(self, f, Q):
+        h = np.zeros(len(Q))
+        for _ in range(2):                                   # update_hessenberg_matrix: two passes
+            for i, q in enumerate(Q):
+                c = self.dot(f, q)
+                self.axpy(f, -c, q)
+                h[i] += c
+        beta = self.norm(f)
+        self.scal(f, 1.0 / beta)
+        return h, beta
+
+    def basis_gemv(self, Q, y, out, im=None):
+        self.be.basis_gemv([q.v for q in Q], y, out.v)
+        out.t = float(sum(np.real(yi) * q.t for yi, q in zip(y, Q)))
+
+    def matvec(self, f, q, mode=NSK_NEWTON):
+        be = self.be
+        be.matvec(f.v, q.v, NSK_NEWTON)                      # (exp(LT) - I) q along the stored orbit
+        be.axpy(f.v, q.t, self.bvec)                         # + d/dt at the end of the orbit * period correction
+        f.t = be.dot(self.btvec, q.v)                        # phase condition: no shift along the orbit at t = 0
+
+
+def newton_krylov_upo(be, q, period, k_dim=100, tol=1e-11, maxiter_newton=20, spng_str=0.0, log=None):
+    """q <- a point of a periodic orbit of the full equations, period <- its period (core/newton_krylov.f:5-167 with
+    uparam(1) = 2.1).  ``q``: device vector holding the initial guess; returns (period, iterations, residual history)."""
+    bb = BorderedBackend(be)
+    fc = be.alloc(1)[0]
+    f, dq = bb.alloc(2)
+    qb = BVec(q, period)
+    hist = []
+    for i in range(1, maxiter_newton + 1):
+        be.set_option("endtime", qb.t)                       # param(10) = q%time; prepare_linearized_solver
+        be.set_orbit(qb.v, spng_str=spng_str, end=fc)        # nonlinear_forward_map, the orbit stored for the linearised maps
+        be.copy(f.v, fc)
+        be.axpy(f.v, -1.0, qb.v)
+        f.t = 0.0
+        residual = bb.norm(f) ** 2
+        hist.append((residual, qb.t))
+        if log:
+            log("newton", i, residual, qb.t)
+        if residual < tol:
+            break
+        bb.time_derivative(bb.bvec, fc)                      # compute_bvec(bvec, fc_nwt)
+        bb.time_derivative(bb.btvec, qb.v)                   # compute_bvec(btvec, ic_nwt)
+        ts_gmres(bb, f, dq, k_dim, tol, log=log)
+        bb.axpy(qb, -1.0, dq)                                # krylov_sub2(q, dq), period included
+    bb.free([f, dq]); be.free([fc]); bb.close()
+    return qb.t, i, hist

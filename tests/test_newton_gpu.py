@@ -98,3 +98,33 @@ def test_newton_from_re40_reaches_reference_baseflow(nosponge):
     print("Newton iterations", its, "distance to the committed base flow", num / den)
     assert num / den < 1e-6
     h.free([q])
+
+
+def test_newton_for_periodic_orbit_refines_the_reference_upo():
+    """Newton-GMRES for unstable periodic orbits (uparam(1) = 2.1; core/newton_krylov.f, newton_linearized_map's bordered
+    branch core/matvec.f:402-418): started from the reference's converged vortex-shedding orbit (the base flow of its Floquet
+    example, period 7.921338 in its header) with the period of examples/cylinder/baseflow/newton_upo's `.par` (7.9), the
+    iteration closes the orbit (|Phi_T(q) - q|^2 below 1e-9) and returns the reference's period."""
+    import os
+    from nekstab_amd import mesh, newton
+    from nekstab_amd.capi import NekStabHip
+    from nekstab_amd.quadrature import gauss_legendre, gauss_lobatto_legendre, interp_matrix
+    from tests.conftest import GOLDEN
+    z = np.load(os.path.join(GOLDEN, "cylinder_upo.npz"))
+    T_ref = float(z["period"])
+    case = mesh.load_case_npz(os.path.join(GOLDEN, "cylinder_case.npz"), 6, endtime=7.9)
+    case.ub[:] = z["u"]
+    case.spng[:] = 0.0                                         # newton_upo/1cyl.par sets no sponge
+    h = NekStabHip(case, case.meta["vert"], case.meta["nvert"], tol_helm=1e-11, tol_pres=1e-3, tol_relative=1,
+                   nproj=8, max_helm_iter=150, max_pres_iter=48)
+    J = interp_matrix(gauss_lobatto_legendre(6)[0], gauss_legendre(4)[0])
+    q = h.alloc(1)[0]
+    h.upload(q, z["u"][0], z["u"][1], J @ z["p"] @ J.T)
+    log = []
+    T, its, hist = newton.newton_krylov_upo(h, q, 7.9, k_dim=60, tol=1e-9, maxiter_newton=6,
+                                            log=lambda *a: log.append(a) if a[0] == "newton" else None)
+    print("Newton UPO: period %.6f (reference %.6f) after %d iterations; residual^2 / period history:" % (T, T_ref, its), hist)
+    assert hist[0][0] > 1e-6                                   # T = 7.9 does not close the orbit
+    assert hist[-1][0] < 1e-9 and its <= 6
+    assert abs(T - T_ref) < 2e-5 * T_ref                       # measured: 7.921337 against the header's 7.921338
+    h.close()
