@@ -28,7 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 K_DIM = 128
-WATCHDOG_S = 1500          # N > 1 only
+WATCHDOG_S = 3000          # N > 1 only
 
 
 def parse():
@@ -308,7 +308,7 @@ def main():
         st = full.stats()
         tsteps = max(st["total_steps"], 1)
         out.update({"helm_iters_per_step": st["total_helm_iters"] / tsteps, "pres_iters_per_step": st["total_pres_iters"] / tsteps,
-                    "map_retries": st["retries"], "graph_recaptures": st["recaptures"],
+                    "map_retries": st["retries"], "graph_recaptures": st["recaptures"], "graph_recapture_s": st["recapture_seconds"],
                     "capped_solves": st["total_capped_solves"], "worst_cap_ratio": st["total_worst_cap_ratio"]})
         # ---- SURVEY 8(d) accounting: algorithmic bytes per matvec from the logged iteration counts
         geom = dict(nel=case.nel, lx1=case.lx1, ndim=2, nvert=int(case.meta["nvert"]), coarse_lda=((int(case.meta["nvert"]) + 255) // 256) * 256,

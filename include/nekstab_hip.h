@@ -155,6 +155,7 @@ typedef struct {
   long long total_capped_solves;            /* the same two since nsk_init */
   double total_worst_cap_ratio;
   long long total_helm_iters, total_pres_iters, total_steps;   /* since nsk_init: what bytes_per_matvec is computed from */
+  double recapture_seconds;                 /* host time spent (re)capturing and instantiating the step graphs since nsk_init */
 } nsk_stats;
 int nsk_get_stats(nsk_ctx* ctx, nsk_stats* s);
 

@@ -42,7 +42,8 @@ class NskStats(C.Structure):
                 ("recaptures", C.c_longlong), ("retries", C.c_longlong),
                 ("capped_solves", C.c_longlong), ("worst_cap_ratio", C.c_double),
                 ("total_capped_solves", C.c_longlong), ("total_worst_cap_ratio", C.c_double),
-                ("total_helm_iters", C.c_longlong), ("total_pres_iters", C.c_longlong), ("total_steps", C.c_longlong)]
+                ("total_helm_iters", C.c_longlong), ("total_pres_iters", C.c_longlong), ("total_steps", C.c_longlong),
+                ("recapture_seconds", C.c_double)]
 
 
 # every symbol include/nekstab_hip.h declares: (restype, argtypes)

@@ -17,6 +17,7 @@
 #include <utility>
 #include <string>
 #include <thread>
+#include <chrono>
 #include <vector>
 
 #include "../../include/nekstab_hip.h"
@@ -77,6 +78,7 @@ struct nsk_ctx {
   int helm_guess = 1;
   double early_pres_mul = 1e-2;         // pressure tolerance factor of time steps 1-3 of every map
   long long recaptures = 0, retries = 0;
+  double recapture_s = 0.0;             // host time spent capturing + instantiating step graphs (since init)
   // since init (nsk_stats: the per-matvec fields are reset by every nsk_matvec, these are not)
   long long tot_capped = 0, tot_helm_iters = 0, tot_pres_iters = 0, tot_steps = 0;
   double tot_worst_cap = 0.0;
@@ -800,6 +802,7 @@ static const int CLS_ISTEP[NCLS] = {1, 2, 3, 4, 7, 17};    // first step of ever
 static int ensure_graph(nsk_ctx* c, int cls, int adjoint) {
   nsk_ctx::StepGraph& g = c->graphs[adjoint][cls];
   if (g.exec && g.nh == c->cur_helm[cls] && g.np == c->cur_pres[cls]) return 0;
+  const auto t_cap0 = std::chrono::steady_clock::now();
   if (g.exec) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }
   hipGraph_t graph = nullptr;
   HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeGlobal));
@@ -811,6 +814,7 @@ static int ensure_graph(nsk_ctx* c, int cls, int adjoint) {
   c->recaptures++;
   HIPCHK(hipGraphDestroy(graph));
   g.nh = c->cur_helm[cls]; g.np = c->cur_pres[cls];
+  c->recapture_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_cap0).count();
   return 0;
 }
 
@@ -1211,6 +1215,7 @@ int nsk_get_stats(nsk_ctx* c, nsk_stats* s) {
   s->capped_solves = h.capped_solves; s->worst_cap_ratio = h.worst_cap_ratio;
   s->total_capped_solves = c->tot_capped; s->total_worst_cap_ratio = c->tot_worst_cap;
   s->total_helm_iters = c->tot_helm_iters; s->total_pres_iters = c->tot_pres_iters; s->total_steps = c->tot_steps;
+  s->recapture_seconds = c->recapture_s;
   return 0;
 }
 
