@@ -67,7 +67,7 @@ def spawn_ranks(a):
     return rc
 
 
-def cpu_baseline(case, threads):
+def cpu_baseline(case, threads, tol):
     """The CPU port of the same step (oracle/cpu_step.c: C + OpenMP, the same PCG / GMRES + Schwarz + coarse algorithms and
     tolerances as the GPU path, no projection space) timed on the host cores.  Thread count: the fastest of {all visible
     cores, 16, 8} on a 4-step calibration (a cgroup quota below the visible core count makes "all" the slowest).  Sample:
@@ -82,8 +82,7 @@ def cpu_baseline(case, threads):
     t0 = time.perf_counter()
     o = LinNS2D(x=case.x, y=case.y, gid=case.gid, nglob=case.nglob, mask=case.mask, ub=case.ub, spng=case.spng, re=case.re,
                 endtime=case.endtime, lxd=case.lxd, has_outflow=case.has_outflow, factorize_pressure=False)
-    cp = CpuPort(o, case.meta["vert"], case.meta["nvert"], tol_helm=cpu_baseline.tol[0], tol_pres=cpu_baseline.tol[1], tol_relative=1,
-                 min_pres=cpu_baseline.tol[2])
+    cp = CpuPort(o, case.meta["vert"], case.meta["nvert"], tol_helm=tol[0], tol_pres=tol[1], tol_relative=1, min_pres=tol[2])
     setup = time.perf_counter() - t0
     log("set-up %.1f s" % setup)
     qx, qy = seed.add_noise(case)
@@ -124,7 +123,7 @@ def cpu_baseline(case, threads):
     return {"value": a["matvecs_per_s"], "unit": "matvecs/s", "cores": a["threads"], "kind": "port",
             "sample": "%s of the same case (lx1=%d, E=%d); oracle/cpu_step.c (C + OpenMP: Jacobi-PCG, GMRES + restricted Schwarz + vertex coarse "
                       "solve, tolerances %g / %g as the GPU run, no projection space); %d cores visible; set-up %.0f s excluded"
-                      % (a["sample"], case.lx1, case.nel, cpu_baseline.tol[0], cpu_baseline.tol[1], visible, setup),
+                      % (a["sample"], case.lx1, case.nel, tol[0], tol[1], visible, setup),
             "wall_time_kdim_s_projected": a["s_per_arnoldi_step"] * K_DIM,
             "config1_k32_4threads": {"matvecs_per_s": b["matvecs_per_s"], "threads": b["threads"],
                                      "wall_time_k32_s_projected": b["s_per_arnoldi_step"] * 32, "sample": b["sample"]},
@@ -203,7 +202,6 @@ def main():
         full.set_option("pres_cap", a.pres_cap)
     if a.fused >= 0:
         full.set_option("fused", a.fused)
-    cpu_baseline.tol = (a.tol_helm, a.tol_pres, a.min_pres)
     qx, qy = seed.add_noise(case)
     zp = np.zeros((case.nel, case.lx1 - 2, case.lx1 - 2))
     h = full
@@ -362,7 +360,7 @@ def main():
         if dist is not None:
             dist.barrier()
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(case, a.cpu_threads)
+        out["cpu_baseline"] = cpu_baseline(case, a.cpu_threads, (a.tol_helm, a.tol_pres, a.min_pres))
     if rank == 0:
         print(json.dumps(out))
     if sharded:

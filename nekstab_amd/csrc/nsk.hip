@@ -57,7 +57,7 @@ struct nsk_ctx {
   int ndim = 2, key = 0;                // key selects the kernel set (DISPATCH_N)
   int hrows = 8, hstride = 8;           // rows of Helmholtz partials per parity / stride of their totals (3-D: 12 / 16)
   // large coarse spaces: sparse operator + Chebyshev-Jacobi polynomial instead of the dense inverse
-  int coarse_iter = 0, cheb_deg = 0;
+  int coarse_iter = 0, cheb_deg = 0, cA_width = 0;      // cA_*: sparse coarse operator, row-major with padded rows of cA_width entries
   double cheb_theta = 0, cheb_delta = 0;
   const int *cA_rp = nullptr, *cA_ci = nullptr;
   const double *cA_va = nullptr, *cA_dinv = nullptr;
