@@ -5,6 +5,7 @@
 // tensor contractions in three LDS passes, dssum as the same fused gather.
 #pragma once
 #include "nsk_kernels.hpp"
+#include "nsk3_mfma_ops.hpp"
 
 namespace nsk {
 namespace k3 {
@@ -106,6 +107,9 @@ template <int N>
 __device__ inline double opdiv3(const double* sJ12, const double* sD12, const double* su, double* sA, double* sB,
                                 int tid, int nt, const double (&w2)[9]) {
   constexpr int NN = N * N * N, M = N - 2, MM = M * M * M, NNM = N * N * M, NMM = N * M * M;
+#ifndef NSK_NO_MFMA_OPS
+  if constexpr (N == 8) return opdiv3_mfma8(sJ12, sD12, su, sA, sB, tid, w2);      // matrix cores (nsk3_mfma_ops.hpp)
+#endif
   double div = 0.0;
 #pragma unroll 1
   for (int c = 0; c < 3; ++c) {
@@ -150,6 +154,9 @@ template <int N>
 __device__ inline void opgradt3(const double* sJ12, const double* sD12, double pval, const double (&w2)[9], double* sP,
                                 double* sC, double* sE, int tid, int nt, bool act, int k, int j, int i, double (&g)[3]) {
   constexpr int M = N - 2, MM = M * M * M, NNM = N * N * M, NMM = N * M * M;
+#ifndef NSK_NO_MFMA_OPS
+  if constexpr (N == 8) { opgradt3_mfma8(sJ12, sD12, pval, w2, sP, sC, sE, tid, g); return; }   // matrix cores (nsk3_mfma_ops.hpp)
+#endif
 #pragma unroll 1
   for (int c = 0; c < 3; ++c) {
     if (tid < MM) {
