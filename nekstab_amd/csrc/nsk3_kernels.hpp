@@ -108,7 +108,7 @@ __device__ inline double opdiv3(const double* sJ12, const double* sD12, const do
                                 int tid, int nt, const double (&w2)[9]) {
   constexpr int NN = N * N * N, M = N - 2, MM = M * M * M, NNM = N * N * M, NMM = N * M * M;
 #ifndef NSK_NO_MFMA_OPS
-  if constexpr (N == 8) return opdiv3_mfma8(sJ12, sD12, su, sA, sB, tid, w2);      // matrix cores (nsk3_mfma_ops.hpp)
+  return opdiv3_mfma<N>(sJ12, sD12, su, sA, sB, tid, nt, w2);      // matrix cores (nsk3_mfma_ops.hpp)
 #endif
   double div = 0.0;
 #pragma unroll 1
@@ -155,7 +155,7 @@ __device__ inline void opgradt3(const double* sJ12, const double* sD12, double p
                                 double* sC, double* sE, int tid, int nt, bool act, int k, int j, int i, double (&g)[3]) {
   constexpr int M = N - 2, MM = M * M * M, NNM = N * N * M, NMM = N * M * M;
 #ifndef NSK_NO_MFMA_OPS
-  if constexpr (N == 8) { opgradt3_mfma8(sJ12, sD12, pval, w2, sP, sC, sE, tid, g); return; }   // matrix cores (nsk3_mfma_ops.hpp)
+  opgradt3_mfma<N>(sJ12, sD12, pval, w2, sP, sC, sE, tid, nt, g); return;      // matrix cores (nsk3_mfma_ops.hpp)
 #endif
 #pragma unroll 1
   for (int c = 0; c < 3; ++c) {

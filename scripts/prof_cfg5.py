@@ -1,0 +1,28 @@
+"""Config 5 (stretched box of hexahedra, lx1 = 10): per-kernel profiling target.  Default 24^3 elements (13 824 elements,
+13.8 M points per field) so that a kernel trace stays small; `46 46 47` is the full size."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+from nekstab_amd import mesh3d
+from nekstab_amd.capi import NekStabHip
+n = [int(x) for x in sys.argv[1:4]] if len(sys.argv) > 3 else [24, 24, 24]
+nst = int(sys.argv[4]) if len(sys.argv) > 4 else 3
+stretch = lambda xi: 0.5 * (1.0 - np.cos(np.pi * xi))
+c = mesh3d.box_case_3d(n[0], n[1], n[2], 10, lengths=(1.0, 1.0, 1.0), re=1000.0, endtime=0.02, stretch=stretch)
+sx, sy, sz = np.sin(np.pi * c.x), np.sin(np.pi * c.y), np.sin(np.pi * c.z)
+c.ub[0] = sx ** 2 * np.sin(2 * np.pi * c.y) * sz ** 2 * c.mask
+c.ub[1] = -np.sin(2 * np.pi * c.x) * sy ** 2 * sz ** 2 * c.mask
+del sx, sy, sz
+t0 = time.time()
+h = NekStabHip(c, c.meta["vert"], c.meta["nvert"], tol_helm=1e-9, tol_pres=1e-2, tol_relative=1, max_helm_iter=400, max_pres_iter=192)
+print("E %d set-up %.0f s, nsteps %d dt %.3e" % (c.nel, time.time() - t0, h.nsteps, h.dt), flush=True)
+q, f = h.alloc(2)
+rng = np.random.default_rng(2)
+w = 1e-2 * rng.standard_normal(c.x.shape) * c.mask
+h.upload3(q, c.ub[0] + w, c.ub[1] - w, w, np.zeros(h.npres))
+h.set_nsteps(nst)
+for rep in range(2):
+    t0 = time.time(); h.matvec(f, q, 0); h.norm(f); dt = time.time() - t0
+    st = h.stats()
+    print("%.1f ms per step (%.1f Helmholtz + %.1f pressure iterations per step)" % (1e3 * dt / nst, st["helm_iters"] / nst, st["pres_iters"] / nst), flush=True)
