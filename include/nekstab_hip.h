@@ -168,6 +168,12 @@ int nsk_get_stats(nsk_ctx* ctx, nsk_stats* s);
  * separate processes use RCCL (build with -DNSK_WITH_RCCL, nsk_comm_init_rccl). */
 int nsk_shard_create(nsk_ctx* parent, const int* part, int rank, int nranks, nsk_ctx** out);
 int nsk_group_matvec(nsk_ctx** shards, int n, int mode, nsk_vec* f, nsk_vec* q);
+/* Once a process has cut its shard(s): free every device array of the parent that shards do not share (element-major geometry,
+ * preconditioner factors, state, work arrays and ALL vectors allocated on the parent -- their handles become invalid).  The 1-D
+ * bases and the replicated coarse operator stay.  The parent then only answers nsk_info / nsk_get_stats / nsk_finalize
+ * (finalize it after its shards).  Option "shard_graph" (nsk_set_option on a shard): the sharded step runs as one hipGraph per
+ * step class; -1 (default) = yes unless an RCCL communicator is attached, 0 = eager, 1 = yes, RCCL calls captured too. */
+int nsk_shard_release_parent(nsk_ctx* parent);
 /* RCCL transport, one process per GPU: rank 0 creates the id, everybody calls init on its shard;
  * afterwards nsk_group_matvec(&shard, 1, ...) exchanges halos / all-reduces over xGMI. */
 /* Host-staged transport for ranks in separate processes WITHOUT RCCL (any host message layer: MPI, torch.distributed gloo;

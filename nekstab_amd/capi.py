@@ -80,6 +80,7 @@ SYMBOLS = {
     "nsk_shard_create": (C.c_int, [_vp, C.POINTER(C.c_int), C.c_int, C.c_int, _vpp]),
     "nsk_group_matvec": (C.c_int, [_vpp, C.c_int, C.c_int, _vpp, _vpp]),
     "nsk_comm_init_host": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "nsk_shard_release_parent": (C.c_int, [_vp]),
     "nsk_comm_unique_id": (C.c_int, [_vp]),
     "nsk_comm_init_rccl": (C.c_int, [_vp, _vp]),
     "nsk_allreduce_host": (C.c_int, [_vp, _dp, C.c_int]),

@@ -84,6 +84,10 @@ struct nsk_ctx {
   double tot_worst_cap = 0.0;
   int debug = 0;
   struct StepGraph { hipGraphExec_t exec = nullptr; int nh = -1, np = -1; } graphs[3][NCLS];
+  std::vector<nsk_ctx*> graph_members;  // sharded step graphs (held by the first rank of a process): the ranks they were captured for
+  double* kacc = nullptr;               // nsk_orth: coefficients accumulated over the two passes + the squared norm (device)
+  bool released = false;                // nsk_shard_release_parent: only the arrays shards share are left on the device
+  int shard_graph = -1;                 // sharded step in a hipGraph: -1 = yes unless a communicator is attached, 0 = no, 1 = yes (also with RCCL)
   double* scratch = nullptr;            // one state vector
   const double* xyz = nullptr;          // GLL coordinates [ndim][nloc] (nsk_seed_noise)
   double* rc_big = nullptr;             // coarse restriction for nvert > 3072
@@ -947,7 +951,31 @@ extern "C" {
 // Cut the shard of `rank` (part[e] = owner of global element e) out of a full-mesh context.
 int nsk_shard_create(nsk_ctx* parent, const int* part, int rank, int nranks, nsk_ctx** out) {
   if (!parent || !part || !out) return fail(NSK_EINVAL, "bad argument");
+  if (parent->released) return fail(NSK_EINVAL, "parent context was released (nsk_shard_release_parent)");
   return shard_create(parent, part, rank, nranks, out);
+}
+
+// Free everything of a full-mesh context that its shards do not share: element-major geometry, preconditioner factors, state,
+// work arrays, Krylov vectors.  What stays on the device: the 1-D bases and the (replicated) coarse operator.  A rank of a
+// multi-process run calls this once its shard is cut, so that its GPU holds one shard, not the whole mesh.
+int nsk_shard_release_parent(nsk_ctx* P) {
+  if (!P) return fail(NSK_EINVAL, "bad argument");
+  if (P->parent) return fail(NSK_EINVAL, "not a full-mesh context");
+  if (P->released) return 0;
+  HIPCHK(hipStreamSynchronize(P->stream));
+  const Dev& d = P->d;
+  const void* keep[] = {d.D, d.J12, d.D12, d.Jd, d.Dd, d.hat, d.Aci, d.Acif, d.p_off, d.p_invoff,
+                        P->cA_rp, P->cA_ci, P->cA_va, P->cA_dinv, P->cw_d0, P->cw_d1, P->cw_r};
+  std::vector<void*> left;
+  for (void* p : P->allocs) {
+    bool k = false;
+    for (const void* q : keep) k = k || (q && q == p);
+    if (k) left.push_back(p); else (void)hipFree(p);
+  }
+  P->allocs.swap(left);
+  for (auto& a : P->graphs) for (auto& g : a) if (g.exec) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; g.nh = -1; }
+  P->released = true;
+  return 0;
 }
 
 // f_r = map(q_r) for the ranks living in this process, in lock-step (virtual ranks: all of them).
@@ -1107,6 +1135,7 @@ int nsk_set_option(nsk_ctx* c, const char* name, double value) {
   if (!c || !name) return fail(NSK_EINVAL, "bad argument");
   const std::string n(name);
   if (n == "use_graph") c->use_graph = (int)value;
+  else if (n == "shard_graph") c->shard_graph = (int)value;
   else if (n == "min_pres_iter") c->min_pres = (int)value;
   else if (n == "pres_cap") {
     if (value > 0 && c->ndim != 2) return fail(NSK_EINVAL, "pres_cap is validated on quadrilateral linearised maps only (DESIGN.md section 1)");
@@ -1137,6 +1166,7 @@ int nsk_set_option(nsk_ctx* c, const char* name, double value) {
 
 int nsk_vec_alloc(nsk_ctx* c, int n, nsk_vec* out) {
   if (!c || !out || n < 0) return fail(NSK_EINVAL, "bad argument");
+  if (c->released) return fail(NSK_EINVAL, "context was released (nsk_shard_release_parent): only its shards compute");
   for (int k = 0; k < n; ++k) {
     double* p = nullptr;
     int rc = dalloc(c, &p, (size_t)c->nstate);
@@ -1221,6 +1251,7 @@ int nsk_get_stats(nsk_ctx* c, nsk_stats* s) {
 
 int nsk_matvec(nsk_ctx* c, int mode, nsk_vec fv, nsk_vec qv) {
   if (!c || !fv || !qv) return fail(NSK_EINVAL, "bad argument");
+  if (c->released) return fail(NSK_EINVAL, "context was released (nsk_shard_release_parent): only its shards compute");
   double* f = (double*)fv; const double* q = (const double*)qv;
   c->hstats = Stats{};
   int rc = 0;
@@ -1413,30 +1444,36 @@ static int dots_allreduce(nsk_ctx* c, int n) {
 }
 
 int nsk_orth(nsk_ctx* c, nsk_vec fv, const nsk_vec* Q, int j, double* h, double* beta) {
-  if (!c || !fv || (j > 0 && !Q) || !h || !beta) return fail(NSK_EINVAL, "bad argument");
+  if (!c || !fv || (j > 0 && !Q) || !h || !beta || j < 0) return fail(NSK_EINVAL, "bad argument");
+  if (j > 1000) return fail(NSK_EINVAL, "too many vectors");
   double* f = (double*)fv;
-  std::vector<double> hh(j, 0.0), pass(j);
-  HIPCHK(hipStreamSynchronize(c->stream));
+  int rc;
+  if (!c->kacc && (rc = dalloc(c, &c->kacc, 1024))) return rc;
+  // Everything below is queued on the stream without a host round trip: pointer table once, then per pass
+  // local dots -> sum over ranks (device all-reduce) -> projection (+ accumulation of the coefficients on the device),
+  // then norm -> sum over ranks -> scaling; ONE download of [h(0..j-1), |f|^2] at the end.
+  HIPCHK(hipStreamSynchronize(c->stream));   // hpin reuse
+  for (int k = 0; k < j; ++k) ((double**)c->hpin)[k] = (double*)Q[k];
+  ((double**)c->hpin)[j] = f;
+  HIPCHK(hipMemcpyAsync(c->kptr, c->hpin, (j + 1) * sizeof(double*), hipMemcpyHostToDevice, c->stream));
+  const unsigned gridn = (unsigned)((c->nstate + 255) / 256);
   for (int ps = 0; ps < 2 && j > 0; ++ps) {        // two projection passes (re-orthogonalisation)
-    int rc = dots_to_device(c, f, Q, j);
-    if (rc) return rc;
+    hipLaunchKernelGGL(k_dots, dim3(c->kblk), dim3(256), 0, c->stream, (const double*)f, (const double* const*)c->kptr, j, c->d.bm1s, c->nloc, c->kpart, c->kblk, c->ndim);
+    hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, c->stream, (const double*)c->kpart, j, c->kblk, c->kout);
     if ((rc = dots_allreduce(c, j))) return rc;
-    hipLaunchKernelGGL(k_project_out, dim3((unsigned)((c->nstate + 255) / 256)), dim3(256), 0, c->stream, f, (const double* const*)c->kptr, j, (const double*)c->kout, c->nstate);
-    HIPCHK(hipMemcpyAsync(pass.data(), c->kout, j * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    for (int k = 0; k < j; ++k) hh[k] += pass[k];
+    hipLaunchKernelGGL(k_project_out_acc, dim3(gridn), dim3(256), 0, c->stream, f, (const double* const*)c->kptr, j, (const double*)c->kout, c->nstate, c->kacc, ps);
   }
-  nsk_vec self = fv;
-  int rc = dots_to_device(c, f, &self, 1);
-  if (rc) return rc;
+  hipLaunchKernelGGL(k_dots, dim3(c->kblk), dim3(256), 0, c->stream, (const double*)f, (const double* const*)(c->kptr + j), 1, c->d.bm1s, c->nloc, c->kpart, c->kblk, c->ndim);
+  hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, c->stream, (const double*)c->kpart, 1, c->kblk, c->kout);
   if ((rc = dots_allreduce(c, 1))) return rc;
-  hipLaunchKernelGGL(k_scale_rsqrt, dim3((unsigned)((c->nstate + 255) / 256)), dim3(256), 0, c->stream, f, (const double*)c->kout, c->nstate);
-  double n2 = 0;
-  HIPCHK(hipMemcpyAsync(&n2, c->kout, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  hipLaunchKernelGGL(k_scale_rsqrt, dim3(gridn), dim3(256), 0, c->stream, f, (const double*)c->kout, c->nstate);
+  HIPCHK(hipMemcpyAsync(c->kacc + j, c->kout, sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  double* res = c->hpin + 2048;                    // pinned; the pointer table (first 1001 slots) was consumed in stream order
+  HIPCHK(hipMemcpyAsync(res, c->kacc, (j + 1) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
-  for (int k = 0; k < j; ++k) { if (std::isnan(hh[k])) return fail(NSK_ENAN, "NaN inner product"); h[k] = hh[k]; }
-  if (std::isnan(n2)) return fail(NSK_ENAN, "NaN norm");
-  *beta = std::sqrt(n2);
+  for (int k = 0; k < j; ++k) { if (std::isnan(res[k])) return fail(NSK_ENAN, "NaN inner product"); h[k] = res[k]; }
+  if (std::isnan(res[j])) return fail(NSK_ENAN, "NaN norm");
+  *beta = std::sqrt(res[j]);
   return 0;
 }
 

@@ -1445,6 +1445,19 @@ __global__ void k_project_out(double* __restrict__ f, const double* const* __res
   f[l] = s;
 }
 
+// the same, and the coefficient vector is accumulated on the device (pass 0 sets, pass 1 adds): update_hessenberg_matrix
+// needs h = h_pass1 + h_pass2, and keeping it here removes the host round trip between the passes
+__global__ void k_project_out_acc(double* __restrict__ f, const double* const* __restrict__ Q, int nq,
+                                  const double* __restrict__ h, long long n, double* __restrict__ acc, int pass) {
+  const long long l = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (blockIdx.x == 0)
+    for (int k = threadIdx.x; k < nq; k += blockDim.x) acc[k] = (pass ? acc[k] : 0.0) + h[k];
+  if (l >= n) return;
+  double s = f[l];
+  for (int k = 0; k < nq; ++k) s -= h[k] * Q[k][l];
+  f[l] = s;
+}
+
 __global__ void k_axpby(double* __restrict__ y, double a, const double* __restrict__ x, double b, long long n) {
   const long long l = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (l < n) y[l] = a * x[l] + b * y[l];

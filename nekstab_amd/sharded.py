@@ -68,6 +68,10 @@ class ShardGroup:
             self.lib.nsk_finalize(c)
         self.ctx = []
 
+    def release_parent(self):
+        """Free the parent's element-major device arrays (nsk_shard_release_parent): the GPU then holds the shards only."""
+        self._chk(self.lib.nsk_shard_release_parent(self.full.ctx))
+
     # ---- vectors
     def alloc(self, n=1):
         per = []
@@ -142,6 +146,10 @@ class ShardGroup:
             self._chk(self.lib.nsk_set_nsteps(c, n))
         self.nsteps = n
 
+    def set_option(self, name, value):
+        for c in self.ctx:
+            self._chk(self.lib.nsk_set_option(c, name.encode(), float(value)))
+
     # ---- vector algebra: rank-local kernels + a sum over ranks (all-reduce when ranks are processes)
     def _dots(self, f, Q):
         tot = np.zeros(len(Q))
@@ -211,7 +219,7 @@ class ShardRank:
     """One rank of an element-sharded run, one process per GPU; halos and reductions over RCCL.
 
     Every process builds the full-mesh parent context on its own GPU (replicated set-up), cuts its
-    shard, and joins the communicator whose id rank 0 created (``unique_id`` is exchanged by the
+    shard (``release_parent()`` then frees the parent's element-major arrays), and joins the communicator whose id rank 0 created (``unique_id`` is exchanged by the
     caller, e.g. with ``torch.distributed.broadcast``).  Same vector interface as NekStabHip, with
     vectors holding this rank's elements only."""
 
@@ -247,6 +255,11 @@ class ShardRank:
         if self.ctx:
             self.lib.nsk_finalize(self.ctx)
             self.ctx = C.c_void_p()
+
+    def release_parent(self):
+        """Free the full-mesh parent's element-major device arrays (nsk_shard_release_parent): from here on this rank's GPU
+        holds its shard, the 1-D bases and the replicated coarse operator only."""
+        self._chk(self.lib.nsk_shard_release_parent(self.full.ctx))
 
     def alloc(self, n=1):
         arr = (C.c_void_p * n)()
@@ -287,6 +300,9 @@ class ShardRank:
     def set_nsteps(self, n):
         self._chk(self.lib.nsk_set_nsteps(self.ctx, n))
         self.nsteps = n
+
+    def set_option(self, name, value):
+        self._chk(self.lib.nsk_set_option(self.ctx, name.encode(), float(value)))
 
     def _dots(self, f, Q):
         arr = (C.c_void_p * len(Q))(*[v.value for v in Q])

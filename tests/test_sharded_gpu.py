@@ -150,3 +150,59 @@ def test_sharded_hexahedral_matvec_equals_single_rank(nranks):
         g.free([sq, sf]); g.close()
     finally:
         h.close()
+
+
+def test_sharded_step_graph_equals_eager(hip6, case6, oracle6_nosolve, modes):
+    """The sharded time step captured in one hipGraph per step class (all ranks of the process, their halo copies and
+    reductions) gives bit for bit what the eager launches give, map after map while the launch budgets adapt."""
+    import time
+    from nekstab_amd.sharded import ShardGroup
+    q = _mode(oracle6_nosolve, modes)
+    hip6.set_tolerances(1e-10, 1e-2, 1)
+    out, dt = {}, {}
+    for mode in (0, -1):                                  # eager, then the default (graph: no communicator attached)
+        g = ShardGroup(hip6, case6, 2)
+        g.set_option("shard_graph", mode)
+        g.set_nsteps(20)
+        sq, sf = g.alloc(2)
+        g.upload(sq, *q)
+        res = []
+        for rep in range(4):                              # budgets shrink after the first maps: graphs are re-captured
+            t0 = time.time(); g.matvec(sf, sq, 0); g.norm(sf); t1 = time.time()
+            res.append(np.concatenate([a.ravel() for a in g.download(sf)]))
+            g.copy(sq, sf); g.scal(sq, 1.0 / g.norm(sq))
+        out[mode], dt[mode] = res, t1 - t0
+        g.free([sq, sf]); g.close()
+    for a, b in zip(out[0], out[-1]):
+        assert np.array_equal(a, b)
+    print("sharded step, 2 virtual ranks, 20 steps: eager %.1f ms, graph %.1f ms" % (1e3 * dt[0], 1e3 * dt[-1]))
+    hip6.set_nsteps(100)
+
+
+def test_release_parent_leaves_working_shards(case6, oracle6_nosolve, modes):
+    """nsk_shard_release_parent: the shards keep computing (bit-identical map) once the full-mesh context has given its
+    element-major device arrays back; the released parent refuses to compute."""
+    import torch
+    from nekstab_amd.capi import NekStabHip, NskError
+    from nekstab_amd.sharded import ShardGroup
+    q = _mode(oracle6_nosolve, modes)
+    free0 = torch.cuda.mem_get_info()[0]
+    full = NekStabHip(case6, case6.meta["vert"], case6.meta["nvert"], tol_helm=1e-10, tol_pres=1e-2, tol_relative=1,
+                      max_helm_iter=120, max_pres_iter=48)
+    g = ShardGroup(full, case6, 2)
+    g.set_nsteps(6)
+    sq, sf = g.alloc(2)
+    g.upload(sq, *q)
+    g.matvec(sf, sq, 0)
+    before = np.concatenate([a.ravel() for a in g.download(sf)])
+    free1 = torch.cuda.mem_get_info()[0]
+    g.release_parent()
+    free2 = torch.cuda.mem_get_info()[0]
+    g.matvec(sf, sq, 0)
+    after = np.concatenate([a.ravel() for a in g.download(sf)])
+    assert np.array_equal(before, after)
+    with pytest.raises(NskError):
+        full.alloc(1)
+    print("device memory: parent + 2 shards %.0f MB, after release %.0f MB" % ((free0 - free1) / 2**20, (free0 - free2) / 2**20))
+    assert free2 > free1
+    g.free([sq, sf]); g.close(); full.close()
