@@ -85,6 +85,8 @@ struct nsk_ctx {
   int debug = 0;
   struct StepGraph { hipGraphExec_t exec = nullptr; int nh = -1, np = -1; } graphs[3][NCLS];
   std::vector<nsk_ctx*> graph_members;  // sharded step graphs (held by the first rank of a process): the ranks they were captured for
+  int merged_iters = 12;                // ... for the first merged_iters iterations of a solve (see pres_solve_launch)
+  int merged_update = 1;                // GMRES column bookkeeping inside the coarse-solve kernel (k_update_coarse)
   double* kacc = nullptr;               // nsk_orth: coefficients accumulated over the two passes + the squared norm (device)
   bool released = false;                // nsk_shard_release_parent: only the arrays shards share are left on the device
   int shard_graph = -1;                 // sharded step in a hipGraph: -1 = yes unless a communicator is attached, 0 = no, 1 = yes (also with RCCL)
@@ -593,6 +595,7 @@ static int build(nsk_ctx* c, const nsk_case& cs) {
       for (int r = 0; r < nvert; ++r) for (int q = 0; q < nvert; ++q) Af[(size_t)r * lda + q] = (float)Ah[(size_t)r * nvert + q];
       if ((rc = dupload(c, &d.Acif, Af))) return rc;
       if (lda > 3072 && (rc = dalloc(c, &c->rc_big, lda))) return rc;
+      if (lda <= 3072 && (rc = dalloc(c, &d.rch, (size_t)MAXMR * lda))) return rc;     // restriction history (k_update_coarse)
     }
   }
   {
@@ -666,6 +669,8 @@ static int build(nsk_ctx* c, const nsk_case& cs) {
   c->fused = 0;
   if (const char* g = std::getenv("NSK_FUSED")) c->fused = std::atoi(g) && fused_possible(c);
   if (const char* g = std::getenv("NSK_USE_GRAPH")) c->use_graph = std::atoi(g);
+  if (const char* g = std::getenv("NSK_MERGED_UPDATE")) c->merged_update = std::atoi(g);
+  if (const char* g = std::getenv("NSK_MERGED_ITERS")) c->merged_iters = std::max(0, std::min(std::atoi(g), MAXMR));
   if (const char* g = std::getenv("NSK_DEBUG")) c->debug = std::atoi(g);
   HIPCHK(hipStreamSynchronize(c->stream));
   return 0;
@@ -686,6 +691,17 @@ static inline double early_tol(const Dev& d, double mul) {
   return d.tol_relative ? std::max(d.tol_pres * mul, std::min(d.tol_pres, 1e-4)) : d.tol_pres;
 }
 
+// k_update_coarse<MAXIT>: the smallest table size that holds coarse_lda / 256 column blocks
+static void launch_update_coarse(nsk_ctx* c, const Dev& d, int j, double scale, int min_iter, int ord) {
+  const unsigned cgrid = (d.nvert + 4 * UC_ROWS - 1) / (4 * UC_ROWS);
+  const size_t sh = d.coarse_lda * sizeof(double);
+  const int nit = d.coarse_lda / 256;
+  if (nit <= 3) hipLaunchKernelGGL(k_update_coarse<3>, dim3(cgrid), dim3(256), sh, c->stream, d, j, scale, min_iter, ord);
+  else if (nit <= 6) hipLaunchKernelGGL(k_update_coarse<6>, dim3(cgrid), dim3(256), sh, c->stream, d, j, scale, min_iter, ord);
+  else if (nit <= 9) hipLaunchKernelGGL(k_update_coarse<9>, dim3(cgrid), dim3(256), sh, c->stream, d, j, scale, min_iter, ord);
+  else hipLaunchKernelGGL(k_update_coarse<12>, dim3(cgrid), dim3(256), sh, c->stream, d, j, scale, min_iter, ord);
+}
+
 static int pres_solve_launch(nsk_ctx* c, double h2, int ord, int np, double tol_mul = 1.0, bool allow_cap = false) {
   Dev d = c->d;                                            // by value: the early steps of a map run with a tighter tolerance
   d.tol_pres = early_tol(d, tol_mul);
@@ -701,7 +717,20 @@ static int pres_solve_launch(nsk_ctx* c, double h2, int ord, int np, double tol_
     if (!d.has_outflow && !c->in_test) { hipLaunchKernelGGL(k_ortho, dim3(c->nblk), dim3(256), 0, c->stream, d); tot_rows(c, d.gpart, 1, d.gtot); }
     if (d.nproj_max > 0 && !c->in_test) { hipLaunchKernelGGL(k_proj_apply, dim3(c->nblk), dim3(256), 0, c->stream, d); tot_rows(c, d.gpart, 1, d.gtot); }
     hipLaunchKernelGGL(k_gmres_update<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, -1, scale, c->min_pres, ord);
-    for (int jt = 0; jt < np; ++jt) {
+    // merged bookkeeping (k_update_coarse): quadrilateral single-rank contexts with the dense in-LDS coarse solve.
+    // Only the first `merged_iters` (12) iterations of a solve: x_c(v_j) by linearity is a recurrence, its rounding error grows by
+    // ~|h_jj / h_{j+1,j}| per iteration (harmless in a preconditioner for a dozen iterations, a stalled solve after forty:
+    // measured on the 1e-8 solves of test_newton_gpu); later iterations take the classic four kernels.
+    const bool merged = c->merged_update && c->ndim == 2 && d.coarse_lda <= 3072 && !d.use_tot && d.nranks <= 1 && d.rch;
+    const int nm = merged ? std::min(np, std::min(c->merged_iters, c->gmres_cycle)) : 0;
+    for (int j = 0; j < nm; ++j) {
+      launch_update_coarse(c, d, j, scale, c->min_pres, ord);
+      hipLaunchKernelGGL(k_schwarz<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, (const double*)(d.V + (size_t)j * d.ps), d.Z + (size_t)j * d.npr, 1, 1);
+      hipLaunchKernelGGL(k_divgs<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, (const double*)d.yl, d.V + (size_t)(j + 1) * d.ps, j, 2);
+    }
+    // closes the last merged column (normalises v_nm and writes its corner restriction: what the classic iteration nm reads)
+    if (nm > 0) hipLaunchKernelGGL(k_gmres_update<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, nm - 1, scale, c->min_pres, ord);
+    for (int jt = nm; jt < np; ++jt) {
       const int j = jt % c->gmres_cycle;                 // index inside the current GMRES cycle
       if (jt > 0 && j == 0) {                            // cycle full and not converged: restart on the residual
         hipLaunchKernelGGL(k_gmres_restart, dim3(c->nblk), dim3(256), 0, c->stream, d, c->gmres_cycle);
@@ -1136,6 +1165,8 @@ int nsk_set_option(nsk_ctx* c, const char* name, double value) {
   const std::string n(name);
   if (n == "use_graph") c->use_graph = (int)value;
   else if (n == "shard_graph") c->shard_graph = (int)value;
+  else if (n == "merged_iters") { c->merged_iters = std::max(0, std::min((int)value, MAXMR)); for (auto& a : c->graphs) for (auto& g : a) g.nh = -1; }
+  else if (n == "merged_update") { c->merged_update = (int)value; for (auto& a : c->graphs) for (auto& g : a) g.nh = -1; }
   else if (n == "min_pres_iter") c->min_pres = (int)value;
   else if (n == "pres_cap") {
     if (value > 0 && c->ndim != 2) return fail(NSK_EINVAL, "pres_cap is validated on quadrilateral linearised maps only (DESIGN.md section 1)");
@@ -1595,6 +1626,54 @@ int nsk_bench_kernel(nsk_ctx* c, const char* name, int reps, double* avg_us) {
       for (int r = 0; r < reps; ++r) { HIPCHK(hipMemsetAsync(c->sync, 0, SYNC_WORDS * sizeof(unsigned), c->stream)); launch_fused<N>(c, sc, its, &d); }
       HIPCHK(hipEventRecord(e1, c->stream));
     });
+  } else if (n == "coarse" || n == "schwarz" || n == "divgs" || n == "gmres_update" || n == "pres_chain" || n == "pres_chain3" || n == "pres_chain_merged" || n.rfind("update_coarse", 0) == 0 || n == "divgs2" ||
+             n == "proj_apply" || n == "proj_update" || n == "pres_update" || n == "vel_update_proj" || n == "pres_rhs" || n == "rhs") {
+    // kernels of the pressure solve, back to back on the state the last map left (run one first).  Tolerance 0 and a cleared
+    // `done` flag: every launch does full work.  `pres_chain`: whole GMRES iterations j = 0..7 (coarse, Schwarz, E, update).
+    if (c->ndim != 2 || d.coarse_lda > 3072) return fail(NSK_EINVAL, "pressure-kernel timing: quadrilateral contexts with the dense in-LDS coarse solve");
+    d.tol_pres = 0.0; d.tol_relative = 0; d.pres_cap = 0;
+    const StepCoef sc = make_coef(c, 17, 0);
+    const double scale = 1.0 / (sc.h2 * std::sqrt(d.vol));
+    const int jj = 3;
+    auto clear_done = [&]() { return hipMemsetAsync((char*)d.gsc + offsetof(GmresScal, done), 0, sizeof(int), c->stream); };
+    HIPCHK(hipStreamSynchronize(c->stream));
+    DISPATCH_N(c->key, {
+      constexpr int NT = Cfg<N>::NT;
+      for (int r = -3; r < reps; ++r) {
+        if (r == 0) HIPCHK(hipEventRecord(e0, c->stream));
+        if (r <= 0 || n.rfind("update_coarse", 0) == 0 || n == "gmres_update") HIPCHK(clear_done());   // (a 4-byte memset node per launch, same for all)
+        if (n == "coarse") hipLaunchKernelGGL(k_coarse, dim3((d.nvert + 4 * CROWS_W - 1) / (4 * CROWS_W)), dim3(256), d.coarse_lda * sizeof(double), c->stream, d);
+        else if (n.rfind("update_coarse", 0) == 0) launch_update_coarse(c, d, std::atoi(n.c_str() + 13), scale, 2, 5);
+        else if (n == "divgs2") hipLaunchKernelGGL(k_divgs<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, (const double*)d.yl, d.V + (size_t)(jj + 1) * d.ps, jj, 2);
+        else if (n == "schwarz") hipLaunchKernelGGL(k_schwarz<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, (const double*)(d.V + (size_t)jj * d.ps), d.Z + (size_t)jj * d.npr, 1, 1);
+        else if (n == "divgs") hipLaunchKernelGGL(k_divgs<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, (const double*)d.yl, d.V + (size_t)(jj + 1) * d.ps, jj, 1);
+        else if (n == "gmres_update") hipLaunchKernelGGL(k_gmres_update<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, jj, scale, 2, 5);
+        else if (n == "proj_apply") hipLaunchKernelGGL(k_proj_apply, dim3(c->nblk), dim3(256), 0, c->stream, d);
+        else if (n == "proj_update") hipLaunchKernelGGL(k_proj_update, dim3(c->nblk), dim3(256), 0, c->stream, d);
+        else if (n == "pres_update") hipLaunchKernelGGL(k_pres_update<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, sc);
+        else if (n == "vel_update_proj") hipLaunchKernelGGL(k_vel_update_proj<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, sc);
+        else if (n == "pres_rhs") hipLaunchKernelGGL(k_pres_rhs<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, sc, 1, 7);
+        else if (n == "rhs") hipLaunchKernelGGL(k_rhs<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, sc);
+        else if (n == "pres_chain_merged") {
+          HIPCHK(clear_done());
+          for (int j = 0; j < 8; ++j) {
+            launch_update_coarse(c, d, j, scale, 2, 5);
+            hipLaunchKernelGGL(k_schwarz<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, (const double*)(d.V + (size_t)j * d.ps), d.Z + (size_t)j * d.npr, 1, 1);
+            hipLaunchKernelGGL(k_divgs<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, (const double*)d.yl, d.V + (size_t)(j + 1) * d.ps, j, 2);
+          }
+        } else {
+          HIPCHK(clear_done());
+          for (int j = 0; j < 8; ++j) {
+            hipLaunchKernelGGL(k_coarse, dim3((d.nvert + 4 * CROWS_W - 1) / (4 * CROWS_W)), dim3(256), d.coarse_lda * sizeof(double), c->stream, d);
+            hipLaunchKernelGGL(k_schwarz<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, (const double*)(d.V + (size_t)j * d.ps), d.Z + (size_t)j * d.npr, 1, 1);
+            hipLaunchKernelGGL(k_divgs<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, (const double*)d.yl, d.V + (size_t)(j + 1) * d.ps, j, 1);
+            if (n == "pres_chain") hipLaunchKernelGGL(k_gmres_update<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, j, scale, 2, 5);
+          }
+        }
+      }
+      HIPCHK(hipEventRecord(e1, c->stream));
+    });
+    if (n == "pres_chain" || n == "pres_chain3" || n == "pres_chain_merged") reps *= 8;                  // per GMRES iteration
   } else {
     return fail(NSK_EINVAL, "unknown kernel " + n);
   }

@@ -39,6 +39,7 @@ struct GmresScal {               // device-resident small state of one pressure 
   int nit;
   int nproj;                     // vectors currently in the projection space
   int nit_prev;                  // iterations of the completed GMRES cycles of this solve (restarts)
+  double gpre[MAXMR + 1];        // g[j] BEFORE the rotation of column j (never rewritten: k_update_coarse reads it in every workgroup)
 };
 
 // Step classes: one captured hipGraph and one launch budget each.  Time steps 1, 2, 3 differ in BDF/EXT order and
@@ -93,6 +94,7 @@ struct Dev {
   // pressure GMRES
   double *V, *Z, *yl, *ec, *xc, *gpart;
   double *xacc;                  // solution accumulated over the completed GMRES cycles (restarted solves)
+  double *rch;                   // [MAXMR][coarse_lda] coarse solutions x_c(v_i) of the GMRES basis vectors (k_update_coarse)
   GmresScal* gsc;
   // projection onto previous pressure solutions (E-orthonormal)
   double *PX, *PEX, *PD, *PED, *ppart;

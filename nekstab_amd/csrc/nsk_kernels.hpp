@@ -888,10 +888,10 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_gmres_update(Dev d, int j, doubl
   if (blockIdx.x == 0 && tid == 0) {
     if (restart) {
       G->nit_prev += G->nit;
-      G->beta0 = hn; G->g[0] = hn; G->nit = 0; G->resid = hn * scale;
+      G->beta0 = hn; G->g[0] = hn; G->gpre[0] = hn; G->nit = 0; G->resid = hn * scale;
       if (!(hn > 0.0)) G->done = 1;
     } else if (j < 0) {
-      G->beta0 = hn; G->g[0] = hn; G->nit = 0; G->nit_prev = 0; G->resid = hn * scale;
+      G->beta0 = hn; G->g[0] = hn; G->gpre[0] = hn; G->nit = 0; G->nit_prev = 0; G->resid = hn * scale;
       if (d.nproj_max <= 0) G->gnorm0 = hn;
       const double tol0 = d.tol_relative ? fmax(d.tol_pres * G->gnorm0 * scale, d.tol_pres_floor) : d.tol_pres;
       const int dn = (!(hn > 0.0) || (min_iter <= 0 && hn * scale <= tol0)) ? 1 : 0;
@@ -913,7 +913,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_gmres_update(Dev d, int j, doubl
       for (int q = 0; q <= j; ++q) G->R[j * MAXMR + q] = col[q];
       const double gj = sgj;
       G->g[j] = cj * gj;
-      G->g[j + 1] = -sj * gj;
+      G->g[j + 1] = -sj * gj; G->gpre[j + 1] = -sj * gj;
       G->nit = j + 1;
       const double res = fabs(sj * gj) * scale;
       G->resid = res;
@@ -1054,6 +1054,195 @@ __global__ __launch_bounds__(256) void k_coarse(Dev d) {
   }
 }
 
+// GMRES bookkeeping of column j-1 and the coarse solve of iteration j in ONE kernel (quadrilateral set, dense in-LDS coarse
+// solve): the chain of a GMRES iteration is 3 dependent kernels instead of 4.  Two independent strands per workgroup:
+//   (a) matrix rows (issued first) + gather of the corner restrictions k_divgs wrote for the RAW w  ->  s = A_c^-1 R w
+//   (b) sum of the dot-product partials of k_divgs(j-1)  ->  Hessenberg column, rotation, convergence (same arithmetic in every
+//       workgroup => the same decision everywhere; workgroup 0 records it)
+// and they meet at the end by LINEARITY:  x_c(v_j) = (s - sum_i h_i x_c(v_i)) / h_{j,j-1},  x_c(v_i) from the history `rch`
+// (every wavefront appends its two rows), together with the pointwise  v_j = (w - sum_i h_i v_i) / h_{j,j-1}  (in place).
+// j = 0: v_0 and its restriction come from k_gmres_update(j = -1).  The column of the LAST launched iteration is closed by
+// k_gmres_update<N>(j = np-1) (a no-op launch when the solve is done).
+// MAXIT >= coarse_lda / 256 (3, 6, 9 or 12) sizes every per-thread table; UC_ROWS rows per wavefront (measured on config 2:
+// 2 rows / 263 workgroups beat 3 rows / 175 workgroups by 5 % of a matvec).
+constexpr int UC_ROWS = 2;
+template <int MAXIT>
+__global__ __launch_bounds__(256) void k_update_coarse(Dev d, int j, double scale, int min_iter, int ord) {
+  extern __shared__ double srcv[];            // lda
+  __shared__ double sh[MAXMR + 2], scs[MAXMR], ssn[MAXMR], scol[MAXMR + 2], sbc[2];
+  const int tid = threadIdx.x;
+  GmresScal* G = d.gsc;
+  if (G->done) return;                        // (first: a launch that finds its solve done must stay cheap)
+  const int nv = d.nvert, lda = d.coarse_lda;
+  const int lane = tid & 63, w = tid >> 6;
+  const int row0 = (blockIdx.x * 4 + w) * UC_ROWS;
+  const int nit = lda / 256;
+  const int jj = j - 1;                       // the column this launch closes (j > 0)
+  // Loads return in issue order: the short dependent chains go first (vertex tables -> corner values; partials of the first
+  // row per wavefront), the 24 independent matrix loads last -- they are needed at the product only.
+  int4 va[MAXIT], vb[MAXIT];
+#pragma unroll
+  for (int i = 0; i < MAXIT; ++i) {
+    const int v = tid + i * 256;
+    if (i < nit && v < nv) { va[i] = reinterpret_cast<const int4*>(d.vtab)[2 * v]; vb[i] = reinterpret_cast<const int4*>(d.vtab)[2 * v + 1]; }
+    else { va[i] = make_int4(-1, -1, -1, -1); vb[i] = va[i]; }
+  }
+  double gj = 0.0;
+  double pr[8], pr2[8];                       // partials of rows `w` and `w + 4` (the first two this wavefront sums): d.nblk <= 512 here
+  const bool prow = j > 0 && w < jj + 2 && d.nblk <= 512, prow2 = j > 0 && w + 4 < jj + 2 && d.nblk <= 512;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) pr[k] = (prow && lane + 64 * k < d.nblk) ? d.gpart[(size_t)w * d.nblk + lane + 64 * k] : 0.0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) pr2[k] = (prow2 && lane + 64 * k < d.nblk) ? d.gpart[(size_t)(w + 4) * d.nblk + lane + 64 * k] : 0.0;
+  // history of the coarse solutions for this wavefront's rows: lane k holds x_c(v_k)[row] (MAXMR <= 64 lanes)
+  double rh[UC_ROWS];
+#pragma unroll
+  for (int r = 0; r < UC_ROWS; ++r) rh[r] = (lane < j && row0 + r < nv) ? d.rch[(size_t)lane * lda + row0 + r] : 0.0;
+  // this thread's entry of v_j and of the basis vectors it is orthogonalised against (the first 8; more in the loop below)
+  const long long q0 = (long long)blockIdx.x * 256 + tid;
+  double vq = 0.0, vk[8];
+  if (j > 0 && q0 < d.npr) vq = d.V[(size_t)j * d.ps + q0];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) vk[k] = (k < j && q0 < d.npr) ? d.V[(size_t)k * d.ps + q0] : 0.0;
+  if (j > 0) {
+    if (tid < jj) { scs[tid] = G->cs[tid]; ssn[tid] = G->sn[tid]; }
+    gj = G->gpre[jj];
+  }
+  float4 am[UC_ROWS][MAXIT];
+#pragma unroll
+  for (int r = 0; r < UC_ROWS; ++r) {
+    const float4* A = reinterpret_cast<const float4*>(d.Acif + (size_t)(row0 + r < nv ? row0 + r : 0) * lda) + lane;
+#pragma unroll
+    for (int i = 0; i < MAXIT; ++i)
+      if (i < nit) am[r][i] = A[i * 64];
+  }
+#pragma unroll
+  for (int i = 0; i < MAXIT; ++i) {           // R w (raw): gather of the element-corner restrictions
+    const int v = tid + i * 256;
+    if (i < nit) {
+      const int4 a = va[i], b = vb[i];
+      const double e0 = (a.x >= 0) ? d.ec[a.x] : 0.0;
+      const double e1 = (a.y >= 0) ? d.ec[a.y] : 0.0, e2 = (a.z >= 0) ? d.ec[a.z] : 0.0, e3 = (a.w >= 0) ? d.ec[a.w] : 0.0;
+      const double e4 = (b.x >= 0) ? d.ec[b.x] : 0.0, e5 = (b.y >= 0) ? d.ec[b.y] : 0.0, e6 = (b.z >= 0) ? d.ec[b.z] : 0.0;
+      const double e7 = (b.w >= 0) ? d.ec[b.w] : 0.0;
+      srcv[v] = ((((((e0 + e1) + e2) + e3) + e4) + e5) + e6) + e7;
+    }
+  }
+  if (j > 0) {
+    if (d.nblk <= 512) {                      // first row per wavefront from the registers, the rest as sum_partials_multi
+      if (prow) {
+        double sacc = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sacc += pr[k];
+        sacc = wave_sum63(sacc);
+        if (lane == 63) sh[w] = sacc;
+      }
+      if (prow2) {
+        double sacc = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sacc += pr2[k];
+        sacc = wave_sum63(sacc);
+        if (lane == 63) sh[w + 4] = sacc;
+      }
+      for (int q = w + 8; q < jj + 2; q += 4) {
+        double sacc = 0.0;
+        for (int k = lane; k < d.nblk; k += 64) sacc += d.gpart[(size_t)q * d.nblk + k];
+        sacc = wave_sum63(sacc);
+        if (lane == 63) sh[q] = sacc;
+      }
+      lds_barrier();
+    } else {
+      sum_partials_multi(d.gpart, d.nblk, jj + 2, sh, tid, 256);   // ends with an LDS barrier
+    }
+  } else {
+    lds_barrier();
+  }
+  if (j > 0 && tid == 0) {                    // one lane rotates the column while the others start on the matrix product
+    double s2 = 0.0;
+    for (int q = 0; q <= jj; ++q) s2 += sh[q] * sh[q];
+    const double hn2 = sh[jj + 1] - s2;
+    const double hn = sqrt(hn2 > 0.0 ? hn2 : 0.0);
+    double* col = scol;
+    for (int q = 0; q <= jj; ++q) col[q] = sh[q];
+    col[jj + 1] = hn;
+    for (int q = 0; q < jj; ++q) {
+      const double t = scs[q] * col[q] + ssn[q] * col[q + 1];
+      col[q + 1] = -ssn[q] * col[q] + scs[q] * col[q + 1];
+      col[q] = t;
+    }
+    const double rho = sqrt(col[jj] * col[jj] + col[jj + 1] * col[jj + 1]);
+    const double cj = (rho > 0.0) ? col[jj] / rho : 1.0, sj = (rho > 0.0) ? col[jj + 1] / rho : 0.0;
+    col[jj] = rho;
+    const double res = fabs(sj * gj) * scale;
+    const double tol = d.tol_relative ? fmax(d.tol_pres * G->gnorm0 * scale, d.tol_pres_floor) : d.tol_pres;
+    const bool conv = (res <= tol && (jj + 1) >= min_iter) || !(hn > 0.0) || (d.pres_cap > 0 && (jj + 1) >= d.pres_cap);
+    sbc[0] = (hn > 0.0) ? 1.0 / hn : 0.0;
+    sbc[1] = conv ? 1.0 : 0.0;
+    if (blockIdx.x == 0) {
+      G->cs[jj] = cj; G->sn[jj] = sj;
+      for (int q = 0; q <= jj; ++q) G->R[jj * MAXMR + q] = col[q];
+      G->g[jj] = cj * gj;
+      G->g[jj + 1] = -sj * gj; G->gpre[jj + 1] = -sj * gj;
+      G->nit = jj + 1;
+      G->resid = res;
+      if (conv) {
+        atomicAdd((unsigned long long*)&d.stats->pres_iters, (unsigned long long)(G->nit_prev + jj + 1));
+        atomicMax((unsigned long long*)&d.stats->max_pres, (unsigned long long)(G->nit_prev + jj + 1));
+        atomicMax((unsigned long long*)&d.stats->max_pres_k[ord], (unsigned long long)(G->nit_prev + jj + 1));
+        d.stats->last_pres_res = res;
+        if (!(res <= tol) && hn > 0.0) {
+          d.stats->capped_solves += 1;
+          if (res / tol > d.stats->worst_cap_ratio) d.stats->worst_cap_ratio = res / tol;
+        }
+        G->done = 1;
+      }
+    }
+  }
+  double sr[UC_ROWS];
+#pragma unroll
+  for (int r = 0; r < UC_ROWS; ++r) sr[r] = 0.0;
+#pragma unroll
+  for (int i = 0; i < MAXIT; ++i)
+    if (i < nit) {
+      const double* x = srcv + i * 256 + lane * 4;
+#pragma unroll
+      for (int r = 0; r < UC_ROWS; ++r)
+        sr[r] += (double)am[r][i].x * x[0] + (double)am[r][i].y * x[1] + (double)am[r][i].z * x[2] + (double)am[r][i].w * x[3];
+    }
+#pragma unroll
+  for (int r = 0; r < UC_ROWS; ++r) sr[r] = wave_sum63(sr[r]);
+  double hinv = 1.0;
+  if (j > 0) {
+    lds_barrier();                            // column rotated
+    hinv = sbc[0];
+    if (sbc[1] != 0.0) return;                // converged: nothing of iteration j is needed
+    if (q0 < d.npr) {                         // first entry: operands already in registers
+      double x = vq;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) if (k < j) x -= sh[k] * vk[k];
+      for (int k = 8; k < j; ++k) x -= sh[k] * d.V[(size_t)k * d.ps + q0];
+      d.V[(size_t)j * d.ps + q0] = x * hinv;
+    }
+    for (long long q = q0 + (long long)gridDim.x * 256; q < d.npr; q += (long long)gridDim.x * 256) {
+      double x = d.V[(size_t)j * d.ps + q];
+#pragma unroll 4
+      for (int k = 0; k < j; ++k) x -= sh[k] * d.V[(size_t)k * d.ps + q];
+      d.V[(size_t)j * d.ps + q] = x * hinv;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < UC_ROWS; ++r) {         // x_c(v_j)[row] = (s - sum_k h_k x_c(v_k)[row]) / h_{j,j-1}: lane k holds term k
+    double t = (lane < j) ? sh[lane] * rh[r] : 0.0;
+    t = wave_sum63(t);
+    sr[r] = (sr[r] - t) * hinv;
+  }
+  if (lane == 63) {
+#pragma unroll
+    for (int r = 0; r < UC_ROWS; ++r)
+      if (row0 + r < nv) { d.xc[row0 + r] = sr[r]; d.rch[(size_t)j * lda + row0 + r] = sr[r]; }
+  }
+}
+
 // large coarse spaces (nvert > 3072, e.g. the 2x2-refined mesh): streaming variant, the vertex
 // restriction r_c is built once per launch in global memory by a separate tiny kernel.
 __global__ __launch_bounds__(256) void k_coarse_restrict(Dev d, double* __restrict__ rc) {
@@ -1108,6 +1297,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_schwarz(Dev d, const double* __r
   if (check_done && d.gsc->done) return;
   const int PS = d.p_stride;
   // front-load: patch indices (2 per thread is enough for PS <= 2*NN), metrics, coarse values, basis
+  // (measured: issuing the patch inverse -- the largest stream -- before the barrier as well makes the kernel SLOWER, 8 -> 14 us)
   int i0 = -1, i1 = -1;
   if (act) {
     if (nd < PS) i0 = d.p_idx[e * PS + nd];
@@ -1194,6 +1384,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_gradt(Dev d, const double* __res
 }
 
 // w = D ( B^-1 mask dssum(yl) ) ; optional dots (w, V_i), i <= j, and (w,w)
+// check_done: 0 = always run, 1 = leave when the solve is done, 2 = the same and write the corner restriction of w to d.ec
 template <int N>
 __global__ __launch_bounds__(Cfg<N>::NT) void k_divgs(Dev d, const double* __restrict__ yl,
                                                       double* __restrict__ wout, int j, int check_done) {
@@ -1228,6 +1419,18 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_divgs(Dev d, const double* __res
   const bool pact = act && nd < MM;
   const long long q = e * MM + nd;
   if (pact) wout[q] = w;
+  if (check_done == 2) {              // merged bookkeeping (k_update_coarse): element-corner restriction of the raw w
+    __shared__ double swr[EPB * MM], shat[4 * MM];
+    for (int k = tid; k < 4 * MM; k += NT) shat[k] = d.hat[k];
+    if (pact) swr[el * MM + nd] = w;
+    lds_barrier();
+    if (act && nd < 4) {
+      double s = 0.0;
+#pragma unroll 6
+      for (int k = 0; k < MM; ++k) s += shat[nd * MM + k] * swr[el * MM + k];
+      d.ec[e * 4 + nd] = s;
+    }
+  }
   if (j >= 0) {
     const int lane = tid & 63, wv = tid >> 6;
 #pragma unroll 4

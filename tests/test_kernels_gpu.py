@@ -138,3 +138,39 @@ def test_pressure_gmres_restart(oracle6, case6):
     print("error vs direct solve: %.1e un-restarted, %.1e restarted" % (e0, e1))
     assert e0 < 1e-3 and e1 < 1e-3
     h.close()
+
+
+def test_merged_gmres_bookkeeping_equals_classic(oracle6, case6, modes):
+    """k_update_coarse (Hessenberg column + coarse solve in one kernel, v_j and x_c(v_j) by linearity) against the classic
+    four-kernel iteration: same iteration count, same pressure solution to rounding, same map."""
+    from nekstab_amd.capi import NekStabHip
+    h = NekStabHip(case6, case6.meta["vert"], case6.meta["nvert"], tol_helm=1e-11, tol_pres=1e-6, tol_relative=1,
+                   schwarz_layers=2, max_helm_iter=120, max_pres_iter=48)
+    rng = np.random.default_rng(12)
+    g = rng.standard_normal((case6.nel, 4, 4))
+    out = {}
+    for merged in (1, 0):
+        h.set_option("merged_update", merged)
+        out[merged] = h.t_pres_solve(g)
+    (x1, it1), (x0, it0) = out[1], out[0]
+    print("iterations merged %d classic %d, max diff %.2e" % (it1, it0, np.abs(x1 - x0).max() / np.abs(x0).max()))
+    assert it1 == it0 and it1 > 5
+    assert np.abs(x1 - x0).max() < 1e-10 * np.abs(x0).max()
+    ref = oracle6.E_solve(g)
+    assert np.abs(x1 - ref).max() < 1e-4 * np.abs(ref).max()
+    # whole maps
+    u = modes["dRe_u"].astype(np.float64)
+    q, f = h.alloc(2)
+    h.upload(q, u[0], u[1], np.zeros((case6.nel, 4, 4)))
+    h.set_nsteps(10)
+    res = {}
+    for merged in (1, 0):
+        h.set_option("merged_update", merged)
+        h.set_option("proj_reset", 1)
+        h.matvec(f, q, 0)
+        res[merged] = np.concatenate([a.ravel() for a in h.download(f)[:2]])
+        st = h.stats()
+        res[(merged, "it")] = st["pres_iters"]
+    assert res[(1, "it")] == res[(0, "it")]
+    assert np.abs(res[1] - res[0]).max() < 1e-9 * np.abs(res[0]).max()
+    h.close()
