@@ -28,7 +28,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 K_DIM = 128
-WATCHDOG_S = 3000          # N > 1 only
+WATCHDOG_S = 2400          # N > 1 only: the whole run
+PROBE_S = 420              # N > 1 only: communicator set-up + the two-step probe map of the sharded path
 
 
 def parse():
@@ -164,17 +165,20 @@ def main():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     dist = None
     if world > 1:
-        # watchdog: a multi-rank run that stalls (an exchange that never completes) must not hang the caller for ever
-        import signal
+        # watchdog: a multi-rank run that stalls (an exchange that never completes) must not hang the caller for ever.  A
+        # THREAD, not SIGALRM: a rank stuck inside a C call (hipStreamSynchronize behind a lost message) never runs a
+        # Python signal handler, but ctypes releases the GIL, so a timer thread still fires.
+        import threading
 
-        def _stalled(signum, frame):
-            print("bench.py rank %d: no result after %d s: giving up" % (rank, WATCHDOG_S), file=sys.stderr, flush=True)
+        def _stalled(what, limit):
+            print("bench.py rank %d: %s: no result after %d s: giving up" % (rank, what, limit), file=sys.stderr, flush=True)
             if rank == 0:
                 print(json.dumps({"metric": "Arnoldi matvecs/sec + wall-time to k_dim=128 eigenpairs, cylinder Re=50", "value": None, "unit": "matvecs/s",
-                                  "n_gpus": world, "error": "multi-rank run stalled for %d s (watchdog)" % WATCHDOG_S}), flush=True)
+                                  "n_gpus": world, "error": "%s stalled for %d s (watchdog)" % (what, limit)}), flush=True)
             os._exit(3)
-        signal.signal(signal.SIGALRM, _stalled)
-        signal.alarm(WATCHDOG_S)
+        wd = threading.Timer(WATCHDOG_S, _stalled, ("multi-rank run", WATCHDOG_S))
+        wd.daemon = True
+        wd.start()
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
@@ -228,6 +232,9 @@ def main():
     # record says so LOUDLY and carries the replica number instead of nothing.
     shard_error = None
     if sharded:
+        pw = threading.Timer(PROBE_S, _stalled, ("sharded probe map (first execution of the RCCL halo path)", PROBE_S))
+        pw.daemon = True
+        pw.start()
         try:
             probe = h.alloc(2)
             h.upload(probe[0], qx, qy, zp)
@@ -247,12 +254,15 @@ def main():
         except Exception as e:                              # noqa: BLE001
             shard_error = shard_error or repr(e)[:400]
             flag = torch.zeros(1)
+        pw.cancel()
         if float(flag.item()) == 0.0:
             shard_error = shard_error or "another rank failed"
             print("bench.py rank %d: SHARDED RUN FAILED (%s): falling back to replicas" % (rank, shard_error), file=sys.stderr, flush=True)
             sharded = False
             h = full
             steps = a.steps if a.steps is not None else 6
+    if sharded and rank != 0:
+        h.release_parent()                                 # this GPU keeps its shard (+ the replicated coarse operator); rank 0's parent times the single-GPU line
     ktot = max(a.warmup + steps, K_DIM if (world == 1 and not a.no_kdim) else 0)
     Q = h.alloc(ktot + 1)
     h.upload(Q[0], qx, qy, zp)
@@ -293,7 +303,7 @@ def main():
                    "base_flow": "reference BF_1cyl0.f00001 (committed fixture), seed = add_noise",
                    "tolerances": "Helmholtz |b-Hu|<=%g|b|, pressure |g-E dp|<=%g|g| with at least %d GMRES iterations per solve%s (time steps 1-3 of a map: pressure tolerance x0.01), projection space %d: DESIGN.md section 1"
                                  % (a.tol_helm, a.tol_pres, a.min_pres, (" and at most %d after time step 3" % a.pres_cap) if a.pres_cap else "", 0 if sharded else a.nproj),
-                   "parallelism": ("element-sharded x%d (RCCL halos, one eigenproblem)" % world if sharded else "replicas x%d" % world) if world > 1 else "1 GPU"},
+                   "parallelism": ("element-sharded x%d (%s, one eigenproblem)" % (world, "RCCL halos" if backend == "nccl" else "host-staged halos over %s: protocol dry run" % backend) if sharded else "replicas x%d" % world) if world > 1 else "1 GPU"},
         "setup_s": setup_s,
         "wall_time_kdim_s": wall_kdim,
         "matvec_s_mean": float(np.mean(stats["matvec_s"][a.warmup:a.warmup + steps])), "orth_s_mean": float(np.mean(stats["orth_s"][a.warmup:a.warmup + steps])),

@@ -24,6 +24,8 @@ alg = {
     "k_convect<8>": perj["K1 convect"], "k_rhs<8>": perj["K2 rhs"], "k_helm<8>": 148.0 * 2 * P, "k_pres_rhs<8>": perj["K4 pres_rhs"],
     "k_coarse": perj["K6 coarse (x n_pres)"] / npr_it, "k_schwarz<8>": perj["K6 schwarz (x n_pres)"] / npr_it,
     "k_divgs<8>": perj["K7 divgs (x n_pres)"] / npr_it, "k_gmres_update<8>": perj["K7 gmres_update (x n_pres)"] / (npr_it + 1),
+    # merged bookkeeping + coarse solve: the bytes of both (the restriction history is nvert doubles per basis vector: negligible)
+    "k_update_coarse<9>": perj["K6 coarse (x n_pres)"] / npr_it + perj["K7 gmres_update (x n_pres)"] / (npr_it + 1),
     "k_pres_update<8>": perj["K10 pres_update"], "k_vel_update_proj<8>": perj["K10 vel_update(+proj)"],
     "k_proj_apply": perj["projection apply/update"] * 0.4, "k_proj_update": perj["projection apply/update"] * 0.6,
 }
