@@ -92,6 +92,9 @@ int nsk_set_tolerances(nsk_ctx* ctx, double tol_helm, double tol_pres, int relat
  * "endtime" (the sampling period T = param(10); used by the next nsk_set_baseflow / nsk_set_orbit),
  * "gmres_cycle" (the pressure GMRES restarts after this many iterations, default and maximum 48; `max_pres_iter` may be up to 4 x 48),
  * "mfma_convect" (hexahedra, lx1 = 8: convection contractions on v_mfma_f64_16x16x4_f64, default 1),
+ * "merged_update" / "merged_iters" (quadrilaterals with the dense in-LDS coarse solve: the GMRES column bookkeeping runs inside
+ * the coarse-solve kernel for the first `merged_iters` iterations of a solve, default 1 / 12; same iteration counts and results to
+ * rounding as the classic four-kernel iteration), "shard_graph" (shard contexts, see nsk_shard_release_parent below),
  * "dbg" (developer ablation mask) */
 int nsk_set_option(nsk_ctx* ctx, const char* name, double value);
 
