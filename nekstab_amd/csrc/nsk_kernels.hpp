@@ -116,6 +116,42 @@ __device__ inline void sum_partials_multi(const double* part, int n, int nq, dou
   lds_barrier();
 }
 
+// the same sums with every load issued before the first wait: R rows per wavefront (rows w, w + 4, ...) of n <= 512 partials
+// live in registers; rows beyond 4 R fall back to the loop.  Same summation order as sum_partials_multi (bit-identical sums).
+// Rows q < nq_issue are LOADED (a bound known from the kernel arguments), rows q < nq are summed into sh.
+template <int R>
+struct PartialRows {
+  double p[R][8];
+  __device__ inline void issue(const double* part, int n, int nq_issue, int tid) {
+    const int lane = tid & 63, w = tid >> 6;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        p[r][k] = (w + 4 * r < nq_issue && lane + 64 * k < n) ? part[(size_t)(w + 4 * r) * n + lane + 64 * k] : 0.0;
+  }
+  __device__ inline void reduce(const double* part, int n, int nq, double* sh, int tid) {
+    const int lane = tid & 63, w = tid >> 6;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (w + 4 * r < nq) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += p[r][k];
+        s = wave_sum63(s);
+        if (lane == 63) sh[w + 4 * r] = s;
+      }
+    }
+    for (int q = w + 4 * R; q < nq; q += 4) {
+      double s = 0.0;
+      for (int k = lane; k < n; k += 64) s += part[(size_t)q * n + k];
+      s = wave_sum63(s);
+      if (lane == 63) sh[q] = s;
+    }
+    lds_barrier();
+  }
+};
+
 // CSR fallback of the gather (valence > 4: hexahedral vertices, irregular 2-D vertices).  Same
 // left-to-right sum as a plain loop, but the index and value loads of up to eight entries are
 // issued together: three dependent round trips instead of two per entry.
@@ -701,6 +737,16 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_pres_rhs(Dev d, StepCoef sc, int
   const long long e = (long long)blockIdx.x * EPB + el;
   const bool act = (el < EPB) && (e < d.nel);
   const long long l = e * NN + nd, nl = d.cs;
+  // stored pressure solutions at this thread's Gauss node, for the projection dots at the end: independent of everything
+  // else in the launch, so they are issued first (the first PXPRE vectors; slots >= nproj are never used)
+  constexpr int PXPRE = 16;
+  double pxr[PXPRE];
+  {
+    const bool pl = act && nd < MM && d.nproj_max > 0;
+    const int npre = d.nproj_max < PXPRE ? d.nproj_max : PXPRE;
+#pragma unroll
+    for (int k = 0; k < PXPRE; ++k) pxr[k] = (pl && k < npre) ? d.PX[(size_t)k * d.npr + e * MM + nd] : 0.0;
+  }
   load_basis<N, EPB>(d, nullptr, nullptr, sJ12, sD12, tid, NT);
   if (check_helm && blockIdx.x == 0) {       // last partials -> final residual of the velocity solve
     double s[8];
@@ -761,8 +807,16 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_pres_rhs(Dev d, StepCoef sc, int
     const int np = d.gsc->nproj;
     __shared__ double sdot[MAXPROJ * 4];
     const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+    for (int k = 0; k < PXPRE; ++k) {
+      if (k < np) {
+        double t = pact ? g * pxr[k] : 0.0;
+        t = wave_sum63(t);
+        if (lane == 63) sdot[k * 4 + wv] = t;
+      }
+    }
 #pragma unroll 4
-    for (int k = 0; k < np; ++k) {
+    for (int k = PXPRE; k < np; ++k) {
       double t = pact ? g * d.PX[(size_t)k * d.npr + e * MM + nd] : 0.0;
       t = wave_sum63(t);
       if (lane == 63) sdot[k * 4 + wv] = t;
@@ -804,23 +858,46 @@ __global__ __launch_bounds__(256) void k_proj_apply(Dev d) {
   const int tid = threadIdx.x;
   GmresScal* G = d.gsc;
   const int np = G->nproj;
+  // every load of this launch is independent of every other: issue them all before the first wait (the space holds at most
+  // nproj_max <= MAXPROJ vectors; the first PRE of them go to registers for this thread's entry -- one entry per thread on
+  // every mesh this runs on; slots >= nproj hold finite stale data and get a zero coefficient)
+  constexpr int PRE = 16;
+  const long long q0 = (long long)blockIdx.x * 256 + tid, stride = (long long)gridDim.x * 256;
+  const bool has = q0 < d.npr;
+  const int npre = d.nproj_max < PRE ? d.nproj_max : PRE;
+  const double g0 = has ? d.V[q0] : 0.0;
+  double pe[PRE];
+#pragma unroll
+  for (int k = 0; k < PRE; ++k) pe[k] = (has && k < npre) ? d.PEX[(size_t)k * d.npr + q0] : 0.0;
+  const double pnv = (tid < MAXPROJ) ? G->pn[tid] : 1.0;
   if (d.use_tot) {
     if (tid < np) sh[tid] = d.ptot[tid];
     if (blockIdx.x == 0 && tid == 0) G->gnorm0 = sqrt(d.ptot[MAXPROJ]);
     __syncthreads();
   } else {
-    sum_partials_multi(d.ppart, d.nblk, np, sh, tid, 256);
+    PartialRows<4> pr;
+    pr.issue(d.ppart, d.nblk, d.nblk <= 512 ? d.nproj_max : 0, tid);
+    if (d.nblk <= 512) pr.reduce(d.ppart, d.nblk, np, sh, tid);
+    else sum_partials_multi(d.ppart, d.nblk, np, sh, tid, 256);
     if (blockIdx.x == 0) {
       double gg[1];
       sum_partials<1>(d.ppart + (size_t)MAXPROJ * d.nblk, d.nblk, gg, sred, tid, 256);
       if (tid == 0) G->gnorm0 = sqrt(gg[0]);
     }
   }
-  if (tid < np) sh[tid] = sh[tid] / G->pn[tid];
+  if (tid < np) sh[tid] = sh[tid] / pnv;
   __syncthreads();
   if (blockIdx.x == 0 && tid < np) G->pa[tid] = sh[tid];
   double v[1] = {0.0};
-  for (long long q = (long long)blockIdx.x * 256 + tid; q < d.npr; q += (long long)gridDim.x * 256) {
+  if (has) {
+    double g = g0;
+#pragma unroll
+    for (int k = 0; k < PRE; ++k) if (k < np) g -= sh[k] * pe[k];
+    for (int k = PRE; k < np; ++k) g -= sh[k] * d.PEX[(size_t)k * d.npr + q0];
+    d.V[q0] = g;
+    v[0] += g * g;
+  }
+  for (long long q = q0 + stride; q < d.npr; q += stride) {
     double g = d.V[q];
     for (int k = 0; k < np; ++k) g -= sh[k] * d.PEX[(size_t)k * d.npr + q];
     d.V[q] = g;
@@ -1465,6 +1542,22 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_pres_update(Dev d, StepCoef sc) 
   const bool act = (el < EPB) && (e < d.nel);
   const GmresScal* G = d.gsc;
   const int nit = G->nit;
+  // this thread's operands first: the preconditioned basis z_k (the first ZPRE; slots >= nit hold finite stale data and are
+  // not used), the stored solutions x_k, the extrapolated pressure and the metrics -- independent of the small triangular solve
+  constexpr int ZPRE = 12, PXPRE = 16;
+  __shared__ double spa[MAXPROJ];
+  const bool pl = act && nd < MM;
+  const long long q = e * MM + nd;
+  double zr[ZPRE], pxr[PXPRE], pe = 0, m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+  {
+    const int npre = d.nproj_max < PXPRE ? d.nproj_max : PXPRE;
+#pragma unroll
+    for (int k = 0; k < ZPRE; ++k) zr[k] = pl ? d.Z[(size_t)k * d.npr + q] : 0.0;
+#pragma unroll
+    for (int k = 0; k < PXPRE; ++k) pxr[k] = (pl && k < npre) ? d.PX[(size_t)k * d.npr + q] : 0.0;
+    if (pl) { pe = d.pext[q]; m0 = d.w2rx[q]; m1 = d.w2sx[q]; m2 = d.w2ry[q]; m3 = d.w2sy[q]; }
+  }
+  if (d.nproj_max > 0 && tid < MAXPROJ) spa[tid] = G->pa[tid];
   for (int k = tid; k < nit * nit; k += NT) { const int cc = k / nit, rr = k % nit; sR[cc * MAXMR + rr] = G->R[cc * MAXMR + rr]; }
   if (tid < nit) sg[tid] = G->g[tid];
   load_basis<N, EPB>(d, nullptr, nullptr, sJ12, sD12, tid, NT);
@@ -1477,21 +1570,24 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_pres_update(Dev d, StepCoef sc) 
     }
   }
   lds_barrier();
-  if (act && nd < MM) {
-    const long long q = e * MM + nd;
+  if (pl) {
     double x = (G->nit_prev > 0) ? d.xacc[q] : 0.0;  // completed GMRES cycles of a restarted solve
-    for (int k = 0; k < nit; ++k) x += sy[k] * d.Z[(size_t)k * d.npr + q];
+#pragma unroll
+    for (int k = 0; k < ZPRE; ++k) if (k < nit) x += sy[k] * zr[k];
+    for (int k = ZPRE; k < nit; ++k) x += sy[k] * d.Z[(size_t)k * d.npr + q];
     if (d.nproj_max > 0) {
       d.PD[q] = x;                                   // GMRES correction delta
       const int np = G->nproj;
-      for (int k = 0; k < np; ++k) x += G->pa[k] * d.PX[(size_t)k * d.npr + q];
+#pragma unroll
+      for (int k = 0; k < PXPRE; ++k) if (k < np) x += spa[k] * pxr[k];
+      for (int k = PXPRE; k < np; ++k) x += spa[k] * d.PX[(size_t)k * d.npr + q];
     }
     const double dp = sc.h2 * x;
-    d.p[q] = d.pext[q] + dp;
-    sP[(0 * EPB + el) * MM + nd] = dp * d.w2rx[q];
-    sP[(1 * EPB + el) * MM + nd] = dp * d.w2sx[q];
-    sP[(2 * EPB + el) * MM + nd] = dp * d.w2ry[q];
-    sP[(3 * EPB + el) * MM + nd] = dp * d.w2sy[q];
+    d.p[q] = pe + dp;
+    sP[(0 * EPB + el) * MM + nd] = dp * m0;
+    sP[(1 * EPB + el) * MM + nd] = dp * m1;
+    sP[(2 * EPB + el) * MM + nd] = dp * m2;
+    sP[(3 * EPB + el) * MM + nd] = dp * m3;
   }
   __syncthreads();
   double gx, gy;
@@ -1517,6 +1613,19 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_vel_update_proj(Dev d, StepCoef 
   const long long e = (long long)blockIdx.x * EPB + el;
   const bool act = (el < EPB) && (e < d.nel);
   const GmresScal* G = d.gsc;
+  // E-images of the stored solutions and the GMRES correction at this thread's Gauss node: used after the divergence below,
+  // independent of it -- issued first (the first PEPRE vectors)
+  constexpr int PEPRE = 16;
+  __shared__ double spa[MAXPROJ];
+  double per[PEPRE], del0 = 0.0;
+  {
+    const bool pl = act && nd < MM;
+    const int npre = d.nproj_max < PEPRE ? d.nproj_max : PEPRE;
+#pragma unroll
+    for (int k = 0; k < PEPRE; ++k) per[k] = (pl && k < npre) ? d.PEX[(size_t)k * d.npr + e * MM + nd] : 0.0;
+    if (pl) del0 = d.PD[e * MM + nd];
+    if (tid < MAXPROJ) spa[tid] = G->pa[tid];
+  }
   load_basis<N, EPB>(d, nullptr, nullptr, sJ12, sD12, tid, NT);
   if (act) {
     const long long l = e * NN + nd;
@@ -1537,18 +1646,32 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_vel_update_proj(Dev d, StepCoef 
   double del = 0.0, edel = 0.0;
   if (pact) {
     edel = w / sc.h2;
-    for (int k = 0; k < np; ++k) edel -= G->pa[k] * d.PEX[(size_t)k * d.npr + q];
-    del = d.PD[q];
+#pragma unroll
+    for (int k = 0; k < PEPRE; ++k) if (k < np) edel -= spa[k] * per[k];
+    for (int k = PEPRE; k < np; ++k) edel -= spa[k] * d.PEX[(size_t)k * d.npr + q];
+    del = del0;
     d.PED[q] = edel;
   }
   __shared__ double sdot[(MAXPROJ + 1) * 4];
   const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+  for (int k = 0; k < PEPRE; ++k) {
+    if (k < np) {
+      double t = pact ? del * per[k] : 0.0;
+      t = wave_sum63(t);
+      if (lane == 63) sdot[k * 4 + wv] = t;
+    }
+  }
 #pragma unroll 4
-  for (int k = 0; k <= np; ++k) {
-    double t = 0.0;
-    if (pact) t = (k < np) ? del * d.PEX[(size_t)k * d.npr + q] : del * edel;
+  for (int k = PEPRE; k < np; ++k) {
+    double t = pact ? del * d.PEX[(size_t)k * d.npr + q] : 0.0;
     t = wave_sum63(t);
     if (lane == 63) sdot[k * 4 + wv] = t;
+  }
+  {
+    double t = pact ? del * edel : 0.0;
+    t = wave_sum63(t);
+    if (lane == 63) sdot[np * 4 + wv] = t;
   }
   lds_barrier();
   if (tid <= np) {
@@ -1567,15 +1690,52 @@ __global__ __launch_bounds__(256) void k_proj_update(Dev d) {
   __shared__ double cf[MAXPROJ];
   const int tid = threadIdx.x;
   GmresScal* G = d.gsc;
-  if (G->nit == 0) return;
-  const int np = G->nproj, nmax = d.nproj_max;
-  const int s = G->pcnt % nmax;
-  if (d.use_tot) { if (tid <= np) sh[tid] = d.ptot[tid]; __syncthreads(); }
-  else sum_partials_multi(d.ppart, d.nblk, np + 1, sh, tid, 256);
+  const int nit = G->nit, np = G->nproj, nmax = d.nproj_max, pcnt = G->pcnt;
+  // as k_proj_apply: all loads first (this thread's entry of delta, E delta and of the first PRE vectors of the space and of
+  // their E-images; partial sums; the scalars), then the arithmetic
+  constexpr int PRE = 16;
+  const long long q0 = (long long)blockIdx.x * 256 + tid, stride = (long long)gridDim.x * 256;
+  const bool has = q0 < d.npr;
+  const int npre = nmax < PRE ? nmax : PRE;
+  double x0 = 0.0, ex0 = 0.0, px[PRE], pex[PRE];
+  if (has) { x0 = d.PD[q0]; ex0 = d.PED[q0]; }
+#pragma unroll
+  for (int k = 0; k < PRE; ++k) {
+    px[k] = (has && k < npre) ? d.PX[(size_t)k * d.npr + q0] : 0.0;
+    pex[k] = (has && k < npre) ? d.PEX[(size_t)k * d.npr + q0] : 0.0;
+  }
+  const double pnv = (tid < MAXPROJ) ? G->pn[tid] : 1.0;
+  PartialRows<5> pr;
+  pr.issue(d.ppart, d.nblk, (!d.use_tot && d.nblk <= 512) ? nmax + 1 : 0, tid);
+  if (nit == 0) return;
+  const int s = pcnt % nmax;
   const double as = (s < np) ? G->pa[s] : 0.0;
-  if (tid < np) cf[tid] = (tid == s) ? 0.0 : sh[tid] / G->pn[tid];
+  if (d.use_tot) { if (tid <= np) sh[tid] = d.ptot[tid]; __syncthreads(); }
+  else if (d.nblk <= 512) pr.reduce(d.ppart, d.nblk, np + 1, sh, tid);
+  else sum_partials_multi(d.ppart, d.nblk, np + 1, sh, tid, 256);
+  if (tid < np) cf[tid] = (tid == s) ? 0.0 : sh[tid] / pnv;
   __syncthreads();
-  for (long long q = (long long)blockIdx.x * 256 + tid; q < d.npr; q += (long long)gridDim.x * 256) {
+  if (has) {
+    double x = x0, ex = ex0, xs = 0.0, exs = 0.0;
+#pragma unroll
+    for (int k = 0; k < PRE; ++k) {
+      if (k < np && k != s) { x -= cf[k] * px[k]; ex -= cf[k] * pex[k]; }
+      if (k == s) { xs = px[k]; exs = pex[k]; }
+    }
+    for (int k = PRE; k < np; ++k) {
+      if (k == s) continue;
+      x -= cf[k] * d.PX[(size_t)k * d.npr + q0];
+      ex -= cf[k] * d.PEX[(size_t)k * d.npr + q0];
+    }
+    if (s < np) {
+      if (s >= PRE) { xs = d.PX[(size_t)s * d.npr + q0]; exs = d.PEX[(size_t)s * d.npr + q0]; }
+      x += as * xs;
+      ex += as * exs;
+    }
+    d.PX[(size_t)s * d.npr + q0] = x;
+    d.PEX[(size_t)s * d.npr + q0] = ex;
+  }
+  for (long long q = q0 + stride; q < d.npr; q += stride) {
     double x = d.PD[q], ex = d.PED[q];
     for (int k = 0; k < np; ++k) {
       if (k == s) continue;
