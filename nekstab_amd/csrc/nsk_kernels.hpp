@@ -327,6 +327,23 @@ __device__ inline void load_basis(const Dev& d, double* sD, double* sDt, double*
     for (int k = tid; k < M * N; k += nt) { sJ12[k] = d.J12[k]; sD12[k] = d.D12[k]; }
 }
 
+// the same in two halves: `issue` puts this thread's entries in registers (the loads go out with the kernel's other
+// front-loaded loads), `commit` stores them to LDS just before the first barrier -- a plain load_basis at the top of a kernel
+// waits for its own loads before the kernel's main loads are issued (one more round trip)
+template <int N>
+struct BasisRegs {
+  static constexpr int NN = N * N, NM = N * (N - 2);
+  double dv = 0.0, j12 = 0.0, d12 = 0.0;
+  __device__ inline void issue(const Dev& d, int tid, bool want_d, bool want_j) {
+    if (want_d && tid < NN) dv = d.D[tid];
+    if (want_j && tid < NM) { j12 = d.J12[tid]; d12 = d.D12[tid]; }
+  }
+  __device__ inline void commit(double* sD, double* sDt, double* sJ12, double* sD12, int tid) const {
+    if (sD && tid < NN) { sD[tid] = dv; if (sDt) sDt[(tid % N) * N + tid / N] = dv; }
+    if (sJ12 && tid < NM) { sJ12[tid] = j12; sD12[tid] = d12; }
+  }
+};
+
 // ---------------------------------------------------------------------------
 // K1: forcing + dealiased convection  -> bf (mass weighted)
 //   makeufp + advabp / advabp_adjoint  [UPSTREAM perturb.f], sponge term of
@@ -342,6 +359,18 @@ __global__ __launch_bounds__(Cfg<N>::NTD) void k_convect(Dev d, const double* __
   __shared__ double su[2][NN], st[2][N * ND], sf[2][NDD], so[2][NDD], sq[2][ND * N];
   const int tid = threadIdx.x;
   const long long e = blockIdx.x;
+  // pointwise operands of the fine-mesh product and of the sponge term: used after two and four barriers, independent of
+  // everything before them -- loaded now
+  double c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0, sbv = 0;
+  if (tid < NDD) {
+    const long long q = e * NDD + tid;
+    if (adjoint == 2) { c0 = d.rxd[q]; c1 = d.ryd[q]; c2 = d.sxd[q]; c3 = d.syd[q]; }
+    else {
+      const long long qb = q + (d.bf_stride ? (long long)(*d.bstep) * d.bf_stride : 0);
+      c0 = d.cUr[qb]; c1 = d.cUs[qb]; c2 = d.GUx[qb]; c3 = d.GUy[qb]; c4 = d.GVx[qb]; c5 = d.GVy[qb];
+    }
+  }
+  if (tid < NN) sbv = d.spng[e * NN + tid] * d.bm1[e * NN + tid];
   for (int k = tid; k < ND * N; k += NT) sJ[k] = d.Jd[k];
   for (int k = tid; k < NDD; k += NT) sDd[k] = d.Dd[k];
   if (tid < NN) {
@@ -383,24 +412,22 @@ __global__ __launch_bounds__(Cfg<N>::NTD) void k_convect(Dev d, const double* __
       ur += dr * sf[0][b * ND + k]; us += ds * sf[0][k * ND + a];
       vr += dr * sf[1][b * ND + k]; vs += ds * sf[1][k * ND + a];
     }
-    const long long q = e * NDD + tid;
     const double uf = sf[0][tid], vf = sf[1][tid];
     double ox, oy;
     if (adjoint == 2) {      // full equations: (u.grad) u   [UPSTREAM advab], newton_krylov's nonlinear map
-      const double cr = d.rxd[q] * uf + d.ryd[q] * vf, cs = d.sxd[q] * uf + d.syd[q] * vf;
+      const double cr = c0 * uf + c1 * vf, cs = c2 * uf + c3 * vf;           // rxd, ryd, sxd, syd
       ox = cr * ur + cs * us;
       oy = cr * vr + cs * vs;
     } else {
-      // base-flow constants: steady, or slot `*bstep` of the stored periodic orbit (Floquet, core/matvec.f:200-236)
-      const long long qb = q + (d.bf_stride ? (long long)(*d.bstep) * d.bf_stride : 0);
-      const double cr = d.cUr[qb], cs = d.cUs[qb];
-      const double conv_u = cr * ur + cs * us, conv_v = cr * vr + cs * vs;   // (U.grad) u'
+      // base-flow constants (steady, or slot `*bstep` of the stored periodic orbit: Floquet, core/matvec.f:200-236):
+      // c0..c5 = cUr, cUs, GUx, GUy, GVx, GVy
+      const double conv_u = c0 * ur + c1 * us, conv_v = c0 * vr + c1 * vs;   // (U.grad) u'
       if (!adjoint) {          // + (u'.grad) U
-        ox = conv_u + uf * d.GUx[qb] + vf * d.GUy[qb];
-        oy = conv_v + uf * d.GVx[qb] + vf * d.GVy[qb];
+        ox = conv_u + uf * c2 + vf * c3;
+        oy = conv_v + uf * c4 + vf * c5;
       } else {                 // (grad U)^T u' - (U.grad) u'
-        ox = uf * d.GUx[qb] + vf * d.GVx[qb] - conv_u;
-        oy = uf * d.GUy[qb] + vf * d.GVy[qb] - conv_v;
+        ox = uf * c2 + vf * c4 - conv_u;
+        oy = uf * c3 + vf * c5 - conv_v;
       }
     }
     so[0][tid] = ox; so[1][tid] = oy;
@@ -429,7 +456,7 @@ __global__ __launch_bounds__(Cfg<N>::NTD) void k_convect(Dev d, const double* __
       s1 += w * sq[1][bb * N + i];
     }
     const long long l = e * NN + tid;
-    const double sb = d.spng[l] * d.bm1[l];
+    const double sb = sbv;
     if (adjoint == 2) {      // DNS sponge: spng_fun (u_ref - u) spng_str   (core/utils.f:165-170)
       const double k = sb * d.nl_spng_str;
       bf[l] = ((k != 0.0) ? k * (d.spng_vr[l] - su[0][tid]) : 0.0) - s0;
@@ -502,7 +529,9 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_rhs(Dev d, StepCoef sc) {
   const bool act = (el < EPB) && (e < d.nel);
   const int j = nd / N, i = nd % N;
   const long long l = e * NN + nd, nl = d.cs;
-  load_basis<N, EPB>(d, sD, sDt, sJ12, sD12, tid, NT);
+  static_assert(NT >= NN, "one basis entry per thread");
+  BasisRegs<N> br;
+  br.issue(d, tid, true, true);
   if (d.bf_stride && sc.adjoint != 2 && blockIdx.x == 0 && tid == 0) *d.bstep += 1;     // next step reads the next orbit slot
   if (d.nproj_max > 0 && blockIdx.x == 0 && tid == 0) {
     GmresScal* G = d.gsc;
@@ -520,36 +549,47 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_rhs(Dev d, StepCoef sc) {
   }
   double u[2] = {0, 0}, bfv[2] = {0, 0}, bm = 0, g1 = 0, g2 = 0, g4 = 0;
   if (act) {
+    // every load first, then the arithmetic and the lag shifts: a store between two loads pins their order (the compiler must
+    // assume the arrays alias), and each pinned load is one more round trip
+    const bool pl = nd < MM;
+    const long long q = e * MM + nd;
+    double un[2], dl1[2], dl2[2], dl3[2], bn[2], e1[2], e2[2], l1[2], l2[2];
+    double pn = 0, plg = 0, m0 = 0, m1 = 0, m2 = 0, m3 = 0;
     bm = d.bm1[l]; g1 = d.g1[l]; g2 = d.g2[l]; g4 = d.g4[l];
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       const long long lc = c * nl + l;
-      const double un = d.u[lc];
-      u[c] = un + sc.xg[0] * d.dulag[lc] + sc.xg[1] * d.dulag[2 * nl + lc] + sc.xg[2] * d.dulag[4 * nl + lc];   // u^n + du0 (extrapolated guess)
+      un[c] = d.u[lc];
+      dl1[c] = d.dulag[lc]; dl2[c] = d.dulag[2 * nl + lc]; dl3[c] = d.dulag[4 * nl + lc];
+      bn[c] = d.bf[lc];
+      e1[c] = d.exlag[lc]; e2[c] = d.exlag[2 * nl + lc];
+      l1[c] = d.ulag[lc]; l2[c] = d.ulag[2 * nl + lc];
+    }
+    if (pl) { pn = d.p[q]; plg = d.plag[q]; m0 = d.w2rx[q]; m1 = d.w2sx[q]; m2 = d.w2ry[q]; m3 = d.w2sy[q]; }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const long long lc = c * nl + l;
+      u[c] = un[c] + sc.xg[0] * dl1[c] + sc.xg[1] * dl2[c] + sc.xg[2] * dl3[c];   // u^n + du0 (extrapolated guess)
       su[(c * EPB + el) * NN + nd] = u[c];
-      const double bn = d.bf[lc];
-      const double e1 = d.exlag[lc], e2 = d.exlag[2 * nl + lc];
-      double b = sc.ab[0] * bn + sc.ab[1] * e1 + sc.ab[2] * e2;      // makextp
-      d.exlag[2 * nl + lc] = e1;
-      d.exlag[lc] = bn;
-      const double l1 = d.ulag[lc], l2 = d.ulag[2 * nl + lc];
-      b += bm * (sc.bd[1] * un + sc.bd[2] * l1 + sc.bd[3] * l2) * sc.invdt;   // makebdfp
-      d.ulag[2 * nl + lc] = l1;                                      // lagfieldp
-      d.ulag[lc] = un;
+      double b = sc.ab[0] * bn[c] + sc.ab[1] * e1[c] + sc.ab[2] * e2[c];      // makextp
+      d.exlag[2 * nl + lc] = e1[c];
+      d.exlag[lc] = bn[c];
+      b += bm * (sc.bd[1] * un[c] + sc.bd[2] * l1[c] + sc.bd[3] * l2[c]) * sc.invdt;   // makebdfp
+      d.ulag[2 * nl + lc] = l1[c];                                   // lagfieldp
+      d.ulag[lc] = un[c];
       bfv[c] = b;
     }
-    if (nd < MM) {                                                   // extrapprp
-      const long long q = e * MM + nd;
-      const double pn = d.p[q];
-      const double pe = (sc.k < 3) ? pn : 2.0 * pn - d.plag[q];
+    if (pl) {                                                        // extrapprp
+      const double pe = (sc.k < 3) ? pn : 2.0 * pn - plg;
       d.plag[q] = pn;
       d.pext[q] = pe;
-      sP[(0 * EPB + el) * MM + nd] = pe * d.w2rx[q];
-      sP[(1 * EPB + el) * MM + nd] = pe * d.w2sx[q];
-      sP[(2 * EPB + el) * MM + nd] = pe * d.w2ry[q];
-      sP[(3 * EPB + el) * MM + nd] = pe * d.w2sy[q];
+      sP[(0 * EPB + el) * MM + nd] = pe * m0;
+      sP[(1 * EPB + el) * MM + nd] = pe * m1;
+      sP[(2 * EPB + el) * MM + nd] = pe * m2;
+      sP[(3 * EPB + el) * MM + nd] = pe * m3;
     }
   }
+  br.commit(sD, sDt, sJ12, sD12, tid);
   __syncthreads();
   double gx, gy;
   opgradt_tiles<N, EPB>(sJ12, sD12, sP, sB, act, el, nd, gx, gy);
@@ -586,35 +626,25 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_helm(Dev d, StepCoef sc, int it,
   const long long l = e * NN + nd, nl = d.cs;
   const int par = it & 1, ppar = par ^ 1;
   NSK_STAMP(0);
-  if (it > 2 && d.hscal[ppar * 8 + 2] != 0.0 && d.hscal[ppar * 8 + 6] != 0.0) {   // finished earlier: cheapest exit
-    if (blockIdx.x == 0 && tid < 8) d.hscal[par * 8 + tid] = d.hscal[ppar * 8 + tid];
-    return;
-  }
-  // ---- phase A: issue every independent global load before anything waits
+  // the previous iteration's scalars and -- with them, so that the neighbour gathers below can go out together with the
+  // rest of phase A instead of one round trip later -- this node's gather-table entry (16 B per thread: what a launch that
+  // finds the solve finished pays on top of the flag)
   double o[8] = {0, 0, 0, 0, 0, 0, 0, 0}, refn[2] = {0, 0};
+  int4 tab = make_int4(0, -1, -1, -1);
   if (it > 1) {
 #pragma unroll
     for (int q = 0; q < 8; ++q) o[q] = d.hscal[ppar * 8 + q];
-    refn[0] = d.hscal[16]; refn[1] = d.hscal[17];
   }
-  double ps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (it > 0) {
-    if (d.nranks > 1 || d.use_tot) {    // totals: all-reduced over ranks, or summed once by k_tot2 (many workgroups)
-#pragma unroll
-      for (int q = 0; q < 8; ++q) ps[q] = (tid == 0) ? d.htot[ppar * 8 + q] : 0.0;
-    } else {
-      const double* part = d.hpart + (size_t)ppar * 8 * d.nblk;
-      for (int k = tid; k < d.nblk; k += NT) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) ps[q] += part[(size_t)q * d.nblk + k];
-      }
-    }
+  if (act) tab = d.gs_tab[l];
+  if (it > 2 && o[2] != 0.0 && o[6] != 0.0) {   // finished earlier: cheapest exit
+    if (blockIdx.x == 0 && tid < 8) d.hscal[par * 8 + tid] = o[tid & 7];
+    return;
   }
-  int4 tab = make_int4(0, -1, -1, -1);
+  // ---- phase A: issue every independent global load before anything waits
+  if (it > 1) { refn[0] = d.hscal[16]; refn[1] = d.hscal[17]; }
   double bm = 0, g1 = 0, g2 = 0, g4 = 0, mk = 0, mi = 0, di = 0;
   double rold[2] = {0, 0}, pold[2] = {0, 0}, sold[2] = {0, 0}, xold[2] = {0, 0};
   if (act) {
-    tab = d.gs_tab[l];
     bm = d.bm1[l]; g1 = d.g1[l]; g2 = d.g2[l]; g4 = d.g4[l]; mk = d.mask[l]; mi = d.minv[l];
     di = d.dinv[(size_t)(sc.k - 1) * d.nloc + l];
     if (it > 0) {
@@ -622,6 +652,22 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_helm(Dev d, StepCoef sc, int it,
       for (int c = 0; c < 2; ++c) {
         const long long lc = c * nl + l;
         rold[c] = d.hr[lc]; pold[c] = d.hp[lc]; sold[c] = d.hs[lc]; xold[c] = d.hx[lc];
+      }
+    }
+  }
+  // the previous kernel's dot-product partials: two per row and thread up to 2 NT workgroups, all in flight at once (a
+  // `for` over them would wait for each round of loads and hold back every load behind it)
+  double ps[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ps1[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (it > 0) {
+    if (d.nranks > 1 || d.use_tot) {    // totals: all-reduced over ranks, or summed once by k_tot2 (many workgroups)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) ps[q] = (tid == 0) ? d.htot[ppar * 8 + q] : 0.0;
+    } else {
+      const double* part = d.hpart + (size_t)ppar * 8 * d.nblk;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        ps[q] = (tid < d.nblk) ? part[(size_t)q * d.nblk + tid] : 0.0;
+        ps1[q] = (tid + NT < d.nblk) ? part[(size_t)q * d.nblk + tid + NT] : 0.0;
       }
     }
   }
@@ -645,6 +691,15 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_helm(Dev d, StepCoef sc, int it,
   double alpha[2] = {0, 0}, beta[2] = {0, 0};
   bool done[2] = {false, false};
   if (it > 0) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) ps[q] += ps1[q];
+    if (!(d.nranks > 1 || d.use_tot)) {
+      const double* part = d.hpart + (size_t)ppar * 8 * d.nblk;
+      for (int k = tid + 2 * NT; k < d.nblk; k += NT) {     // more than 2 NT workgroups without the totals path: not a built configuration
+#pragma unroll
+        for (int q = 0; q < 8; ++q) ps[q] += part[(size_t)q * d.nblk + k];
+      }
+    }
     block_reduce<8>(ps, sred, tid, NT);
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
@@ -747,7 +802,18 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_pres_rhs(Dev d, StepCoef sc, int
 #pragma unroll
     for (int k = 0; k < PXPRE; ++k) pxr[k] = (pl && k < npre) ? d.PX[(size_t)k * d.npr + e * MM + nd] : 0.0;
   }
-  load_basis<N, EPB>(d, nullptr, nullptr, sJ12, sD12, tid, NT);
+  BasisRegs<N> br;
+  br.issue(d, tid, false, true);
+  // velocity increments and their lags: loaded before the block-0 bookkeeping and before any store (see k_rhs)
+  double un_[2] = {0, 0}, l1_[2] = {0, 0}, l2_[2] = {0, 0}, l3_[2] = {0, 0}, hx_[2] = {0, 0};
+  if (act) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const long long lc = c * nl + l;
+      l1_[c] = d.dulag[lc]; l2_[c] = d.dulag[2 * nl + lc]; l3_[c] = d.dulag[4 * nl + lc];
+      hx_[c] = d.hx[lc]; un_[c] = d.u[lc];
+    }
+  }
   if (check_helm && blockIdx.x == 0) {       // last partials -> final residual of the velocity solve
     double s[8];
     if (d.nranks > 1 || d.use_tot) {
@@ -775,16 +841,17 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_pres_rhs(Dev d, StepCoef sc, int
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       const long long lc = c * nl + l;
-      const double l1 = d.dulag[lc], l2 = d.dulag[2 * nl + lc], l3 = d.dulag[4 * nl + lc];
-      const double du = sc.xg[0] * l1 + sc.xg[1] * l2 + sc.xg[2] * l3 + d.hx[lc];     // guess + CG correction
+      const double l1 = l1_[c], l2 = l2_[c], l3 = l3_[c];
+      const double du = sc.xg[0] * l1 + sc.xg[1] * l2 + sc.xg[2] * l3 + hx_[c];     // guess + CG correction
       d.dulag[4 * nl + lc] = l2;
       d.dulag[2 * nl + lc] = l1;
       d.dulag[lc] = du;
-      const double us = d.u[lc] + du;
+      const double us = un_[c] + du;
       d.u[lc] = us;
       su[(c * EPB + el) * NN + nd] = us;
     }
   }
+  br.commit(nullptr, nullptr, sJ12, sD12, tid);
   __syncthreads();
   const double div = opdiv_tiles<N, EPB>(sJ12, sD12, su, sA, act, el, nd, d, e);
   double v[1] = {0.0};
@@ -1560,7 +1627,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_pres_update(Dev d, StepCoef sc) 
   if (d.nproj_max > 0 && tid < MAXPROJ) spa[tid] = G->pa[tid];
   for (int k = tid; k < nit * nit; k += NT) { const int cc = k / nit, rr = k % nit; sR[cc * MAXMR + rr] = G->R[cc * MAXMR + rr]; }
   if (tid < nit) sg[tid] = G->g[tid];
-  load_basis<N, EPB>(d, nullptr, nullptr, sJ12, sD12, tid, NT);
+  load_basis<N, EPB>(d, nullptr, nullptr, sJ12, sD12, tid, NT);     // (after the operand loads above: nothing waits on it before them)
   lds_barrier();
   if (tid == 0) {                      // back substitution R y = g (nit <= MAXMR), from LDS
     for (int q = nit - 1; q >= 0; --q) {
@@ -1626,18 +1693,21 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_vel_update_proj(Dev d, StepCoef 
     if (pl) del0 = d.PD[e * MM + nd];
     if (tid < MAXPROJ) spa[tid] = G->pa[tid];
   }
-  load_basis<N, EPB>(d, nullptr, nullptr, sJ12, sD12, tid, NT);
+  BasisRegs<N> br;
+  br.issue(d, tid, false, true);
   if (act) {
     const long long l = e * NN + nd;
     const double bi = d.binv[l];
+    const double u0 = d.u[l], u1 = d.u[d.cs + l];                 // loads before the stores below (see k_rhs)
     const double vx = bi * gs_gather(d.yl, d, l);
     const double vy = bi * gs_gather(d.yl + d.cs, d, l);
-    d.u[l] += vx / sc.h2;
-    d.u[d.cs + l] += vy / sc.h2;
+    d.u[l] = u0 + vx / sc.h2;
+    d.u[d.cs + l] = u1 + vy / sc.h2;
     su[(0 * EPB + el) * NN + nd] = vx;
     su[(1 * EPB + el) * NN + nd] = vy;
   }
   if (G->nit == 0) return;                      // nothing new to absorb
+  br.commit(nullptr, nullptr, sJ12, sD12, tid);
   __syncthreads();
   const double w = opdiv_tiles<N, EPB>(sJ12, sD12, su, sA, act, el, nd, d, e);
   const bool pact = act && nd < MM;

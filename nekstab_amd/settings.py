@@ -2,12 +2,15 @@
 row, against the reference's Spectre_Hd.dat / Spectre_Ha.dat and against this build's fully converged spectra
 (DESIGN.md section 1 has the sweep they come from).
 
- * Helmholtz   |b - H u| <= 1e-11 |b|   (the wake-branch eigenvalues move by 3e-5 at 1e-10, by 7e-6 at 1e-11)
- * pressure    |g - E dp| <= 1e-1 |g| with at least two GMRES iterations per solve, x 0.01 in time steps 1-3 of a map
+ * Helmholtz   |b - H u| <= 3e-12 |b|
+ * pressure    |g - E dp| <= 3e-2 |g| with at least two GMRES iterations per solve, x 0.01 in time steps 1-3 of a map
+   (the cheapest pair that holds every converged wake-branch row of the direct spectrum below 5e-6 in BOTH of two
+   arithmetically equivalent realisations of the run -- worst row 1e-6; 1e-11 / 1e-1, the first choice of this round, sits AT
+   5e-6 on two rows and above it in some realisations: scripts/pin_noise.py)
  * projection space of 16 previous pressure solutions (Nek5000's residualProj; mxprev = 20 in the reference's SIZE)
  * no upper bound on the pressure iterations (``pres_cap`` of round 1 is gone: it diverges on the adjoint case)
 """
-PRODUCTION = dict(tol_helm=1e-11, tol_pres=1e-1, tol_relative=1, nproj=16, schwarz_layers=2, max_helm_iter=100, max_pres_iter=48)
+PRODUCTION = dict(tol_helm=3e-12, tol_pres=3e-2, tol_relative=1, nproj=16, schwarz_layers=2, max_helm_iter=100, max_pres_iter=48)
 PRODUCTION_OPTIONS = dict(min_pres_iter=2)
 
 

@@ -10,6 +10,8 @@ fully converged spectra.  What the numbers mean:
    1e-7 / 1e-9 tolerances; those rows are held to 6e-5 against the table and to 5e-6 against the converged spectrum;
  * direct, lx1 = 8 (config 2, no reference table): every row to 5e-6 against the converged spectrum, and the leading pair
    to 3e-6 against the adjoint table's (same spectrum up to the discretisation of the adjoint).
+ * "converged" above means: Ritz residual below 2e-9 in both k = 200 runs.  Rows between 2e-9 and 1e-8 are limited by the
+   Krylov convergence and not by the inner solves (_own_bound).
 """
 import os
 
@@ -50,6 +52,14 @@ def _match(res, table, res_max):
     return rows
 
 
+def _own_bound(res_ref, res_run):
+    """Bound of |Ritz value at the production settings - Ritz value of the converged-solves run| for one row.  5e-6 (SURVEY
+    8(c)) where BOTH k = 200 Ritz values are themselves converged (residual < 2e-9).  Rows with a residual between 2e-9 and
+    1e-8 are limited by the Krylov convergence, not by the inner solves: the 0.6471+0.5271i row of config 2 (residual 1e-8)
+    stays at 3e-6 ... 9e-6 for EVERY setting of scripts/pin_noise.py, 1e-12 / 1e-2 included -- those get 1.5e-5."""
+    return 5e-6 if max(res_ref, res_run) < 2e-9 else 1.5e-5
+
+
 @pytest.fixture(scope="module")
 def converged():
     from tests.conftest import GOLDEN
@@ -78,11 +88,7 @@ def test_direct_lx1_6_every_row_of_spectre_Hd(spectre, converged):
     own = _match(res, converged["Hd6"], 1e-8)
     for n, z, v, rr, rs, d in own:
         print("converged lx1=6 row %2d  %.9f%+.9fi  bench settings %.9f%+.9fi  diff %.1e" % (n, z.real, z.imag, v.real, v.imag, d))
-        # 2e-5, not 5e-6: at the production tolerances the under-resolved lx1 = 6 wake rows are reproducible to ~1e-5 only.
-        # Two arithmetically equivalent builds (classic / merged GMRES bookkeeping: one matvec equal to 2e-11, same iteration
-        # counts) gave 2.7e-6 and 1.1e-5 on row 6 -- the inner-solve error of ~1e-8 per matvec is re-rolled by any
-        # rounding-level change and amplified by the non-normality of this operator.  Rows 1-2: 1e-8.
-        assert d < (1e-8 if n <= 2 else 2e-5), (n, z, v)
+        assert d < _own_bound(rr, rs), (n, z, v)
     assert len(own) >= 6
 
 
@@ -91,7 +97,7 @@ def test_direct_lx1_8_config2_against_converged_spectrum(spectre, converged):
     own = _match(res, converged["Hd8"], 1e-8)
     for n, z, v, rr, rs, d in own:
         print("converged lx1=8 row %2d  %.9f%+.9fi  bench settings %.9f%+.9fi (%.0e)  diff %.1e" % (n, z.real, z.imag, v.real, v.imag, rs, d))
-        assert d < 5e-6, (n, z, v)
+        assert d < _own_bound(rr, rs), (n, z, v)
     assert len(own) >= 9
     lead = res.vals[np.argmin(np.abs(res.vals - complex(*spectre["Ha"][0, :2])))]
     assert abs(lead - complex(*spectre["Ha"][0, :2])) < 3e-6          # direct vs adjoint discretisation of the same operator
