@@ -122,27 +122,29 @@ __device__ inline void sum_partials_multi(const double* part, int n, int nq, dou
 template <int R>
 struct PartialRows {
   double p[R][8];
-  __device__ inline void issue(const double* part, int n, int nq_issue, int tid) {
+  __device__ inline void issue(const double* part, int n, int nq_issue, int tid, int row0 = 0) {
     const int lane = tid & 63, w = tid >> 6;
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
       for (int k = 0; k < 8; ++k)
-        p[r][k] = (w + 4 * r < nq_issue && lane + 64 * k < n) ? part[(size_t)(w + 4 * r) * n + lane + 64 * k] : 0.0;
+        p[r][k] = (row0 + w + 4 * r < nq_issue && lane + 64 * k < n) ? part[(size_t)(row0 + w + 4 * r) * n + lane + 64 * k] : 0.0;
   }
-  __device__ inline void reduce(const double* part, int n, int nq, double* sh, int tid) {
+  // sums rows row0 .. row0 + 4 R - 1 (those below nq) from the registers; `tail`: the rows behind them by the loop, then a barrier
+  __device__ inline void reduce(const double* part, int n, int nq, double* sh, int tid, int row0 = 0, bool tail = true) {
     const int lane = tid & 63, w = tid >> 6;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      if (w + 4 * r < nq) {
+      if (row0 + w + 4 * r < nq) {
         double s = 0.0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) s += p[r][k];
         s = wave_sum63(s);
-        if (lane == 63) sh[w + 4 * r] = s;
+        if (lane == 63) sh[row0 + w + 4 * r] = s;
       }
     }
-    for (int q = w + 4 * R; q < nq; q += 4) {
+    if (!tail) return;
+    for (int q = row0 + w + 4 * R; q < nq; q += 4) {
       double s = 0.0;
       for (int k = lane; k < n; k += 64) s += part[(size_t)q * n + k];
       s = wave_sum63(s);
@@ -794,7 +796,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_pres_rhs(Dev d, StepCoef sc, int
   const long long l = e * NN + nd, nl = d.cs;
   // stored pressure solutions at this thread's Gauss node, for the projection dots at the end: independent of everything
   // else in the launch, so they are issued first (the first PXPRE vectors; slots >= nproj are never used)
-  constexpr int PXPRE = 16;
+  constexpr int PXPRE = MAXPROJ;
   double pxr[PXPRE];
   {
     const bool pl = act && nd < MM && d.nproj_max > 0;
@@ -928,7 +930,7 @@ __global__ __launch_bounds__(256) void k_proj_apply(Dev d) {
   // every load of this launch is independent of every other: issue them all before the first wait (the space holds at most
   // nproj_max <= MAXPROJ vectors; the first PRE of them go to registers for this thread's entry -- one entry per thread on
   // every mesh this runs on; slots >= nproj hold finite stale data and get a zero coefficient)
-  constexpr int PRE = 16;
+  constexpr int PRE = MAXPROJ;
   const long long q0 = (long long)blockIdx.x * 256 + tid, stride = (long long)gridDim.x * 256;
   const bool has = q0 < d.npr;
   const int npre = d.nproj_max < PRE ? d.nproj_max : PRE;
@@ -942,10 +944,12 @@ __global__ __launch_bounds__(256) void k_proj_apply(Dev d) {
     if (blockIdx.x == 0 && tid == 0) G->gnorm0 = sqrt(d.ptot[MAXPROJ]);
     __syncthreads();
   } else {
-    PartialRows<4> pr;
+    PartialRows<4> pr;                  // 16 rows per pass: a second pass for spaces of more than 16 vectors
     pr.issue(d.ppart, d.nblk, d.nblk <= 512 ? d.nproj_max : 0, tid);
-    if (d.nblk <= 512) pr.reduce(d.ppart, d.nblk, np, sh, tid);
-    else sum_partials_multi(d.ppart, d.nblk, np, sh, tid, 256);
+    if (d.nblk <= 512) {
+      pr.reduce(d.ppart, d.nblk, np, sh, tid, 0, np <= 16);
+      if (np > 16) { pr.issue(d.ppart, d.nblk, np, tid, 16); pr.reduce(d.ppart, d.nblk, np, sh, tid, 16); }
+    } else sum_partials_multi(d.ppart, d.nblk, np, sh, tid, 256);
     if (blockIdx.x == 0) {
       double gg[1];
       sum_partials<1>(d.ppart + (size_t)MAXPROJ * d.nblk, d.nblk, gg, sred, tid, 256);
@@ -1611,7 +1615,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_pres_update(Dev d, StepCoef sc) 
   const int nit = G->nit;
   // this thread's operands first: the preconditioned basis z_k (the first ZPRE; slots >= nit hold finite stale data and are
   // not used), the stored solutions x_k, the extrapolated pressure and the metrics -- independent of the small triangular solve
-  constexpr int ZPRE = 12, PXPRE = 16;
+  constexpr int ZPRE = 12, PXPRE = MAXPROJ;
   __shared__ double spa[MAXPROJ];
   const bool pl = act && nd < MM;
   const long long q = e * MM + nd;
@@ -1682,7 +1686,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_vel_update_proj(Dev d, StepCoef 
   const GmresScal* G = d.gsc;
   // E-images of the stored solutions and the GMRES correction at this thread's Gauss node: used after the divergence below,
   // independent of it -- issued first (the first PEPRE vectors)
-  constexpr int PEPRE = 16;
+  constexpr int PEPRE = MAXPROJ;
   __shared__ double spa[MAXPROJ];
   double per[PEPRE], del0 = 0.0;
   {
@@ -1763,7 +1767,7 @@ __global__ __launch_bounds__(256) void k_proj_update(Dev d) {
   const int nit = G->nit, np = G->nproj, nmax = d.nproj_max, pcnt = G->pcnt;
   // as k_proj_apply: all loads first (this thread's entry of delta, E delta and of the first PRE vectors of the space and of
   // their E-images; partial sums; the scalars), then the arithmetic
-  constexpr int PRE = 16;
+  constexpr int PRE = MAXPROJ;
   const long long q0 = (long long)blockIdx.x * 256 + tid, stride = (long long)gridDim.x * 256;
   const bool has = q0 < d.npr;
   const int npre = nmax < PRE ? nmax : PRE;
@@ -1781,7 +1785,10 @@ __global__ __launch_bounds__(256) void k_proj_update(Dev d) {
   const int s = pcnt % nmax;
   const double as = (s < np) ? G->pa[s] : 0.0;
   if (d.use_tot) { if (tid <= np) sh[tid] = d.ptot[tid]; __syncthreads(); }
-  else if (d.nblk <= 512) pr.reduce(d.ppart, d.nblk, np + 1, sh, tid);
+  else if (d.nblk <= 512) {
+    pr.reduce(d.ppart, d.nblk, np + 1, sh, tid, 0, np + 1 <= 20);
+    if (np + 1 > 20) { pr.issue(d.ppart, d.nblk, np + 1, tid, 20); pr.reduce(d.ppart, d.nblk, np + 1, sh, tid, 20); }
+  }
   else sum_partials_multi(d.ppart, d.nblk, np + 1, sh, tid, 256);
   if (tid < np) cf[tid] = (tid == s) ? 0.0 : sh[tid] / pnv;
   __syncthreads();

@@ -7,10 +7,11 @@ row, against the reference's Spectre_Hd.dat / Spectre_Ha.dat and against this bu
    (the cheapest pair that holds every converged wake-branch row of the direct spectrum below 5e-6 in BOTH of two
    arithmetically equivalent realisations of the run -- worst row 1e-6; 1e-11 / 1e-1, the first choice of this round, sits AT
    5e-6 on two rows and above it in some realisations: scripts/pin_noise.py)
- * projection space of 16 previous pressure solutions (Nek5000's residualProj; mxprev = 20 in the reference's SIZE)
+ * projection space of 32 previous pressure solutions (Nek5000's residualProj; mxprev = 20 in the reference's SIZE): 6.7 GMRES
+   iterations per step against 7.8 with 16 vectors and 7.2 with 24, same accuracy; the kernels hold all 32 in registers
  * no upper bound on the pressure iterations (``pres_cap`` of round 1 is gone: it diverges on the adjoint case)
 """
-PRODUCTION = dict(tol_helm=3e-12, tol_pres=3e-2, tol_relative=1, nproj=16, schwarz_layers=2, max_helm_iter=100, max_pres_iter=48)
+PRODUCTION = dict(tol_helm=3e-12, tol_pres=3e-2, tol_relative=1, nproj=32, schwarz_layers=2, max_helm_iter=100, max_pres_iter=48)
 PRODUCTION_OPTIONS = dict(min_pres_iter=2)
 
 

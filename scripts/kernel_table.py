@@ -16,7 +16,8 @@ for r in rows:
 pmc = json.load(open(pmc_json)) if os.path.exists(pmc_json) else {}
 line = json.loads([l for l in open(bench_json) if l.startswith("{")][-1])
 nh, npr_it = line["helm_iters_per_step"], line["pres_iters_per_step"]
-geom = dict(nel=1996, lx1=8, ndim=2, nvert=2033, coarse_lda=2048, patch_stride=100, nproj=16)
+from nekstab_amd.settings import PRODUCTION
+geom = dict(nel=1996, lx1=8, ndim=2, nvert=2033, coarse_lda=2048, patch_stride=100, nproj=PRODUCTION["nproj"])
 per = roofline.per_step_bytes(helm_iters=1.0, pres_iters=1.0, **geom)        # per iteration entries with counts = 1
 perj = roofline.per_step_bytes(helm_iters=nh, pres_iters=npr_it, **geom)
 P = 1996 * 64
