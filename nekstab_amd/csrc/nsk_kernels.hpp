@@ -361,9 +361,11 @@ __global__ __launch_bounds__(Cfg<N>::NTD) void k_convect(Dev d, const double* __
   __shared__ double su[2][NN], st[2][N * ND], sf[2][NDD], so[2][NDD], sq[2][ND * N];
   const int tid = threadIdx.x;
   const long long e = blockIdx.x;
-  // pointwise operands of the fine-mesh product and of the sponge term: used after two and four barriers, independent of
-  // everything before them -- loaded now
-  double c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0, sbv = 0;
+  // the field first (the first barrier waits for it; loads return in issue order), then the pointwise operands of the
+  // fine-mesh product and of the sponge term, which are used after two and four barriers and depend on nothing
+  double u0 = 0, u1 = 0;
+  if (tid < NN) { u0 = uin[e * NN + tid]; u1 = uin[d.cs + e * NN + tid]; }
+  double c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0, sp0 = 0, bm0 = 0;
   if (tid < NDD) {
     const long long q = e * NDD + tid;
     if (adjoint == 2) { c0 = d.rxd[q]; c1 = d.ryd[q]; c2 = d.sxd[q]; c3 = d.syd[q]; }
@@ -372,13 +374,10 @@ __global__ __launch_bounds__(Cfg<N>::NTD) void k_convect(Dev d, const double* __
       c0 = d.cUr[qb]; c1 = d.cUs[qb]; c2 = d.GUx[qb]; c3 = d.GUy[qb]; c4 = d.GVx[qb]; c5 = d.GVy[qb];
     }
   }
-  if (tid < NN) sbv = d.spng[e * NN + tid] * d.bm1[e * NN + tid];
+  if (tid < NN) { sp0 = d.spng[e * NN + tid]; bm0 = d.bm1[e * NN + tid]; }     // (multiplied where they are used: no wait here)
   for (int k = tid; k < ND * N; k += NT) sJ[k] = d.Jd[k];
   for (int k = tid; k < NDD; k += NT) sDd[k] = d.Dd[k];
-  if (tid < NN) {
-    su[0][tid] = uin[e * NN + tid];
-    su[1][tid] = uin[d.cs + e * NN + tid];
-  }
+  if (tid < NN) { su[0][tid] = u0; su[1][tid] = u1; }
   __syncthreads();
   // interpolate in r: st[c][j][a] = sum_i Jd[a][i] u[j][i]
   if (tid < N * ND) {
@@ -458,7 +457,7 @@ __global__ __launch_bounds__(Cfg<N>::NTD) void k_convect(Dev d, const double* __
       s1 += w * sq[1][bb * N + i];
     }
     const long long l = e * NN + tid;
-    const double sb = sbv;
+    const double sb = sp0 * bm0;
     if (adjoint == 2) {      // DNS sponge: spng_fun (u_ref - u) spng_str   (core/utils.f:165-170)
       const double k = sb * d.nl_spng_str;
       bf[l] = ((k != 0.0) ? k * (d.spng_vr[l] - su[0][tid]) : 0.0) - s0;
