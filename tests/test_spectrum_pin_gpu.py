@@ -60,6 +60,12 @@ def _own_bound(res_ref, res_run):
     return 5e-6 if max(res_ref, res_run) < 2e-9 else 1.5e-5
 
 
+# lx1 = 6 is not the timed configuration and its under-resolved wake rows are the most sensitive ones: the two equivalent
+# realisations of scripts/pin_noise.py give 3.4e-6 and 1.7e-6 on the worst row at the production settings (1.1e-5 and 2.7e-6 at
+# 1e-11 / 1e-1), so the 5e-6 of the better-resolved lx1 = 8 case would be a coin toss here: 1e-5.
+OWN_BOUND_LX1_6 = 1e-5
+
+
 @pytest.fixture(scope="module")
 def converged():
     from tests.conftest import GOLDEN
@@ -88,7 +94,7 @@ def test_direct_lx1_6_every_row_of_spectre_Hd(spectre, converged):
     own = _match(res, converged["Hd6"], 1e-8)
     for n, z, v, rr, rs, d in own:
         print("converged lx1=6 row %2d  %.9f%+.9fi  bench settings %.9f%+.9fi  diff %.1e" % (n, z.real, z.imag, v.real, v.imag, d))
-        assert d < _own_bound(rr, rs), (n, z, v)
+        assert d < (1e-8 if n <= 2 else max(OWN_BOUND_LX1_6, _own_bound(rr, rs))), (n, z, v)
     assert len(own) >= 6
 
 
