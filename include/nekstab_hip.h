@@ -104,6 +104,12 @@ int nsk_vec_free(nsk_ctx* ctx, int n, nsk_vec* v);
 /* nopcopy / outpost / load_files (core/utils.f:471-550, core/IO.f:15-60) */
 int nsk_vec_upload(nsk_ctx* ctx, nsk_vec v, const double* vx, const double* vy, const double* pr);
 int nsk_vec_download(nsk_ctx* ctx, nsk_vec v, double* vx, double* vy, double* pr);
+/* krylov_vector%theta(:, m) (core/krylov_subspace.f:13): after nsk_set_option(ctx, "nscal", ldimt) -- set it before the first
+ * nsk_vec_alloc -- every vector carries `nscal` scalar fields of P entries behind the pressure; the inner product adds their
+ * bm1s-weighted products (:46-50), the vector operations scale / add / rotate them, and the time steppers pass them through
+ * unchanged, as the reference does when ifheat = .false. (no case in scope solves a scalar equation) */
+int nsk_vec_upload_scalar(nsk_ctx* ctx, nsk_vec v, int m, const double* theta);
+int nsk_vec_download_scalar(nsk_ctx* ctx, nsk_vec v, int m, double* theta);
 /* hexahedral contexts (krylov_vector carries vz, core/krylov_subspace.f:9-11) */
 int nsk_vec_upload3(nsk_ctx* ctx, nsk_vec v, const double* vx, const double* vy, const double* vz, const double* pr);
 int nsk_vec_download3(nsk_ctx* ctx, nsk_vec v, double* vx, double* vy, double* vz, double* pr);

@@ -61,6 +61,8 @@ SYMBOLS = {
     "nsk_vec_free": (C.c_int, [_vp, C.c_int, _vpp]),
     "nsk_vec_upload": (C.c_int, [_vp, _vp, _dp, _dp, _dp]),
     "nsk_vec_download": (C.c_int, [_vp, _vp, _dp, _dp, _dp]),
+    "nsk_vec_upload_scalar": (C.c_int, [_vp, _vp, C.c_int, _dp]),
+    "nsk_vec_download_scalar": (C.c_int, [_vp, _vp, C.c_int, _dp]),
     "nsk_vec_upload3": (C.c_int, [_vp, _vp, _dp, _dp, _dp, _dp]),
     "nsk_vec_download3": (C.c_int, [_vp, _vp, _dp, _dp, _dp, _dp]),
     "nsk_matvec": (C.c_int, [_vp, C.c_int, _vp, _vp]),
@@ -191,6 +193,22 @@ class NekStabHip:
     def free(self, vecs):
         arr = (C.c_void_p * len(vecs))(*[v.value for v in vecs])
         self._chk(self.lib.nsk_vec_free(self.ctx, len(vecs), arr))
+
+    def set_nscal(self, nscal):
+        """Carry ``nscal`` scalar fields (krylov_vector%theta) in every vector allocated from now on."""
+        self.set_option("nscal", nscal)
+        self.nscal = int(nscal)
+        self.nstate = self.ndim * self.nvel + self.npres + self.nscal * self.nvel
+
+    def upload_scalar(self, v, m, theta):
+        theta = np.ascontiguousarray(theta, dtype=np.float64)
+        assert theta.size == self.nvel
+        self._chk(self.lib.nsk_vec_upload_scalar(self.ctx, v, int(m), _p(theta)))
+
+    def download_scalar(self, v, m):
+        out = np.empty(self.nvel)
+        self._chk(self.lib.nsk_vec_download_scalar(self.ctx, v, int(m), _p(out)))
+        return out
 
     def upload3(self, v, vx, vy, vz, pr):
         vx, vy, vz, pr = (np.ascontiguousarray(a, dtype=np.float64) for a in (vx, vy, vz, pr))

@@ -64,6 +64,7 @@ struct nsk_ctx {
   double *cw_d0 = nullptr, *cw_d1 = nullptr, *cw_r = nullptr;
   int nel = 0, nblk = 0, nvert = 0;
   long long nloc = 0, npr = 0, nstate = 0;
+  int nscal = 0;                        // scalar fields theta(:, 1..ldimt) carried behind the pressure (option "nscal")
   double dt = 0, re = 0, endtime = 0;
   int nsteps = 0;
   int max_helm = 60, max_pres = 40, min_pres = 0, pres_cap = 0, layers = 1;
@@ -884,6 +885,10 @@ static int run_map(nsk_ctx* c, int adjoint, double* f, const double* q) {
   for (int cc = 0; cc < c->ndim; ++cc)
     HIPCHK(hipMemcpyAsync(f + cc * d.nloc, d.u + cc * d.cs, d.nloc * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(f + c->ndim * d.nloc, d.p, d.npr * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  if (c->nscal > 0) {                         // ifheat = .false.: the stepper leaves the scalars alone (core/matvec.f nopcopy in / out)
+    const long long toff = (long long)c->ndim * d.nloc + d.npr;
+    HIPCHK(hipMemcpyAsync(f + toff, q + toff, (size_t)c->nscal * d.nloc * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  }
   return 0;
 }
 
@@ -981,6 +986,7 @@ extern "C" {
 int nsk_shard_create(nsk_ctx* parent, const int* part, int rank, int nranks, nsk_ctx** out) {
   if (!parent || !part || !out) return fail(NSK_EINVAL, "bad argument");
   if (parent->released) return fail(NSK_EINVAL, "parent context was released (nsk_shard_release_parent)");
+  if (parent->nscal > 0) return fail(NSK_EINVAL, "sharded vectors do not carry scalar fields yet");
   return shard_create(parent, part, rank, nranks, out);
 }
 
@@ -1087,7 +1093,7 @@ int nsk_local_dots(nsk_ctx* c, nsk_vec f, const nsk_vec* Q, int nq, double* out)
   if (nq > 1024) return fail(NSK_EINVAL, "too many vectors");
   for (int k = 0; k < nq; ++k) ((double**)c->hpin)[k] = (double*)Q[k];
   HIPCHK(hipMemcpyAsync(c->kptr, c->hpin, nq * sizeof(double*), hipMemcpyHostToDevice, c->stream));
-  hipLaunchKernelGGL(k_dots, dim3(c->kblk), dim3(256), 0, c->stream, (const double*)f, (const double* const*)c->kptr, nq, c->d.bm1s, c->nloc, c->kpart, c->kblk, c->ndim);
+  hipLaunchKernelGGL(k_dots, dim3(c->kblk), dim3(256), 0, c->stream, (const double*)f, (const double* const*)c->kptr, nq, c->d.bm1s, c->nloc, c->kpart, c->kblk, c->ndim, (long long)c->ndim * c->nloc + c->npr, c->nscal);
   hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, c->stream, (const double*)c->kpart, nq, c->kblk, c->kout);
   HIPCHK(hipMemcpyAsync(out, c->kout, nq * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -1165,6 +1171,15 @@ int nsk_set_option(nsk_ctx* c, const char* name, double value) {
   const std::string n(name);
   if (n == "use_graph") c->use_graph = (int)value;
   else if (n == "shard_graph") c->shard_graph = (int)value;
+  else if (n == "nscal") {
+    // krylov_vector%theta (core/krylov_subspace.f:13): carried by every vector operation and by the inner product; the time
+    // steppers act on it as the reference does with ifheat = .false. -- identity (the scalar equation itself is not built)
+    if (value < 0 || value > 8 || c->parent) return fail(NSK_EINVAL, "nscal: 0..8, full-mesh contexts only");
+    c->nscal = (int)value;
+    c->nstate = (long long)c->ndim * c->nloc + c->npr + (long long)c->nscal * c->nloc;
+    int rc = dalloc(c, &c->scratch, (size_t)c->nstate);       // vectors allocated before this call keep the old length: set it first
+    if (rc) return rc;
+  }
   else if (n == "merged_iters") { c->merged_iters = std::max(0, std::min((int)value, MAXMR)); for (auto& a : c->graphs) for (auto& g : a) g.nh = -1; }
   else if (n == "merged_update") { c->merged_update = (int)value; for (auto& a : c->graphs) for (auto& g : a) g.nh = -1; }
   else if (n == "min_pres_iter") c->min_pres = (int)value;
@@ -1227,6 +1242,19 @@ int nsk_vec_upload(nsk_ctx* c, nsk_vec v, const double* vx, const double* vy, co
   if (vx) HIPCHK(hipMemcpy(p, vx, c->nloc * sizeof(double), hipMemcpyHostToDevice));
   if (vy) HIPCHK(hipMemcpy(p + c->nloc, vy, c->nloc * sizeof(double), hipMemcpyHostToDevice));
   if (pr) HIPCHK(hipMemcpy(p + 2 * c->nloc, pr, c->npr * sizeof(double), hipMemcpyHostToDevice));
+  return 0;
+}
+
+int nsk_vec_upload_scalar(nsk_ctx* c, nsk_vec v, int m, const double* theta) {
+  if (!c || !v || !theta || m < 0 || m >= c->nscal) return fail(NSK_EINVAL, "bad argument (scalar index < nscal)");
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipMemcpy((double*)v + (long long)c->ndim * c->nloc + c->npr + (long long)m * c->nloc, theta, c->nloc * sizeof(double), hipMemcpyHostToDevice));
+  return 0;
+}
+int nsk_vec_download_scalar(nsk_ctx* c, nsk_vec v, int m, double* theta) {
+  if (!c || !v || !theta || m < 0 || m >= c->nscal) return fail(NSK_EINVAL, "bad argument (scalar index < nscal)");
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipMemcpy(theta, (const double*)v + (long long)c->ndim * c->nloc + c->npr + (long long)m * c->nloc, c->nloc * sizeof(double), hipMemcpyDeviceToHost));
   return 0;
 }
 
@@ -1420,7 +1448,7 @@ static int dots_to_device(nsk_ctx* c, const double* f, const nsk_vec* Q, int nq)
   if (nq > 1024) return fail(NSK_EINVAL, "too many vectors");
   for (int k = 0; k < nq; ++k) ((double**)c->hpin)[k] = (double*)Q[k];
   HIPCHK(hipMemcpyAsync(c->kptr, c->hpin, nq * sizeof(double*), hipMemcpyHostToDevice, c->stream));
-  hipLaunchKernelGGL(k_dots, dim3(c->kblk), dim3(256), 0, c->stream, f, (const double* const*)c->kptr, nq, c->d.bm1s, c->nloc, c->kpart, c->kblk, c->ndim);
+  hipLaunchKernelGGL(k_dots, dim3(c->kblk), dim3(256), 0, c->stream, f, (const double* const*)c->kptr, nq, c->d.bm1s, c->nloc, c->kpart, c->kblk, c->ndim, (long long)c->ndim * c->nloc + c->npr, c->nscal);
   hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, c->stream, (const double*)c->kpart, nq, c->kblk, c->kout);
   return 0;
 }
@@ -1489,12 +1517,12 @@ int nsk_orth(nsk_ctx* c, nsk_vec fv, const nsk_vec* Q, int j, double* h, double*
   HIPCHK(hipMemcpyAsync(c->kptr, c->hpin, (j + 1) * sizeof(double*), hipMemcpyHostToDevice, c->stream));
   const unsigned gridn = (unsigned)((c->nstate + 255) / 256);
   for (int ps = 0; ps < 2 && j > 0; ++ps) {        // two projection passes (re-orthogonalisation)
-    hipLaunchKernelGGL(k_dots, dim3(c->kblk), dim3(256), 0, c->stream, (const double*)f, (const double* const*)c->kptr, j, c->d.bm1s, c->nloc, c->kpart, c->kblk, c->ndim);
+    hipLaunchKernelGGL(k_dots, dim3(c->kblk), dim3(256), 0, c->stream, (const double*)f, (const double* const*)c->kptr, j, c->d.bm1s, c->nloc, c->kpart, c->kblk, c->ndim, (long long)c->ndim * c->nloc + c->npr, c->nscal);
     hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, c->stream, (const double*)c->kpart, j, c->kblk, c->kout);
     if ((rc = dots_allreduce(c, j))) return rc;
     hipLaunchKernelGGL(k_project_out_acc, dim3(gridn), dim3(256), 0, c->stream, f, (const double* const*)c->kptr, j, (const double*)c->kout, c->nstate, c->kacc, ps);
   }
-  hipLaunchKernelGGL(k_dots, dim3(c->kblk), dim3(256), 0, c->stream, (const double*)f, (const double* const*)(c->kptr + j), 1, c->d.bm1s, c->nloc, c->kpart, c->kblk, c->ndim);
+  hipLaunchKernelGGL(k_dots, dim3(c->kblk), dim3(256), 0, c->stream, (const double*)f, (const double* const*)(c->kptr + j), 1, c->d.bm1s, c->nloc, c->kpart, c->kblk, c->ndim, (long long)c->ndim * c->nloc + c->npr, c->nscal);
   hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, c->stream, (const double*)c->kpart, 1, c->kblk, c->kout);
   if ((rc = dots_allreduce(c, 1))) return rc;
   hipLaunchKernelGGL(k_scale_rsqrt, dim3(gridn), dim3(256), 0, c->stream, f, (const double*)c->kout, c->nstate);

@@ -1845,9 +1845,10 @@ __global__ void k_vel_update(Dev d, StepCoef sc) {
 // Krylov vector algebra (core/krylov_subspace.f).  State = [vx | vy | pr].
 // ---------------------------------------------------------------------------
 // partial dots of f with nq vectors, bm1s-weighted, velocity only  (krylov_inner_product)
+// (+ the scalar fields theta_1..nscal behind the pressure, same weights: core/krylov_subspace.f:46-50)
 __global__ __launch_bounds__(256) void k_dots(const double* __restrict__ f, const double* const* __restrict__ Q,
                                               int nq, const double* __restrict__ w, long long nloc,
-                                              double* __restrict__ part, int nblk, int ndim) {
+                                              double* __restrict__ part, int nblk, int ndim, long long toff, int nscal) {
   __shared__ double sred[16];
   const int tid = threadIdx.x;
   for (int k = 0; k < nq; ++k) {
@@ -1857,6 +1858,7 @@ __global__ __launch_bounds__(256) void k_dots(const double* __restrict__ f, cons
       const double ww = w[l];
       double t = f[l] * q[l] + f[nloc + l] * q[nloc + l];
       if (ndim == 3) t += f[2 * nloc + l] * q[2 * nloc + l];
+      for (int m = 0; m < nscal; ++m) t += f[toff + m * nloc + l] * q[toff + m * nloc + l];
       v[0] += ww * t;
     }
     block_reduce<1>(v, sred, tid, 256);

@@ -174,3 +174,38 @@ def test_merged_gmres_bookkeeping_equals_classic(oracle6, case6, modes):
     assert res[(1, "it")] == res[(0, "it")]
     assert np.abs(res[1] - res[0]).max() < 1e-9 * np.abs(res[0]).max()
     h.close()
+
+
+def test_scalar_fields_in_the_krylov_vector(case6, oracle6_nosolve, modes):
+    """krylov_vector%theta (core/krylov_subspace.f:13, 46-50): with `nscal` set, vectors carry scalar fields behind the
+    pressure; the inner product adds their bm1s-weighted products, axpy / scal / orth act on them, and the linearised map
+    passes them through unchanged (the reference with ifheat = .false.)."""
+    from nekstab_amd.capi import NekStabHip
+    o = oracle6_nosolve
+    w = o.bm1s()
+    h = NekStabHip(case6, case6.meta["vert"], case6.meta["nvert"], tol_helm=1e-10, tol_pres=1e-3, tol_relative=1, nproj=8)
+    n0 = h.nstate
+    h.set_nscal(2)
+    assert h.nstate == n0 + 2 * h.nvel
+    rng = np.random.default_rng(21)
+    u = modes["dRe_u"].astype(np.float64)
+    zp = np.zeros((case6.nel, 4, 4))
+    p, q, f = h.alloc(3)
+    th = [rng.standard_normal(case6.x.shape) for _ in range(4)]
+    h.upload(p, u[0], u[1], zp); h.upload_scalar(p, 0, th[0]); h.upload_scalar(p, 1, th[1])
+    h.upload(q, u[1], u[0], zp); h.upload_scalar(q, 0, th[2]); h.upload_scalar(q, 1, th[3])
+    ref = np.sum(w * (2.0 * u[0] * u[1] + th[0] * th[2] + th[1] * th[3]))
+    got = h.dot(p, q)
+    assert abs(got - ref) < 1e-12 * np.sum(w * (np.abs(th[0] * th[2]) + np.abs(th[1] * th[3])))
+    h.axpy(p, 0.5, q)                                           # p <- p + 0.5 q
+    assert np.abs(h.download_scalar(p, 1) - (th[1] + 0.5 * th[3]).ravel()).max() < 1e-14
+    h.scal(q, 2.0)
+    assert np.abs(h.download_scalar(q, 0) - 2.0 * th[2].ravel()).max() < 1e-14
+    h.set_nsteps(3)
+    h.matvec(f, q, 0)                                           # identity on the scalars
+    assert np.array_equal(h.download_scalar(f, 0), h.download_scalar(q, 0))
+    assert np.array_equal(h.download_scalar(f, 1), h.download_scalar(q, 1))
+    h.scal(q, 1.0 / h.norm(q))
+    hh, beta = h.orth(f, [q])                                   # Gram-Schmidt over velocity AND scalars
+    assert np.isfinite(beta) and abs(h.dot(f, q)) < 1e-12
+    h.close()
