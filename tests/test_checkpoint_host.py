@@ -1,0 +1,94 @@
+"""Arnoldi checkpoint / restart (nekstab_amd/checkpoint.py: arnoldi_checkpoint core/eigensolvers.f:802-905, the restart
+branch :284-325) on the CPU: a numpy backend with the device vector interface on the real cylinder mesh; the same files
+through the HIP library are exercised in tests/test_krylov_gpu.py."""
+import os
+
+import numpy as np
+
+from nekstab_amd import checkpoint, krylov, nekio
+
+
+class FieldBackend:
+    """Vectors = (vx, vy, pr) on the case's meshes; the 'time stepper' is a fixed linear map on the velocity (a weighted
+    neighbour average inside every element plus a rotation of the two components), the inner product is mass weighted and
+    excludes the pressure -- what krylov_inner_product does."""
+
+    def __init__(self, case, w):
+        self.case, self.w = case, w
+        self.nsteps = 7
+        n = case.lx1
+        rng = np.random.default_rng(4)
+        self.S = np.eye(n) * 0.6 + 0.4 * rng.random((n, n)) / n
+        self.th = 0.3
+
+    def alloc(self, k=1):
+        m = self.case.lx1 - 2
+        return [[np.zeros(self.case.x.shape), np.zeros(self.case.x.shape), np.zeros((self.case.nel, m, m))] for _ in range(k)]
+
+    def upload(self, v, vx, vy, pr):
+        v[0], v[1], v[2] = np.array(vx, dtype=float), np.array(vy, dtype=float), np.array(pr, dtype=float)
+
+    def download(self, v):
+        return v[0].copy(), v[1].copy(), v[2].copy()
+
+    def matvec(self, f, q, mode=0):
+        a = np.einsum("ij,ejk,lk->eil", self.S, q[0], self.S)
+        b = np.einsum("ij,ejk,lk->eil", self.S, q[1], self.S)
+        c, s = np.cos(self.th), np.sin(self.th)
+        f[0], f[1], f[2] = c * a - s * b, s * a + c * b, 0.5 * q[2]
+
+    def dot(self, p, q):
+        return float(np.sum(self.w * (p[0] * q[0] + p[1] * q[1])))
+
+    def norm(self, p):
+        return np.sqrt(self.dot(p, p))
+
+    def scal(self, p, a):
+        for k in range(3):
+            p[k] = p[k] * a
+
+    def orth(self, f, Q):
+        h = np.zeros(len(Q))
+        for _ in range(2):
+            c = np.array([self.dot(f, q) for q in Q])
+            for ci, q in zip(c, Q):
+                for k in range(3):
+                    f[k] = f[k] - ci * q[k]
+            h += c
+        beta = self.norm(f)
+        self.scal(f, 1.0 / beta)
+        return h, beta
+
+
+def test_checkpoint_files_restart_the_same_factorisation(tmp_path, case6, oracle6_nosolve):
+    be = FieldBackend(case6, oracle6_nosolve.bm1)
+    rng = np.random.default_rng(8)
+    k_dim = 7
+    Q = be.alloc(k_dim + 1)
+    be.upload(Q[0], rng.standard_normal(case6.x.shape), rng.standard_normal(case6.x.shape), rng.standard_normal((case6.nel, 4, 4)))
+    be.scal(Q[0], 1.0 / be.norm(Q[0]))
+    H = np.zeros((k_dim + 1, k_dim))
+    out = str(tmp_path)
+    for k in range(1, k_dim + 1):
+        krylov.arnoldi_factorization(be, Q, H, k, k)
+        checkpoint.arnoldi_checkpoint(be, case6, Q, H, k, out, session="1cyl", evop="d", sampling_period=2.0)
+    # the files the reference's restart reads
+    for k in range(1, k_dim + 1):
+        assert os.path.exists(os.path.join(out, "HES1cyl%04d" % k)) and os.path.exists(os.path.join(out, "Spectre_Hd%04d.dat" % k))
+    assert sorted(f for f in os.listdir(out) if f.startswith("KRY")) == ["KRY1cyl0.f%05d" % i for i in range(1, k_dim + 2)]
+    sp = np.loadtxt(os.path.join(out, "Spectre_Hd%04d.dat" % k_dim))
+    vals, _ = krylov.eig_sorted(H[:k_dim, :k_dim])
+    assert np.abs(sp[:, 0] + 1j * sp[:, 1] - vals).max() < 1e-6              # (3E15.7)
+    # restart after step 3 (uparam(2) = 3) and finish: the same Hessenberg matrix and the same last vector
+    Q2, H2, mstart = checkpoint.load_checkpoint(be, case6, out, k_dim, 3, session="1cyl")
+    assert mstart == 4 and np.array_equal(H2[:4, :3], H[:4, :3])
+    krylov.arnoldi_factorization(be, Q2, H2, mstart, k_dim)
+    assert np.abs(H2 - H).max() < 1e-11 * np.abs(H).max()
+    for a, b in zip(Q2[k_dim][:2], Q[k_dim][:2]):
+        assert np.abs(a - b).max() < 1e-10
+    # the pressure travels on mesh 1 in the file and comes back on mesh 2 (map21 then map12: exact for its polynomial degree)
+    v = be.alloc(1)[0]
+    checkpoint.read_krylov_vector(be, case6, v, os.path.join(out, "KRY1cyl0.f00001"))
+    assert np.abs(v[2] - Q[0][2]).max() < 1e-12 * max(1.0, np.abs(Q[0][2]).max())
+    f = nekio.read_fld(os.path.join(out, "KRY1cyl0.f00003"))
+    assert abs(f.time - 2.0) < 1e-12 and f.u.shape[0] == 2
