@@ -16,6 +16,7 @@ class FieldBackend:
     def __init__(self, case, w):
         self.case, self.w = case, w
         self.nsteps = 7
+        self.dt = 0.25
         n = case.lx1
         rng = np.random.default_rng(4)
         self.S = np.eye(n) * 0.6 + 0.4 * rng.random((n, n)) / n
@@ -92,3 +93,58 @@ def test_checkpoint_files_restart_the_same_factorisation(tmp_path, case6, oracle
     assert np.abs(v[2] - Q[0][2]).max() < 1e-12 * max(1.0, np.abs(Q[0][2]).max())
     f = nekio.read_fld(os.path.join(out, "KRY1cyl0.f00003"))
     assert abs(f.time - 2.0) < 1e-12 and f.u.shape[0] == 2
+
+
+class FieldBackend2(FieldBackend):
+    def copy(self, dst, src):
+        for k in range(3):
+            dst[k] = src[k].copy()
+
+    def free(self, vs):
+        pass
+
+    def basis_gemv(self, Q, y, re, im=None):
+        for k in range(3):
+            M = np.stack([q[k] for q in Q], axis=-1)
+            re[k] = M @ np.real(y)
+            if im is not None:
+                im[k] = M @ np.imag(y)
+
+
+def test_krylov_schur_and_outpost_files(tmp_path, case6, oracle6_nosolve):
+    """krylov_schur -> outpost_ks (core/eigensolvers.f:141-388, :502-727) end to end on the numpy backend: spectra tables,
+    eigenmode field files of the converged pairs with the reference's names and normalisation, the .info manifest."""
+    from nekstab_amd import outpost
+    be = FieldBackend2(case6, oracle6_nosolve.bm1)
+    rng = np.random.default_rng(9)
+    q0 = be.alloc(1)[0]
+    be.upload(q0, rng.standard_normal(case6.x.shape), rng.standard_normal(case6.x.shape), np.zeros((case6.nel, 4, 4)))
+    res = krylov.krylov_schur(be, q0, 40, mode=0, schur_tgt=0, eigen_tol=1e-8)
+    nconv = int(np.sum(res.residual < 1e-8))
+    assert nconv >= 2 and res.matvecs == 40
+    out = str(tmp_path)
+    files = outpost.outpost_ks(be, res, case6, out, evop="d", sampling_period=2.0, eigen_tol=1e-8, maxmodes=4, session="1cyl", wdsize=8)
+    nmodes = min(nconv, 4)
+    assert [os.path.basename(f) for f in files] == [n for i in range(1, nmodes + 1) for n in ("dRe1cyl0.f%05d" % i, "dIm1cyl0.f%05d" % i)]
+    sp = np.loadtxt(os.path.join(out, "Spectre_Hd.dat"))
+    assert sp.shape == (40, 3) and np.abs(sp[:, 0] + 1j * sp[:, 1] - res.vals).max() < 1e-6
+    ns = np.loadtxt(os.path.join(out, "Spectre_NSd.dat"))
+    assert np.abs(ns[:, 0] + 1j * ns[:, 1] - np.log(res.vals.astype(complex)) / 2.0).max() < 1e-6
+    info = outpost.read_info(os.path.join(out, "Spectre_d.info"))
+    assert info["nsteps"] == "7" and info["k_dim"] == "40" and int(info["outposted"]) == nmodes
+    # the first outposted mode is an eigenvector of the backend's map: M (re + i im) = mu (re + i im), unit norm
+    i0 = int(np.argmax(res.residual < 1e-8))
+    re, im = be.alloc(2)
+    fr, fi = nekio.read_fld(files[0]), nekio.read_fld(files[1])
+    be.upload(re, fr.u[0, :, 0], fr.u[1, :, 0], np.zeros((case6.nel, 4, 4)))
+    be.upload(im, fi.u[0, :, 0], fi.u[1, :, 0], np.zeros((case6.nel, 4, 4)))
+    assert abs(be.dot(re, re) + be.dot(im, im) - 1.0) < 1e-10
+    mre, mim = be.alloc(2)
+    be.matvec(mre, re); be.matvec(mim, im)
+    mu = res.vals[i0]
+    err = 0.0
+    for c in range(2):
+        lhs = mre[c] + 1j * mim[c]
+        rhs = mu * (re[c] + 1j * im[c])
+        err = max(err, np.abs(lhs - rhs).max())
+    assert err < 1e-6
