@@ -80,3 +80,113 @@ def test_newton_krylov_reaches_the_fixed_point_quadratically():
     h = [x for x in hist if x > 0]
     k = next(i for i, x in enumerate(h) if x < 1e-3)
     assert h[k + 1] < 10.0 * h[k] ** 2 + 1e-28
+
+
+class OrbitBackend:
+    """A planar oscillator with a limit cycle (x' = mu x - w y - r^2 x, y' = w x + mu y - r^2 y: radius sqrt(mu), period
+    2 pi / w) behind the interface newton_krylov_upo uses: full-equation map over `nsteps` RK4 steps of dt = endtime / nsteps,
+    the orbit stored by set_orbit, the NEWTON matvec = monodromy along that orbit minus the identity."""
+
+    def __init__(self, mu=0.25, w=1.3, nsteps=200):
+        self.mu, self.w = mu, w
+        self.nsteps_full, self.nsteps = nsteps, nsteps
+        self.endtime = 1.0
+        self.orbit = None
+
+    @property
+    def dt(self):
+        return self.endtime / self.nsteps_full
+
+    def rhs(self, z):
+        x, y = z
+        r2 = x * x + y * y
+        return np.array([self.mu * x - self.w * y - r2 * x, self.w * x + self.mu * y - r2 * y])
+
+    def jac(self, z):
+        x, y = z
+        r2 = x * x + y * y
+        return np.array([[self.mu - r2 - 2 * x * x, -self.w - 2 * x * y], [self.w - 2 * x * y, self.mu - r2 - 2 * y * y]])
+
+    def rk4(self, z, h):
+        k1 = self.rhs(z); k2 = self.rhs(z + 0.5 * h * k1); k3 = self.rhs(z + 0.5 * h * k2); k4 = self.rhs(z + h * k3)
+        return z + h / 6.0 * (k1 + 2 * k2 + 2 * k3 + k4)
+
+    # ---- vector interface
+    def alloc(self, n=1):
+        return [DenseVec() for _ in range(n)]
+
+    def free(self, vs):
+        pass
+
+    def copy(self, dst, src):
+        dst.a = src.a.copy()
+
+    def zero(self, p):
+        p.a = np.zeros(2)
+
+    def scal(self, p, a):
+        p.a = p.a * a
+
+    def axpy(self, p, a, q):
+        p.a = p.a + a * q.a
+
+    def dot(self, p, q):
+        return float(p.a @ q.a)
+
+    def basis_gemv(self, Q, y, out, im=None):
+        out.a = sum(np.real(yi) * q.a for yi, q in zip(y, Q))
+
+    # ---- time steppers
+    def set_option(self, name, value):
+        assert name == "endtime"
+        self.endtime = float(value)
+
+    def set_nsteps(self, n):
+        self.nsteps = n
+
+    def nonlinear_map(self, out, state, subtract_q=False):
+        z = state.a.copy()
+        for _ in range(self.nsteps):
+            z = self.rk4(z, self.dt)
+        out.a = z - (state.a if subtract_q else 0.0)
+
+    def set_orbit(self, q, spng_str=0.0, end=None):
+        z = q.a.copy()
+        self.orbit = [z.copy()]
+        for _ in range(self.nsteps_full):
+            z = self.rk4(z, self.dt)
+            self.orbit.append(z.copy())
+        if end is not None:
+            end.a = z.copy()
+
+    def matvec(self, f, q, mode=0):
+        assert mode == NSK_NEWTON and self.orbit is not None
+        v, h = q.a.copy(), self.dt
+        for z in self.orbit[:-1]:                              # RK4 on the variational equation, Jacobian frozen per step
+            J = self.jac(z)
+            k1 = J @ v; k2 = J @ (v + 0.5 * h * k1); k3 = J @ (v + 0.5 * h * k2); k4 = J @ (v + h * k3)
+            v = v + h / 6.0 * (k1 + 2 * k2 + 2 * k3 + k4)
+        f.a = v - q.a
+
+
+class DenseVec:
+    def __init__(self):
+        self.a = np.zeros(2)
+
+
+def test_newton_for_periodic_orbits_finds_the_limit_cycle():
+    """newton_krylov_upo + BorderedBackend (core/newton_krylov.f with uparam(1) = 2.1, core/matvec.f:402-475): from a point
+    off the cycle and a period 8 % off, Newton on the bordered system returns a point ON the cycle and its period."""
+    be = OrbitBackend()
+    q = be.alloc(1)[0]
+    q.a = np.array([0.58, 0.07])                                # radius 0.584 instead of 0.5
+    T0 = 0.92 * 2.0 * np.pi / be.w
+    period, it, hist = newton.newton_krylov_upo(be, q, T0, k_dim=3, tol=1e-22, maxiter_newton=25)
+    assert it < 25 and hist[-1][0] < 1e-22
+    assert abs(period - 2.0 * np.pi / be.w) < 1e-6              # RK4 with 200 steps per period: O(dt^4)
+    assert abs(np.hypot(*q.a) - np.sqrt(be.mu)) < 1e-6
+    # the returned state closes the orbit under the full map
+    out = be.alloc(1)[0]
+    be.set_option("endtime", period)
+    be.nonlinear_map(out, q, subtract_q=True)
+    assert np.abs(out.a).max() < 1e-10
