@@ -71,8 +71,8 @@ def spawn_ranks(a):
 
 def cpu_baseline(case, threads, tol):
     """The CPU port of the same step (oracle/cpu_step.c: C + OpenMP, the same PCG / GMRES + Schwarz + coarse algorithms and
-    tolerances as the GPU path, no projection space) timed on the host cores.  Thread count: the fastest of {all visible
-    cores, 16, 8} on a 4-step calibration (a cgroup quota below the visible core count makes "all" the slowest).  Sample:
+    tolerances as the GPU path, no projection space) timed on the host cores.  Thread count: the fastest of {8, 16, 32, 64}
+    (capped at the visible cores) on a short calibration.  Sample:
     ONE whole Arnoldi step (nsteps time steps + orthogonalisation) when that fits the time bound, otherwise as many
     time steps of it as fit, extrapolated; the same on 4 threads for BASELINE configs[0] (k_dim = 32 on 4 CPU ranks)."""
     import numpy as np
@@ -93,10 +93,17 @@ def cpu_baseline(case, threads, tol):
         visible = len(os.sched_getaffinity(0))
     except AttributeError:
         visible = os.cpu_count() or 1
-    cands = [threads] if threads else sorted({visible, min(visible, 16), min(visible, 8)}, reverse=True)
+    # candidates in ascending order, at most 64 threads: this problem has 128 k points per field, and with one thread per
+    # visible core of a 256-core host a time step takes 67 s instead of 35 ms (measured: the first version of this
+    # calibration spent 4.5 minutes finding that out on every run)
+    cands = [threads] if threads else sorted({min(visible, 8), min(visible, 16), min(visible, 32), min(visible, 64)})
     best = None
-    for nt in cands:                                        # calibration: 4 time steps each
+    for nt in cands:                                        # calibration: one time step, then three more unless it is already hopeless
         cp.set_threads(nt)
+        t0 = time.perf_counter(); cp.matvec(q0, nsteps=1); t = time.perf_counter() - t0
+        if best is not None and t > 3.0 * best[1]:
+            log("calibration: %d threads %.1f ms for the first time step: skipped" % (nt, 1e3 * t))
+            continue
         t0 = time.perf_counter(); cp.matvec(q0, nsteps=4); t = (time.perf_counter() - t0) / 4
         log("calibration: %d threads %.1f ms per time step" % (nt, 1e3 * t))
         if best is None or t < best[1]:
