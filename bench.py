@@ -140,7 +140,7 @@ def cpu_baseline(case, threads, tol):
 
 
 def pmc_traffic(kernel_key):
-    """HBM-side bytes per launch of the dominant kernel from the committed PMC passes (scripts/pmc_traffic.sh ->
+    """HBM-side bytes per launch of the dominant kernel from the committed PMC passes (scripts/profile_r02.sh ->
     profiles/r02_pmc_traffic.json): used only when that file was produced by THIS build of the library."""
     path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
     stamp = os.path.join(ROOT, "nekstab_amd", "lib", "libnekstab_hip.so.srchash")

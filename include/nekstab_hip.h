@@ -176,7 +176,16 @@ int nsk_get_stats(nsk_ctx* ctx, nsk_stats* s);
  * use) advance in lock-step through nsk_group_matvec with loop-back copies as transport; ranks in
  * separate processes use RCCL (build with -DNSK_WITH_RCCL, nsk_comm_init_rccl). */
 int nsk_shard_create(nsk_ctx* parent, const int* part, int rank, int nranks, nsk_ctx** out);
-int nsk_group_matvec(nsk_ctx** shards, int n, int mode, nsk_vec* f, nsk_vec* q);
+int nsk_group_matvec(nsk_ctx** shards, int n, int mode, nsk_vec* f, nsk_vec* q);    /* every mode of nsk_matvec */
+/* The rest of the operator interface on shards, for the ranks living in this process (the reference runs all of it under MPI):
+ *   nsk_group_nonlinear_map  nonlinear_forward_map, core/newton_krylov.f:336-378 (subtract_q != 0: Phi_T(q) - q)
+ *   nsk_group_set_baseflow   new linearisation point + prepare_linearized_solver: dt / nsteps from the CFL maximum over ALL ranks
+ *   nsk_group_set_orbit      time-periodic base flow (uparam(1) = 3.11 / 3.21, core/matvec.f:191-236), stored per rank
+ * Singular pressure operators (adjoint runs, closed domains) shard like the others: `ortho` takes its mean over all ranks.
+ * Shards keep the parent's pressure projection space size (nsk_case.nproj), so the sharded operator is the single-rank one. */
+int nsk_group_nonlinear_map(nsk_ctx** shards, int n, nsk_vec* f, nsk_vec* q, int subtract_q);
+int nsk_group_set_baseflow(nsk_ctx** shards, int n, nsk_vec* q);
+int nsk_group_set_orbit(nsk_ctx** shards, int n, nsk_vec* q0, double spng_str, nsk_vec* end);
 /* Once a process has cut its shard(s): free every device array of the parent that shards do not share (element-major geometry,
  * preconditioner factors, state, work arrays and ALL vectors allocated on the parent -- their handles become invalid).  The 1-D
  * bases and the replicated coarse operator stay.  The parent then only answers nsk_info / nsk_get_stats / nsk_finalize

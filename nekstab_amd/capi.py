@@ -81,6 +81,9 @@ SYMBOLS = {
     "nsk_seed_noise": (C.c_int, [_vp, _vp]),
     "nsk_shard_create": (C.c_int, [_vp, C.POINTER(C.c_int), C.c_int, C.c_int, _vpp]),
     "nsk_group_matvec": (C.c_int, [_vpp, C.c_int, C.c_int, _vpp, _vpp]),
+    "nsk_group_nonlinear_map": (C.c_int, [_vpp, C.c_int, _vpp, _vpp, C.c_int]),
+    "nsk_group_set_baseflow": (C.c_int, [_vpp, C.c_int, _vpp]),
+    "nsk_group_set_orbit": (C.c_int, [_vpp, C.c_int, _vpp, C.c_double, _vpp]),
     "nsk_comm_init_host": (C.c_int, [_vp, _vp, _vp, _vp]),
     "nsk_shard_release_parent": (C.c_int, [_vp]),
     "nsk_comm_unique_id": (C.c_int, [_vp]),

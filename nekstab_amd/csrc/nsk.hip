@@ -90,6 +90,10 @@ struct nsk_ctx {
   int merged_update = 1;                // GMRES column bookkeeping inside the coarse-solve kernel (k_update_coarse)
   double* kacc = nullptr;               // nsk_orth: coefficients accumulated over the two passes + the squared norm (device)
   bool released = false;                // nsk_shard_release_parent: only the arrays shards share are left on the device
+  static constexpr int ORTH_CHUNKS = 4;
+  int orth_overlap = 1;                 // nsk_orth on RCCL ranks: chunked all-reduces on comm_stream overlapped with the next chunk's dots
+  hipStream_t comm_stream = nullptr;
+  hipEvent_t orth_ev[2 * ORTH_CHUNKS] = {};
   int shard_graph = -1;                 // sharded step in a hipGraph: -1 = yes unless a communicator is attached, 0 = no, 1 = yes (also with RCCL)
   double* scratch = nullptr;            // one state vector
   const double* xyz = nullptr;          // GLL coordinates [ndim][nloc] (nsk_seed_noise)
@@ -117,7 +121,8 @@ struct nsk_ctx {
   int nvh = 0;                                          // velocity halo entries = ghost slots
   const int *vh_off = nullptr, *vh_idx = nullptr;       // pack CSR
   std::vector<int> peers, vh_poff, vh_pcnt;             // per peer: slice of [0, nvh)
-  double *vsend = nullptr, *vrecv = nullptr;            // [4][nvh]
+  double *vsend = nullptr, *vrecv = nullptr;            // [peer][component][entry], 4 * nvh doubles
+  const int2* vh_seg = nullptr;                         // halo slot -> {first slot, slot count} of its peer
   int nps = 0, npg = 0;                                 // pressure halo: send entries / ghost entries
   const int* ph_sidx = nullptr;
   std::vector<int> ph_soff, ph_scnt, ph_goff, ph_gcnt;  // per peer
@@ -854,7 +859,10 @@ static int ensure_graph(nsk_ctx* c, int cls, int adjoint) {
 
 static int run_map(nsk_ctx* c, int adjoint, double* f, const double* q) {
   Dev& d = c->d;
-  if (c->use_graph)
+  // one- and two-step maps (newton.py: time derivative of the orbit) run eagerly: capturing six step-class graphs for them
+  // costs more than the steps, and their iteration counts say nothing about the budgets of the real maps
+  const bool use_graph = c->use_graph && c->nsteps > 2;
+  if (use_graph)
     for (int k = 0; k < NCLS; ++k) { int rc = ensure_graph(c, k, adjoint); if (rc) return rc; }
   for (int cc = 0; cc < c->ndim; ++cc)
     HIPCHK(hipMemcpyAsync(d.u + cc * d.cs, q + cc * d.nloc, d.nloc * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
@@ -864,7 +872,7 @@ static int run_map(nsk_ctx* c, int adjoint, double* f, const double* q) {
     HIPCHK(hipMemsetAsync(d.bstep, 0, sizeof(int), c->stream));
   }
   for (int istep = 1; istep <= c->nsteps; ++istep) {
-    if (c->use_graph) {
+    if (use_graph) {
       HIPCHK(hipGraphLaunch(c->graphs[adjoint][step_class(istep)].exec, c->stream));
     } else {
       int rc = step(c, istep, adjoint);
@@ -958,7 +966,7 @@ static int run_map_adaptive(nsk_ctx* c, int adjoint, double* f, const double* q)
     }
     if (h.sync_timeouts) return fail(NSK_EHIP, "grid barrier of the persistent velocity solve timed out (workgroups not co-resident?): set option fused = 0");
     if (h.unconverged == 0) {
-      budgets_update(c, h);
+      if (c->nsteps > 2) budgets_update(c, h);
       return 0;
     }
     bool capped = true;
@@ -1016,9 +1024,194 @@ int nsk_shard_release_parent(nsk_ctx* P) {
 // f_r = map(q_r) for the ranks living in this process, in lock-step (virtual ranks: all of them).
 int nsk_group_matvec(nsk_ctx** shards, int n, int mode, nsk_vec* f, nsk_vec* q) {
   if (!shards || n < 1 || !f || !q) return fail(NSK_EINVAL, "bad argument");
-  if (mode != NSK_DIRECT && mode != NSK_ADJOINT) return fail(NSK_EINVAL, "sharded runs: direct or adjoint map");
   std::vector<nsk_ctx*> G(shards, shards + n);
-  return group_run_map(G, mode == NSK_ADJOINT, (double* const*)f, (const double* const*)q);
+  int rc;
+  switch (mode) {
+    case NSK_DIRECT: return group_run_map(G, 0, (double* const*)f, (const double* const*)q);
+    case NSK_ADJOINT: return group_run_map(G, 1, (double* const*)f, (const double* const*)q);
+    case NSK_DIRECT_ADJOINT:                                     // core/matvec.f:343-346 (f may not alias q on shards)
+      for (int r = 0; r < n; ++r) if (f[r] == q[r]) return fail(NSK_EINVAL, "sharded composed maps need f != q");
+      if ((rc = group_run_map(G, 0, (double* const*)f, (const double* const*)q))) return rc;
+      for (int r = 0; r < n; ++r) HIPCHK(hipMemcpyAsync(G[r]->scratch, f[r], G[r]->nstate * sizeof(double), hipMemcpyDeviceToDevice, G[r]->stream));
+      {
+        std::vector<const double*> src(n);
+        for (int r = 0; r < n; ++r) src[r] = G[r]->scratch;
+        return group_run_map(G, 1, (double* const*)f, src.data());
+      }
+    case NSK_NEWTON:                                             // core/matvec.f:398-401
+      for (int r = 0; r < n; ++r) if (f[r] == q[r]) return fail(NSK_EINVAL, "newton map needs f != q");
+      if ((rc = group_run_map(G, 0, (double* const*)f, (const double* const*)q))) return rc;
+      for (int r = 0; r < n; ++r)
+        hipLaunchKernelGGL(k_axpby, dim3((unsigned)((G[r]->nstate + 255) / 256)), dim3(256), 0, G[r]->stream, (double*)f[r], -1.0, (const double*)q[r], 1.0, G[r]->nstate);
+      return 0;
+    default: return fail(NSK_EINVAL, "unknown mode");
+  }
+}
+
+// Phi_T(q) of the full equations on the ranks of this process (nonlinear_forward_map, core/newton_krylov.f:336-378, which the
+// reference runs under MPI like every other map); subtract_q != 0 returns Phi_T(q) - q.
+int nsk_group_nonlinear_map(nsk_ctx** shards, int n, nsk_vec* f, nsk_vec* q, int subtract_q) {
+  if (!shards || n < 1 || !f || !q) return fail(NSK_EINVAL, "bad argument");
+  for (int r = 0; r < n; ++r) if (!shards[r] || !f[r] || !q[r] || f[r] == q[r]) return fail(NSK_EINVAL, "needs f != q on every rank");
+  std::vector<nsk_ctx*> G(shards, shards + n);
+  int rc = group_run_map(G, 2, (double* const*)f, (const double* const*)q);
+  if (rc) return rc;
+  if (subtract_q)
+    for (int r = 0; r < n; ++r) {
+      nsk_ctx* c = G[r];
+      hipLaunchKernelGGL(k_axpby, dim3((unsigned)((c->nstate + 255) / 256)), dim3(256), 0, c->stream, (double*)f[r], -1.0, (const double*)q[r], 1.0, c->nstate);
+    }
+  return 0;
+}
+
+// max over all ranks of a per-rank scalar through the sum transports: every rank fills its own slot of a zeroed vector
+static int group_allmax(std::vector<nsk_ctx*>& G, double* vals) {
+  nsk_ctx* c0 = G[0];
+  const int nr = c0->nranks;
+  std::vector<double> slot(nr, 0.0);
+  for (size_t r = 0; r < G.size(); ++r) slot[G[r]->rank] = vals[r];
+  if (G.size() == 1 && (c0->comm || c0->host_allred)) { int rc = nsk_allreduce_host(c0, slot.data(), nr); if (rc) return rc; }
+  double m = 0.0;
+  for (double v : slot) m = std::max(m, v);
+  for (size_t r = 0; r < G.size(); ++r) vals[r] = m;
+  return 0;
+}
+
+// New linearisation point on element shards (nsk_set_baseflow for the ranks of this process): every rank recomputes the
+// base-flow constants of its own elements; dt / nsteps follow from the CFL maximum over ALL ranks (compute_cfl is a glmax).
+static int group_set_baseflow(std::vector<nsk_ctx*>& G, const double* const* q) {
+  std::vector<double> ctarg(G.size(), 0.0);
+  for (size_t r = 0; r < G.size(); ++r) {
+    nsk_ctx* c = G[r]; nsk_ctx* P = c->parent; Dev& d = c->d;
+    if (!P) return fail(NSK_EINVAL, "needs shard contexts");
+    const int nd = c->ndim, NN = c->NN;
+    DISPATCH_N(c->key, {                                   // (hexahedra: Dev::cUr aliases the 12-constant array bfc)
+      hipLaunchKernelGGL(k_baseflow<N>, dim3(c->nel), dim3(Cfg<N>::NTD), 0, c->stream, d, q[r], (double*)d.cUr, (double*)d.cUs,
+                         (double*)d.GUx, (double*)d.GUy, (double*)d.GVx, (double*)d.GVy);
+    });
+    std::vector<double> u((size_t)nd * c->nloc);
+    HIPCHK(hipMemcpyAsync(u.data(), q[r], (size_t)nd * c->nloc * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    double ct = 0.0;
+    for (int le = 0; le < c->nel; ++le)
+      for (int k = 0; k < NN; ++k) {
+        const long long l = (long long)le * NN + k, lg = (long long)c->elems[le] * NN + k;
+        double sm = 0.0;
+        for (int a = 0; a < nd; ++a) {
+          double t = 0.0;
+          for (int cc = 0; cc < nd; ++cc) t += u[(size_t)cc * c->nloc + l] * P->h_cflg[(size_t)nd * nd * lg + a * nd + cc];
+          sm += std::fabs(t);
+        }
+        ct = std::max(ct, sm);
+      }
+    ctarg[r] = ct;
+  }
+  int rc = group_allmax(G, ctarg.data());
+  if (rc) return rc;
+  if (!(ctarg[0] > 0.0)) return fail(NSK_EINVAL, "base flow is zero");
+  for (size_t r = 0; r < G.size(); ++r) {
+    nsk_ctx* c = G[r]; nsk_ctx* P = c->parent; Dev& d = c->d;
+    const int NN = c->NN;
+    const double dt0 = P->cfl_target / ctarg[r];
+    c->nsteps = (int)std::ceil(c->endtime / dt0);
+    c->dt = c->endtime / c->nsteps;
+    d.dt = c->dt;
+    std::vector<double> dinv((size_t)3 * c->nloc);
+    const double bd0[3] = {1.0, 1.5, 11.0 / 6.0};
+    for (int k = 0; k < 3; ++k)
+      for (int le = 0; le < c->nel; ++le)
+        for (int i = 0; i < NN; ++i) {
+          const long long lg = (long long)c->elems[le] * NN + i;
+          dinv[(size_t)k * c->nloc + (size_t)le * NN + i] = P->h_mask[lg] / (d.nu * P->h_dAs[lg] + bd0[k] / c->dt * P->h_bs[lg]);
+        }
+    HIPCHK(hipMemcpy((double*)d.dinv, dinv.data(), dinv.size() * sizeof(double), hipMemcpyHostToDevice));
+    for (auto& a : c->graphs) for (auto& g : a) g.nh = -1;
+    for (int k = 0; k < NCLS; ++k) { c->cur_helm[k] = c->max_helm; c->cur_pres[k] = c->max_pres; }
+    c->bh_n = 0;
+  }
+  return 0;
+}
+int nsk_group_set_baseflow(nsk_ctx** shards, int n, nsk_vec* q) {
+  if (!shards || n < 1 || !q) return fail(NSK_EINVAL, "bad argument");
+  std::vector<nsk_ctx*> G(shards, shards + n);
+  for (int r = 0; r < n; ++r) if (!G[r] || !q[r]) return fail(NSK_EINVAL, "bad argument");
+  if (G[0]->d.bf_stride) return fail(NSK_EINVAL, "a stored orbit is active: call nsk_group_set_orbit again instead");
+  return group_set_baseflow(G, (const double* const*)q);
+}
+
+// Time-periodic base flow on element shards (nsk_set_orbit for the ranks of this process): the full equations are integrated
+// over one period by the sharded stepper and every rank stores the base-flow constants of its own elements per step.
+int nsk_group_set_orbit(nsk_ctx** shards, int n, nsk_vec* q0, double spng_str, nsk_vec* end) {
+  if (!shards || n < 1 || !q0) return fail(NSK_EINVAL, "bad argument");
+  std::vector<nsk_ctx*> G(shards, shards + n);
+  for (int r = 0; r < n; ++r) {
+    if (!G[r] || !q0[r] || !G[r]->parent) return fail(NSK_EINVAL, "needs shard contexts");
+    if (G[r]->ndim != 2) return fail(NSK_EINVAL, "time-periodic base flows: 2-D only in this build");
+  }
+  int rc;
+  for (nsk_ctx* c : G) {
+    Dev& d = c->d;
+    if (d.bf_stride) {                                            // back to the steady arrays first
+      d.cUr = c->steady[0]; d.cUs = c->steady[1]; d.GUx = c->steady[2]; d.GUy = c->steady[3]; d.GVx = c->steady[4]; d.GVy = c->steady[5];
+      d.bf_stride = 0;
+    }
+  }
+  if ((rc = group_set_baseflow(G, (const double* const*)q0))) return rc;
+  for (size_t r = 0; r < G.size(); ++r) {
+    nsk_ctx* c = G[r]; Dev& d = c->d;
+    const long long nfine = (long long)c->nel * c->NDD;
+    for (int k = 0; k < 6; ++k) {
+      if (c->orbit[k]) { nsk_vec v = c->orbit[k]; nsk_vec_free(c, 1, &v); c->orbit[k] = nullptr; }
+      if ((rc = dalloc(c, &c->orbit[k], (size_t)c->nsteps * nfine))) return rc;
+    }
+    double* vr = const_cast<double*>(d.spng_vr);
+    if (!vr && (rc = dalloc(c, &vr, 2 * d.cs))) return rc;
+    const double* q = (const double*)q0[r];
+    HIPCHK(hipMemcpyAsync(vr, q, d.nloc * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(vr + d.cs, q + d.nloc, d.nloc * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    d.spng_vr = vr; d.nl_spng_str = spng_str;
+    if (!d.bstep && (rc = dalloc(c, &d.bstep, 4))) return rc;
+    HIPCHK(hipMemsetAsync(d.stats, 0, sizeof(Stats), c->stream));
+    HIPCHK(hipMemcpyAsync(d.u, q, d.nloc * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(d.u + d.cs, q + d.nloc, d.nloc * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(d.p, q + 2 * d.nloc, d.npr * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  }
+  const int nsteps = G[0]->nsteps;
+  for (int istep = 1; istep <= nsteps; ++istep) {
+    for (nsk_ctx* c : G) {
+      Dev& d = c->d;
+      const long long off = (long long)(istep - 1) * c->nel * c->NDD;
+      // k_baseflow reads a state vector (component stride nloc); the stepper's field has stride cs = nloc + ghost slots
+      for (int cc = 0; cc < 2; ++cc)
+        HIPCHK(hipMemcpyAsync(c->scratch + cc * d.nloc, d.u + cc * d.cs, d.nloc * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+      DISPATCH_N(c->key, {
+        hipLaunchKernelGGL(k_baseflow<N>, dim3(c->nel), dim3(Cfg<N>::NTD), 0, c->stream, d, (const double*)c->scratch, c->orbit[0] + off, c->orbit[1] + off,
+                           c->orbit[2] + off, c->orbit[3] + off, c->orbit[4] + off, c->orbit[5] + off);
+      });
+    }
+    if ((rc = group_step(G, istep, 2))) return rc;
+  }
+  Stats h;
+  HIPCHK(hipMemcpyAsync(&h, G[0]->d.stats, sizeof(Stats), hipMemcpyDeviceToHost, G[0]->stream));
+  for (size_t r = 0; r < G.size(); ++r) {
+    nsk_ctx* c = G[r]; Dev& d = c->d;
+    if (end && end[r]) {
+      double* f = (double*)end[r];
+      HIPCHK(hipMemcpyAsync(f, d.u, d.nloc * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+      HIPCHK(hipMemcpyAsync(f + d.nloc, d.u + d.cs, d.nloc * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+      HIPCHK(hipMemcpyAsync(f + 2 * d.nloc, d.p, d.npr * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    }
+  }
+  HIPCHK(hipStreamSynchronize(G[0]->stream));
+  if (h.unconverged > 0) return fail(NSK_ENOCONV, "inner solve hit its iteration cap while integrating the base-flow orbit (sharded)");
+  for (nsk_ctx* c : G) {
+    Dev& d = c->d;
+    c->steady[0] = d.cUr; c->steady[1] = d.cUs; c->steady[2] = d.GUx; c->steady[3] = d.GUy; c->steady[4] = d.GVx; c->steady[5] = d.GVy;
+    d.cUr = c->orbit[0]; d.cUs = c->orbit[1]; d.GUx = c->orbit[2]; d.GUy = c->orbit[3]; d.GVx = c->orbit[4]; d.GVy = c->orbit[5];
+    d.bf_stride = (long long)c->nel * c->NDD; c->orbit_steps = c->nsteps;
+    for (auto& a : c->graphs) for (auto& g : a) g.nh = -1;
+  }
+  return 0;
 }
 
 // ---- RCCL transport for ranks in separate processes (one process per GPU) ----
@@ -1135,6 +1328,7 @@ int nsk_finalize(nsk_ctx* c) {
   if (c->hpin) (void)hipHostFree(c->hpin);
   if (c->hs_send) (void)hipHostFree(c->hs_send);
   if (c->hs_recv) (void)hipHostFree(c->hs_recv);
+  if (c->comm_stream) { (void)hipStreamSynchronize(c->comm_stream); for (auto& e : c->orth_ev) if (e) (void)hipEventDestroy(e); (void)hipStreamDestroy(c->comm_stream); }
   if (c->comm && rccl_rt::CommDestroy) (void)rccl_rt::CommDestroy(c->comm);
   if (c->stream && !c->parent) (void)hipStreamDestroy(c->stream);      // shards share the parent's stream
   delete c;
@@ -1171,6 +1365,7 @@ int nsk_set_option(nsk_ctx* c, const char* name, double value) {
   const std::string n(name);
   if (n == "use_graph") c->use_graph = (int)value;
   else if (n == "shard_graph") c->shard_graph = (int)value;
+  else if (n == "orth_overlap") c->orth_overlap = (int)value;
   else if (n == "nscal") {
     // krylov_vector%theta (core/krylov_subspace.f:13): carried by every vector operation and by the inner product; the time
     // steppers act on it as the reference does with ifheat = .false. -- identity (the scalar equation itself is not built)
@@ -1391,8 +1586,8 @@ int nsk_set_orbit(nsk_ctx* c, nsk_vec q0v, double spng_str, nsk_vec end) {
     if (c->orbit[k]) { nsk_vec v = c->orbit[k]; nsk_vec_free(c, 1, &v); c->orbit[k] = nullptr; }
     if ((rc = dalloc(c, &c->orbit[k], (size_t)c->nsteps * nfine))) return rc;
   }
-  double* vr = nullptr;
-  if ((rc = dalloc(c, &vr, 2 * d.cs))) return rc;
+  double* vr = const_cast<double*>(d.spng_vr);                  // one buffer per context: Newton calls this every iteration
+  if (!vr && (rc = dalloc(c, &vr, 2 * d.cs))) return rc;
   HIPCHK(hipMemcpyAsync(vr, q0, d.nloc * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(vr + d.cs, q0 + d.nloc, d.nloc * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
   d.spng_vr = vr; d.nl_spng_str = spng_str;
@@ -1516,10 +1711,32 @@ int nsk_orth(nsk_ctx* c, nsk_vec fv, const nsk_vec* Q, int j, double* h, double*
   ((double**)c->hpin)[j] = f;
   HIPCHK(hipMemcpyAsync(c->kptr, c->hpin, (j + 1) * sizeof(double*), hipMemcpyHostToDevice, c->stream));
   const unsigned gridn = (unsigned)((c->nstate + 255) / 256);
+  // RCCL ranks: the all-reduce of one chunk of coefficients runs on a second stream WHILE the dots of the next chunk are
+  // computed (north_star: "inner-product all-reduces overlapped with orthogonalisation"; the reference issues 2 j
+  // sequential scalar all-reduces, core/krylov_decomposition.f:165-196).  Chunks of >= 16 vectors, at most ORTH_CHUNKS.
+  const bool overlap = c->parent && c->comm && !c->host_allred && c->orth_overlap && j >= 32;
+  if (overlap && !c->comm_stream) {
+    HIPCHK(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+    for (auto& e : c->orth_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
   for (int ps = 0; ps < 2 && j > 0; ++ps) {        // two projection passes (re-orthogonalisation)
-    hipLaunchKernelGGL(k_dots, dim3(c->kblk), dim3(256), 0, c->stream, (const double*)f, (const double* const*)c->kptr, j, c->d.bm1s, c->nloc, c->kpart, c->kblk, c->ndim, (long long)c->ndim * c->nloc + c->npr, c->nscal);
-    hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, c->stream, (const double*)c->kpart, j, c->kblk, c->kout);
-    if ((rc = dots_allreduce(c, j))) return rc;
+    if (overlap) {
+      const int nch = std::min(nsk_ctx::ORTH_CHUNKS, j / 16);
+      for (int ch = 0; ch < nch; ++ch) {
+        const int o = (int)((long long)j * ch / nch), m = (int)((long long)j * (ch + 1) / nch) - o;
+        hipLaunchKernelGGL(k_dots, dim3(c->kblk), dim3(256), 0, c->stream, (const double*)f, (const double* const*)(c->kptr + o), m, c->d.bm1s, c->nloc, c->kpart + (size_t)o * c->kblk, c->kblk, c->ndim, (long long)c->ndim * c->nloc + c->npr, c->nscal);
+        hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, c->stream, (const double*)(c->kpart + (size_t)o * c->kblk), m, c->kblk, c->kout + o);
+        HIPCHK(hipEventRecord(c->orth_ev[2 * ch], c->stream));
+        HIPCHK(hipStreamWaitEvent(c->comm_stream, c->orth_ev[2 * ch], 0));
+        if (rccl_rt::AllReduce(c->kout + o, c->kout + o, m, rccl_rt::kDouble, rccl_rt::kSum, c->comm, c->comm_stream) != 0) return fail(NSK_EHIP, "ncclAllReduce failed (nsk_orth)");
+        HIPCHK(hipEventRecord(c->orth_ev[2 * ch + 1], c->comm_stream));
+      }
+      for (int ch = 0; ch < nch; ++ch) HIPCHK(hipStreamWaitEvent(c->stream, c->orth_ev[2 * ch + 1], 0));
+    } else {
+      hipLaunchKernelGGL(k_dots, dim3(c->kblk), dim3(256), 0, c->stream, (const double*)f, (const double* const*)c->kptr, j, c->d.bm1s, c->nloc, c->kpart, c->kblk, c->ndim, (long long)c->ndim * c->nloc + c->npr, c->nscal);
+      hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, c->stream, (const double*)c->kpart, j, c->kblk, c->kout);
+      if ((rc = dots_allreduce(c, j))) return rc;
+    }
     hipLaunchKernelGGL(k_project_out_acc, dim3(gridn), dim3(256), 0, c->stream, f, (const double* const*)c->kptr, j, (const double*)c->kout, c->nstate, c->kacc, ps);
   }
   hipLaunchKernelGGL(k_dots, dim3(c->kblk), dim3(256), 0, c->stream, (const double*)f, (const double* const*)(c->kptr + j), 1, c->d.bm1s, c->nloc, c->kpart, c->kblk, c->ndim, (long long)c->ndim * c->nloc + c->npr, c->nscal);

@@ -938,7 +938,7 @@ __global__ __launch_bounds__(256) void k_proj_apply(Dev d) {
 #pragma unroll
   for (int k = 0; k < PRE; ++k) pe[k] = (has && k < npre) ? d.PEX[(size_t)k * d.npr + q0] : 0.0;
   const double pnv = (tid < MAXPROJ) ? G->pn[tid] : 1.0;
-  if (d.use_tot) {
+  if (d.nranks > 1 || d.use_tot) {      // totals: all-reduced over ranks, or summed once by k_tot2
     if (tid < np) sh[tid] = d.ptot[tid];
     if (blockIdx.x == 0 && tid == 0) G->gnorm0 = sqrt(d.ptot[MAXPROJ]);
     __syncthreads();
@@ -1779,11 +1779,12 @@ __global__ __launch_bounds__(256) void k_proj_update(Dev d) {
   }
   const double pnv = (tid < MAXPROJ) ? G->pn[tid] : 1.0;
   PartialRows<5> pr;
-  pr.issue(d.ppart, d.nblk, (!d.use_tot && d.nblk <= 512) ? nmax + 1 : 0, tid);
+  const bool totals = d.nranks > 1 || d.use_tot;
+  pr.issue(d.ppart, d.nblk, (!totals && d.nblk <= 512) ? nmax + 1 : 0, tid);
   if (nit == 0) return;
   const int s = pcnt % nmax;
   const double as = (s < np) ? G->pa[s] : 0.0;
-  if (d.use_tot) { if (tid <= np) sh[tid] = d.ptot[tid]; __syncthreads(); }
+  if (totals) { if (tid <= np) sh[tid] = d.ptot[tid]; __syncthreads(); }
   else if (d.nblk <= 512) {
     pr.reduce(d.ppart, d.nblk, np + 1, sh, tid, 0, np + 1 <= 20);
     if (np + 1 > 20) { pr.issue(d.ppart, d.nblk, np + 1, tid, 20); pr.reduce(d.ppart, d.nblk, np + 1, sh, tid, 20); }
@@ -2004,23 +2005,27 @@ __global__ __launch_bounds__(256) void k_basis_gemm_mfma(double* const* __restri
 // ---------------------------------------------------------------------------
 // element sharding: halo of the gather-scatter and of the Schwarz overlap, rank-level sums
 // ---------------------------------------------------------------------------
-// sendbuf[c][k] = sum of this rank's copies of shared node k (one entry per (peer, shared global node))
+// One message per peer holding every component: buffer = [peer][component][entry], i.e. halo slot k (seg[k] = {first slot,
+// slot count} of its peer) of component c sits at  ncomp * seg.x + c * seg.y + (k - seg.x).
+// sendbuf[..] = sum of this rank's copies of shared node k (one entry per (peer, shared global node))
 __global__ void k_halo_pack(const double* __restrict__ f, long long cstride, int ncomp, const int* __restrict__ off,
-                            const int* __restrict__ idx, int n, double* __restrict__ sendbuf) {
+                            const int* __restrict__ idx, const int2* __restrict__ seg, int n, double* __restrict__ sendbuf) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
+  const int2 sg = seg[k];
   for (int c = 0; c < ncomp; ++c) {
     double s = 0.0;
     for (int i = off[k]; i < off[k + 1]; ++i) s += f[c * cstride + idx[i]];
-    sendbuf[(size_t)c * n + k] = s;
+    sendbuf[(size_t)ncomp * sg.x + (size_t)c * sg.y + (k - sg.x)] = s;
   }
 }
 // ghost slots of every component <- received partial sums
-__global__ void k_halo_unpack(double* __restrict__ f, long long cstride, long long nloc, int ncomp, int n,
+__global__ void k_halo_unpack(double* __restrict__ f, long long cstride, long long nloc, int ncomp, const int2* __restrict__ seg, int n,
                               const double* __restrict__ recvbuf) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
-  for (int c = 0; c < ncomp; ++c) f[c * cstride + nloc + k] = recvbuf[(size_t)c * n + k];
+  const int2 sg = seg[k];
+  for (int c = 0; c < ncomp; ++c) f[c * cstride + nloc + k] = recvbuf[(size_t)ncomp * sg.x + (size_t)c * sg.y + (k - sg.x)];
 }
 // pressure-vector halo (Schwarz overlap into neighbouring ranks' elements): plain gather / copy
 __global__ void k_phalo_pack(const double* __restrict__ v, const int* __restrict__ idx, int n, double* __restrict__ sendbuf) {

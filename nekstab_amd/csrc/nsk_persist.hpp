@@ -105,15 +105,17 @@ __device__ inline bool grid_barrier(unsigned* sync, unsigned epoch, int nblk, in
     const unsigned want = leader ? epoch * ngroups : epoch;
     unsigned spins = 0;
     bool bad = false;
-    while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+    unsigned seen;
+    while ((seen = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < want) {
       __builtin_amdgcn_s_sleep(2);
       if (++spins > SYNC_SPIN_LIMIT || ((spins & 255u) == 0u && __hip_atomic_load(failw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) { bad = true; break; }
     }
-    if (bad) {
-      __hip_atomic_store(failw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // tell everybody; stop waiting for good
-      *s_fail = 1;
-    }
-    if (leader) __hip_atomic_store(gen, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // release the group (also after a time-out)
+    if (bad) __hip_atomic_store(failw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // tell everybody; stop waiting for good
+    // A leader that timed out still releases its group (below), so a member can leave the poll loop on `gen` without ever
+    // having looked at `failw`: every workgroup reloads it once after the loop and treats non-zero as its own failure
+    // (otherwise such a member continues on unsynchronised data and the time-out goes unreported).
+    if (bad || (!leader && (seen & 0x80000000u)) || __hip_atomic_load(failw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) *s_fail = 1;
+    if (leader) __hip_atomic_store(gen, epoch | (bad ? 0x80000000u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // release the group (also after a time-out: marked)
 #if NSK_BARRIER_ACQUIRE
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -299,9 +301,14 @@ __global__ __launch_bounds__(Cfg<N>::NT, 2) void k_helm_fused(Dev d, StepCoef sc
     if (tid < 8) st_sc1(d.hpart + ((size_t)par * 8 + tid) * d.nblk + blockIdx.x, v[tid]);
     ok = grid_barrier(sync, epoch++, d.nblk, &s_fail);
   }
+  // a time-out anywhere in the grid (this workgroup's own, or one it has not looked at since its last barrier) ends the
+  // step here: nothing below may overwrite u / dulag / V on unsynchronised data, and EVERY workgroup that sees it counts it
+  if (ok && tid == 0 && __hip_atomic_load(sync + (SYNC_GROUPS + 1) * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) s_fail = 1;
+  __syncthreads();
+  ok = ok && (s_fail == 0);
+  if (!ok && tid == 0) atomicAdd((unsigned long long*)&d.stats->sync_timeouts, 1ull);
   if (blockIdx.x == 0 && tid == 0) {
-    if (!ok) atomicAdd((unsigned long long*)&d.stats->sync_timeouts, 1ull);
-    else {
+    if (ok) {
       atomicAdd((unsigned long long*)&d.stats->helm_iters, (unsigned long long)used);
       atomicMax((unsigned long long*)&d.stats->max_helm, (unsigned long long)used);
       atomicMax((unsigned long long*)&d.stats->max_helm_k[sc.cls], (unsigned long long)used);

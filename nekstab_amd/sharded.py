@@ -89,7 +89,7 @@ class ShardGroup:
     def upload3(self, v, vx, vy, vz, pr):
         for r, c in enumerate(self.ctx):
             e = self.elems[r]
-            a, b, w, p = (np.ascontiguousarray(f[e], dtype=np.float64) for f in (vx, vy, vz, pr))
+            a, b, w, p = (np.ascontiguousarray(np.asarray(f).reshape(self.nel, -1)[e], dtype=np.float64) for f in (vx, vy, vz, pr))
             self._chk(self.lib.nsk_vec_upload3(c, v.parts[r], a.ctypes.data_as(_dp), b.ctypes.data_as(_dp), w.ctypes.data_as(_dp), p.ctypes.data_as(_dp)))
 
     def download3(self, v):
@@ -106,7 +106,7 @@ class ShardGroup:
     def upload(self, v, vx, vy, pr):
         for r, c in enumerate(self.ctx):
             e = self.elems[r]
-            a, b, p = (np.ascontiguousarray(f[e], dtype=np.float64) for f in (vx, vy, pr))
+            a, b, p = (np.ascontiguousarray(np.asarray(f).reshape(self.nel, -1)[e], dtype=np.float64) for f in (vx, vy, pr))   # flat or (nel, ...) arrays
             self._chk(self.lib.nsk_vec_upload(c, v.parts[r], a.ctypes.data_as(_dp), b.ctypes.data_as(_dp), p.ctypes.data_as(_dp)))
 
     def download(self, v):
@@ -140,6 +140,36 @@ class ShardGroup:
             from .capi import NskStats
             st = NskStats(); self.lib.nsk_get_stats(self.ctx[0], C.byref(st))
             raise NskError(rc, self.lib.nsk_last_error().decode() + " stats=" + str({f: getattr(st, f) for f, _ in NskStats._fields_}))
+
+    def nonlinear_map(self, f, q, subtract_q=False):
+        """Phi_T(q) of the full equations on the shards (nonlinear_forward_map, core/newton_krylov.f:336-378)."""
+        fa = (C.c_void_p * self.R)(*[p.value for p in f.parts])
+        qa = (C.c_void_p * self.R)(*[p.value for p in q.parts])
+        self._chk(self.lib.nsk_group_nonlinear_map(self._arr, self.R, fa, qa, int(bool(subtract_q))))
+
+    def _refresh_info(self):
+        dt, ns = C.c_double(), C.c_int()
+        self._chk(self.lib.nsk_get_info(self.ctx[0], C.byref(dt), C.byref(ns), None, None, None))
+        self.dt, self.nsteps = dt.value, ns.value
+
+    def set_baseflow(self, q):
+        """New linearisation point on every shard; dt / nsteps from the CFL maximum over all ranks."""
+        qa = (C.c_void_p * self.R)(*[p.value for p in q.parts])
+        self._chk(self.lib.nsk_group_set_baseflow(self._arr, self.R, qa))
+        self._refresh_info()
+
+    def set_orbit(self, q0, spng_str=0.0, end=None):
+        """Time-periodic base flow stored per shard (Floquet, core/matvec.f:191-236)."""
+        qa = (C.c_void_p * self.R)(*[p.value for p in q0.parts])
+        ea = (C.c_void_p * self.R)(*[p.value for p in end.parts]) if end is not None else None
+        self._chk(self.lib.nsk_group_set_orbit(self._arr, self.R, qa, float(spng_str), ea))
+        self._refresh_info()
+
+    def stats(self):
+        from .capi import NskStats
+        st = NskStats()
+        self._chk(self.lib.nsk_get_stats(self.ctx[0], C.byref(st)))
+        return {f: getattr(st, f) for f, _ in NskStats._fields_}
 
     def set_nsteps(self, n):
         for c in self.ctx:
@@ -272,12 +302,12 @@ class ShardRank:
 
     def upload(self, v, vx, vy, pr):
         """vx, vy, pr: full-mesh arrays; this rank keeps its own elements."""
-        a, b, p = (np.ascontiguousarray(f[self.elems], dtype=np.float64) for f in (vx, vy, pr))
+        a, b, p = (np.ascontiguousarray(np.asarray(f).reshape(len(self.part), -1)[self.elems], dtype=np.float64) for f in (vx, vy, pr))
         self._chk(self.lib.nsk_vec_upload(self.ctx, v, a.ctypes.data_as(_dp), b.ctypes.data_as(_dp), p.ctypes.data_as(_dp)))
 
     def upload3(self, v, vx, vy, vz, pr):
         """hexahedral contexts: full-mesh arrays, this rank keeps its own elements."""
-        a, b, w, p = (np.ascontiguousarray(f[self.elems], dtype=np.float64) for f in (vx, vy, vz, pr))
+        a, b, w, p = (np.ascontiguousarray(np.asarray(f).reshape(len(self.part), -1)[self.elems], dtype=np.float64) for f in (vx, vy, vz, pr))
         self._chk(self.lib.nsk_vec_upload3(self.ctx, v, a.ctypes.data_as(_dp), b.ctypes.data_as(_dp), w.ctypes.data_as(_dp), p.ctypes.data_as(_dp)))
 
     def download3_local(self, v):
@@ -296,6 +326,33 @@ class ShardRank:
         fa = (C.c_void_p * 1)(f.value)
         qa = (C.c_void_p * 1)(q.value)
         self._chk(self.lib.nsk_group_matvec(self._one, 1, mode, fa, qa))
+
+    def nonlinear_map(self, f, q, subtract_q=False):
+        fa = (C.c_void_p * 1)(f.value)
+        qa = (C.c_void_p * 1)(q.value)
+        self._chk(self.lib.nsk_group_nonlinear_map(self._one, 1, fa, qa, int(bool(subtract_q))))
+
+    def _refresh_info(self):
+        dt, ns = C.c_double(), C.c_int()
+        self._chk(self.lib.nsk_get_info(self.ctx, C.byref(dt), C.byref(ns), None, None, None))
+        self.dt, self.nsteps = dt.value, ns.value
+
+    def set_baseflow(self, q):
+        qa = (C.c_void_p * 1)(q.value)
+        self._chk(self.lib.nsk_group_set_baseflow(self._one, 1, qa))
+        self._refresh_info()
+
+    def set_orbit(self, q0, spng_str=0.0, end=None):
+        qa = (C.c_void_p * 1)(q0.value)
+        ea = (C.c_void_p * 1)(end.value) if end is not None else None
+        self._chk(self.lib.nsk_group_set_orbit(self._one, 1, qa, float(spng_str), ea))
+        self._refresh_info()
+
+    def stats(self):
+        from .capi import NskStats
+        st = NskStats()
+        self._chk(self.lib.nsk_get_stats(self.ctx, C.byref(st)))
+        return {f: getattr(st, f) for f, _ in NskStats._fields_}
 
     def set_nsteps(self, n):
         self._chk(self.lib.nsk_set_nsteps(self.ctx, n))

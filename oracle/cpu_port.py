@@ -44,11 +44,22 @@ class CpuStats(C.Structure):
                 ("unconverged", C.c_longlong), ("last_helm_res", C.c_double), ("last_pres_res", C.c_double)]
 
 
+CFLAGS = ["-O3", "-mavx2", "-mfma", "-ffp-contract=off", "-fopenmp", "-fPIC", "-shared"]
+
+
 def build_library(force=False):
-    """gcc -O3 -fopenmp -> oracle/_build/libcpu_step.so (git-ignored, travels with the snapshot)."""
+    """gcc -O3 -fopenmp -> oracle/_build/libcpu_step.so (git-ignored, travels with the snapshot).  The cache is keyed on a
+    hash of the source and the flags (not on mtimes: the snapshot that travels to the GPU box resets them)."""
+    import hashlib
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
-    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(SRC):
-        subprocess.run(["gcc", "-O3", "-march=x86-64-v3", "-ffp-contract=off", "-fopenmp", "-fPIC", "-shared", "-o", LIB, SRC, "-lm"], check=True)
+    with open(SRC, "rb") as fh:
+        key = hashlib.sha256(fh.read() + " ".join(CFLAGS).encode()).hexdigest()
+    stamp = LIB + ".srchash"
+    have = open(stamp).read().strip() if os.path.exists(stamp) else ""
+    if force or not os.path.exists(LIB) or have != key:
+        subprocess.run(["gcc"] + CFLAGS + ["-o", LIB, SRC, "-lm"], check=True)
+        with open(stamp, "w") as fh:
+            fh.write(key)
     return LIB
 
 
