@@ -9,7 +9,106 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+def _gather_fields(dist, sh, loc, ref_like, rank, world):
+    gathered = [None] * world
+    dist.gather_object((sh.elems, loc), gathered if rank == 0 else None, dst=0)
+    if rank != 0:
+        return None
+    got = [np.empty_like(r) for r in ref_like]
+    for elems, l in gathered:
+        for g, x in zip(got, l):
+            g[elems] = x
+    return got
+
+
+def main_r3(kind):
+    """Round-3 features across processes: 'adjoint' (singular pressure: `ortho` over all ranks), 'proj' (pressure projection
+    space in shards, two consecutive maps), 'nonlinear' (closed cavity: nonlinear map, set_baseflow with the CFL maximum over
+    the ranks, linearised map about the new base flow)."""
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    from nekstab_amd import mesh, seed
+    from nekstab_amd.capi import NekStabHip
+    from nekstab_amd.sharded import ShardRank, attach_host_transport, partition_rcb
+    golden = os.path.join(ROOT, "tests", "golden")
+    errs = []
+    if kind in ("adjoint", "proj"):
+        adj = kind == "adjoint"
+        case = mesh.load_case_npz(os.path.join(golden, "cylinder_case.npz"), 8 if adj else 6, adjoint=adj)
+        full = NekStabHip(case, case.meta["vert"], case.meta["nvert"], tol_helm=1e-12, tol_pres=1e-6, tol_relative=1, nproj=8,
+                          max_helm_iter=150, max_pres_iter=48)
+        qx, qy = seed.add_noise(case)
+        q = (qx, qy, np.zeros((case.nel, case.lx1 - 2, case.lx1 - 2)))
+        sh = ShardRank(full, case, rank, world, None, partition_rcb(case, world))
+        tr = attach_host_transport(sh, dist)
+        ns = 5 if adj else 12
+        sh.set_nsteps(ns); full.set_nsteps(ns)
+        vq, vf = sh.alloc(2)
+        sh.upload(vq, *q)
+        a, b = full.alloc(2)
+        if rank == 0:
+            full.upload(a, *q)
+        for rep in range(1 if adj else 2):
+            sh.matvec(vf, vq, 1 if adj else 0)
+            if rank == 0:
+                full.matvec(b, a, 1 if adj else 0)
+                ref = full.download(b)
+            else:
+                ref = [np.empty(case.x.shape), np.empty(case.x.shape), np.empty(q[2].shape)]
+            got = _gather_fields(dist, sh, sh.download_local(vf), ref, rank, world)
+            if rank == 0:
+                sc = max(np.abs(ref[0]).max(), np.abs(ref[1]).max())
+                errs.append(max(np.abs(g - r).max() for g, r in zip(got[:2], ref[:2])) / sc)
+                errs.append(abs(sh.stats()["pres_iters"] - full.stats()["pres_iters"]) * 1e-12)     # same iteration counts
+                full.copy(a, b)
+            sh.copy(vq, vf)
+    else:
+        from tests.test_sharded_r3_gpu import _cavity
+        c2, p2 = _cavity()
+        full = NekStabHip(c2, c2.meta["vert"], c2.meta["nvert"], tol_helm=1e-12, tol_pres=1e-5, tol_relative=1, nproj=0, max_helm_iter=150, max_pres_iter=48)
+        bump = 1e-2 * np.sin(np.pi * c2.x) * np.sin(np.pi * c2.y / 1.2) * c2.mask
+        q = (c2.ub[0] + bump, c2.ub[1] - 0.5 * bump, p2)
+        sh = ShardRank(full, c2, rank, world, None, partition_rcb(c2, world))
+        tr = attach_host_transport(sh, dist)
+        sh.set_nsteps(6); full.set_nsteps(6)
+        vq, vf = sh.alloc(2); a, b = full.alloc(2)
+        sh.upload(vq, *q)
+        sh.nonlinear_map(vf, vq)
+        if rank == 0:
+            full.upload(a, *q); full.nonlinear_map(b, a); ref = full.download(b)
+        else:
+            ref = [np.empty(c2.x.shape), np.empty(c2.x.shape), np.empty(p2.shape)]
+        got = _gather_fields(dist, sh, sh.download_local(vf), ref, rank, world)
+        sh.set_baseflow(vf)
+        if rank == 0:
+            errs.append(max(np.abs(g - r).max() for g, r in zip(got[:2], ref[:2])) / np.abs(ref[0]).max())
+            full.set_baseflow(b)
+            errs.append(abs(full.dt - sh.dt) + abs(full.nsteps - sh.nsteps))
+        sh.set_nsteps(4); full.set_nsteps(4)
+        pert = (bump, 2.0 * bump, np.zeros(p2.shape))
+        sh.upload(vq, *pert)
+        sh.matvec(vf, vq, 0)
+        if rank == 0:
+            full.upload(a, *pert); full.matvec(b, a, 0); ref = full.download(b)
+        got = _gather_fields(dist, sh, sh.download_local(vf), ref, rank, world)
+        if rank == 0:
+            errs.append(max(np.abs(g - r).max() for g, r in zip(got[:2], ref[:2])) / np.abs(ref[0]).max())
+    ok = True
+    if rank == 0:
+        print("MPSHARD3 %s world %d: errors %s exchanges %d allreduces %d" % (kind, world, " ".join("%.2e" % e for e in errs), tr.n_exchange, tr.n_allreduce), flush=True)
+        ok = max(errs) < 1e-8 and tr.n_exchange > 0
+    flag = torch.tensor([1.0 if ok else 0.0])
+    dist.broadcast(flag, 0)
+    sh.close(); full.close()
+    dist.destroy_process_group()
+    sys.exit(0 if flag.item() == 1.0 else 1)
+
+
 def main():
+    if len(sys.argv) > 2:
+        return main_r3(sys.argv[2])
     import torch
     import torch.distributed as dist
     dist.init_process_group("gloo")
