@@ -77,6 +77,7 @@ struct nsk_ctx {
   unsigned* sync = nullptr;             // grid-barrier counters of the persistent kernels
   int in_test = 0;
   int helm_guess = 1;
+  int dbg_max_order = 3, dbg_ab2 = 0, dbg_pext = 1;      // time-scheme sensitivity switches (options of the same names)
   double early_pres_mul = 1e-2;         // pressure tolerance factor of time steps 1-3 of every map
   long long recaptures = 0, retries = 0;
   double recapture_s = 0.0;             // host time spent capturing + instantiating step graphs (since init)
@@ -161,10 +162,14 @@ static int dupload(nsk_ctx* c, const T** p, const std::vector<T>& h) {
 static StepCoef make_coef(const nsk_ctx* c, int istep, int adjoint) {
   static const double BD[3][4] = {{1.0, 1.0, 0.0, 0.0}, {1.5, 2.0, -0.5, 0.0}, {11.0 / 6.0, 3.0, -1.5, 1.0 / 3.0}};
   static const double AB[3][3] = {{1.0, 0.0, 0.0}, {2.0, -1.0, 0.0}, {3.0, -3.0, 1.0}};
-  const int k = std::min(istep, 3);
+  // (the dbg_* members are sensitivity switches of scripts/wake_bisect.py: what the time scheme's details do to the spectrum;
+  //  their defaults are the scheme of SURVEY Appendix A)
+  const int k = std::min(istep, std::min(3, std::max(1, c->dbg_max_order)));
   StepCoef s;
   for (int q = 0; q < 4; ++q) s.bd[q] = BD[k - 1][q];
   for (int q = 0; q < 3; ++q) s.ab[q] = AB[k - 1][q];
+  if (k == 2 && c->dbg_ab2 == 1) { s.ab[0] = 1.5; s.ab[1] = -0.5; }          // Adams-Bashforth 2 instead of the BDF2-consistent extrapolation
+  s.pxt = (c->dbg_pext == 0) ? 0.0 : ((k == 3 || (c->dbg_pext == 2 && k == 2 && istep > 1)) ? 1.0 : 0.0);
   s.h2 = s.bd[0] / c->dt;
   s.invdt = 1.0 / c->dt;
   s.k = k;
@@ -1383,6 +1388,9 @@ int nsk_set_option(nsk_ctx* c, const char* name, double value) {
     c->pres_cap = (int)value;
   }
   else if (n == "helm_guess") c->helm_guess = (int)value;
+  else if (n == "dbg_max_order") c->dbg_max_order = (int)value;
+  else if (n == "dbg_ab2") c->dbg_ab2 = (int)value;
+  else if (n == "dbg_pext") c->dbg_pext = (int)value;
   else if (n == "mfma_convect") c->mfma_convect = (int)value;
   else if (n == "endtime") {                     // param(10): the sampling period T (Newton for periodic orbits changes it every iteration)
     if (!(value > 0.0)) return fail(NSK_EINVAL, "endtime must be positive");

@@ -480,7 +480,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_rhs(Dev d, StepCoef sc) {
   if (tid < MM) {                                                    // extrapprp
     const long long q = e * MM + tid;
     const double pn = d.p[q];
-    pe = (sc.k < 3) ? pn : 2.0 * pn - d.plag[q];
+    pe = (sc.pxt == 0.0) ? pn : 2.0 * pn - d.plag[q];
     d.plag[q] = pn;
     d.pext[q] = pe;
     load_w2(d, q, w2);

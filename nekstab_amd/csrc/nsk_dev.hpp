@@ -18,6 +18,7 @@ struct StepCoef {                // order k = min(istep,3)  [UPSTREAM setordbd/s
   int adjoint;
   double xg[3];                  // Helmholtz initial guess  du0 = xg0*du^{n-1} + xg1*du^{n-2} + xg2*du^{n-3}
   int cls;                       // step_class(istep): one captured graph + budget each
+  double pxt;                    // pressure extrapolation p* = p^n + pxt (p^n - p^{n-1}): 0 for k < 3, 1 for k = 3  [UPSTREAM extrapprp]
 };
 
 struct GmresScal {               // device-resident small state of one pressure solve

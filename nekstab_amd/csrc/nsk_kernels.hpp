@@ -581,7 +581,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_rhs(Dev d, StepCoef sc) {
       bfv[c] = b;
     }
     if (pl) {                                                        // extrapprp
-      const double pe = (sc.k < 3) ? pn : 2.0 * pn - plg;
+      const double pe = (sc.pxt == 0.0) ? pn : ((sc.pxt == 1.0) ? 2.0 * pn - plg : pn + sc.pxt * (pn - plg));
       d.plag[q] = pn;
       d.pext[q] = pe;
       sP[(0 * EPB + el) * MM + nd] = pe * m0;

@@ -192,7 +192,7 @@ __global__ __launch_bounds__(Cfg<N>::NT, 2) void k_helm_fused(Dev d, StepCoef sc
       if (nd < MM) {                                                            // extrapprp
         const long long q = e * MM + nd;
         const double pn = d.p[q];
-        const double pe = (sc.k < 3) ? pn : 2.0 * pn - d.plag[q];
+        const double pe = (sc.pxt == 0.0) ? pn : 2.0 * pn - d.plag[q];
         d.plag[q] = pn;
         d.pext[q] = pe;
         sP[(0 * EPB + el) * MM + nd] = pe * d.w2rx[q];

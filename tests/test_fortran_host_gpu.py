@@ -15,6 +15,7 @@ pytestmark = pytest.mark.gpu
 
 
 def test_fortran_arnoldi_matches_python_host(tmp_path):
+    # (`spectre` fixture not needed here)
     exe = os.path.join(ROOT, "host", "arnoldi_host")
     if not os.path.exists(exe):
         if shutil.which("flang") is None:
@@ -34,10 +35,9 @@ def test_fortran_arnoldi_matches_python_host(tmp_path):
     ritz = np.loadtxt(str(tmp_path / "ritz_full.txt"))
     spec = np.loadtxt(str(tmp_path / "Spectre_Hd.dat"))
     assert spec.shape == (k, 3)
-    # same factorisation from the Python host
-    from nekstab_amd.capi import NekStabHip
-    h = NekStabHip(case, case.meta["vert"], case.meta["nvert"], tol_helm=1e-11, tol_pres=1e-1, tol_relative=1,
-                   schwarz_layers=2, max_helm_iter=100, max_pres_iter=48, nproj=8)
+    # same factorisation from the Python host, at the SAME settings: the production ones, which the case file carries
+    from nekstab_amd.settings import production_context
+    h = production_context(case)
     v0 = h.alloc(1)[0]
     h.upload(v0, qx, qy, pr)
     res = krylov.krylov_schur(h, v0, k, schur_tgt=0)
@@ -47,4 +47,66 @@ def test_fortran_arnoldi_matches_python_host(tmp_path):
     assert np.abs(np.sort(np.abs(fv)) - np.sort(np.abs(res.vals))).max() < 1e-6
     assert np.all(np.diff(np.abs(fv)) <= 1e-12)                 # sorted by decreasing modulus
     assert np.allclose(spec[:, 0], ritz[:, 0], rtol=2e-7, atol=1e-12)   # (3E15.7) table vs full precision
+    assert "3.00E-12" in out.stdout and "3.00E-02" in out.stdout and "nproj = 32" in out.stdout      # read from the case file, not hard-coded
+    h.close()
+
+
+def test_fortran_krylov_schur_restart_and_modes(tmp_path, spectre):
+    """The whole reference loop from Fortran (host/krylov_host.f90): Krylov-Schur with schur_tgt = 2 (restarts through dgees /
+    dtrsen and nsk_basis_gemm), spectra tables, eigenmode assembly (nsk_basis_gemv) and normalisation.  The converged leading
+    pair is the reference's Spectre_Hd.dat row 1, the written mode satisfies M (Re + i Im) = mu (Re + i Im) through the Python
+    binding of the same library, and the first restart's H equals the Python host's."""
+    exe = os.path.join(ROOT, "host", "arnoldi_host")
+    if not os.path.exists(exe):
+        pytest.skip("host/arnoldi_host not built")
+    from nekstab_amd import casefile, krylov, mesh, seed
+    case = mesh.load_case_npz(os.path.join(GOLDEN, "cylinder_case.npz"), 6)
+    qx, qy = seed.add_noise(case)
+    pr = np.zeros((case.nel, 4, 4))
+    cb = str(tmp_path / "case.bin")
+    casefile.write_case_bin(cb, case, (qx, qy, pr))
+    k = 48
+    out = subprocess.run([exe, cb, str(k), str(tmp_path), "2", "d"], capture_output=True, text=True, timeout=1200)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    print(out.stdout[-600:])
+    assert "Schur restart 1" in out.stdout
+    ritz = np.loadtxt(str(tmp_path / "ritz_full.txt"))
+    fv = ritz[:, 0] + 1j * ritz[:, 1]
+    ref = complex(*spectre["Hd"][0, :2])
+    j = int(np.argmin(np.abs(fv - ref)))
+    assert abs(fv[j] - ref) < 5e-7 and ritz[j, 2] < 1e-6, (fv[j], ref, ritz[j, 2])
+    conv = np.loadtxt(str(tmp_path / "Spectre_NSd_conv.dat"))
+    assert conv.shape[0] >= 2                                         # schur_tgt = 2 converged pairs
+    assert abs(complex(conv[0, 0], abs(conv[0, 1])) - complex(*spectre["NSd_conv"][0, :2])) < 2e-6
+    # the written mode: unit norm and an eigenvector of the map
+    from nekstab_amd.settings import production_context
+    h = production_context(case)
+    n, m = case.lx1, case.lx1 - 2
+    def load(name):
+        raw = np.fromfile(str(tmp_path / name))
+        nv = case.nel * n * n
+        return raw[:nv].reshape(case.nel, n, n), raw[nv:2 * nv].reshape(case.nel, n, n), raw[2 * nv:].reshape(case.nel, m, m)
+    re_, im_ = load("dRe00001.bin"), load("dIm00001.bin")
+    vr, vi, fr, fi = h.alloc(4)
+    h.upload(vr, *re_); h.upload(vi, *im_)
+    assert abs(h.dot(vr, vr) + h.dot(vi, vi) - 1.0) < 1e-10          # core/eigensolvers.f:619-622
+    h.matvec(fr, vr, 0); h.matvec(fi, vi, 0)
+    mu = fv[j] if ritz[j, 1] > 0 else np.conj(fv[j])
+    # file 00001 is the first converged row of the table: its eigenvalue is row `first` of ritz_full
+    first = int(np.argmax(ritz[:, 2] < 1e-6))
+    mu = fv[first]
+    h.axpy(fr, -mu.real, vr); h.axpy(fr, mu.imag, vi)                # M Re - (mu_r Re - mu_i Im)
+    h.axpy(fi, -mu.imag, vr); h.axpy(fi, -mu.real, vi)               # M Im - (mu_i Re + mu_r Im)
+    resid = np.sqrt(h.dot(fr, fr) + h.dot(fi, fi))
+    print("eigen-relation residual of the Fortran-written mode:", resid)
+    assert resid < 1e-5
+    # the same Krylov-Schur run from the Python host (nekstab_amd/krylov.py): same restarts, same converged pair
+    v0 = h.alloc(1)[0]
+    h.upload(v0, qx, qy, pr)
+    res = krylov.krylov_schur(h, v0, k, schur_tgt=2)
+    nrest = int(out.stdout.count("Schur restart"))
+    lead = res.vals[np.argmin(np.abs(res.vals - ref))]
+    print("restarts: Fortran %d, Python %d; leading pair: Fortran %s, Python %s" % (nrest, res.schur_cnt, fv[j], lead))
+    assert abs(nrest - res.schur_cnt) <= 1
+    assert abs(lead - fv[j]) < 1e-6
     h.close()

@@ -207,3 +207,84 @@ def test_scripts_compile():
     listed = open(os.path.join(sdir, "README.md")).read()
     for f in names:
         assert f in listed, f + " is not described in scripts/README.md"
+
+
+def test_fortran_module_binds_every_header_entry():
+    """host/nekstab_hip_mod.f90 (the iso_c_binding block INTEGRATION.md hands to a nekStab maintainer) binds EVERY function
+    include/nekstab_hip.h declares -- VERDICT r2, row n2."""
+    import re
+    hdr = open(os.path.join(ROOT, "include", "nekstab_hip.h")).read()
+    declared = set(re.findall(r"^(?:int|const char\*)\s+(nsk_\w+)\s*\(", hdr, flags=re.M))
+    mod = open(os.path.join(ROOT, "host", "nekstab_hip_mod.f90")).read()
+    bound = set(re.findall(r"bind\(c, name='(nsk_\w+)'\)", mod))
+    assert declared and not (declared - bound), sorted(declared - bound)
+    assert not (bound - declared), sorted(bound - declared)
+
+
+def test_fortran_dense_restart_equals_python_host(tmp_path):
+    """The Fortran host's eig / schur / select_eigenvalues / ordschur / truncation (host/krylov_host.f90, the host part of
+    schur_condensation, core/eigensolvers.f:395-499) against nekstab_amd/krylov.py on the same Hessenberg matrix: same
+    eigenvalues in the same order, same number of kept vectors, same truncated H and basis rotation Z."""
+    import shutil
+    import subprocess
+    exe = os.path.join(ROOT, "host", "dense_check")
+    if not os.path.exists(exe):
+        if shutil.which("flang") is None:
+            pytest.skip("flang not available and host/dense_check not prebuilt")
+        subprocess.run(["make", "-C", os.path.join(ROOT, "host"), "dense_check"], check=True, stdout=subprocess.DEVNULL)
+    from nekstab_amd import krylov
+    from tests.dense_backend import DenseBackend, Vec
+    rng = np.random.default_rng(11)
+    k, tgt, delta = 30, 3, 0.10
+    # a Hessenberg matrix with a few eigenvalues outside the circle of radius 0.9 (what a restart is asked to keep)
+    blocks, i = np.zeros((k, k)), 0
+    for z in (1.02 * np.exp(0.7j), 0.95 + 0j, 0.93 * np.exp(0.3j)):
+        if z.imag == 0:
+            blocks[i, i] = z.real; i += 1
+        else:
+            blocks[i:i + 2, i:i + 2] = [[z.real, z.imag], [-z.imag, z.real]]; i += 2
+    while i + 1 < k:
+        z = 0.85 * rng.random() * np.exp(2j * np.pi * rng.random())
+        blocks[i:i + 2, i:i + 2] = [[z.real, z.imag], [-z.imag, z.real]]; i += 2
+    if i < k:
+        blocks[i, i] = 0.4
+    X = rng.standard_normal((k, k))
+    A = X @ blocks @ np.linalg.inv(X)
+    import scipy.linalg as sla
+    Hk, _ = sla.hessenberg(A, calc_q=True)
+    H = np.zeros((k + 1, k))
+    H[:k] = Hk
+    H[k, k - 1] = 0.37
+    fin, fout = str(tmp_path / "H.bin"), str(tmp_path / "out.bin")
+    np.asfortranarray(H).T.ravel().tofile(fin)          # column-major stream
+    out = subprocess.run([exe, fin, fout, str(k), str(tgt), str(delta)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    raw = np.fromfile(fout)
+    vals_f = raw[:2 * k:2] + 1j * raw[1:2 * k:2]
+    o = 2 * k
+    vecs_f = (raw[o:o + 2 * k * k:2] + 1j * raw[o + 1:o + 2 * k * k:2]).reshape(k, k).T
+    o += 2 * k * k
+    ms_f = int(raw[o]); o += 1
+    Hn_f = raw[o:o + (k + 1) * k].reshape(k, k + 1).T; o += (k + 1) * k
+    Z_f = raw[o:o + k * k].reshape(k, k).T
+    # eig: same values, same order (decreasing modulus; conjugates may swap within a pair of equal modulus)
+    vals_p, vecs_p = krylov.eig_sorted(H[:k, :k])
+    assert np.abs(np.abs(vals_f) - np.abs(vals_p)).max() < 1e-12
+    assert np.abs(np.sort_complex(vals_f) - np.sort_complex(vals_p)).max() < 1e-11
+    res_f = np.abs(H[k, k - 1] * vecs_f[k - 1, :]) / np.linalg.norm(vecs_f, axis=0)
+    res_p = np.abs(H[k, k - 1] * vecs_p[k - 1, :]) / np.linalg.norm(vecs_p, axis=0)
+    assert np.abs(np.sort(res_f) - np.sort(res_p)).max() < 1e-11
+    # restart: python host on an identity 'basis' => its rotated basis IS Z
+    be = DenseBackend(np.eye(k + 1))
+    Q = [Vec(k + 1) for _ in range(k + 1)]
+    for j in range(k + 1):
+        Q[j].a[j] = 1.0
+    Hp = H.copy()
+    mstart = krylov.schur_condensation(be, Q, Hp, k, 1, delta, tgt)
+    assert mstart == ms_f + 1 and ms_f >= tgt + 4
+    Z_p = np.stack([q.a[:k] for q in Q[:k]], axis=1)
+    assert np.abs(Hn_f - Hp).max() < 1e-11 * np.abs(H).max()
+    assert np.abs(Z_f[:, :ms_f] - Z_p[:, :ms_f]).max() < 1e-11
+    # and the restarted factorisation is still a Krylov decomposition:  A Z_1 = Z_1 T + z_{k+1} b^T Z
+    T = Hn_f[:ms_f, :ms_f]
+    assert np.abs(H[:k, :k] @ Z_f[:, :ms_f] - Z_f[:, :ms_f] @ T).max() < 1e-11
