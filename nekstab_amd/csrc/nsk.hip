@@ -62,6 +62,10 @@ struct nsk_ctx {
   const int *cA_rp = nullptr, *cA_ci = nullptr;
   const double *cA_va = nullptr, *cA_dinv = nullptr;
   double *cw_d0 = nullptr, *cw_d1 = nullptr, *cw_r = nullptr;
+  // block-circulant coarse solve (meshes of uniform periodic layers): nsk3_setup.inc
+  int circ_nz = 0, circ_nv2 = 0, circ_nmat = 0, circ_lda = 0;
+  const float* circ_Binv = nullptr; const double* circ_F = nullptr; const int2* circ_cols = nullptr;
+  double *circ_rh = nullptr, *circ_xh = nullptr;
   int nel = 0, nblk = 0, nvert = 0;
   long long nloc = 0, npr = 0, nstate = 0;
   int nscal = 0;                        // scalar fields theta(:, 1..ldimt) carried behind the pressure (option "nscal")
@@ -77,6 +81,7 @@ struct nsk_ctx {
   unsigned* sync = nullptr;             // grid-barrier counters of the persistent kernels
   int in_test = 0;
   int helm_guess = 1;
+  int gs2_from = 12;                    // quadrilaterals: GMRES columns from this iteration (of a cycle) on get a second Gram-Schmidt pass
   int dbg_max_order = 3, dbg_ab2 = 0, dbg_pext = 1;      // time-scheme sensitivity switches (options of the same names)
   double early_pres_mul = 1e-2;         // pressure tolerance factor of time steps 1-3 of every map
   long long recaptures = 0, retries = 0;
@@ -270,7 +275,11 @@ static int build(nsk_ctx* c, const nsk_case& cs) {
   d.tol_helm = cs.tol_helm > 0 ? cs.tol_helm : 1e-9;
   d.tol_pres = cs.tol_pres > 0 ? cs.tol_pres : 1e-7;
   d.tol_relative = cs.tol_relative; d.max_mr = std::min(c->max_pres, MAXMR); d.has_outflow = cs.has_outflow;
-  d.nproj_max = cs.has_outflow ? std::min(cs.nproj, MAXPROJ) : 0;   // with the pressure null space the projected solves stagnate (measured): off
+  // projection space also with the pressure null space (adjoint runs, closed domains): with the restart policy of k_proj_update it
+  // cuts config 4's pressure iterations from 26 to 15 per step (rounds 1-2 switched it off there: their merge policy made such solves slower)
+  d.nproj_max = (cs.has_outflow || !std::getenv("NSK_NO_PROJ_SINGULAR")) ? std::min(cs.nproj, MAXPROJ) : 0;
+  d.proj_restart = 1;
+  if (const char* g = std::getenv("NSK_PROJ_RESTART")) d.proj_restart = std::atoi(g);
 
   // ---- bases
   std::vector<double> z1, w1, z2, w2, zd, wd;
@@ -478,7 +487,7 @@ static int build(nsk_ctx* c, const nsk_case& cs) {
       (rc = dalloc(c, &d.hwl, 4 * d.cs)) || (rc = dalloc(c, &d.hpart, (size_t)16 * c->nblk)) || (rc = dalloc(c, &d.hscal, 32)) ||
       (rc = dalloc(c, &d.V, (size_t)(MAXMR + 1) * d.ps)) || (rc = dalloc(c, &d.Z, (size_t)MAXMR * npr)) ||
       (rc = dalloc(c, &d.yl, 2 * d.cs)) || (rc = dalloc(c, &d.ec, (size_t)nel * 4)) ||
-      (rc = dalloc(c, &d.gpart, (size_t)(MAXMR + 2) * c->nblk)) || (rc = dalloc(c, &d.gsc, 1)) ||
+      (rc = dalloc(c, &d.gpart, (size_t)(MAXMR + 2) * c->nblk)) || (rc = dalloc(c, &d.gpart2, (size_t)(MAXMR + 2) * c->nblk)) || (rc = dalloc(c, &d.gsc, 1)) ||
       (rc = dalloc(c, &d.stats, 1)) || (rc = dalloc(c, &c->wv1, 2 * d.cs)) || (rc = dalloc(c, &c->wv2, 2 * d.cs)) ||
       (rc = dalloc(c, &c->wp1, npr)) || (rc = dalloc(c, &c->wp2, npr)) || (rc = dalloc(c, &c->scratch, (size_t)c->nstate))) return rc;
   if (d.nproj_max > 0)
@@ -670,7 +679,7 @@ static int build(nsk_ctx* c, const nsk_case& cs) {
   // (k_tot2) instead of in every consumer workgroup, which is O(nblk^2)
   if (c->nblk > 1024 || std::getenv("NSK_USE_TOT")) {
     d.use_tot = 1;
-    if ((rc = dalloc(c, &d.htot, 32)) || (rc = dalloc(c, &d.gtot, MAXMR + 8)) || (rc = dalloc(c, &d.ptot, MAXPROJ + 2))) return rc;
+    if ((rc = dalloc(c, &d.htot, 32)) || (rc = dalloc(c, &d.gtot, MAXMR + 8)) || (rc = dalloc(c, &d.gtot2, MAXMR + 8)) || (rc = dalloc(c, &d.ptot, MAXPROJ + 2))) return rc;
   }
   for (int k = 0; k < NCLS; ++k) { c->cur_helm[k] = c->max_helm; c->cur_pres[k] = c->max_pres; }
   c->bh_n = 0;
@@ -760,13 +769,15 @@ static int pres_solve_launch(nsk_ctx* c, double h2, int ord, int np, double tol_
       }
       hipLaunchKernelGGL(k_schwarz<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, (const double*)(d.V + (size_t)j * d.ps), d.Z + (size_t)j * d.npr, 1, 1);
       hipLaunchKernelGGL(k_divgs<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, (const double*)d.yl, d.V + (size_t)(j + 1) * d.ps, j, 1);
-      if (c->ndim != 3) tot_rows(c, d.gpart, j + 2, d.gtot, &d.gsc->done);
-      if (c->ndim == 3) {
-        tot_rows(c, d.gpart, j + 2, d.gtot, &d.gsc->done);
+      tot_rows(c, d.gpart, j + 2, d.gtot, &d.gsc->done);
+      // second Gram-Schmidt pass: always on hexahedra, on quadrilaterals from iteration gs2_from of a cycle on
+      const bool two = c->ndim == 3 || j >= c->gs2_from;
+      if (two) {
         hipLaunchKernelGGL(k_gmres_reorth<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, j);
         tot_rows(c, d.gpart2, j + 2, d.gtot2, &d.gsc->done);
       }
-      hipLaunchKernelGGL(k_gmres_update<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, j, scale, c->min_pres, ord);
+      Dev d2 = d; d2.gs2 = two ? 1 : 0;
+      hipLaunchKernelGGL(k_gmres_update<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d2, j, scale, c->min_pres, ord);
     }
   });
   return 0;
@@ -1013,7 +1024,8 @@ int nsk_shard_release_parent(nsk_ctx* P) {
   HIPCHK(hipStreamSynchronize(P->stream));
   const Dev& d = P->d;
   const void* keep[] = {d.D, d.J12, d.D12, d.Jd, d.Dd, d.hat, d.Aci, d.Acif, d.p_off, d.p_invoff,
-                        P->cA_rp, P->cA_ci, P->cA_va, P->cA_dinv, P->cw_d0, P->cw_d1, P->cw_r};
+                        P->cA_rp, P->cA_ci, P->cA_va, P->cA_dinv, P->cw_d0, P->cw_d1, P->cw_r,
+                        P->circ_Binv, P->circ_F, P->circ_cols, P->circ_rh, P->circ_xh};
   std::vector<void*> left;
   for (void* p : P->allocs) {
     bool k = false;
@@ -1388,6 +1400,7 @@ int nsk_set_option(nsk_ctx* c, const char* name, double value) {
     c->pres_cap = (int)value;
   }
   else if (n == "helm_guess") c->helm_guess = (int)value;
+  else if (n == "gs2_from") c->gs2_from = std::max(0, (int)value);
   else if (n == "dbg_max_order") c->dbg_max_order = (int)value;
   else if (n == "dbg_ab2") c->dbg_ab2 = (int)value;
   else if (n == "dbg_pext") c->dbg_pext = (int)value;
@@ -1404,6 +1417,7 @@ int nsk_set_option(nsk_ctx* c, const char* name, double value) {
   }
   else if (n == "early_pres_mul") c->early_pres_mul = value;
   else if (n == "proj_reset") c->d.proj_reset = (int)value;
+  else if (n == "proj_restart") c->d.proj_restart = (int)value;
   else if (n == "pres_floor") c->d.tol_pres_floor = value;
   else if (n == "dbg") { int v = (int)value; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), &v, sizeof(int))); }
   else if (n == "budget_helm") { for (int k = 0; k < NCLS; ++k) c->cur_helm[k] = std::min(c->max_helm, std::max(1, (int)value)); }

@@ -448,9 +448,13 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_rhs(Dev d, StepCoef sc) {
     if (G->st_pending) {
       G->st_pending = 0;
       if (G->st_n > 0.0) {
-        G->pn[G->st_slot] = G->st_n;
-        G->pcnt += 1;
-        G->nproj = (G->pcnt < d.nproj_max) ? G->pcnt : d.nproj_max;
+        if (G->st_slot < 0) {                        // restart of a full space on the latest total solution (k_proj_update)
+          G->pn[0] = G->st_n; G->pcnt = 1; G->nproj = 1;
+        } else {
+          G->pn[G->st_slot] = G->st_n;
+          G->pcnt += 1;
+          G->nproj = (G->pcnt < d.nproj_max) ? G->pcnt : d.nproj_max;
+        }
       } else { G->pcnt = 0; G->nproj = 0; }
     }
     if (d.proj_reset && sc.cls == 0) { G->pcnt = 0; G->nproj = 0; }

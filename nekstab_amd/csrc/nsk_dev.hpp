@@ -62,7 +62,8 @@ struct Stats {
 };
 
 struct Dev {
-  int nel, nblk, nvert, adj_dummy;
+  int nel, nblk, nvert;
+  int gs2;                       // set per launch: the GMRES column of this k_gmres_update had a second Gram-Schmidt pass (k_gmres_reorth)
   long long nloc, npr;
   long long cs, ps;              // component stride of velocity-mesh arrays / stride of the GMRES basis V
                                  // (= nloc, npr on one rank; + ghost slots when elements are sharded)
@@ -70,6 +71,7 @@ struct Dev {
   double nu, dt, vol, tol_helm, tol_pres;
   int tol_relative, max_mr, has_outflow, nproj_max;
   int proj_reset;                // 1: every map starts with an empty pressure projection space
+  int proj_restart;              // 1: a full projection space restarts on the latest total solution (Nek5000); 0: merge into the oldest slot
   int pres_cap;                  // > 0: a pressure solve stops after this many GMRES iterations whatever its residual (set per launch)
   double tol_pres_floor;         // relative pressure tolerance never asks for less than this (units of GmresScal::resid); 0 = off
   // bases

@@ -1,6 +1,8 @@
 """Hexahedral (3-D) hot path through the C-ABI against the 3-D oracle (BASELINE configs 4 and 5 are 3-D):
 element kernels, Helmholtz and pressure solves, direct / adjoint / nonlinear steps on small deformed boxes,
 and the z-extruded cylinder against the 2-D GPU path."""
+import os
+
 import numpy as np
 import pytest
 
@@ -416,3 +418,35 @@ def test_chebyshev_coarse_solve_matches_dense_inverse(monkeypatch):
         assert 0 < it1 <= it0 + 3, (it0, it1)
     finally:
         h.close()
+
+
+def test_block_circulant_coarse_solve_equals_dense_inverse(monkeypatch):
+    """Meshes made of uniform periodic layers (BASELINE config 4: 30 spanwise layers) have a block-circulant vertex operator:
+    the coarse solve is exact through a real Fourier transform in z and one stored inverse per wavenumber (nsk3_setup.inc),
+    three launches instead of the Chebyshev polynomial's dozens.  Forced on a small extrusion (closed cavity: the singular
+    wavenumber-0 block included; and the cylinder with its outflow) it must reproduce the dense inverse's pressure solution
+    AND its GMRES iteration count (both coarse solves are exact)."""
+    from nekstab_amd import mesh
+    from nekstab_amd.capi import NekStabHip
+    from tests.conftest import GOLDEN
+    c2a, _ = _cavity_2d(3600.0)
+    c2b = mesh.load_case_npz(os.path.join(GOLDEN, "cylinder_case.npz"), 6)
+    for c2, nz, lz in ((c2a, 5, 1.0), (c2b, 4, 2.0)):
+        c3 = mesh3d.extrude_case(c2, nz, lz, periodic=True)
+        rng = np.random.default_rng(4)
+        g = rng.standard_normal((c3.nel, 4, 4, 4))
+        out = {}
+        for name, env in (("dense", {"NSK_COARSE_ITER": "0", "NSK_COARSE_CIRC": "0"}), ("circulant", {"NSK_COARSE_ITER": "0", "NSK_COARSE_CIRC": "1"}),
+                          ("chebyshev", {"NSK_COARSE_ITER": "1", "NSK_COARSE_CIRC": "0"})):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            h = NekStabHip(c3, c3.meta["vert"], c3.meta["nvert"], tol_helm=1e-10, tol_pres=1e-8, tol_relative=1, max_helm_iter=200, max_pres_iter=48)
+            try:
+                out[name] = h.t_pres_solve(g)
+            finally:
+                h.close()
+        xd, itd = out["dense"]; xc, itc = out["circulant"]; xp, itp = out["chebyshev"]
+        print("extrusion of %d elements over %d layers: GMRES iterations dense %d, block-circulant %d, Chebyshev polynomial %d" % (c2.nel, nz, itd, itc, itp))
+        assert abs(itc - itd) <= 1, (itd, itc)
+        sc = np.abs(xd - xd.mean()).max()
+        assert np.abs((xc - xc.mean()) - (xd - xd.mean())).max() < 1e-5 * sc

@@ -12,7 +12,7 @@ from tests.conftest import GOLDEN
 
 pytestmark = pytest.mark.gpu
 
-KW = dict(tol_helm=1e-11, tol_pres=1e-5, tol_relative=1, nproj=8, max_helm_iter=150, max_pres_iter=48)
+KW = dict(tol_helm=1e-11, tol_pres=1e-5, tol_relative=1, nproj=8, max_helm_iter=150, max_pres_iter=192)     # (closed domain: some projected solves need a second GMRES cycle)
 KW3 = dict(KW, tol_pres=1e-3)      # hexahedral FDM-Schwarz, closed domain (no projection space): 26 iterations per step at 1e-3
 
 
