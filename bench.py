@@ -176,19 +176,22 @@ def cpu_baseline(case, threads, tol):
 
 
 def pmc_traffic(kernel_key):
-    """HBM-side bytes per launch of the dominant kernel from the committed PMC passes (scripts/profile_r02.sh ->
-    profiles/r02_pmc_traffic.json): used only when that file was produced by THIS build of the library."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    """HBM-side bytes per launch of the dominant kernel from the committed PMC passes (scripts/profile_r03.sh ->
+    profiles/rNN_pmc_traffic.json): used only when the file was produced by THIS build of the library (source hash)."""
+    import glob
     stamp = os.path.join(ROOT, "nekstab_amd", "lib", "libnekstab_hip.so.srchash")
-    if not (os.path.exists(path) and os.path.exists(stamp)):
+    if not os.path.exists(stamp):
         return None, "no PMC pass of this build"
-    tab = json.load(open(path))
-    if tab.get("srchash") != open(stamp).read().strip():
-        return None, "profiles/r02_pmc_traffic.json is from another build"
-    rec = tab.get("kernels", {}).get(kernel_key)
-    if not rec:
-        return None, "kernel not in the PMC table"
-    return rec["bytes_per_launch"], "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this build (2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction)"
+    mine = open(stamp).read().strip()
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+        tab = json.load(open(path))
+        if tab.get("srchash") != mine:
+            continue
+        rec = tab.get("kernels", {}).get(kernel_key)
+        if not rec:
+            return None, "kernel not in the PMC table of " + os.path.basename(path)
+        return rec["bytes_per_launch"], "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this build (2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction): profiles/" + os.path.basename(path)
+    return None, "the committed PMC tables (profiles/r*_pmc_traffic.json) are from other builds of the library"
 
 
 def build_case(name, lx1_override=None):

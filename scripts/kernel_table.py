@@ -1,7 +1,7 @@
 """Per-kernel table of the profiled bench run: algorithmic bytes per launch (nekstab_amd/roofline.py), launch
 duration (rocprofv3 kernel trace, p90 = launches that do full work, p10 = launches that find their solve converged), the
 resulting TB/s, and the HBM-side bytes from the PMC passes (2 x FETCH_SIZE + WRITE_SIZE).  Also writes
-profiles-style r02_pmc_traffic.json (bytes per launch keyed by kernel, stamped with the library's source hash).
+profiles-style rNN_pmc_traffic.json (bytes per launch keyed by kernel, stamped with the library's source hash).
 Usage: kernel_table.py <trace_dir> <pmc_summary.json> <bench_line.json>"""
 import collections, csv, glob, json, os, sys
 import numpy as np
@@ -50,5 +50,5 @@ for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
         "%.2f" % (a / p90 / 1e6) if a else "-", "%.2f" % (a / p90 / 1e6 / 8.0) if a else "-", "%.2f" % (pm / 1e6) if pm is not None else "-"))
 stamp = os.path.join(ROOT, "nekstab_amd", "lib", "libnekstab_hip.so.srchash")
 json.dump({"srchash": open(stamp).read().strip() if os.path.exists(stamp) else None, "kernels": traffic,
-           "source": "scripts/profile_r02.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, eager launches), p90 over launches"},
-          open(os.path.join(os.path.dirname(pmc_json), "r02_pmc_traffic.json"), "w"), indent=1)
+           "source": "scripts/profile_r0N.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, eager launches), p90 over launches"},
+          open(os.path.join(os.path.dirname(pmc_json), os.path.basename(pmc_json).split("_")[0] + "_pmc_traffic.json"), "w"), indent=1)

@@ -15,14 +15,14 @@ c.ub[0] = sx ** 2 * np.sin(2 * np.pi * c.y) * sz ** 2 * c.mask
 c.ub[1] = -np.sin(2 * np.pi * c.x) * sy ** 2 * sz ** 2 * c.mask
 del sx, sy, sz
 t0 = time.time()
-h = NekStabHip(c, c.meta["vert"], c.meta["nvert"], tol_helm=1e-9, tol_pres=1e-2, tol_relative=1, max_helm_iter=400, max_pres_iter=192)
+h = NekStabHip(c, c.meta["vert"], c.meta["nvert"], tol_helm=1e-9, tol_pres=1e-2, tol_relative=1, max_helm_iter=400, max_pres_iter=192, nproj=int(os.environ.get('NPROJ', '0')))
 print("E %d set-up %.0f s, nsteps %d dt %.3e" % (c.nel, time.time() - t0, h.nsteps, h.dt), flush=True)
 q, f = h.alloc(2)
 rng = np.random.default_rng(2)
 w = 1e-2 * rng.standard_normal(c.x.shape) * c.mask
 h.upload3(q, c.ub[0] + w, c.ub[1] - w, w, np.zeros(h.npres))
 h.set_nsteps(nst)
-for rep in range(2):
+for rep in range(int(os.environ.get('REPS', '2'))):
     t0 = time.time(); h.matvec(f, q, 0); h.norm(f); dt = time.time() - t0
     st = h.stats()
     print("%.1f ms per step (%.1f Helmholtz + %.1f pressure iterations per step)" % (1e3 * dt / nst, st["helm_iters"] / nst, st["pres_iters"] / nst), flush=True)
