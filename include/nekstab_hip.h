@@ -35,7 +35,8 @@ enum nsk_mode {          /* `evop`, core/matvec.f:124-151 */
   NSK_DIRECT = 0,        /* 'd'  forward_linearized_map   core/matvec.f:163-243 */
   NSK_ADJOINT = 1,       /* 'a'  adjoint_linearized_map   core/matvec.f:249-326 */
   NSK_DIRECT_ADJOINT = 2,/* 'p'  transient_growth_map     core/matvec.f:332-349 */
-  NSK_NEWTON = 3         /* 'n'  newton_linearized_map    core/matvec.f:381-428 (exp(LT)-I) */
+  NSK_NEWTON = 3,        /* 'n'  newton_linearized_map    core/matvec.f:381-428 (exp(LT)-I) */
+  NSK_FORCE_SENSITIVITY = 4 /*  ts_force_sensitivity_map   core/matvec.f:357-374 (uparam(1) = 4: (I - exp(L^+ T)) q, adjoint map) */
 };
 
 /* Case description = what Nek5000 holds in COMMON when nekStab_init runs
@@ -95,6 +96,12 @@ int nsk_set_tolerances(nsk_ctx* ctx, double tol_helm, double tol_pres, int relat
  * "merged_update" / "merged_iters" (quadrilaterals with the dense in-LDS coarse solve: the GMRES column bookkeeping runs inside
  * the coarse-solve kernel for the first `merged_iters` iterations of a solve, default 1 / 12; same iteration counts and results to
  * rounding as the classic four-kernel iteration), "shard_graph" (shard contexts, see nsk_shard_release_parent below),
+ * "proj_restart" (1, default: a full projection space restarts on the latest total solution -- Fischer's / Nek5000's rule; 0: the
+ * rounds-1-2 policy of merging into the oldest slot, kept for A/B runs), "gs2_from" (quadrilaterals: GMRES columns from this
+ * iteration of a cycle on get a second Gram-Schmidt pass, default 12; hexahedra always), "orth_overlap" (RCCL ranks: nsk_orth
+ * all-reduces its coefficients in chunks on a second stream while the next chunk's dots are computed, default 1),
+ * "budget_freeze" / "budget_add_helm" / "budget_add_pres" (measurement switches of scripts/noop_cost.py),
+ * "dbg_max_order" / "dbg_ab2" / "dbg_pext" (time-scheme sensitivity switches of scripts/wake_bisect.py; defaults = SURVEY App. A),
  * "dbg" (developer ablation mask) */
 int nsk_set_option(nsk_ctx* ctx, const char* name, double value);
 

@@ -14,7 +14,7 @@ import numpy as np
 _LIB = None
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libnekstab_hip.so")
 
-NSK_DIRECT, NSK_ADJOINT, NSK_DIRECT_ADJOINT, NSK_NEWTON = 0, 1, 2, 3
+NSK_DIRECT, NSK_ADJOINT, NSK_DIRECT_ADJOINT, NSK_NEWTON, NSK_FORCE_SENSITIVITY = 0, 1, 2, 3, 4
 
 _dp = C.POINTER(C.c_double)
 _lp = C.POINTER(C.c_longlong)

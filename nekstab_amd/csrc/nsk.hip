@@ -81,6 +81,7 @@ struct nsk_ctx {
   unsigned* sync = nullptr;             // grid-barrier counters of the persistent kernels
   int in_test = 0;
   int helm_guess = 1;
+  int budget_freeze = 0;
   int gs2_from = 12;                    // quadrilaterals: GMRES columns from this iteration (of a cycle) on get a second Gram-Schmidt pass
   int dbg_max_order = 3, dbg_ab2 = 0, dbg_pext = 1;      // time-scheme sensitivity switches (options of the same names)
   double early_pres_mul = 1e-2;         // pressure tolerance factor of time steps 1-3 of every map
@@ -924,6 +925,7 @@ static int run_map(nsk_ctx* c, int adjoint, double* f, const double* q) {
 // for (start-up budgets, doubled budgets after a redone map).
 constexpr int BW = 8, BHEAD = 3;
 static void budgets_update(nsk_ctx* c, const Stats& h) {
+  if (c->budget_freeze) return;                         // measurement switch (scripts/noop_cost.py): budgets stay where the caller put them
   const int slot = c->bh_n % BW;
   for (int k = 0; k < NCLS; ++k) { c->bh_helm[k][slot] = (int)h.max_helm_k[k]; c->bh_pres[k][slot] = (int)h.max_pres_k[k]; }
   c->bh_n++;
@@ -1060,6 +1062,12 @@ int nsk_group_matvec(nsk_ctx** shards, int n, int mode, nsk_vec* f, nsk_vec* q) 
       if ((rc = group_run_map(G, 0, (double* const*)f, (const double* const*)q))) return rc;
       for (int r = 0; r < n; ++r)
         hipLaunchKernelGGL(k_axpby, dim3((unsigned)((G[r]->nstate + 255) / 256)), dim3(256), 0, G[r]->stream, (double*)f[r], -1.0, (const double*)q[r], 1.0, G[r]->nstate);
+      return 0;
+    case NSK_FORCE_SENSITIVITY:                                  // core/matvec.f:357-374
+      for (int r = 0; r < n; ++r) if (f[r] == q[r]) return fail(NSK_EINVAL, "force-sensitivity map needs f != q");
+      if ((rc = group_run_map(G, 1, (double* const*)f, (const double* const*)q))) return rc;
+      for (int r = 0; r < n; ++r)
+        hipLaunchKernelGGL(k_axpby, dim3((unsigned)((G[r]->nstate + 255) / 256)), dim3(256), 0, G[r]->stream, (double*)f[r], 1.0, (const double*)q[r], -1.0, G[r]->nstate);
       return 0;
     default: return fail(NSK_EINVAL, "unknown mode");
   }
@@ -1422,6 +1430,9 @@ int nsk_set_option(nsk_ctx* c, const char* name, double value) {
   else if (n == "dbg") { int v = (int)value; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), &v, sizeof(int))); }
   else if (n == "budget_helm") { for (int k = 0; k < NCLS; ++k) c->cur_helm[k] = std::min(c->max_helm, std::max(1, (int)value)); }
   else if (n == "budget_pres") { for (int k = 0; k < NCLS; ++k) c->cur_pres[k] = std::min(c->max_pres, std::max(1, (int)value)); }
+  else if (n == "budget_add_helm") { for (int k = 0; k < NCLS; ++k) c->cur_helm[k] = std::min(c->max_helm, std::max(1, c->cur_helm[k] + (int)value)); }
+  else if (n == "budget_add_pres") { for (int k = 0; k < NCLS; ++k) c->cur_pres[k] = std::min(c->max_pres, std::max(1, c->cur_pres[k] + (int)value)); }
+  else if (n == "budget_freeze") c->budget_freeze = (int)value;
   else return fail(NSK_EINVAL, "unknown option " + n);
   for (auto& a : c->graphs) for (auto& g : a) g.nh = -1;
   return 0;
@@ -1542,6 +1553,11 @@ int nsk_matvec(nsk_ctx* c, int mode, nsk_vec fv, nsk_vec qv) {
       if (f == q) return fail(NSK_EINVAL, "newton map needs f != q");
       rc = run_map_adaptive(c, 0, f, q);
       if (!rc) hipLaunchKernelGGL(k_axpby, dim3((unsigned)((c->nstate + 255) / 256)), dim3(256), 0, c->stream, f, -1.0, q, 1.0, c->nstate);
+      break;
+    case NSK_FORCE_SENSITIVITY:                                  // core/matvec.f:366-371: f = -(exp(L^+ T) q - q)
+      if (f == q) return fail(NSK_EINVAL, "force-sensitivity map needs f != q");
+      rc = run_map_adaptive(c, 1, f, q);
+      if (!rc) hipLaunchKernelGGL(k_axpby, dim3((unsigned)((c->nstate + 255) / 256)), dim3(256), 0, c->stream, f, 1.0, q, -1.0, c->nstate);
       break;
     default: return fail(NSK_EINVAL, "unknown mode");
   }

@@ -1,6 +1,6 @@
 """Summarise a rocprofv3 kernel trace: per-kernel duration percentiles, and -- for kernels that are launched on a budget and
 leave at once when their solve has converged -- the split into WORKING launches and launches that found nothing to do
-(duration < 35 % of the kernel's 95th percentile).
+(duration < 60 % of the kernel's 95th percentile).
 
     python scripts/trace_summary.py <rocprof output dir> [--last FRACTION]
 
@@ -28,7 +28,7 @@ for k, v in sorted(d.items(), key=lambda kv: -sum(kv[1])):
     v = np.array(v)
     if len(v) < 20:
         continue
-    thr = 0.35 * np.percentile(v, 95)
+    thr = 0.6 * np.percentile(v, 95)
     w, n = v[v >= thr], v[v < thr]
     print("%-46s %7d %9.0f %6.1f %7.2f %7.2f %7.2f | %7d %8.2f %7d %8.2f" % (k, len(v), v.sum(), 100 * v.sum() / tot, *np.percentile(v, [10, 50, 90]),
           len(w), w.mean() if len(w) else 0.0, len(n), n.mean() if len(n) else 0.0))

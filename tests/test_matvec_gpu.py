@@ -117,5 +117,13 @@ def test_composed_maps(hip6, oracle6, modes):
     num = np.sqrt(sum(np.sum(o.bm1 * (x - y) ** 2) for x, y in zip(f[:2], ref[:2])))
     den = np.sqrt(sum(np.sum(o.bm1 * y ** 2) for y in fw[:2]))
     assert num / den < 1e-9
+    # ts_force_sensitivity_map = (I - exp(L^+ T)) q  (core/matvec.f:357-374, uparam(1) = 4)
+    hip6.matvec(vf, vq, 4)
+    f = hip6.download(vf)
+    ad = o.matvec(q, adjoint=True, nsteps=3)
+    ref = tuple(b - a for a, b in zip(ad, q))
+    num = np.sqrt(sum(np.sum(o.bm1 * (x - y) ** 2) for x, y in zip(f[:2], ref[:2])))
+    den = np.sqrt(sum(np.sum(o.bm1 * y ** 2) for y in ad[:2]))
+    assert num / den < 1e-9
     hip6.set_nsteps(100)
     hip6.free([vq, vf])
