@@ -126,4 +126,5 @@ def test_composed_maps(hip6, oracle6, modes):
     den = np.sqrt(sum(np.sum(o.bm1 * y ** 2) for y in ad[:2]))
     assert num / den < 1e-9
     hip6.set_nsteps(100)
+    hip6.set_tolerances(1e-13, 1e-13, 0)           # the session fixture's settings (tests that follow rely on them)
     hip6.free([vq, vf])
