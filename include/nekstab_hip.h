@@ -98,7 +98,7 @@ int nsk_set_tolerances(nsk_ctx* ctx, double tol_helm, double tol_pres, int relat
  * rounding as the classic four-kernel iteration), "shard_graph" (shard contexts, see nsk_shard_release_parent below),
  * "proj_restart" (1, default: a full projection space restarts on the latest total solution -- Fischer's / Nek5000's rule; 0: the
  * rounds-1-2 policy of merging into the oldest slot, kept for A/B runs), "gs2_from" (quadrilaterals: GMRES columns from this
- * iteration of a cycle on get a second Gram-Schmidt pass, default 12; hexahedra always), "orth_overlap" (RCCL ranks: nsk_orth
+ * iteration of a cycle on get a second Gram-Schmidt pass, default 48 = never; hexahedra always), "orth_overlap" (RCCL ranks: nsk_orth
  * all-reduces its coefficients in chunks on a second stream while the next chunk's dots are computed, default 1),
  * "budget_freeze" / "budget_add_helm" / "budget_add_pres" (measurement switches of scripts/noop_cost.py),
  * "dbg_max_order" / "dbg_ab2" / "dbg_pext" (time-scheme sensitivity switches of scripts/wake_bisect.py; defaults = SURVEY App. A),

@@ -82,7 +82,7 @@ struct nsk_ctx {
   int in_test = 0;
   int helm_guess = 1;
   int budget_freeze = 0;
-  int gs2_from = 12;                    // quadrilaterals: GMRES columns from this iteration (of a cycle) on get a second Gram-Schmidt pass
+  int gs2_from = MAXMR;                 // quadrilaterals: GMRES columns from this iteration (of a cycle) on get a second Gram-Schmidt pass (default: never)
   int dbg_max_order = 3, dbg_ab2 = 0, dbg_pext = 1;      // time-scheme sensitivity switches (options of the same names)
   double early_pres_mul = 1e-2;         // pressure tolerance factor of time steps 1-3 of every map
   long long recaptures = 0, retries = 0;

@@ -1156,11 +1156,11 @@ __global__ __launch_bounds__(256) void k_gmres_restart(Dev d, int m) {
 
 namespace k2 {
 // Second Gram-Schmidt pass (as the hexahedral set's): w' = w - sum_i h_i v_i is formed and projected once more,
-// gpart2[k] = (w', v_k), k <= j, gpart2[j+1] = (w', w').  The quadrilateral solves of the cylinder stay below ~12 iterations
-// and run single-pass; solves that go beyond `gs2_from` iterations (closed domains, adjoint runs: 20-45 iterations) lose
-// orthogonality with one classical pass -- measured on the closed backward-facing step: an estimated residual of 1e-5 against
-// a true one of ~1e-1, which is also why a projection space built from such solutions removed 90 % of the right-hand side
-// where exact solutions remove 99.95 % -- so from iteration gs2_from on the column gets this pass.
+// gpart2[k] = (w', v_k), k <= j, gpart2[j+1] = (w', w').  OFF by default on quadrilaterals (option "gs2_from" = first
+// iteration of a cycle that gets it; default MAXMR = never): measured on the closed backward-facing step, whose solves take
+// 20-45 iterations, the single classical pass keeps the residual estimate honest (same iterates with and without this pass,
+// true residual = estimate: scripts/dbg_proj.py) -- what had looked like lost orthogonality there was the projection
+// space's merge policy (k_proj_update).  Kept for meshes where one pass is not enough, as the hexahedral solves showed.
 template <int N>
 __global__ __launch_bounds__(Cfg<N>::NT) void k_gmres_reorth(Dev d, int j) {
   using C = Cfg<N>;

@@ -209,3 +209,20 @@ def test_scalar_fields_in_the_krylov_vector(case6, oracle6_nosolve, modes):
     hh, beta = h.orth(f, [q])                                   # Gram-Schmidt over velocity AND scalars
     assert np.isfinite(beta) and abs(h.dot(f, q)) < 1e-12
     h.close()
+
+
+def test_second_gram_schmidt_pass_quadrilaterals(hip6, oracle6, fields):
+    """Option "gs2_from": the GMRES columns of a quadrilateral pressure solve get a second Gram-Schmidt pass (k_gmres_reorth, the
+    hexahedral set always has it).  Off by default -- one classical pass keeps these solves honest -- so the
+    path is exercised here: same solution as the one-pass solve and as the oracle's direct solve."""
+    o = oracle6
+    g = -o.opdiv(fields[0] * o.mask, fields[1] * o.mask)
+    ref = o.E_solve(g)
+    hip6.set_option("merged_update", 0)                 # classic four-kernel iterations from the first one on
+    x1, _ = hip6.t_pres_solve(g)
+    hip6.set_option("gs2_from", 0)
+    x2, _ = hip6.t_pres_solve(g)
+    hip6.set_option("gs2_from", 48)
+    hip6.set_option("merged_update", 1)
+    assert rel(x2, ref) < 1e-7 and rel(x1, ref) < 1e-7
+    assert rel(x2, x1) < 1e-8
