@@ -499,6 +499,23 @@ def main():
             "round1_bench_settings": dict(rate(1e-9, 3e-1, 8, {"min_pres_iter": 2, "pres_cap": 4}), settings="1e-9 / 3e-1, 2-4 GMRES iterations, 8 projection vectors (BENCH_r01: 15.2 matvecs/s)"),
             "round2_initial_settings": dict(rate(1e-11, 1e-1, 16, {"min_pres_iter": 2}), settings="1e-11 / 1e-1, at least 2 GMRES iterations, 16 projection vectors (9.78 matvecs/s at the start of round 2)"),
         }
+    if rank == 0 and headline and not a.no_kdim and not a.no_settings_comparison:
+        # two and three maps in flight on as many lanes (nsk_matvec_batch) inside a band Arnoldi factorisation: NOT part of `value`
+        # -- the single-vector factorisation is the reference's algorithm and the pinned default; a band of b seeds holds polynomial
+        # degree k_dim / b per seed
+        lanes = {}
+        for bw in (2, 3):
+            sd = full.alloc(bw)
+            full.copy(sd[0], Q[0])
+            for j in range(1, bw):
+                full.upload(sd[j], qy * np.cos(0.2 * j * case.x), qx * np.cos(0.3 * j * case.y), zp)
+            torch.cuda.synchronize(); tb = time.perf_counter()
+            rb = krylov.band_arnoldi(full, sd, 48)
+            torch.cuda.synchronize(); tb = time.perf_counter() - tb
+            lanes["band_width_%d" % bw] = {"matvecs_per_s": 48 / tb, "maps": 48, "vs_this_run_steps_1_48": (48 / tb) / (48.0 / float(np.sum(step_s[:48])))}
+            full.free(rb.Q); full.free(sd)
+        lanes["note"] = "band Arnoldi, b seeds, the b maps of a step in flight on b lanes of the same GPU (own streams and solver state, shared operators); compared with Arnoldi steps 1-48 of the timed single-vector run"
+        out["lanes"] = lanes
     if rank == 0 and headline and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(case, a.cpu_threads, (a.tol_helm, a.tol_pres, a.min_pres))
     if sharded:

@@ -223,6 +223,19 @@ module nekstab_hip
       type(c_ptr), value :: ctx
       type(c_ptr), value :: v
     end function
+    integer(c_int) function nsk_clone(ctx, lane) bind(c, name='nsk_clone')
+      import
+      type(c_ptr), value :: ctx
+      type(c_ptr), intent(out) :: lane
+    end function
+    integer(c_int) function nsk_matvec_batch(lanes, b, mode, f, q) bind(c, name='nsk_matvec_batch')
+      import
+      type(c_ptr), dimension(*) :: lanes
+      integer(c_int), value :: b
+      integer(c_int), value :: mode
+      type(c_ptr), dimension(*) :: f
+      type(c_ptr), dimension(*) :: q
+    end function
     integer(c_int) function nsk_get_stats(ctx, s) bind(c, name='nsk_get_stats')
       import
       type(c_ptr), value :: ctx

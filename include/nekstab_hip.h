@@ -156,6 +156,16 @@ int nsk_basis_gemv(nsk_ctx* ctx, const nsk_vec* Q, int k, const double* y_re,
 /* add_noise seed (core/utils.f:344-408): deterministic pseudo-noise, dssum-averaged, masked */
 int nsk_seed_noise(nsk_ctx* ctx, nsk_vec v);
 
+/* ---- lanes: independent maps in flight at once on one GPU ----
+ * nsk_clone gives a context a second LANE: its own stream, time-stepper state, solver work arrays and projection space; geometry,
+ * operators and preconditioner are shared (quadrilateral full-mesh contexts).  nsk_matvec_batch(lanes, b, mode, f, q) runs
+ * f[k] = map(q[k]) on lane k, all b maps queued before any is waited for: a single map is a chain of dependent 5-15 us kernels and
+ * leaves the launch pipeline ~40 % idle on BASELINE config 2; two lanes reach ~1.6x the matvecs/s of one.  The reference has no
+ * counterpart (one MPI job = one map); users: band Arnoldi (nekstab_amd/krylov.py: band_arnoldi), sweeps.  Vectors allocated on
+ * any lane are usable on all of them; finalize clones before the context they were cloned from. */
+int nsk_clone(nsk_ctx* ctx, nsk_ctx** lane);
+int nsk_matvec_batch(nsk_ctx** lanes, int b, int mode, nsk_vec* f, nsk_vec* q);
+
 /* ---- statistics of the last nsk_matvec (define the algorithmic bytes) ---- */
 typedef struct {
   long long steps;

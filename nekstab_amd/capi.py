@@ -79,6 +79,8 @@ SYMBOLS = {
     "nsk_basis_gemm": (C.c_int, [_vp, _vpp, C.c_int, _dp, C.c_int]),
     "nsk_basis_gemv": (C.c_int, [_vp, _vpp, C.c_int, _dp, _dp, _vp, _vp]),
     "nsk_seed_noise": (C.c_int, [_vp, _vp]),
+    "nsk_clone": (C.c_int, [_vp, _vpp]),
+    "nsk_matvec_batch": (C.c_int, [_vpp, C.c_int, C.c_int, _vpp, _vpp]),
     "nsk_shard_create": (C.c_int, [_vp, C.POINTER(C.c_int), C.c_int, C.c_int, _vpp]),
     "nsk_group_matvec": (C.c_int, [_vpp, C.c_int, C.c_int, _vpp, _vpp]),
     "nsk_group_nonlinear_map": (C.c_int, [_vpp, C.c_int, _vpp, _vpp, C.c_int]),
@@ -184,6 +186,9 @@ class NekStabHip:
 
     def close(self):
         if self.ctx:
+            for lane in getattr(self, "_lanes", [])[1:]:        # clones before the context they share their operators with
+                self.lib.nsk_finalize(lane)
+            self._lanes = []
             self.lib.nsk_finalize(self.ctx)
             self.ctx = C.c_void_p()
 
@@ -234,6 +239,33 @@ class NekStabHip:
         vx = np.empty((self.nel, n, n)); vy = np.empty((self.nel, n, n)); pr = np.empty((self.nel, m, m))
         self._chk(self.lib.nsk_vec_download(self.ctx, v, _p(vx), _p(vy), _p(pr)))
         return vx, vy, pr
+
+    # ---- lanes (nsk_clone / nsk_matvec_batch): independent maps in flight at once
+    def add_lane(self):
+        """A further lane of this context (own stream and state, shared operators).  Returns its index; lane 0 is the context."""
+        if not hasattr(self, "_lanes"):
+            self._lanes = [self.ctx]
+        out = C.c_void_p()
+        self._chk(self.lib.nsk_clone(self.ctx, C.byref(out)))
+        self._lanes.append(out)
+        return len(self._lanes) - 1
+
+    def matvec_batch(self, fs, qs, mode=NSK_DIRECT):
+        """f[k] = map(q[k]) on lane k, k = 0 .. len(qs) - 1, all maps in flight at once."""
+        b = len(qs)
+        lanes = getattr(self, "_lanes", [self.ctx])
+        while len(lanes) < b:
+            self.add_lane()
+            lanes = self._lanes
+        la = (C.c_void_p * b)(*[l.value for l in lanes[:b]])
+        fa = (C.c_void_p * b)(*[v.value for v in fs])
+        qa = (C.c_void_p * b)(*[v.value for v in qs])
+        self._chk(self.lib.nsk_matvec_batch(la, b, mode, fa, qa))
+
+    def lane_stats(self, k):
+        st = NskStats()
+        self._chk(self.lib.nsk_get_stats(self._lanes[k], C.byref(st)))
+        return {f: getattr(st, f) for f, _ in NskStats._fields_}
 
     # ---- operator + vector algebra
     def matvec(self, f, q, mode=NSK_DIRECT):

@@ -112,6 +112,8 @@ struct nsk_ctx {
   // krylov scratch
   double* kpart = nullptr; double* kout = nullptr; double** kptr = nullptr; int kblk = 0;
   double* hpin = nullptr;   // pinned host scratch
+  Stats* hstat_pin = nullptr;           // device counters of the last map attempt (pinned)
+  nsk_ctx* clone_of = nullptr;          // a second lane of another context (nsk_clone): shares every immutable device array
   // work vectors for tests / setup
   double *wv1 = nullptr, *wv2 = nullptr, *wp1 = nullptr, *wp2 = nullptr;
   std::vector<double> bm1s_host;
@@ -498,6 +500,7 @@ static int build(nsk_ctx* c, const nsk_case& cs) {
   c->kblk = 256;
   if ((rc = dalloc(c, &c->kpart, (size_t)c->kblk * 1024)) || (rc = dalloc(c, &c->kout, 1024)) || (rc = dalloc(c, &c->kptr, 1024))) return rc;
   HIPCHK(hipHostMalloc((void**)&c->hpin, 4096 * sizeof(double)));
+  HIPCHK(hipHostMalloc((void**)&c->hstat_pin, sizeof(Stats)));
 
   // ---- element adjacency (shared GLL nodes)
   std::vector<std::vector<int>> nb(nel);
@@ -861,7 +864,7 @@ static int ensure_graph(nsk_ctx* c, int cls, int adjoint) {
   const auto t_cap0 = std::chrono::steady_clock::now();
   if (g.exec) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }
   hipGraph_t graph = nullptr;
-  HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeGlobal));
+  HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
   int rc = step(c, CLS_ISTEP[cls], adjoint);
   hipError_t e = hipStreamEndCapture(c->stream, &graph);
   if (rc) return rc;
@@ -952,6 +955,58 @@ static void budgets_update(nsk_ctx* c, const Stats& h) {
 // run one map with the adaptive launch budgets: every inner solve early-exits on its
 // own convergence flag; a solve that runs out of launched iterations is counted on the
 // device and the whole map is redone with larger budgets.
+// One attempt of a map, asynchronous: everything is queued on the lane's stream, the device-side counters follow into pinned
+// host memory; map_finish waits, books the counters and says whether the attempt stands (0), must be redone with larger
+// launch budgets (1) or failed (< 0).  Split so that several lanes (nsk_matvec_batch) can have their maps in flight at once.
+static int map_launch(nsk_ctx* c, int adjoint, double* f, const double* src) {
+  HIPCHK(hipMemsetAsync(c->d.stats, 0, sizeof(Stats), c->stream));
+  int rc = run_map(c, adjoint, f, src);
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(c->hstat_pin, c->d.stats, sizeof(Stats), hipMemcpyDeviceToHost, c->stream));
+  return 0;
+}
+static int map_finish(nsk_ctx* c) {
+  HIPCHK(hipStreamSynchronize(c->stream));
+  const Stats h = *c->hstat_pin;
+  c->hstats.helm_iters += h.helm_iters; c->hstats.pres_iters += h.pres_iters; c->hstats.steps += c->nsteps;
+  c->hstats.max_helm = std::max(c->hstats.max_helm, h.max_helm); c->hstats.max_pres = std::max(c->hstats.max_pres, h.max_pres);
+  c->hstats.last_helm_res = h.last_helm_res; c->hstats.last_pres_res = h.last_pres_res;
+  c->hstats.capped_solves += h.capped_solves; c->hstats.worst_cap_ratio = std::max(c->hstats.worst_cap_ratio, h.worst_cap_ratio);
+  c->tot_capped += h.capped_solves; c->tot_worst_cap = std::max(c->tot_worst_cap, h.worst_cap_ratio);
+  c->tot_helm_iters += h.helm_iters; c->tot_pres_iters += h.pres_iters; c->tot_steps += c->nsteps;
+  for (int k = 0; k < NCLS; ++k) {
+    c->hstats.max_helm_k[k] = std::max(c->hstats.max_helm_k[k], h.max_helm_k[k]);
+    c->hstats.max_pres_k[k] = std::max(c->hstats.max_pres_k[k], h.max_pres_k[k]);
+  }
+  if (c->debug >= 2) {
+    fprintf(stderr, "map: unconverged %llu | helm max/budget", (unsigned long long)h.unconverged);
+    for (int k = 0; k < NCLS; ++k) fprintf(stderr, " %llu/%d", (unsigned long long)h.max_helm_k[k], c->cur_helm[k]);
+    fprintf(stderr, " | pres max/budget");
+    for (int k = 0; k < NCLS; ++k) fprintf(stderr, " %llu/%d", (unsigned long long)h.max_pres_k[k], c->cur_pres[k]);
+    fprintf(stderr, "\n");
+  }
+  if (h.sync_timeouts) return fail(NSK_EHIP, "grid barrier of the persistent velocity solve timed out (workgroups not co-resident?): set option fused = 0");
+  if (h.unconverged == 0) {
+    if (c->nsteps > 2) budgets_update(c, h);
+    return 0;
+  }
+  bool capped = true;
+  for (int k = 0; k < NCLS; ++k) capped = capped && c->cur_helm[k] >= c->max_helm && c->cur_pres[k] >= c->max_pres;
+  if (capped) {
+    c->hstats.unconverged += h.unconverged;
+    return fail(NSK_ENOCONV, "inner solve hit its iteration cap (" + std::to_string(h.unconverged) + " solves)");
+  }
+  c->retries++;
+  for (int k = 0; k < NCLS; ++k) {
+    c->cur_helm[k] = std::min(c->max_helm, 2 * c->cur_helm[k] + 4);
+    c->cur_pres[k] = std::min(c->max_pres, 2 * c->cur_pres[k] + 4);
+  }
+  return 1;
+}
+
+// run one map with the adaptive launch budgets: every inner solve early-exits on its
+// own convergence flag; a solve that runs out of launched iterations is counted on the
+// device and the whole map is redone with larger budgets.
 static int run_map_adaptive(nsk_ctx* c, int adjoint, double* f, const double* q) {
   const double* src = q;
   if (f == q) {
@@ -959,45 +1014,10 @@ static int run_map_adaptive(nsk_ctx* c, int adjoint, double* f, const double* q)
     src = c->scratch;
   }
   for (;;) {
-    HIPCHK(hipMemsetAsync(c->d.stats, 0, sizeof(Stats), c->stream));
-    int rc = run_map(c, adjoint, f, src);
+    int rc = map_launch(c, adjoint, f, src);
     if (rc) return rc;
-    Stats h;
-    HIPCHK(hipMemcpyAsync(&h, c->d.stats, sizeof(Stats), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    c->hstats.helm_iters += h.helm_iters; c->hstats.pres_iters += h.pres_iters; c->hstats.steps += c->nsteps;
-    c->hstats.max_helm = std::max(c->hstats.max_helm, h.max_helm); c->hstats.max_pres = std::max(c->hstats.max_pres, h.max_pres);
-    c->hstats.last_helm_res = h.last_helm_res; c->hstats.last_pres_res = h.last_pres_res;
-    c->hstats.capped_solves += h.capped_solves; c->hstats.worst_cap_ratio = std::max(c->hstats.worst_cap_ratio, h.worst_cap_ratio);
-    c->tot_capped += h.capped_solves; c->tot_worst_cap = std::max(c->tot_worst_cap, h.worst_cap_ratio);
-    c->tot_helm_iters += h.helm_iters; c->tot_pres_iters += h.pres_iters; c->tot_steps += c->nsteps;
-    for (int k = 0; k < NCLS; ++k) {
-      c->hstats.max_helm_k[k] = std::max(c->hstats.max_helm_k[k], h.max_helm_k[k]);
-      c->hstats.max_pres_k[k] = std::max(c->hstats.max_pres_k[k], h.max_pres_k[k]);
-    }
-    if (c->debug >= 2) {
-      fprintf(stderr, "map: unconverged %llu | helm max/budget", (unsigned long long)h.unconverged);
-      for (int k = 0; k < NCLS; ++k) fprintf(stderr, " %llu/%d", (unsigned long long)h.max_helm_k[k], c->cur_helm[k]);
-      fprintf(stderr, " | pres max/budget");
-      for (int k = 0; k < NCLS; ++k) fprintf(stderr, " %llu/%d", (unsigned long long)h.max_pres_k[k], c->cur_pres[k]);
-      fprintf(stderr, "\n");
-    }
-    if (h.sync_timeouts) return fail(NSK_EHIP, "grid barrier of the persistent velocity solve timed out (workgroups not co-resident?): set option fused = 0");
-    if (h.unconverged == 0) {
-      if (c->nsteps > 2) budgets_update(c, h);
-      return 0;
-    }
-    bool capped = true;
-    for (int k = 0; k < NCLS; ++k) capped = capped && c->cur_helm[k] >= c->max_helm && c->cur_pres[k] >= c->max_pres;
-    if (capped) {
-      c->hstats.unconverged += h.unconverged;
-      return fail(NSK_ENOCONV, "inner solve hit its iteration cap (" + std::to_string(h.unconverged) + " solves)");
-    }
-    c->retries++;
-    for (int k = 0; k < NCLS; ++k) {
-      c->cur_helm[k] = std::min(c->max_helm, 2 * c->cur_helm[k] + 4);
-      c->cur_pres[k] = std::min(c->max_pres, 2 * c->cur_pres[k] + 4);
-    }
+    rc = map_finish(c);
+    if (rc <= 0) return rc;
   }
 }
 
@@ -1351,11 +1371,12 @@ int nsk_finalize(nsk_ctx* c) {
   for (auto& a : c->graphs) for (auto& g : a) if (g.exec) (void)hipGraphExecDestroy(g.exec);
   for (void* p : c->allocs) (void)hipFree(p);
   if (c->hpin) (void)hipHostFree(c->hpin);
+  if (c->hstat_pin) (void)hipHostFree(c->hstat_pin);
   if (c->hs_send) (void)hipHostFree(c->hs_send);
   if (c->hs_recv) (void)hipHostFree(c->hs_recv);
   if (c->comm_stream) { (void)hipStreamSynchronize(c->comm_stream); for (auto& e : c->orth_ev) if (e) (void)hipEventDestroy(e); (void)hipStreamDestroy(c->comm_stream); }
   if (c->comm && rccl_rt::CommDestroy) (void)rccl_rt::CommDestroy(c->comm);
-  if (c->stream && !c->parent) (void)hipStreamDestroy(c->stream);      // shards share the parent's stream
+  if (c->stream && !c->parent) (void)hipStreamDestroy(c->stream);      // shards share the parent's stream (clones have their own)
   delete c;
   return 0;
 }
@@ -1568,7 +1589,8 @@ int nsk_matvec(nsk_ctx* c, int mode, nsk_vec fv, nsk_vec qv) {
 // constants of the convection kernels, dt / nsteps from the CFL rule, Jacobi diagonals for the new dt.
 int nsk_set_baseflow(nsk_ctx* c, nsk_vec qv) {
   if (!c || !qv) return fail(NSK_EINVAL, "bad argument");
-  if (c->parent || c->nranks > 1) return fail(NSK_EINVAL, "set_baseflow on shards is not built yet");
+  if (c->parent || c->nranks > 1) return fail(NSK_EINVAL, "shards: use nsk_group_set_baseflow");
+  if (c->clone_of) return fail(NSK_EINVAL, "lanes share the base-flow constants of the context they were cloned from: set the base flow there, before nsk_clone");
   Dev& d = c->d;
   const double* q = (const double*)qv;
   DISPATCH_N(c->key, {
@@ -1609,7 +1631,8 @@ int nsk_set_baseflow(nsk_ctx* c, nsk_vec qv) {
 // maps then read slot istep-1 at step istep.  Returns Phi_T(q0) in `end` (periodicity check) if not NULL.
 int nsk_set_orbit(nsk_ctx* c, nsk_vec q0v, double spng_str, nsk_vec end) {
   if (!c || !q0v) return fail(NSK_EINVAL, "bad argument");
-  if (c->parent) return fail(NSK_EINVAL, "orbit on shards is not built yet");
+  if (c->parent) return fail(NSK_EINVAL, "shards: use nsk_group_set_orbit");
+  if (c->clone_of) return fail(NSK_EINVAL, "not on a lane (nsk_clone)");
   if (c->ndim != 2) return fail(NSK_EINVAL, "time-periodic base flows: 2-D only in this build");
   Dev& d = c->d;
   const double* q0 = (const double*)q0v;
@@ -1667,7 +1690,7 @@ int nsk_set_orbit(nsk_ctx* c, nsk_vec q0v, double spng_str, nsk_vec end) {
 int nsk_nonlinear_map(nsk_ctx* c, nsk_vec fv, nsk_vec qv, int subtract_q) {
   if (!c || !fv || !qv) return fail(NSK_EINVAL, "bad argument");
   if (fv == qv) return fail(NSK_EINVAL, "needs f != q");
-  if (c->parent) return fail(NSK_EINVAL, "nonlinear map on shards is not built yet");
+  if (c->parent) return fail(NSK_EINVAL, "shards: use nsk_group_nonlinear_map");
   c->hstats = Stats{};
   int rc = run_map_adaptive(c, 2, (double*)fv, (const double*)qv);
   if (rc) return rc;
@@ -1856,6 +1879,98 @@ int nsk_debug_stamps(nsk_ctx* c, unsigned long long* out, int nblk_max) {
   HIPCHK(hipStreamSynchronize(c->stream));
   HIPCHK(hipMemcpy(out, d.dbg, (size_t)16 * std::min(nblk_max, c->nblk) * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   unsigned long long* p = d.dbg; d.dbg = nullptr; (void)p;
+  return 0;
+}
+
+// ---- a second LANE of a context: its own stream and state, every immutable device array shared -----------------------------
+// A single map leaves ~40 % of the launch pipeline idle on config 2 (a time step is a chain of dependent 5-15 us kernels);
+// independent maps on separate streams fill it: two lanes reach 1.6x the matvecs/s of one.  Who has two
+// independent vectors: a band (block) Arnoldi factorisation (nekstab_amd/krylov.py: band_arnoldi), parameter sweeps.
+// Quadrilateral, full-mesh contexts; vectors of any lane are plain device memory and may be used on every lane.
+int nsk_clone(nsk_ctx* P, nsk_ctx** out) {
+  if (!P || !out) return fail(NSK_EINVAL, "bad argument");
+  if (P->parent || P->clone_of || P->ndim != 2 || P->released) return fail(NSK_EINVAL, "nsk_clone: quadrilateral full-mesh contexts only");
+  if (P->d.bf_stride) return fail(NSK_EINVAL, "nsk_clone: not with a stored base-flow orbit");
+  nsk_ctx* c = new nsk_ctx();
+  auto bail = [&](int rc) { std::string keep = g_err; nsk_finalize(c); g_err = keep; return rc; };
+  // scalars and options
+  c->N = P->N; c->NN = P->NN; c->M = P->M; c->MM = P->MM; c->ND = P->ND; c->NDD = P->NDD; c->EPB = P->EPB; c->NT = P->NT; c->NTD = P->NTD;
+  c->ndim = 2; c->key = P->key; c->hrows = P->hrows; c->hstride = P->hstride;
+  c->nel = P->nel; c->nblk = P->nblk; c->nvert = P->nvert; c->nloc = P->nloc; c->npr = P->npr; c->nstate = P->nstate; c->nscal = 0;
+  if (P->nscal) { delete c; return fail(NSK_EINVAL, "nsk_clone: not with scalar fields"); }
+  c->dt = P->dt; c->re = P->re; c->endtime = P->endtime; c->nsteps = P->nsteps;
+  c->max_helm = P->max_helm; c->max_pres = P->max_pres; c->min_pres = P->min_pres; c->pres_cap = P->pres_cap; c->layers = P->layers;
+  c->use_graph = P->use_graph; c->gmres_cycle = P->gmres_cycle; c->helm_guess = P->helm_guess; c->early_pres_mul = P->early_pres_mul;
+  c->merged_iters = P->merged_iters; c->merged_update = P->merged_update; c->gs2_from = P->gs2_from; c->debug = P->debug;
+  c->dbg_max_order = P->dbg_max_order; c->dbg_ab2 = P->dbg_ab2; c->dbg_pext = P->dbg_pext;
+  c->PS = P->PS; c->coarse_lda = P->coarse_lda; c->cfl_target = P->cfl_target; c->xyz = P->xyz;
+  c->clone_of = P;
+  for (int k = 0; k < NCLS; ++k) { c->cur_helm[k] = c->max_helm; c->cur_pres[k] = c->max_pres; }
+  if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return fail(NSK_EHIP, "hipStreamCreate"); }
+  Dev& d = c->d;
+  d = P->d;                                               // every immutable pointer: geometry, bases, gather tables, preconditioner
+  d.dbg = nullptr;
+  const long long npr = c->npr;
+  int rc;
+  // the mutable set of build(): time-stepper state, CG / GMRES work arrays, projection space, partial sums, counters
+  if ((rc = dalloc(c, &d.u, 2 * d.cs)) || (rc = dalloc(c, &d.p, npr)) || (rc = dalloc(c, &d.plag, npr)) ||
+      (rc = dalloc(c, &d.pext, npr)) || (rc = dalloc(c, &d.ulag, 4 * d.cs)) || (rc = dalloc(c, &d.exlag, 4 * d.cs)) ||
+      (rc = dalloc(c, &d.bf, 2 * d.cs)) || (rc = dalloc(c, &d.rloc, 2 * d.cs)) || (rc = dalloc(c, &d.bloc, 2 * d.cs)) || (rc = dalloc(c, &d.dulag, 6 * d.cs)) || (rc = dalloc(c, &d.hx, 2 * d.cs)) ||
+      (rc = dalloc(c, &d.hr, 2 * d.cs)) || (rc = dalloc(c, &d.hp, 2 * d.cs)) || (rc = dalloc(c, &d.hs, 2 * d.cs)) ||
+      (rc = dalloc(c, &d.hwl, 4 * d.cs)) || (rc = dalloc(c, &d.hpart, (size_t)16 * c->nblk)) || (rc = dalloc(c, &d.hscal, 32)) ||
+      (rc = dalloc(c, &d.V, (size_t)(MAXMR + 1) * d.ps)) || (rc = dalloc(c, &d.Z, (size_t)MAXMR * npr)) ||
+      (rc = dalloc(c, &d.yl, 2 * d.cs)) || (rc = dalloc(c, &d.ec, (size_t)c->nel * 4)) ||
+      (rc = dalloc(c, &d.gpart, (size_t)(MAXMR + 2) * c->nblk)) || (rc = dalloc(c, &d.gpart2, (size_t)(MAXMR + 2) * c->nblk)) || (rc = dalloc(c, &d.gsc, 1)) ||
+      (rc = dalloc(c, &d.stats, 1)) || (rc = dalloc(c, &c->wv1, 2 * d.cs)) || (rc = dalloc(c, &c->wv2, 2 * d.cs)) ||
+      (rc = dalloc(c, &c->wp1, npr)) || (rc = dalloc(c, &c->wp2, npr)) || (rc = dalloc(c, &c->scratch, (size_t)c->nstate)) ||
+      (rc = dalloc(c, &d.xacc, npr)) || (rc = dalloc(c, &d.xc, c->nvert))) return bail(rc);
+  if (d.nproj_max > 0)
+    if ((rc = dalloc(c, &d.PX, (size_t)d.nproj_max * npr)) || (rc = dalloc(c, &d.PEX, (size_t)d.nproj_max * npr)) ||
+        (rc = dalloc(c, &d.PD, npr)) || (rc = dalloc(c, &d.PED, npr)) || (rc = dalloc(c, &d.ppart, (size_t)(MAXPROJ + 2) * c->nblk))) return bail(rc);
+  if (P->rc_big && (rc = dalloc(c, &c->rc_big, c->coarse_lda))) return bail(rc);
+  if (P->d.rch && (rc = dalloc(c, &d.rch, (size_t)MAXMR * c->coarse_lda))) return bail(rc);
+  if (d.use_tot && ((rc = dalloc(c, &d.htot, 32)) || (rc = dalloc(c, &d.gtot, MAXMR + 8)) || (rc = dalloc(c, &d.gtot2, MAXMR + 8)) || (rc = dalloc(c, &d.ptot, MAXPROJ + 2)))) return bail(rc);
+  if ((rc = dalloc(c, &c->sync, SYNC_WORDS))) return bail(rc);
+  c->kblk = 256;
+  if ((rc = dalloc(c, &c->kpart, (size_t)c->kblk * 1024)) || (rc = dalloc(c, &c->kout, 1024)) || (rc = dalloc(c, &c->kptr, 1024))) return bail(rc);
+  if (hipHostMalloc((void**)&c->hpin, 4096 * sizeof(double)) != hipSuccess || hipHostMalloc((void**)&c->hstat_pin, sizeof(Stats)) != hipSuccess)
+    return bail(fail(NSK_ENOMEM, "hipHostMalloc"));
+  c->bm1s_host = P->bm1s_host;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  *out = c;
+  return 0;
+}
+
+// b independent maps f_k = map(q_k), one per lane, all in flight at once: launch everything, then collect; a lane whose
+// launch budgets ran out repeats its map on its own.
+int nsk_matvec_batch(nsk_ctx** lanes, int b, int mode, nsk_vec* f, nsk_vec* q) {
+  if (!lanes || b < 1 || b > 8 || !f || !q) return fail(NSK_EINVAL, "bad argument (1 <= b <= 8)");
+  if (mode != NSK_DIRECT && mode != NSK_ADJOINT) return fail(NSK_EINVAL, "nsk_matvec_batch: direct or adjoint map");
+  for (int k = 0; k < b; ++k) {
+    if (!lanes[k] || !f[k] || !q[k] || f[k] == q[k]) return fail(NSK_EINVAL, "nsk_matvec_batch: needs f != q on every lane");
+    if (lanes[k]->parent || lanes[k]->released) return fail(NSK_EINVAL, "nsk_matvec_batch: full-mesh lanes only");
+    for (int j = 0; j < k; ++j) if (lanes[j] == lanes[k]) return fail(NSK_EINVAL, "nsk_matvec_batch: one map per lane");
+    lanes[k]->hstats = Stats{};
+  }
+  const int adj = mode == NSK_ADJOINT ? 1 : 0;
+  // inputs were written on other lanes' streams (orthogonalisation runs on lane 0): every lane starts behind all of them
+  for (int k = 0; k < b; ++k) HIPCHK(hipStreamSynchronize(lanes[k]->stream));
+  // one host thread per lane: a map is ~180 graph launches (or ~10^4 kernel launches in eager mode), and two lanes fed by one
+  // thread reach 1.3x the rate of one where two threads reach 1.5-1.6x (scripts/lanes_bench.py)
+  std::vector<int> rcs(b, 0);
+  std::vector<std::string> errs(b);
+  auto run_lane = [&](int k) {
+    for (;;) {
+      int rc = map_launch(lanes[k], adj, (double*)f[k], (const double*)q[k]);
+      if (!rc) rc = map_finish(lanes[k]);
+      if (rc <= 0) { rcs[k] = rc; if (rc) errs[k] = g_err; return; }       // 1: redo with the larger budgets map_finish has set
+    }
+  };
+  std::vector<std::thread> th;
+  for (int k = 1; k < b; ++k) th.emplace_back(run_lane, k);
+  run_lane(0);
+  for (auto& t : th) t.join();
+  for (int k = 0; k < b; ++k) if (rcs[k]) return fail(rcs[k], "lane " + std::to_string(k) + ": " + errs[k]);
   return 0;
 }
 

@@ -22,6 +22,10 @@ class DenseBackend:
         f.a = (self.A if mode == 0 else self.A.T) @ q.a
         self.nmat += 1
 
+    def matvec_batch(self, fs, qs, mode=0):
+        for f, q in zip(fs, qs):
+            self.matvec(f, q, mode)
+
     def dot(self, p, q):
         return float(np.sum(p.a * self.w * q.a))
 

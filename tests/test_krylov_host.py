@@ -68,3 +68,42 @@ def test_log_transform():
     mu = np.array([0.7387113 + 0.6972442j])
     lam = krylov.log_transform(mu, 1.0)
     assert abs(lam[0] - (0.01567373 + 0.7565285j)) < 2e-7      # Spectre_NSd_conv.dat:1
+
+
+def test_band_arnoldi_relation_and_ritz_values():
+    """Band (block) Arnoldi with two seeds (nekstab_amd/krylov.py: band_arnoldi) on a dense numpy backend: the band relation
+    M Q_k = Q_{k+2} H holds to rounding, the basis is orthonormal in the weighted inner product, and the leading Ritz values
+    converge to the eigenvalues of M with residuals that tell the truth."""
+    from nekstab_amd import krylov
+    from tests.dense_backend import DenseBackend
+    rng = np.random.default_rng(5)
+    n, k, b = 120, 40, 2
+    lam = np.concatenate([[1.05 * np.exp(0.6j), 1.05 * np.exp(-0.6j), 0.97, 0.9 * np.exp(1.1j), 0.9 * np.exp(-1.1j)], 0.6 * rng.random(n - 5)])
+    blocks, i = np.zeros((n, n)), 0
+    for z in (lam[0], lam[2], lam[3]):
+        if z.imag == 0:
+            blocks[i, i] = z.real; i += 1
+        else:
+            blocks[i:i + 2, i:i + 2] = [[z.real, z.imag], [-z.imag, z.real]]; i += 2
+    for z in lam[5:]:
+        blocks[i, i] = z.real; i += 1
+    X = np.eye(n) + 0.3 * rng.standard_normal((n, n)) / np.sqrt(n)
+    A = X @ blocks @ np.linalg.inv(X)
+    w = 0.5 + rng.random(n)
+    be = DenseBackend(A, w)
+    seeds = be.alloc(b)
+    for s_ in seeds:
+        s_.a = rng.standard_normal(n)
+    res = krylov.band_arnoldi(be, seeds, k)
+    Qm = np.stack([q.a for q in res.Q], axis=1)
+    assert np.abs(Qm.T @ (w[:, None] * Qm) - np.eye(k + b)).max() < 1e-10
+    assert np.abs(A @ Qm[:, :k] - Qm @ res.H).max() < 1e-10
+    assert np.abs(np.tril(res.H, -b - 1)).max() == 0.0            # band Hessenberg
+    for z in (lam[0], lam[2], lam[3]):
+        j = int(np.argmin(np.abs(res.vals - z)))
+        assert abs(res.vals[j] - z) < 1e-6 and res.residual[j] < 1e-5, (z, res.vals[j], res.residual[j])
+    # the residual formula is the true residual of the Ritz pair
+    y = res.vecs[:, 0]
+    x = Qm[:, :k] @ y
+    true = A @ x - res.vals[0] * x
+    assert abs(np.sqrt(np.sum(w * np.abs(true) ** 2)) - res.residual[0]) < 1e-10
