@@ -19,7 +19,10 @@ h = NekStabHip(c, c.meta["vert"], c.meta["nvert"], tol_helm=1e-9, tol_pres=1e-2,
 print("E %d set-up %.0f s, nsteps %d dt %.3e" % (c.nel, time.time() - t0, h.nsteps, h.dt), flush=True)
 q, f = h.alloc(2)
 rng = np.random.default_rng(2)
-w = 1e-2 * rng.standard_normal(c.x.shape) * c.mask
+if os.environ.get("SMOOTH", "0") == "1":      # a smooth, continuous, three-dimensional perturbation (what a Krylov vector of a physical run looks like after a few maps)
+    w = 1e-2 * np.sin(2 * np.pi * c.x) * np.sin(3 * np.pi * c.y) * np.sin(2 * np.pi * c.z) * c.mask
+else:                                          # node-wise noise: discontinuous across elements, the hardest input there is
+    w = 1e-2 * rng.standard_normal(c.x.shape) * c.mask
 h.upload3(q, c.ub[0] + w, c.ub[1] - w, w, np.zeros(h.npres))
 h.set_nsteps(nst)
 for rep in range(int(os.environ.get('REPS', '2'))):
