@@ -68,6 +68,9 @@ def _free_port():
     return port
 
 
+NO_GPU_EXIT = 3
+
+
 def supervise(a):
     """N > 1.  This process never touches the GPU: it starts worker processes (NSK_BENCH_WORKER=1) and waits.
     Without a launcher it starts all N ranks; under torch.distributed.run (RANK / WORLD_SIZE in the environment) it starts
@@ -98,6 +101,8 @@ def supervise(a):
             rc = max(rc, abs(p.wait()))
         if rc == 0:
             return 0
+        if rc == NO_GPU_EXIT:                                   # nothing a second attempt could change
+            break
         print("bench.py supervisor: attempt %d (%s) failed with code %d%s" % (att, "captured step graphs" if mode else "eager launches", rc,
               ": retrying with eager launches in fresh processes" if att + 1 < len(modes) else ""), file=sys.stderr, flush=True)
     if 0 in ranks:
@@ -219,7 +224,8 @@ def main():
     import numpy as np
     import torch
     if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+        print("bench.py needs a GPU: the hot path has no CPU fallback", file=sys.stderr, flush=True)
+        raise SystemExit(NO_GPU_EXIT)
     dist = None
     if world > 1:
         # watchdog: a multi-rank run that stalls (an exchange that never completes) must not hang the caller for ever.  A
@@ -278,7 +284,7 @@ def main():
             from nekstab_amd.sharded import attach_host_transport
             attach_host_transport(sh, dist)
         else:
-            sh.set_option("shard_graph", shard_graph)      # 1: the sharded step as one captured graph per step class, RCCL calls included
+            sh.set_option("shard_graph", 0)                # eager until the first exchanges have run (RCCL sets its peer connections up lazily: not inside a capture)
         return sh
 
     def barrier():
@@ -314,7 +320,10 @@ def main():
             h.scal(probe[0], 1.0 / h.norm(probe[0]))
             ns = h.nsteps
             h.set_nsteps(2)
-            h.matvec(probe[1], probe[0], 0)
+            h.matvec(probe[1], probe[0], 0)                 # eager: every peer connection and the all-reduce ring exist after this
+            if shard_graph == 1 and backend == "nccl":
+                h.set_option("shard_graph", 1)             # from here on: one captured graph per step class, RCCL calls inside
+                h.matvec(probe[1], probe[0], 0)
             h.set_nsteps(ns)
             h.free(probe)
         except Exception as e:                              # noqa: BLE001
@@ -449,6 +458,8 @@ def main():
             case3 = build_case("cfg3")
             full = make_context(case3)
             h = make_shard(full, case3)
+            if shard_graph == 1 and backend == "nccl":
+                h.set_option("shard_graph", 1)             # (connections exist since the headline run)
             x3, y3 = seed.add_noise(case3)
             z3 = np.zeros((case3.nel, case3.lx1 - 2, case3.lx1 - 2))
             n3 = 2

@@ -249,6 +249,54 @@ module nekstab_hip
       integer(c_int), value :: nranks
       type(c_ptr), intent(out) :: shard
     end function
+    integer(c_int) function nsk_init_local(sub, own, ctx) bind(c, name='nsk_init_local')
+      import
+      type(nsk_case), intent(in) :: sub
+      integer(c_int), dimension(*) :: own
+      type(c_ptr), intent(out) :: ctx
+    end function
+    integer(c_int) function nsk_local_info(ctx, vol_own, ctarg, fd_lmax, npr_own, nrows) bind(c, name='nsk_local_info')
+      import
+      type(c_ptr), value :: ctx
+      real(c_double), intent(out) :: vol_own
+      real(c_double), intent(out) :: ctarg
+      real(c_double), intent(out) :: fd_lmax
+      integer(c_long_long), intent(out) :: npr_own
+      integer(c_long_long), intent(out) :: nrows
+    end function
+    integer(c_int) function nsk_local_rows(ctx, u, v, a) bind(c, name='nsk_local_rows')
+      import
+      type(c_ptr), value :: ctx
+      integer(c_int), dimension(*) :: u
+      integer(c_int), dimension(*) :: v
+      real(c_double), dimension(*) :: a
+    end function
+    integer(c_int) function nsk_local_finish(ctx, vol, ctarg, fd_lmax, npr_glob, nrows, u, v, a) bind(c, name='nsk_local_finish')
+      import
+      type(c_ptr), value :: ctx
+      real(c_double), value :: vol
+      real(c_double), value :: ctarg
+      real(c_double), value :: fd_lmax
+      integer(c_long_long), value :: npr_glob
+      integer(c_long_long), value :: nrows
+      integer(c_int), dimension(*) :: u
+      integer(c_int), dimension(*) :: v
+      real(c_double), dimension(*) :: a
+    end function
+    integer(c_int) function nsk_shard_create_local(parent, part_sub, elem_glob, rank, nranks, shard) bind(c, name='nsk_shard_create_local')
+      import
+      type(c_ptr), value :: parent
+      integer(c_int), dimension(*) :: part_sub
+      integer(c_long_long), dimension(*) :: elem_glob
+      integer(c_int), value :: rank
+      integer(c_int), value :: nranks
+      type(c_ptr), intent(out) :: shard
+    end function
+    integer(c_int) function nsk_shard_share_stream(shard, leader) bind(c, name='nsk_shard_share_stream')
+      import
+      type(c_ptr), value :: shard
+      type(c_ptr), value :: leader
+    end function
     integer(c_int) function nsk_group_matvec(shards, n, mode, f, q) bind(c, name='nsk_group_matvec')
       import
       type(c_ptr), dimension(*) :: shards

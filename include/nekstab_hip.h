@@ -209,6 +209,27 @@ int nsk_group_set_orbit(nsk_ctx** shards, int n, nsk_vec* q0, double spng_str, n
  * (finalize it after its shards).  Option "shard_graph" (nsk_set_option on a shard): the sharded step runs as one hipGraph per
  * step class; -1 (default) = yes unless an RCCL communicator is attached, 0 = eager, 1 = yes, RCCL calls captured too. */
 int nsk_shard_release_parent(nsk_ctx* parent);
+/* ---- rank-local set-up (what Nek5000 does by construction: every MPI rank sets up its own elements) ------------
+ * Instead of the whole mesh, a rank hands over ITS sub-mesh: the elements it owns plus two rings of node-sharing
+ * neighbours, in ascending global element id, with the global node ids (gid), the global vertex ids (vert / nvert) and
+ * nglob of the whole mesh; own[e] = 1 for the owned elements.  On the owned elements everything element-local is then
+ * exactly what the whole-mesh set-up computes (assembled mass, Jacobi diagonals, Schwarz factors: their stencils end
+ * inside the rings).  Global facts travel through the caller (MPI / torch.distributed / a loop over virtual ranks):
+ *   nsk_local_info    vol_own (sum), ctarg (max), fd_lmax (max), npr_own (sum), nrows = entries of this rank's coarse rows
+ *   nsk_local_rows    the rows of the vertex coarse operator A_c of the vertices this rank owns, as (u, v, a) triplets
+ *   nsk_local_finish  the reduced scalars and the triplets of ALL ranks (concatenated): sets dt / nsteps, the Jacobi
+ *                     diagonals for that dt and builds the (replicated, vertex-level) coarse solve
+ *   nsk_shard_create_local   part_sub[e] = owning rank of sub-mesh element e, elem_glob[e] = its global id
+ * The shard behaves exactly like one cut from a whole-mesh parent by nsk_shard_create (tests/test_local_setup_gpu.py holds
+ * the two against each other); set-up time and memory scale with the sub-mesh. */
+int nsk_init_local(const nsk_case* sub, const int* own, nsk_ctx** out);
+int nsk_local_info(nsk_ctx* ctx, double* vol_own, double* ctarg, double* fd_lmax, long long* npr_own, long long* nrows);
+int nsk_local_rows(nsk_ctx* ctx, int* u, int* v, double* a);
+int nsk_local_finish(nsk_ctx* ctx, double vol, double ctarg, double fd_lmax, long long npr_glob, long long nrows, const int* u,
+                     const int* v, const double* a);
+int nsk_shard_create_local(nsk_ctx* local_parent, const int* part_sub, const long long* elem_glob, int rank, int nranks, nsk_ctx** out);
+/* virtual ranks made from separate rank-local parents: move `shard` onto `leader`'s stream (one process, lock-step) */
+int nsk_shard_share_stream(nsk_ctx* shard, nsk_ctx* leader);
 /* RCCL transport, one process per GPU: rank 0 creates the id, everybody calls init on its shard;
  * afterwards nsk_group_matvec(&shard, 1, ...) exchanges halos / all-reduces over xGMI. */
 /* Host-staged transport for ranks in separate processes WITHOUT RCCL (any host message layer: MPI, torch.distributed gloo;

@@ -52,6 +52,12 @@ _vpp = C.POINTER(C.c_void_p)
 SYMBOLS = {
     "nsk_init": (C.c_int, [C.POINTER(NskCase), _vpp]),
     "nsk_finalize": (C.c_int, [_vp]),
+    "nsk_init_local": (C.c_int, [C.POINTER(NskCase), C.POINTER(C.c_int), _vpp]),
+    "nsk_local_info": (C.c_int, [_vp, _dp, _dp, _dp, _lp, _lp]),
+    "nsk_local_rows": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), _dp]),
+    "nsk_local_finish": (C.c_int, [_vp, C.c_double, C.c_double, C.c_double, C.c_longlong, C.c_longlong, C.POINTER(C.c_int), C.POINTER(C.c_int), _dp]),
+    "nsk_shard_create_local": (C.c_int, [_vp, C.POINTER(C.c_int), _lp, C.c_int, C.c_int, _vpp]),
+    "nsk_shard_share_stream": (C.c_int, [_vp, _vp]),
     "nsk_last_error": (C.c_char_p, []),
     "nsk_get_info": (C.c_int, [_vp, _dp, C.POINTER(C.c_int), _lp, _lp, _lp]),
     "nsk_set_nsteps": (C.c_int, [_vp, C.c_int]),
@@ -152,7 +158,9 @@ class NekStabHip:
     """Device context for one case (``nsk_init`` ... ``nsk_finalize``)."""
 
     def __init__(self, case, vert, nvert, *, tol_helm=1e-9, tol_pres=1e-7, tol_relative=0,
-                 schwarz_layers=2, max_helm_iter=80, max_pres_iter=40, nproj=0):
+                 schwarz_layers=2, max_helm_iter=80, max_pres_iter=40, nproj=0, local_own=None):
+        """``local_own`` (rank-local set-up, sharded.LocalParent): ``case`` is a rank's sub-mesh and local_own[e] = 1 marks the
+        elements it owns -> nsk_init_local."""
         self.lib = load_library()
         c = case
         f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)
@@ -173,7 +181,11 @@ class NekStabHip:
                      max_pres_iter=max_pres_iter, nproj=nproj,
                      z=_p(k["z"]) if self.ndim == 3 else None, wb=_p(k["wb"]) if self.ndim == 3 else None)
         self.ctx = C.c_void_p()
-        self._chk(self.lib.nsk_init(C.byref(cs), C.byref(self.ctx)))
+        if local_own is None:
+            self._chk(self.lib.nsk_init(C.byref(cs), C.byref(self.ctx)))
+        else:
+            own = np.ascontiguousarray(local_own, dtype=np.int32)
+            self._chk(self.lib.nsk_init_local(C.byref(cs), own.ctypes.data_as(C.POINTER(C.c_int)), C.byref(self.ctx)))
         dt, ns = C.c_double(), C.c_int()
         a, b, d = C.c_longlong(), C.c_longlong(), C.c_longlong()
         self._chk(self.lib.nsk_get_info(self.ctx, C.byref(dt), C.byref(ns), C.byref(a), C.byref(b), C.byref(d)))

@@ -141,6 +141,15 @@ struct nsk_ctx {
   // host-staged transport (nsk_comm_init_host): ranks in separate processes without RCCL, e.g. several ranks on one GPU
   nsk_exchange_fn host_xchg = nullptr; nsk_allreduce_fn host_allred = nullptr; void* host_user = nullptr;
   double *hs_send = nullptr, *hs_recv = nullptr; size_t hs_cap = 0;
+  // ---- rank-local set-up (nsk_init_local): this context covers a SUB-MESH = the elements a rank owns + two rings of
+  // neighbours; everything element-local is exact on the owned elements, the few global facts are exchanged by the caller
+  bool local = false;
+  std::vector<char> local_own;                          // [nel] 1 = owned by this rank
+  std::vector<int> crow_u, crow_v; std::vector<double> crow_a;      // rows of A_c of the vertices this rank owns (triplets)
+  double vol_own = 0.0, ctarg = 0.0, fd_lmax = 0.0;
+  long long npr_glob = 0;                               // pressure dofs of the WHOLE mesh (0: this context is the whole mesh)
+  int has_outflow = 1;
+  bool local_done = false;
   // ---- time-periodic base flow (Floquet)
   double* orbit[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   const double* steady[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -251,6 +260,34 @@ __global__ void k_gj_update(double* __restrict__ A, int n, int k, const double* 
 // nsk_init
 // ---------------------------------------------------------------------------
 static int fused_possible(nsk_ctx* c);
+
+// dense coarse solve: A_c (nvert x nvert, host) -> its inverse on the device (Gauss-Jordan), fp64 (Dev::Aci) and fp32 with
+// padded rows (Dev::Acif).  A singular pressure operator has the constant in A_c's null space: shifted out first.
+static int coarse_dense_inverse(nsk_ctx* c, std::vector<double>& Ac, bool has_outflow) {
+  Dev& d = c->d;
+  const int nvert = c->nvert, lda = c->coarse_lda;
+  int rc;
+  if (!has_outflow) {               // constant null space: shift it out (coarse constant = sum of hats)
+    double tr = 0; for (int v = 0; v < nvert; ++v) tr += Ac[(size_t)v * nvert + v];
+    const double sh = tr / nvert / nvert;
+    for (size_t k = 0; k < Ac.size(); ++k) Ac[k] += sh;
+  }
+  double* dA = nullptr; double *drow = nullptr, *dcol = nullptr;
+  if ((rc = dalloc(c, &dA, Ac.size())) || (rc = dalloc(c, &drow, nvert)) || (rc = dalloc(c, &dcol, nvert))) return rc;
+  HIPCHK(hipMemcpy(dA, Ac.data(), Ac.size() * sizeof(double), hipMemcpyHostToDevice));
+  for (int k = 0; k < nvert; ++k) {
+    hipLaunchKernelGGL(k_gj_extract, dim3((nvert + 255) / 256), dim3(256), 0, c->stream, (const double*)dA, nvert, k, drow, dcol);
+    hipLaunchKernelGGL(k_gj_update, dim3((nvert + 255) / 256, nvert), dim3(256), 0, c->stream, dA, nvert, k, (const double*)drow, (const double*)dcol);
+  }
+  HIPCHK(hipStreamSynchronize(c->stream));
+  d.Aci = dA;
+  std::vector<double> Ah(Ac.size());
+  HIPCHK(hipMemcpy(Ah.data(), dA, Ah.size() * sizeof(double), hipMemcpyDeviceToHost));
+  std::vector<float> Af((size_t)nvert * lda, 0.0f);
+  for (int r = 0; r < nvert; ++r) for (int q = 0; q < nvert; ++q) Af[(size_t)r * lda + q] = (float)Ah[(size_t)r * nvert + q];
+  return dupload(c, &d.Acif, Af);
+}
+
 static int build(nsk_ctx* c, const nsk_case& cs) {
   const int N = cs.lx1, NN = N * N, M = N - 2, MM = M * M, ND = cs.lxd > 0 ? cs.lxd : 3 * N / 2, NDD = ND * ND;
   if (cs.ndim != 2) return fail(NSK_EINVAL, "build(): ndim must be 2");
@@ -417,6 +454,7 @@ static int build(nsk_ctx* c, const nsk_case& cs) {
       binv[l] = mk / bs[l];
       bm1s[l] = (spng[l] != 0.0) ? 0.0 : bm1[l];      // core/usr_extra.f:116-118
       vol += bm1[l];
+      if (c->local && c->local_own[l / NN]) c->vol_own += bm1[l];
     }
     d.vol = vol;
   }
@@ -440,6 +478,7 @@ static int build(nsk_ctx* c, const nsk_case& cs) {
           c->h_cflg[4 * l + 0] = rx[l] / jac[l] * dri[i]; c->h_cflg[4 * l + 1] = ry[l] / jac[l] * dri[i];
           c->h_cflg[4 * l + 2] = sx[l] / jac[l] * dri[j]; c->h_cflg[4 * l + 3] = sy[l] / jac[l] * dri[j];
         }
+    c->ctarg = ctarg;
     double dt = cs.cfl / ctarg;
     c->nsteps = (int)std::ceil(cs.endtime / dt);
     c->dt = cs.endtime / c->nsteps;
@@ -596,36 +635,28 @@ static int build(nsk_ctx* c, const nsk_case& cs) {
             Ac[(size_t)evert[a * 4 + cc] * nvert + evert[b * 4 + c2]] += t;
           }
       }
-    if (!cs.has_outflow) {            // constant null space: shift it out (coarse constant = sum of hats)
-      double tr = 0; for (int v = 0; v < nvert; ++v) tr += Ac[(size_t)v * nvert + v];
-      const double sh = tr / nvert / nvert;
-      for (size_t k = 0; k < Ac.size(); ++k) Ac[k] += sh;
-    }
-    double* dA = nullptr; double *drow = nullptr, *dcol = nullptr;
-    if ((rc = dalloc(c, &dA, Ac.size())) || (rc = dalloc(c, &drow, nvert)) || (rc = dalloc(c, &dcol, nvert))) return rc;
-    HIPCHK(hipMemcpy(dA, Ac.data(), Ac.size() * sizeof(double), hipMemcpyHostToDevice));
-    for (int k = 0; k < nvert; ++k) {
-      hipLaunchKernelGGL(k_gj_extract, dim3((nvert + 255) / 256), dim3(256), 0, c->stream, (const double*)dA, nvert, k, drow, dcol);
-      hipLaunchKernelGGL(k_gj_update, dim3((nvert + 255) / 256, nvert), dim3(256), 0, c->stream, dA, nvert, k, (const double*)drow, (const double*)dcol);
-    }
-    HIPCHK(hipStreamSynchronize(c->stream));
-    d.Aci = dA;
-    {
-      std::vector<double> Ah(Ac.size());
-      HIPCHK(hipMemcpy(Ah.data(), dA, Ah.size() * sizeof(double), hipMemcpyDeviceToHost));
-      const int lda = ((nvert + 255) / 256) * 256;
-      d.coarse_lda = lda; c->coarse_lda = lda;
-      std::vector<float> Af((size_t)nvert * lda, 0.0f);
-      for (int r = 0; r < nvert; ++r) for (int q = 0; q < nvert; ++q) Af[(size_t)r * lda + q] = (float)Ah[(size_t)r * nvert + q];
-      if ((rc = dupload(c, &d.Acif, Af))) return rc;
-      if (lda > 3072 && (rc = dalloc(c, &c->rc_big, lda))) return rc;
-      if (lda <= 3072 && (rc = dalloc(c, &d.rch, (size_t)MAXMR * lda))) return rc;     // restriction history (k_update_coarse)
-    }
+    const int lda = ((nvert + 255) / 256) * 256;
+    d.coarse_lda = lda; c->coarse_lda = lda;
+    if (lda > 3072 && (rc = dalloc(c, &c->rc_big, lda))) return rc;
+    if (lda <= 3072 && (rc = dalloc(c, &d.rch, (size_t)MAXMR * lda))) return rc;     // restriction history (k_update_coarse)
+    if (c->local) {
+      // rank-local set-up: the rows of the vertices this rank owns (owner = the rank of the lowest element at the vertex; all
+      // elements at it, their neighbours and the mass of their nodes are inside the two rings, so these rows are complete);
+      // the inverse is built from ALL ranks' rows in nsk_local_finish
+      for (int u = 0; u < nvert; ++u) {
+        if (v_off[u + 1] == v_off[u] || !c->local_own[v_ent[v_off[u]] / 4]) continue;
+        for (int v = 0; v < nvert; ++v) {
+          const double a = Ac[(size_t)u * nvert + v];
+          if (a != 0.0) { c->crow_u.push_back(u); c->crow_v.push_back(v); c->crow_a.push_back(a); }
+        }
+      }
+    } else if ((rc = coarse_dense_inverse(c, Ac, cs.has_outflow != 0))) return rc;
   }
   {
     std::vector<int> vtab((size_t)nvert * CVT, -1);
     for (int v = 0; v < nvert; ++v) {
       const int n = v_off[v + 1] - v_off[v];
+      if (n == 0 && c->local) continue;               // (a vertex outside this rank's sub-mesh)
       if (n < 1 || n > CVT) return fail(NSK_EINVAL, "vertex valence outside 1.." + std::to_string(CVT));
       for (int k = 0; k < n; ++k) vtab[(size_t)v * CVT + k] = v_ent[v_off[v] + k];
     }
@@ -1362,6 +1393,115 @@ int nsk_init(const nsk_case* cs, nsk_ctx** out) {
   int rc = (cs->ndim == 3) ? build3(c, *cs) : build(c, *cs);
   if (rc) { std::string keep = g_err; nsk_finalize(c); g_err = keep; return rc; }
   *out = c;
+  return 0;
+}
+
+// ---- rank-local set-up --------------------------------------------------------------------------------------------------
+// A rank of an element-sharded run builds a context over ITS sub-mesh (own elements + two rings of node-sharing neighbours,
+// ascending global element id, global node / vertex ids kept), not over the whole mesh:
+//   nsk_init_local   geometry, gather tables, Jacobi diagonals, Schwarz factors: exact on the owned elements;
+//                    the coarse operator: the rows of the vertices this rank owns
+//   nsk_local_info / nsk_local_rows      what the other ranks need: volume of the owned elements, CFL maximum, the largest
+//                    fast-diagonalisation eigenvalue, the coarse rows
+//   nsk_local_finish the same, reduced / gathered over all ranks by the caller: dt and nsteps, Jacobi diagonals for that dt,
+//                    the replicated coarse solve
+//   nsk_shard_create_local   the rank's shard, halos keyed by global ids
+// Set-up time and memory then scale with the sub-mesh; only the vertex-level coarse operator is replicated.
+int nsk_init_local(const nsk_case* cs, const int* own, nsk_ctx** out) {
+  if (!cs || !own || !out) return fail(NSK_EINVAL, "null argument");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return fail(NSK_EHIP, "no HIP device: libnekstab_hip has no CPU fallback");
+  nsk_ctx* c = new nsk_ctx();
+  c->local = true;
+  c->local_own.assign(own, own + cs->nel);
+  for (char& f : c->local_own) f = f ? 1 : 0;
+  c->has_outflow = cs->has_outflow;
+  int rc = (cs->ndim == 3) ? build3(c, *cs) : build(c, *cs);
+  if (rc) { std::string keep = g_err; nsk_finalize(c); g_err = keep; return rc; }
+  *out = c;
+  return 0;
+}
+
+int nsk_local_info(nsk_ctx* c, double* vol_own, double* ctarg, double* fd_lmax, long long* npr_own, long long* nrows) {
+  if (!c || !c->local) return fail(NSK_EINVAL, "needs a context made by nsk_init_local");
+  long long nown = 0;
+  for (char f : c->local_own) nown += f;
+  if (vol_own) *vol_own = c->vol_own;
+  if (ctarg) *ctarg = c->ctarg;
+  if (fd_lmax) *fd_lmax = c->fd_lmax;
+  if (npr_own) *npr_own = nown * c->MM;
+  if (nrows) *nrows = (long long)c->crow_u.size();
+  return 0;
+}
+
+int nsk_local_rows(nsk_ctx* c, int* u, int* v, double* a) {
+  if (!c || !c->local || !u || !v || !a) return fail(NSK_EINVAL, "needs a context made by nsk_init_local");
+  std::copy(c->crow_u.begin(), c->crow_u.end(), u);
+  std::copy(c->crow_v.begin(), c->crow_v.end(), v);
+  std::copy(c->crow_a.begin(), c->crow_a.end(), a);
+  return 0;
+}
+
+int nsk_local_finish(nsk_ctx* c, double vol, double ctarg, double fd_lmax, long long npr_glob, long long nrows, const int* u, const int* v,
+                     const double* a) {
+  if (!c || !c->local) return fail(NSK_EINVAL, "needs a context made by nsk_init_local");
+  if (c->local_done) return fail(NSK_EINVAL, "nsk_local_finish was already called");
+  if (!(vol > 0.0) || !(ctarg > 0.0) || npr_glob < 1 || nrows < 1 || !u || !v || !a) return fail(NSK_EINVAL, "bad argument");
+  Dev& d = c->d;
+  int rc;
+  d.vol = vol; c->npr_glob = npr_glob; d.npr_glob = npr_glob;
+  c->ctarg = ctarg;
+  const double dt0 = c->cfl_target / ctarg;
+  c->nsteps = (int)std::ceil(c->endtime / dt0);
+  c->dt = c->endtime / c->nsteps;
+  d.dt = c->dt;
+  {
+    std::vector<double> dinv((size_t)3 * c->nloc);
+    const double bd0[3] = {1.0, 1.5, 11.0 / 6.0};
+    for (int k = 0; k < 3; ++k)
+      for (long long l = 0; l < c->nloc; ++l) dinv[(size_t)k * c->nloc + l] = c->h_mask[l] / (d.nu * c->h_dAs[l] + bd0[k] / c->dt * c->h_bs[l]);
+    HIPCHK(hipMemcpy((double*)d.dinv, dinv.data(), dinv.size() * sizeof(double), hipMemcpyHostToDevice));
+  }
+  const int nvert = c->nvert;
+  for (long long k = 0; k < nrows; ++k)
+    if (u[k] < 0 || u[k] >= nvert || v[k] < 0 || v[k] >= nvert) return fail(NSK_EINVAL, "coarse row entry outside 0..nvert-1");
+  if (c->ndim == 3) {
+    c->fd_lmax = fd_lmax; d.fd_eps = 1e-11 * fd_lmax;
+    std::vector<std::vector<std::pair<int, double>>> rows(nvert);
+    for (long long k = 0; k < nrows; ++k) rows[u[k]].push_back({v[k], a[k]});
+    for (int w = 0; w < nvert; ++w) if (rows[w].empty()) return fail(NSK_EINVAL, "coarse operator: no row for vertex " + std::to_string(w) + " (rows of all ranks are needed)");
+    if ((rc = coarse_build3(c, rows, c->has_outflow != 0))) return rc;
+  } else {
+    std::vector<double> Ac((size_t)nvert * nvert, 0.0);
+    std::vector<char> seen(nvert, 0);
+    for (long long k = 0; k < nrows; ++k) { Ac[(size_t)u[k] * nvert + v[k]] = a[k]; seen[u[k]] = 1; }
+    for (int w = 0; w < nvert; ++w) if (!seen[w]) return fail(NSK_EINVAL, "coarse operator: no row for vertex " + std::to_string(w) + " (rows of all ranks are needed)");
+    if ((rc = coarse_dense_inverse(c, Ac, c->has_outflow != 0))) return rc;
+  }
+  std::vector<int>().swap(c->crow_u); std::vector<int>().swap(c->crow_v); std::vector<double>().swap(c->crow_a);
+  c->local_done = true;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int nsk_shard_create_local(nsk_ctx* P, const int* part_sub, const long long* elem_glob, int rank, int nranks, nsk_ctx** out) {
+  if (!P || !part_sub || !elem_glob || !out) return fail(NSK_EINVAL, "bad argument");
+  if (!P->local || !P->local_done) return fail(NSK_EINVAL, "needs a context made by nsk_init_local and completed by nsk_local_finish");
+  if (P->released) return fail(NSK_EINVAL, "parent context was released (nsk_shard_release_parent)");
+  for (int e = 0; e < P->nel; ++e) {
+    if (e && elem_glob[e] <= elem_glob[e - 1]) return fail(NSK_EINVAL, "elem_glob must ascend");
+    if ((part_sub[e] == rank) != (P->local_own[e] != 0)) return fail(NSK_EINVAL, "part_sub disagrees with the own flags given to nsk_init_local");
+  }
+  return shard_create(P, part_sub, rank, nranks, out, elem_glob);
+}
+
+// Virtual ranks (several shards in one process) advance in stream order on ONE stream.  Shards cut from one parent share its
+// stream; shards of separate rank-local parents are moved onto the first one's stream with this call.
+int nsk_shard_share_stream(nsk_ctx* shard, nsk_ctx* leader) {
+  if (!shard || !leader || !shard->parent || !leader->parent) return fail(NSK_EINVAL, "needs two shard contexts");
+  HIPCHK(hipStreamSynchronize(shard->stream));
+  shard->stream = leader->stream;
   return 0;
 }
 

@@ -37,6 +37,108 @@ def partition_rcb(case, nranks: int) -> np.ndarray:
     return part
 
 
+def rank_submesh(case, part, rank: int, rings: int = 2) -> np.ndarray:
+    """Global ids (ascending) of the elements ``rank`` owns plus ``rings`` rings of node-sharing neighbours: the sub-mesh a
+    rank-local set-up works on (two rings: the assembled mass of every node of every element that shares a node with an
+    owned element is complete, which is what the Schwarz patches and the coarse rows of the owned elements reach)."""
+    gid = np.asarray(case.gid).reshape(case.nel, -1)
+    sel = np.asarray(part) == rank
+    for _ in range(rings):
+        nodes = np.zeros(int(case.nglob), dtype=bool)
+        nodes[gid[sel].ravel()] = True
+        sel = nodes[gid].any(axis=1)
+    return np.where(sel)[0]
+
+
+def subset_case(case, sub):
+    """The case restricted to the elements ``sub`` (global node / vertex ids and nglob / nvert kept)."""
+    import dataclasses
+    kw = {}
+    for f in dataclasses.fields(case):
+        v = getattr(case, f.name)
+        if not isinstance(v, np.ndarray):
+            continue
+        if f.name == "ub":
+            kw[f.name] = v[:, sub]
+        elif v.shape[0] == case.nel:
+            kw[f.name] = v[sub]
+    meta = dict(case.meta)
+    meta["vert"] = np.asarray(case.meta["vert"]).reshape(case.nel, -1)[sub]
+    return dataclasses.replace(case, nel=len(sub), meta=meta, **kw)
+
+
+class LocalParent(NekStabHip):
+    """Rank-local set-up (nsk_init_local ... nsk_local_finish): the context of ONE rank's sub-mesh.  What Nek5000 does by
+    construction -- every MPI rank sets up its own elements -- instead of the whole-mesh parent every rank of ``ShardRank``
+    used to build.  ``finish`` takes the four scalars and the coarse rows reduced / gathered over all ranks."""
+
+    def __init__(self, case, part, rank: int, **kw):
+        part = np.asarray(part)
+        self.rank = rank
+        self.sub = np.ascontiguousarray(rank_submesh(case, part, rank), dtype=np.int64)
+        self.part_sub = np.ascontiguousarray(part[self.sub], dtype=np.int32)
+        sc = subset_case(case, self.sub)
+        super().__init__(sc, sc.meta["vert"], sc.meta["nvert"], local_own=(self.part_sub == rank), **kw)
+        vol, ct, lm = C.c_double(), C.c_double(), C.c_double()
+        npo, nr = C.c_longlong(), C.c_longlong()
+        self._chk(self.lib.nsk_local_info(self.ctx, C.byref(vol), C.byref(ct), C.byref(lm), C.byref(npo), C.byref(nr)))
+        self.vol_own, self.ctarg, self.fd_lmax, self.npr_own = vol.value, ct.value, lm.value, npo.value
+        n = nr.value
+        self.rows_u, self.rows_v, self.rows_a = np.empty(n, np.int32), np.empty(n, np.int32), np.empty(n, np.float64)
+        ip = C.POINTER(C.c_int)
+        self._chk(self.lib.nsk_local_rows(self.ctx, self.rows_u.ctypes.data_as(ip), self.rows_v.ctypes.data_as(ip), self.rows_a.ctypes.data_as(_dp)))
+
+    def finish(self, vol, ctarg, fd_lmax, npr_glob, u, v, a):
+        u, v = np.ascontiguousarray(u, dtype=np.int32), np.ascontiguousarray(v, dtype=np.int32)
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        ip = C.POINTER(C.c_int)
+        self._chk(self.lib.nsk_local_finish(self.ctx, float(vol), float(ctarg), float(fd_lmax), int(npr_glob), len(a),
+                                            u.ctypes.data_as(ip), v.ctypes.data_as(ip), a.ctypes.data_as(_dp)))
+        dt, ns = C.c_double(), C.c_int()
+        x, y, z = C.c_longlong(), C.c_longlong(), C.c_longlong()
+        self._chk(self.lib.nsk_get_info(self.ctx, C.byref(dt), C.byref(ns), C.byref(x), C.byref(y), C.byref(z)))
+        self.dt, self.nsteps = dt.value, ns.value
+        self.rows_u = self.rows_v = self.rows_a = None
+
+    def finish_dist(self, dist):
+        """The exchange of ``finish`` over torch.distributed (any backend: host tensors for gloo, device tensors for nccl)."""
+        import torch
+        dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        s = torch.tensor([self.vol_own, float(self.npr_own)], dtype=torch.float64, device=dev)
+        m = torch.tensor([self.ctarg, self.fd_lmax], dtype=torch.float64, device=dev)
+        dist.all_reduce(s)
+        dist.all_reduce(m, op=dist.ReduceOp.MAX)
+        cnt = torch.zeros(dist.get_world_size(), dtype=torch.int64, device=dev)
+        cnt[dist.get_rank()] = len(self.rows_a)
+        dist.all_reduce(cnt)
+        cnt = cnt.cpu().numpy()
+        off = np.concatenate([[0], np.cumsum(cnt)])
+        tot = int(off[-1])
+        # rows of all ranks: every rank fills its slice of a zeroed array, one sum per array (works on every backend)
+        U, V, A = (torch.zeros(tot, dtype=torch.float64, device=dev) for _ in range(3))
+        lo, hi = int(off[dist.get_rank()]), int(off[dist.get_rank() + 1])
+        for T, src in ((U, self.rows_u), (V, self.rows_v), (A, self.rows_a)):
+            T[lo:hi] = torch.from_numpy(np.asarray(src, dtype=np.float64)).to(dev)
+            dist.all_reduce(T)
+        s, m = s.cpu().numpy(), m.cpu().numpy()
+        self.finish(s[0], m[0], m[1], int(round(s[1])), U.cpu().numpy().astype(np.int32), V.cpu().numpy().astype(np.int32), A.cpu().numpy())
+
+
+def local_parents(case, nranks: int, part=None, **kw):
+    """The rank-local set-up of all ``nranks`` ranks inside ONE process (virtual ranks: what the single-GPU tests use), with
+    the exchange done by plain loops.  Returns (parents, part)."""
+    part = np.ascontiguousarray(partition_rcb(case, nranks) if part is None else part, dtype=np.int32)
+    P = [LocalParent(case, part, r, **kw) for r in range(nranks)]
+    vol = sum(p.vol_own for p in P)
+    npr = sum(p.npr_own for p in P)
+    ct = max(p.ctarg for p in P)
+    lm = max(p.fd_lmax for p in P)
+    u, v, a = (np.concatenate([getattr(p, k) for p in P]) for k in ("rows_u", "rows_v", "rows_a"))
+    for p in P:
+        p.finish(vol, ct, lm, npr, u, v, a)
+    return P, part
+
+
 class ShardVec:
     def __init__(self, parts):
         self.parts = parts            # one device handle per rank
@@ -45,17 +147,30 @@ class ShardVec:
 class ShardGroup:
     """R virtual ranks of one full-mesh context; same interface as NekStabHip for krylov.py."""
 
-    def __init__(self, full: NekStabHip, case, nranks: int, part=None):
+    def __init__(self, full, case, nranks: int, part=None):
+        """``full``: the whole-mesh context the shards are cut from, or the list of the ranks' ``LocalParent`` contexts
+        (rank-local set-up, ``local_parents``)."""
+        self.parents = list(full) if isinstance(full, (list, tuple)) else None
+        if self.parents is not None:
+            full = self.parents[0]
         self.full, self.lib, self.R = full, full.lib, nranks
         self.part = np.ascontiguousarray(partition_rcb(case, nranks) if part is None else part, dtype=np.int32)
         self.nsteps, self.dt = full.nsteps, full.dt
-        self.nel, self.lx1, self.lx2 = full.nel, full.lx1, full.lx2
-        self.npres, self.nvel = full.npres, full.nvel
+        ndim = int(getattr(case, "ndim", 2))
+        self.nel, self.lx1, self.lx2 = case.nel, full.lx1, full.lx2
+        self.npres, self.nvel = case.nel * self.lx2 ** ndim, case.nel * self.lx1 ** ndim
         self.elems = [np.where(self.part == r)[0] for r in range(nranks)]
         self.ctx = []
         for r in range(nranks):
             out = C.c_void_p()
-            self._chk(self.lib.nsk_shard_create(full.ctx, self.part.ctypes.data_as(C.POINTER(C.c_int)), r, nranks, C.byref(out)))
+            if self.parents is None:
+                self._chk(self.lib.nsk_shard_create(full.ctx, self.part.ctypes.data_as(C.POINTER(C.c_int)), r, nranks, C.byref(out)))
+            else:
+                p = self.parents[r]
+                self._chk(self.lib.nsk_shard_create_local(p.ctx, p.part_sub.ctypes.data_as(C.POINTER(C.c_int)),
+                                                          p.sub.ctypes.data_as(C.POINTER(C.c_longlong)), r, nranks, C.byref(out)))
+                if r:
+                    self._chk(self.lib.nsk_shard_share_stream(out, self.ctx[0]))     # virtual ranks run in stream order
             self.ctx.append(out)
         self._arr = (C.c_void_p * nranks)(*[c.value for c in self.ctx])
 
@@ -70,7 +185,8 @@ class ShardGroup:
 
     def release_parent(self):
         """Free the parent's element-major device arrays (nsk_shard_release_parent): the GPU then holds the shards only."""
-        self._chk(self.lib.nsk_shard_release_parent(self.full.ctx))
+        for p in (self.parents or [self.full]):
+            self._chk(self.lib.nsk_shard_release_parent(p.ctx))
 
     # ---- vectors
     def alloc(self, n=1):
@@ -263,7 +379,11 @@ class ShardRank:
         self.ndim = int(getattr(case, "ndim", 2))
         self.npres, self.nvel = self.nel * self.lx2 ** self.ndim, self.nel * self.lx1 ** self.ndim
         self.ctx = C.c_void_p()
-        self._chk(self.lib.nsk_shard_create(full.ctx, self.part.ctypes.data_as(C.POINTER(C.c_int)), rank, nranks, C.byref(self.ctx)))
+        if isinstance(full, LocalParent):                          # rank-local set-up: `full` covers this rank's sub-mesh only
+            self._chk(self.lib.nsk_shard_create_local(full.ctx, full.part_sub.ctypes.data_as(C.POINTER(C.c_int)),
+                                                      full.sub.ctypes.data_as(C.POINTER(C.c_longlong)), rank, nranks, C.byref(self.ctx)))
+        else:
+            self._chk(self.lib.nsk_shard_create(full.ctx, self.part.ctypes.data_as(C.POINTER(C.c_int)), rank, nranks, C.byref(self.ctx)))
         if unique_id is not None:
             buf = C.create_string_buffer(bytes(unique_id), 128)
             self._chk(self.lib.nsk_comm_init_rccl(self.ctx, C.cast(buf, C.c_void_p)))
