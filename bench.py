@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--no-settings-comparison", action="store_true", help="skip the 2 x 28 extra Arnoldi steps at the earlier rounds' solver settings")
     ap.add_argument("--no-cfg3-probe", action="store_true", help="N>1: skip the short sharded run of cfg3 next to the headline workload")
     ap.add_argument("--replicas", action="store_true", help="N>1: N independent replicas of the N=1 workload instead of one sharded eigenproblem")
+    ap.add_argument("--whole-mesh-setup", action="store_true", help="N>1: every rank builds the whole-mesh context and cuts its shard from it (default: rank-local set-up, whole-mesh in the retry attempt)")
     ap.add_argument("--shard-graph", type=int, default=-1, help="N>1: 1 = captured step graphs only, 0 = eager only, -1 = graphs first, eager retry in fresh processes")
     from nekstab_amd.settings import PRODUCTION, PRODUCTION_OPTIONS      # the settings tests/test_spectrum_pin_gpu.py pins
     ap.add_argument("--tol-helm", type=float, default=PRODUCTION["tol_helm"])
@@ -261,10 +262,29 @@ def main():
             hh.set_option("min_pres_iter", a.min_pres)
         return hh
 
+    # Sharded runs: RANK-LOCAL set-up in the first attempt (every rank sets up its own elements + two rings and the ranks
+    # exchange the volume, the CFL maximum and their coarse rows: sharded.LocalParent); the retry attempt cuts the shards from
+    # a whole-mesh context on every rank, as rounds 1-2 did.  Rank 0 builds the whole-mesh context AFTER the sharded run, for
+    # the one-GPU number of the same steps.
+    local_setup = sharded and not a.whole_mesh_setup and int(os.environ.get("NSK_BENCH_ATTEMPT", "0")) == 0
+    parts = {}
+
+    def make_parent(cs):
+        from nekstab_amd.sharded import LocalParent, partition_rcb
+        parts[id(cs)] = partition_rcb(cs, world)
+        if not local_setup:
+            return make_context(cs)
+        lp = LocalParent(cs, parts[id(cs)], rank, tol_helm=a.tol_helm, tol_pres=a.tol_pres, tol_relative=1, schwarz_layers=2, max_helm_iter=100,
+                         max_pres_iter=48, nproj=a.nproj)
+        lp.finish_dist(dist)
+        if a.min_pres > 0:
+            lp.set_option("min_pres_iter", a.min_pres)
+        return lp
+
     t0 = time.perf_counter()
-    full = make_context(case)
+    full = make_parent(case) if sharded else make_context(case)
     setup_s = time.perf_counter() - t0
-    print("[bench] rank %d: context ready in %.1f s (E=%d, lx1=%d)" % (rank, setup_s, case.nel, case.lx1), file=sys.stderr, flush=True)
+    print("[bench] rank %d: context ready in %.1f s (%d of E=%d elements, lx1=%d)" % (rank, setup_s, full.nel, case.nel, case.lx1), file=sys.stderr, flush=True)
     if a.pres_cap > 0 and not sharded:
         full.set_option("pres_cap", a.pres_cap)
     if a.fused >= 0:
@@ -279,7 +299,7 @@ def main():
         if rank == 0 and backend == "nccl":
             idt = torch.tensor(list(ShardRank.new_unique_id(parent.lib)), dtype=torch.uint8, device=dev)
         dist.broadcast(idt, 0)
-        sh = ShardRank(parent, cs, rank, world, bytes(idt.cpu().tolist()) if backend == "nccl" else None)
+        sh = ShardRank(parent, cs, rank, world, bytes(idt.cpu().tolist()) if backend == "nccl" else None, parts[id(cs)])
         if backend != "nccl":
             from nekstab_amd.sharded import attach_host_transport
             attach_host_transport(sh, dist)
@@ -446,6 +466,14 @@ def main():
             ctx.free(Q1)
             return nst / t1
 
+        setup_local = {"rank_local": bool(local_setup), "seconds_rank0": setup_s, "elements_rank0": int(full.nel), "elements_mesh": int(case.nel)}
+        if local_setup:
+            h.close(); full.close()                              # (the shard and its sub-mesh context: done)
+            if rank == 0:
+                t0 = time.perf_counter()
+                full = make_context(case)
+                setup_local["whole_mesh_seconds_rank0"] = time.perf_counter() - t0
+        out["setup"] = setup_local
         if rank == 0:
             r1 = one_gpu_same_steps(full, case, steps)
             out["single_gpu_same_config"] = {"matvecs_per_s": r1, "sample": "the same %d + %d Arnoldi steps of the same case on rank 0's full-mesh context (hipGraph path), timed after the sharded run" % (a.warmup, steps),
@@ -453,10 +481,15 @@ def main():
         dist.barrier()
         # ---- BASELINE configs[2] next to the headline workload: where element sharding is meant to pay (1.15 M points per field)
         if a.case == "cfg2" and not a.no_cfg3_probe:
-            h.close()
-            full.close()
+            if not local_setup:
+                h.close()
+                full.close()
+            elif rank == 0:
+                full.close()
             case3 = build_case("cfg3")
-            full = make_context(case3)
+            t0 = time.perf_counter()
+            full = make_parent(case3)
+            setup3_s = time.perf_counter() - t0
             h = make_shard(full, case3)
             if shard_graph == 1 and backend == "nccl":
                 h.set_option("shard_graph", 1)             # (connections exist since the headline run)
@@ -474,7 +507,14 @@ def main():
             tt = torch.tensor([t3], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             rec3 = {"workload": "cylinder Re=50 direct Arnoldi (BASELINE configs[2]): E=%d, lx1=%d, nsteps=%d/matvec" % (case3.nel, case3.lx1, h.nsteps),
-                    "matvecs_per_s": n3 / float(tt.item()), "steps": n3, "warmup": 1}
+                    "matvecs_per_s": n3 / float(tt.item()), "steps": n3, "warmup": 1,
+                    "setup": {"rank_local": bool(local_setup), "seconds_rank0": setup3_s, "elements_rank0": int(full.nel), "elements_mesh": int(case3.nel)}}
+            if local_setup:
+                h.close(); full.close()
+                if rank == 0:
+                    t0 = time.perf_counter()
+                    full = make_context(case3)
+                    rec3["setup"]["whole_mesh_seconds_rank0"] = time.perf_counter() - t0
             if rank == 0:
                 saved = a.warmup
                 a.warmup = 1

@@ -101,27 +101,35 @@ class LocalParent(NekStabHip):
         self.rows_u = self.rows_v = self.rows_a = None
 
     def finish_dist(self, dist):
-        """The exchange of ``finish`` over torch.distributed (any backend: host tensors for gloo, device tensors for nccl)."""
-        import torch
-        dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
-        s = torch.tensor([self.vol_own, float(self.npr_own)], dtype=torch.float64, device=dev)
-        m = torch.tensor([self.ctarg, self.fd_lmax], dtype=torch.float64, device=dev)
-        dist.all_reduce(s)
-        dist.all_reduce(m, op=dist.ReduceOp.MAX)
-        cnt = torch.zeros(dist.get_world_size(), dtype=torch.int64, device=dev)
-        cnt[dist.get_rank()] = len(self.rows_a)
-        dist.all_reduce(cnt)
-        cnt = cnt.cpu().numpy()
-        off = np.concatenate([[0], np.cumsum(cnt)])
-        tot = int(off[-1])
-        # rows of all ranks: every rank fills its slice of a zeroed array, one sum per array (works on every backend)
-        U, V, A = (torch.zeros(tot, dtype=torch.float64, device=dev) for _ in range(3))
-        lo, hi = int(off[dist.get_rank()]), int(off[dist.get_rank() + 1])
-        for T, src in ((U, self.rows_u), (V, self.rows_v), (A, self.rows_a)):
-            T[lo:hi] = torch.from_numpy(np.asarray(src, dtype=np.float64)).to(dev)
-            dist.all_reduce(T)
-        s, m = s.cpu().numpy(), m.cpu().numpy()
-        self.finish(s[0], m[0], m[1], int(round(s[1])), U.cpu().numpy().astype(np.int32), V.cpu().numpy().astype(np.int32), A.cpu().numpy())
+        """``finish`` with the exchange done over torch.distributed (any backend)."""
+        self.finish(*exchange_local(dist, self.vol_own, self.npr_own, self.ctarg, self.fd_lmax, self.rows_u, self.rows_v, self.rows_a))
+
+
+def exchange_local(dist, vol_own, npr_own, ctarg, fd_lmax, u, v, a):
+    """What the ranks of a rank-local set-up tell each other, over torch.distributed (host tensors for gloo, device tensors
+    for nccl): sums of the owned volume and pressure dofs, maxima of the CFL number and of the fast-diagonalisation
+    eigenvalue, and the coarse rows of all ranks concatenated in rank order (every rank fills its slice of a zeroed array
+    and the arrays are summed: one collective per array on any backend).  Returns the arguments of ``LocalParent.finish``."""
+    import torch
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    rank, world = dist.get_rank(), dist.get_world_size()
+    s = torch.tensor([vol_own, float(npr_own)], dtype=torch.float64, device=dev)
+    m = torch.tensor([ctarg, fd_lmax], dtype=torch.float64, device=dev)
+    dist.all_reduce(s)
+    dist.all_reduce(m, op=dist.ReduceOp.MAX)
+    cnt = torch.zeros(world, dtype=torch.int64, device=dev)
+    cnt[rank] = len(a)
+    dist.all_reduce(cnt)
+    off = np.concatenate([[0], np.cumsum(cnt.cpu().numpy())])
+    lo, hi, tot = int(off[rank]), int(off[rank + 1]), int(off[-1])
+    out = []
+    for src, dt in ((u, torch.int32), (v, torch.int32), (a, torch.float64)):
+        T = torch.zeros(tot, dtype=dt, device=dev)
+        T[lo:hi] = torch.from_numpy(np.ascontiguousarray(src)).to(dev)
+        dist.all_reduce(T)
+        out.append(T.cpu().numpy())
+    s, m = s.cpu().numpy(), m.cpu().numpy()
+    return float(s[0]), float(m[0]), float(m[1]), int(round(s[1])), out[0], out[1], out[2]
 
 
 def local_parents(case, nranks: int, part=None, **kw):

@@ -31,9 +31,11 @@ def main_r3(kind):
     rank, world = dist.get_rank(), dist.get_world_size()
     from nekstab_amd import mesh, seed
     from nekstab_amd.capi import NekStabHip
-    from nekstab_amd.sharded import ShardRank, attach_host_transport, partition_rcb
+    from nekstab_amd.sharded import LocalParent, ShardRank, attach_host_transport, partition_rcb
     golden = os.path.join(ROOT, "tests", "golden")
     errs = []
+    local = kind.endswith("-local")         # rank-local set-up: this rank's sub-mesh only, global facts through dist (LocalParent.finish_dist)
+    kind = kind.replace("-local", "")
     if kind in ("adjoint", "proj"):
         adj = kind == "adjoint"
         case = mesh.load_case_npz(os.path.join(golden, "cylinder_case.npz"), 8 if adj else 6, adjoint=adj)
@@ -41,7 +43,14 @@ def main_r3(kind):
                           max_helm_iter=150, max_pres_iter=48)
         qx, qy = seed.add_noise(case)
         q = (qx, qy, np.zeros((case.nel, case.lx1 - 2, case.lx1 - 2)))
-        sh = ShardRank(full, case, rank, world, None, partition_rcb(case, world))
+        part = partition_rcb(case, world)
+        if local:
+            lp = LocalParent(case, part, rank, tol_helm=1e-12, tol_pres=1e-6, tol_relative=1, nproj=8, max_helm_iter=150, max_pres_iter=48)
+            lp.finish_dist(dist)
+            assert lp.nel < 0.8 * case.nel and lp.nsteps == full.nsteps and abs(lp.dt - full.dt) < 1e-15
+            sh = ShardRank(lp, case, rank, world, None, part)
+        else:
+            sh = ShardRank(full, case, rank, world, None, part)
         tr = attach_host_transport(sh, dist)
         ns = 5 if adj else 12
         sh.set_nsteps(ns); full.set_nsteps(ns)

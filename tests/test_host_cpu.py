@@ -288,3 +288,55 @@ def test_fortran_dense_restart_equals_python_host(tmp_path):
     # and the restarted factorisation is still a Krylov decomposition:  A Z_1 = Z_1 T + z_{k+1} b^T Z
     T = Hn_f[:ms_f, :ms_f]
     assert np.abs(H[:k, :k] @ Z_f[:, :ms_f] - Z_f[:, :ms_f] @ T).max() < 1e-11
+
+
+def test_rank_submesh_and_subset_case():
+    """Rank-local set-up, host side: the sub-mesh of a rank = its own elements + two rings of node-sharing neighbours, in
+    ascending global order, with global node / vertex ids kept."""
+    from nekstab_amd import mesh
+    from nekstab_amd.sharded import partition_rcb, rank_submesh, subset_case
+    case = mesh.load_case_npz(os.path.join(GOLDEN, "cylinder_case.npz"), 6)
+    part = partition_rcb(case, 3)
+    gid = case.gid.reshape(case.nel, -1)
+    seen = np.zeros(case.nel, dtype=int)
+    for r in range(3):
+        sub = rank_submesh(case, part, r)
+        own = np.where(part == r)[0]
+        assert np.all(np.diff(sub) > 0) and np.isin(own, sub).all() and len(sub) < 0.6 * case.nel
+        # ring 1 = every element touching a node of an owned element; ring 2 = the same once more
+        ring1 = np.where(np.isin(gid, np.unique(gid[own])).any(axis=1))[0]
+        ring2 = np.where(np.isin(gid, np.unique(gid[ring1])).any(axis=1))[0]
+        assert np.array_equal(sub, ring2)
+        assert len(rank_submesh(case, part, r, rings=1)) == len(ring1)
+        sc = subset_case(case, sub)
+        assert sc.nel == len(sub) and sc.nglob == case.nglob and sc.meta["nvert"] == case.meta["nvert"]
+        assert np.array_equal(sc.gid, case.gid[sub]) and np.array_equal(sc.ub, case.ub[:, sub]) and np.array_equal(sc.meta["vert"], np.asarray(case.meta["vert"]).reshape(case.nel, -1)[sub])
+        assert sc.x.shape == (len(sub), 6, 6) and case.nel == 1996           # (the whole-mesh case is untouched)
+        seen[own] += 1
+    assert np.all(seen == 1)
+
+
+def test_local_setup_exchange_over_gloo(tmp_path):
+    """The exchange of the rank-local set-up (sharded.exchange_local) between two processes: sums, maxima, and every rank's
+    coarse rows concatenated in rank order."""
+    script = tmp_path / "w.py"
+    script.write_text(
+        "import sys, numpy as np, torch.distributed as dist\n"
+        "sys.path.insert(0, %r)\n"
+        "from nekstab_amd.sharded import exchange_local\n"
+        "dist.init_process_group('gloo')\n"
+        "r = dist.get_rank()\n"
+        "n = 3 + 2 * r\n"
+        "u = np.arange(n, dtype=np.int32) + 100 * r; v = u[::-1].copy(); a = np.linspace(0.5, 1.5, n) * (r + 1)\n"
+        "vol, ct, lm, npr, U, V, A = exchange_local(dist, 1.25 + r, 160 * (r + 1), 3.0 - r, 7.0 + 2 * r, u, v, a)\n"
+        "assert vol == 3.5 and npr == 480 and ct == 3.0 and lm == 9.0\n"
+        "eu = np.concatenate([np.arange(3), np.arange(5) + 100]); ea = np.concatenate([np.linspace(0.5, 1.5, 3), 2 * np.linspace(0.5, 1.5, 5)])\n"
+        "assert U.dtype == np.int32 and np.array_equal(U, eu) and np.array_equal(V, np.concatenate([np.arange(3)[::-1], (np.arange(5) + 100)[::-1]]))\n"
+        "assert np.array_equal(A, ea)\n"
+        "dist.barrier(); dist.destroy_process_group()\n"
+        "print('ok', r)\n" % ROOT)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29617", str(script)],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-2000:]
+    assert out.stdout.count("ok") == 2
