@@ -297,9 +297,86 @@ __device__ inline void fine_grad(const double* sDd, const double* f, int a, int 
   g[0] = ur; g[1] = us; g[2] = ut;
 }
 
+// lx1 = 10: 1024 threads per workgroup leave 128 registers per lane; the register form below (twelve to twenty-four
+// accumulators per lane, four fine-mesh points per lane unrolled) spilled 272 bytes per lane there.  This form keeps the
+// three output components (linearised maps) or the three fine-mesh velocity components (full equations) in LDS -- 81 KB next
+// to the 60 KB of tiles, one workgroup per CU either way -- and walks a lane's points one at a time: no scratch.
+template <int N>
+__device__ inline void convect_lds(const Dev& d, const double* __restrict__ uin, double* __restrict__ bf, int adjoint) {
+  using C = Cfg<N>;
+  constexpr int NN = C::NN, ND = C::ND, NDD = C::NDD, NT = C::NT;
+  __shared__ double sJ[ND * N], sDd[ND * ND];
+  __shared__ double sf[NDD], t1[N * N * ND], t2[N * ND * ND], so[3 * NDD];
+  const int tid = threadIdx.x;
+  const long long e = blockIdx.x;
+  const bool act = tid < NN;
+  const int k = tid / (N * N), j = (tid / N) % N, i = tid % N;
+  for (int p = tid; p < ND * N; p += NT) sJ[p] = d.Jd[p];
+  for (int p = tid; p < ND * ND; p += NT) sDd[p] = d.Dd[p];
+  const size_t nf = (size_t)d.nfine;
+  const long long l = e * NN + tid;
+  double sb = 0.0;
+  if (act) sb = d.spng[l] * d.bm1[l];
+  if (adjoint == 2) {                                  // full equations   [UPSTREAM advab]
+#pragma unroll 1
+    for (int c = 0; c < 3; ++c) to_fine<N>(sJ, uin + c * d.cs + e * NN, so + c * NDD, t1, t2, tid, NT);
+#pragma unroll 1
+    for (int c = 0; c < 3; ++c) {
+#pragma unroll 1
+      for (int p = tid; p < NDD; p += NT) {
+        const int a = p % ND, b = (p / ND) % ND, cc = p / (ND * ND);
+        double g[3];
+        fine_grad<N>(sDd, so + c * NDD, a, b, cc, g);
+        const size_t q = (size_t)e * NDD + p;
+        const double u0 = so[p], u1 = so[NDD + p], u2 = so[2 * NDD + p];
+        double v = 0.0;
+#pragma unroll
+        for (int a2 = 0; a2 < 3; ++a2)               // convecting field c_a = w_d J (u . grad xi_a)
+          v += (d.mtd[(a2 * 3 + 0) * nf + q] * u0 + d.mtd[(a2 * 3 + 1) * nf + q] * u1 + d.mtd[(a2 * 3 + 2) * nf + q] * u2) * g[a2];
+        sf[p] = v;
+      }
+      lds_barrier();
+      const double s = from_fine<N>(sJ, sf, t1, t2, tid, NT, act, k, j, i);
+      if (act) {
+        const double kk = sb * d.nl_spng_str;
+        bf[c * d.cs + l] = ((kk != 0.0) ? kk * (d.spng_vr[c * d.cs + l] - uin[c * d.cs + l]) : 0.0) - s;
+      }
+    }
+    return;
+  }
+  for (int p = tid; p < 3 * NDD; p += NT) so[p] = 0.0;
+#pragma unroll 1
+  for (int c = 0; c < 3; ++c) {
+    to_fine<N>(sJ, uin + c * d.cs + e * NN, sf, t1, t2, tid, NT);
+#pragma unroll 1
+    for (int p = tid; p < NDD; p += NT) {
+      const int a = p % ND, b = (p / ND) % ND, cc = p / (ND * ND);
+      double g[3];
+      fine_grad<N>(sDd, sf, a, b, cc, g);
+      const double uf = sf[p];
+      const size_t q = (size_t)e * NDD + p;
+      const double conv = d.bfc[0 * nf + q] * g[0] + d.bfc[1 * nf + q] * g[1] + d.bfc[2 * nf + q] * g[2];   // (U.grad) u'_c
+      so[c * NDD + p] += adjoint ? -conv : conv;
+#pragma unroll
+      for (int x = 0; x < 3; ++x) {
+        // direct:  + u'_c dU_x/dx_c   (u'.grad) U ;   adjoint:  + u'_c dU_c/dx_x   (grad U)^T u'
+        const double G = adjoint ? d.bfc[(3 + 3 * c + x) * nf + q] : d.bfc[(3 + 3 * x + c) * nf + q];
+        so[x * NDD + p] += uf * G;
+      }
+    }
+    lds_barrier();
+  }
+#pragma unroll 1
+  for (int c = 0; c < 3; ++c) {
+    const double s = from_fine<N>(sJ, so + c * NDD, t1, t2, tid, NT, act, k, j, i);
+    if (act) bf[c * d.cs + l] = -(sb * uin[c * d.cs + l] + s);
+  }
+}
+
 template <int N>
 __global__ __launch_bounds__(Cfg<N>::NT) void k_convect(Dev d, const double* __restrict__ uin,
                                                         double* __restrict__ bf, int adjoint) {
+  if constexpr (N >= 10) { convect_lds<N>(d, uin, bf, adjoint); return; }
   using C = Cfg<N>;
   constexpr int NN = C::NN, ND = C::ND, NDD = C::NDD, NT = C::NT;
   constexpr int PPT = (NDD + NT - 1) / NT;

@@ -229,9 +229,11 @@ def test_arnoldi_3d_matches_oracle():
         h.close()
 
 
-def test_nonlinear_map_and_relinearisation_3d():
-    """Full-equation steps (newton_krylov's nonlinear map) and a new linearisation point on hexahedra."""
-    c = _case(6, True)
+@pytest.mark.parametrize("lx1", [6, 10])
+def test_nonlinear_map_and_relinearisation_3d(lx1):
+    """Full-equation steps (newton_krylov's nonlinear map) and a new linearisation point on hexahedra (lx1 = 10: the
+    convection kernel with its accumulators in LDS, both of its branches)."""
+    c = _case(lx1, True)
     o = _oracle(c)
     h = _hip(c)
     try:
