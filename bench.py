@@ -549,6 +549,8 @@ def main():
             "this_run_same_window": {"matvecs_per_s": 24.0 / float(np.sum(step_s[4:28])) if len(step_s) >= 28 else None, "settings": "production (as `value`)"},
             "round1_bench_settings": dict(rate(1e-9, 3e-1, 8, {"min_pres_iter": 2, "pres_cap": 4}), settings="1e-9 / 3e-1, 2-4 GMRES iterations, 8 projection vectors (BENCH_r01: 15.2 matvecs/s)"),
             "round2_initial_settings": dict(rate(1e-11, 1e-1, 16, {"min_pres_iter": 2}), settings="1e-11 / 1e-1, at least 2 GMRES iterations, 16 projection vectors (9.78 matvecs/s at the start of round 2)"),
+            "production_without_projection_space": dict(rate(a.tol_helm, a.tol_pres, 0, {"min_pres_iter": a.min_pres}),
+                                                         settings="production tolerances, NO projection space: the algorithm `cpu_baseline` runs (its C port has no projection space), for a like-for-like GPU / CPU ratio"),
         }
     if rank == 0 and headline and not a.no_kdim and not a.no_settings_comparison:
         # two and three maps in flight on as many lanes (nsk_matvec_batch) inside a band Arnoldi factorisation: NOT part of `value`

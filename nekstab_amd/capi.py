@@ -158,9 +158,10 @@ class NekStabHip:
     """Device context for one case (``nsk_init`` ... ``nsk_finalize``)."""
 
     def __init__(self, case, vert, nvert, *, tol_helm=1e-9, tol_pres=1e-7, tol_relative=0,
-                 schwarz_layers=2, max_helm_iter=80, max_pres_iter=40, nproj=0, local_own=None):
+                 schwarz_layers=2, max_helm_iter=80, max_pres_iter=40, nproj=0, local_own=None, ifbf2d=False):
         """``local_own`` (rank-local set-up, sharded.LocalParent): ``case`` is a rank's sub-mesh and local_own[e] = 1 marks the
-        elements it owns -> nsk_init_local."""
+        elements it owns -> nsk_init_local.  ``ifbf2d``: hexahedral run about a two-dimensional base flow -- the third base-flow
+        component is forced to zero before the linearised solver is prepared (core/matvec.f:110-112, 'Forcing vz=0')."""
         self.lib = load_library()
         c = case
         f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)
@@ -170,7 +171,7 @@ class NekStabHip:
                           vert=np.ascontiguousarray(vert, dtype=np.int64))
         k = self._keep
         if self.ndim == 3:
-            k["z"], k["wb"] = f64(c.z), f64(c.ub[2])
+            k["z"], k["wb"] = f64(c.z), (np.zeros_like(k["ub"]) if ifbf2d else f64(c.ub[2]))
         cs = NskCase(ndim=self.ndim, nel=c.nel, lx1=c.lx1, lxd=c.lxd, nglob=c.nglob,
                      x=_p(k["x"]), y=_p(k["y"]), gid=k["gid"].ctypes.data_as(_lp), mask=_p(k["mask"]),
                      ub=_p(k["ub"]), vb=_p(k["vb"]), spng=_p(k["spng"]),

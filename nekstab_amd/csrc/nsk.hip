@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -291,6 +292,14 @@ static int coarse_dense_inverse(nsk_ctx* c, std::vector<double>& Ac, bool has_ou
 static int build(nsk_ctx* c, const nsk_case& cs) {
   const int N = cs.lx1, NN = N * N, M = N - 2, MM = M * M, ND = cs.lxd > 0 ? cs.lxd : 3 * N / 2, NDD = ND * ND;
   if (cs.ndim != 2) return fail(NSK_EINVAL, "build(): ndim must be 2");
+  const bool timing = std::getenv("NSK_SETUP_TIMING") != nullptr;       // seconds per set-up section on stderr
+  auto t_last = std::chrono::steady_clock::now();
+  auto tick = [&](const char* what) {
+    if (!timing) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "set-up %-44s %7.3f s\n", what, std::chrono::duration<double>(now - t_last).count());
+    t_last = now;
+  };
   c->ndim = 2; c->key = cs.lx1; c->d.ndim = 2;
   if (!(N == 6 || N == 8 || N == 10 || N == 12)) return fail(NSK_EINVAL, "lx1 must be 6, 8, 10 or 12");
   if (ND != 3 * N / 2) return fail(NSK_EINVAL, "lxd must be 3*lx1/2");
@@ -404,6 +413,7 @@ static int build(nsk_ctx* c, const nsk_case& cs) {
     }
   }
 
+  tick("bases + geometry");
   // ---- gather-scatter CSR from the global numbering
   std::vector<int> gs_off(nloc + 1), gs_idx(nloc);
   std::vector<std::pair<long long, int>> srt(nloc);
@@ -460,6 +470,7 @@ static int build(nsk_ctx* c, const nsk_case& cs) {
   }
   c->bm1s_host = bm1s;
 
+  tick("gather-scatter tables, masks");
   // ---- dt rule  (core/matvec.f:26-46, [UPSTREAM compute_cfl])
   c->cfl_target = cs.cfl;
   {
@@ -521,6 +532,7 @@ static int build(nsk_ctx* c, const nsk_case& cs) {
     if ((rc = dupload(c, &c->xyz, xy))) return rc;
   }
 
+  tick("dt rule, Jacobi diagonals, uploads");
   // ---- state + solver work arrays
   if ((rc = dalloc(c, &d.u, 2 * d.cs)) || (rc = dalloc(c, &d.p, npr)) || (rc = dalloc(c, &d.plag, npr)) ||
       (rc = dalloc(c, &d.pext, npr)) || (rc = dalloc(c, &d.ulag, 4 * d.cs)) || (rc = dalloc(c, &d.exlag, 4 * d.cs)) ||
@@ -541,6 +553,7 @@ static int build(nsk_ctx* c, const nsk_case& cs) {
   HIPCHK(hipHostMalloc((void**)&c->hpin, 4096 * sizeof(double)));
   HIPCHK(hipHostMalloc((void**)&c->hstat_pin, sizeof(Stats)));
 
+  tick("work arrays");
   // ---- element adjacency (shared GLL nodes)
   std::vector<std::vector<int>> nb(nel);
   for (int e = 0; e < nel; ++e) {
@@ -579,6 +592,7 @@ static int build(nsk_ctx* c, const nsk_case& cs) {
       if (cc == ncolour) ++ncolour;
     }
   }
+  tick("adjacency + colouring");
   // ---- probe E = D B^-1 D^T block-sparsely on the device
   std::vector<double> Eblk((size_t)blk_off[nel]);
   {
@@ -611,6 +625,7 @@ static int build(nsk_ctx* c, const nsk_case& cs) {
     return 0.0;
   };
 
+  tick("E blocks probed on the device");
   // ---- coarse space: bilinear vertex functions sampled at the Gauss nodes
   const int nvert = (int)cs.nvert;
   c->nvert = nvert; d.nvert = nvert;
@@ -666,6 +681,7 @@ static int build(nsk_ctx* c, const nsk_case& cs) {
   if ((rc = dupload(c, &d.v_off, v_off)) || (rc = dupload(c, &d.v_ent, v_ent)) || (rc = dupload(c, &d.evert, evert)) ||
       (rc = dalloc(c, &d.xc, nvert))) return rc;
 
+  tick("coarse operator + its inverse");
   // ---- restricted additive Schwarz patches: own Gauss nodes + `layers` rows of every neighbour
   {
     const int L = c->layers;
@@ -674,9 +690,13 @@ static int build(nsk_ctx* c, const nsk_case& cs) {
     d.p_stride = PS;
     std::vector<int> p_idx((size_t)nel * PS, -1);
     std::vector<float> p_inv((size_t)nel * PS * MM, 0.0f);
+    // one dense inverse of ~(lx2 + 2 layers)^2 unknowns per element: 15 s on one host thread at config 3's size -> host threads
+    const int nth = std::max(1, std::min<int>(16, (int)std::thread::hardware_concurrency()));
+    std::atomic<int> singular{0};
+    auto patch_range = [&](int t0) {
     std::vector<int> pe, pr;            // patch dof -> (element, local Gauss index)
     std::vector<double> A;
-    for (int e = 0; e < nel; ++e) {
+    for (int e = t0; e < nel; e += nth) {
       pe.clear(); pr.clear();
       for (int k = 0; k < MM; ++k) { pe.push_back(e); pr.push_back(k); }
       for (size_t s = 1; s < nb[e].size(); ++s) {
@@ -701,15 +721,24 @@ static int build(nsk_ctx* c, const nsk_case& cs) {
       for (int q = 0; q < np; ++q)
         for (int r = 0; r < np; ++r) A[(size_t)r * np + q] = Eentry(pe[r], pr[r], pe[q], pr[q]);
       if (!cs.has_outflow) { double tr = 0; for (int q = 0; q < np; ++q) tr += A[(size_t)q * np + q]; for (int q = 0; q < np; ++q) A[(size_t)q * np + q] += 1e-10 * tr / np; }
-      if (!invert_dense(A, np)) return fail(NSK_EINVAL, "singular Schwarz patch");
+      if (!invert_dense(A, np)) { singular = 1; return; }
       for (int q = 0; q < np; ++q) {
         p_idx[(size_t)e * PS + q] = pe[q] * MM + pr[q];
         for (int r = 0; r < MM; ++r) p_inv[(size_t)e * PS * MM + ((size_t)(q / 4) * MM + r) * 4 + (q % 4)] = (float)A[(size_t)r * np + q];   // [q/4][own row][q%4]
       }
     }
+    };
+    {
+      std::vector<std::thread> pool;
+      for (int t = 1; t < nth; ++t) pool.emplace_back(patch_range, t);
+      patch_range(0);
+      for (auto& th : pool) th.join();
+    }
+    if (singular) return fail(NSK_EINVAL, "singular Schwarz patch");
     c->h_pidx = p_idx; c->PS = PS;
     if ((rc = dupload(c, &d.p_idx, p_idx)) || (rc = dupload(c, &d.p_inv, p_inv))) return rc;
   }
+  tick("Schwarz patches (host inversions)");
   // many workgroups (lx1 = 12 has one element per workgroup: config 3 has 7984): sum every row of partials once
   // (k_tot2) instead of in every consumer workgroup, which is O(nblk^2)
   if (c->nblk > 1024 || std::getenv("NSK_USE_TOT")) {

@@ -202,6 +202,37 @@ def test_extruded_cylinder_matches_2d():
         h2.close(); h3.close()
 
 
+def test_ifbf2d_forces_the_third_base_flow_component_to_zero():
+    """core/matvec.f:110-112: a hexahedral run about a two-dimensional base flow zeroes the base flow's vz before the
+    linearised solver is prepared.  A context given a polluted third component with ifbf2d equals the context of the clean
+    extrusion: same dt / nsteps, same map."""
+    import dataclasses
+    import os
+    from nekstab_amd import mesh
+    here = os.path.dirname(os.path.abspath(__file__))
+    c2 = mesh.load_case_npz(os.path.join(here, "golden", "cylinder_case.npz"), 6)
+    c3 = mesh3d.extrude_case(c2, 2, 1.0, periodic=True)
+    ub = c3.ub.copy()
+    ub[2] = 0.3 * np.sin(c3.x) * c3.mask                       # what a restart file of a 3-D DNS may carry in vz
+    dirty = dataclasses.replace(c3, ub=ub)
+    kw = dict(tol_helm=1e-11, tol_pres=1e-5, tol_relative=1, max_helm_iter=150, max_pres_iter=144)
+    ha, hb, hc = _hip(c3, **kw), _hip(dirty, ifbf2d=True, **kw), _hip(dirty, **kw)
+    try:
+        assert hb.nsteps == ha.nsteps and hb.dt == ha.dt
+        x, y, z = c3.x, c3.y, c3.z
+        q = [np.sin(x + np.pi * z) * c3.mask, np.cos(y) * np.cos(np.pi * z) * c3.mask, np.sin(x - y) * c3.mask, np.zeros(ha.npres)]
+        out = []
+        for h in (ha, hb, hc):
+            v0, v1 = h.alloc(2)
+            h.upload3(v0, *q); h.set_nsteps(3); h.matvec(v1, v0, 0)
+            out.append(h.download3(v1))
+        for k in range(3):
+            assert np.array_equal(out[0][k], out[1][k])
+        assert np.abs(out[2][0] - out[0][0]).max() > 1e-6 * np.abs(out[0][0]).max()     # (without the switch vz does act)
+    finally:
+        ha.close(); hb.close(); hc.close()
+
+
 def test_arnoldi_3d_matches_oracle():
     """Short Arnoldi factorisation on the hexahedral path (full-length maps, host loop of krylov.py) against
     the oracle's Arnoldi (reference algorithm: core/krylov_decomposition.f:7-202)."""
