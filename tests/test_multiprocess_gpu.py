@@ -40,3 +40,24 @@ def test_round3_shard_features_across_processes(kind, world, port):
     print(line, out.stderr[-1500:] if out.returncode else "")
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert line
+
+
+def test_bench_two_ranks_under_the_launcher_dry_run():
+    """`bench.py --gpus 2` exactly as the driver starts it (torch.distributed.run, one supervisor per rank, each starting its
+    worker), with the ranks sharing this GPU and the halos travelling over gloo (NSK_DIST_BACKEND=gloo: the protocol dry run):
+    rank-local set-up, a sharded probe map, the timed sharded Arnoldi steps, ONE JSON line from rank 0 that names the same
+    workload as the N = 1 record and carries the one-GPU rate of the same steps."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", NSK_DIST_BACKEND="gloo")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29661", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cfg3-probe"],
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    r = json.loads(lines[0])
+    print({k: r[k] for k in ("value", "n_gpus", "scaling", "setup")}, r["config"]["parallelism"])
+    assert r["n_gpus"] == 2 and r["steps"] == 2 and r["value"] > 0 and r["scaling"] == "strong"
+    assert "BASELINE configs[1]" in r["config"]["workload"] and "E=1996, lx1=8" in r["config"]["workload"]
+    assert r["setup"]["rank_local"] and r["setup"]["elements_rank0"] < 0.8 * r["setup"]["elements_mesh"]
+    assert r["single_gpu_same_config"]["matvecs_per_s"] > 0
