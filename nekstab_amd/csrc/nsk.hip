@@ -103,6 +103,13 @@ struct nsk_ctx {
   hipStream_t comm_stream = nullptr;
   hipEvent_t orth_ev[2 * ORTH_CHUNKS] = {};
   int shard_graph = -1;                 // sharded step in a hipGraph: -1 = yes unless a communicator is attached, 0 = no, 1 = yes (also with RCCL)
+  // Eager sharded steps with a real transport: every launched iteration costs its halo exchange and all-reduce whether the solve
+  // has converged or not (the host enqueues them; a launch that finds its solve converged is 2 us, a collective is not).  With
+  // "shard_hostcheck" the host reads the device's convergence flags (identical on every rank: they come from all-reduced
+  // sums) and stops issuing iterations: -1 = yes with a communicator / host transport, 0 = never, 1 = always.
+  int shard_hostcheck = -1;
+  int hc_helm[NCLS] = {}, hc_pres[NCLS] = {};           // iterations the last solve of the class used: where the next one is first checked
+  long long hc_checks = 0;                              // flag reads since init (diagnostics)
   double* scratch = nullptr;            // one state vector
   const double* xyz = nullptr;          // GLL coordinates [ndim][nloc] (nsk_seed_noise)
   double* rc_big = nullptr;             // coarse restriction for nvert > 3072
@@ -1580,6 +1587,7 @@ int nsk_set_option(nsk_ctx* c, const char* name, double value) {
   const std::string n(name);
   if (n == "use_graph") c->use_graph = (int)value;
   else if (n == "shard_graph") c->shard_graph = (int)value;
+  else if (n == "shard_hostcheck") c->shard_hostcheck = (int)value;
   else if (n == "orth_overlap") c->orth_overlap = (int)value;
   else if (n == "nscal") {
     // krylov_vector%theta (core/krylov_subspace.f:13): carried by every vector operation and by the inner product; the time

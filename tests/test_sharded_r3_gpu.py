@@ -302,3 +302,55 @@ def test_sharded_adjoint_spectrum_against_reference_table(spectre):
         g.close()
     finally:
         h.close()
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+def test_host_checked_convergence_equals_budgeted_launches(case6, oracle6_nosolve, modes, dim):
+    """Option shard_hostcheck (the default once a transport is attached: a launched iteration costs its halo exchange and its
+    all-reduce whether the solve has converged or not): the host reads the device's convergence flags and stops issuing
+    iterations.  Launches that find their solve converged change nothing, so the maps are BIT-identical to the budgeted ones
+    (eager and captured), with the same iteration counts."""
+    from nekstab_amd.capi import NekStabHip
+    from nekstab_amd.sharded import ShardGroup
+    if dim == 2:
+        case = case6
+        u = modes["dRe_u"].astype(np.float64)
+        q = (u[0], u[1], oracle6_nosolve.J12 @ modes["dRe_p"].astype(np.float64) @ oracle6_nosolve.J12.T)
+        kw = dict(tol_helm=1e-12, tol_pres=1e-6, tol_relative=1, nproj=8, max_helm_iter=120, max_pres_iter=48)
+        nst, R = 14, 3
+    else:
+        from nekstab_amd import mesh3d
+        ubf = lambda x, y, z: np.stack([1.0 - 0.3 * y * y + 0.1 * np.sin(x + z), 0.2 * np.cos(x) * y + 0.1 * z, 0.15 * np.sin(y + 0.5 * z)])
+        case = mesh3d.box_case_3d(4, 3, 2, 6, lengths=(2.0, 1.0, 0.8), outflow_xmax=True, re=40.0, endtime=0.05, ub_func=ubf, warp=0.05)
+        x, y, z = case.x, case.y, case.z
+        q = (np.sin(1.3 * x + z) * np.cos(2.0 * y) * case.mask, np.cos(0.7 * x + 0.2) * np.sin(3.0 * y - z) * case.mask,
+             np.sin(x + y) * np.cos(2.0 * z) * case.mask, np.zeros((case.nel, 4, 4, 4)))
+        kw = dict(tol_helm=1e-12, tol_pres=1e-7, tol_relative=1, max_helm_iter=200, max_pres_iter=48)
+        nst, R = 4, 2
+    h = NekStabHip(case, case.meta["vert"], case.meta["nvert"], **kw)
+    try:
+        out, its = {}, {}
+        for name, opts in (("graph", {}), ("eager", {"shard_graph": 0}), ("hostcheck", {"shard_hostcheck": 1})):
+            g = ShardGroup(h, case, R)
+            for k, v in opts.items():
+                g.set_option(k, v)
+            g.set_nsteps(nst)
+            a, b = g.alloc(2)
+            (g.upload if dim == 2 else g.upload3)(a, *q)
+            res = []
+            for rep in range(2):
+                g.matvec(b, a, 0)
+                res.append((g.download if dim == 2 else g.download3)(b))
+                g.copy(a, b)
+            out[name] = res
+            st = g.stats()
+            its[name] = (st["helm_iters"], st["pres_iters"])
+            g.free([a, b]); g.close()
+        print("iterations of the last map (velocity, pressure):", its)
+        for name in ("eager", "hostcheck"):
+            for rep in range(2):
+                for x0, x1 in zip(out["graph"][rep], out[name][rep]):
+                    assert np.array_equal(x0, x1), (name, rep)
+            assert its[name] == its["graph"]
+    finally:
+        h.close()
