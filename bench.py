@@ -333,6 +333,7 @@ def main():
         pw.daemon = True
         pw.start()
         err = None
+        shard_mode = {}
         try:
             h = make_shard(full, case)
             probe = h.alloc(2)
@@ -342,8 +343,26 @@ def main():
             h.set_nsteps(2)
             h.matvec(probe[1], probe[0], 0)                 # eager: every peer connection and the all-reduce ring exist after this
             if shard_graph == 1 and backend == "nccl":
-                h.set_option("shard_graph", 1)             # from here on: one captured graph per step class, RCCL calls inside
-                h.matvec(probe[1], probe[0], 0)
+                # Two ways to run the sharded step over RCCL, and no hardware to have measured them on before this run: (a) one
+                # captured graph per step class with the RCCL calls inside (no host work per step, but every BUDGETED iteration
+                # pays its exchange and all-reduce); (b) eager launches with the convergence flags read on the host (half to a
+                # third of the collectives, a stream synchronisation per solve).  Time 24 time steps each way, keep the faster.
+                h.set_nsteps(24)
+                times = {}
+                for name, (gr, hcq) in (("graph", (1, 0)), ("hostcheck", (0, 1))):
+                    h.set_option("shard_graph", gr)
+                    h.set_option("shard_hostcheck", hcq)
+                    h.matvec(probe[1], probe[0], 0)         # (captures / settles)
+                    barrier(); tq = time.perf_counter()
+                    h.matvec(probe[1], probe[0], 0)
+                    barrier(); tq = time.perf_counter() - tq
+                    tt = torch.tensor([tq], device="cuda", dtype=torch.float64)
+                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                    times[name] = float(tt.item())
+                shard_mode.update(times, picked="graph" if times["graph"] <= times["hostcheck"] else "hostcheck")
+                gr, hcq = (1, 0) if shard_mode["picked"] == "graph" else (0, 1)
+                h.set_option("shard_graph", gr)
+                h.set_option("shard_hostcheck", hcq)
             h.set_nsteps(ns)
             h.free(probe)
         except Exception as e:                              # noqa: BLE001
@@ -383,7 +402,7 @@ def main():
     par = "1 GPU"
     if world > 1:
         par = ("element-sharded x%d (%s, one eigenproblem, %s)" % (world, "RCCL halos" if backend == "nccl" else "host-staged halos over %s: protocol dry run" % backend,
-               "step graphs" if (shard_graph == 1 and backend == "nccl") else "eager launches")) if sharded else "replicas x%d" % world
+               "step graphs" if (shard_graph == 1 and backend == "nccl" and shard_mode.get("picked") == "graph") else "eager launches, host-read convergence flags")) if sharded else "replicas x%d" % world
     out = {
         "metric": METRIC,
         "value": (world if (world > 1 and not sharded) else 1) * steps / elapsed, "unit": "matvecs/s", "n_gpus": world, "steps": steps, "warmup": a.warmup,
@@ -474,6 +493,8 @@ def main():
                 full = make_context(case)
                 setup_local["whole_mesh_seconds_rank0"] = time.perf_counter() - t0
         out["setup"] = setup_local
+        out["shard_mode"] = dict(shard_mode, note="seconds for 24 sharded time steps with captured step graphs (RCCL calls inside) / with eager launches and host-read convergence flags; the timed run uses the faster") if shard_mode else \
+            {"picked": "hostcheck" if backend != "nccl" or shard_graph == 0 else "graph", "note": "not compared in this attempt"}
         if rank == 0:
             r1 = one_gpu_same_steps(full, case, steps)
             out["single_gpu_same_config"] = {"matvecs_per_s": r1, "sample": "the same %d + %d Arnoldi steps of the same case on rank 0's full-mesh context (hipGraph path), timed after the sharded run" % (a.warmup, steps),
@@ -491,8 +512,9 @@ def main():
             full = make_parent(case3)
             setup3_s = time.perf_counter() - t0
             h = make_shard(full, case3)
-            if shard_graph == 1 and backend == "nccl":
-                h.set_option("shard_graph", 1)             # (connections exist since the headline run)
+            if shard_graph == 1 and backend == "nccl":     # (connections exist since the headline run; the mode that was faster there)
+                h.set_option("shard_graph", 1 if shard_mode.get("picked") == "graph" else 0)
+                h.set_option("shard_hostcheck", 0 if shard_mode.get("picked") == "graph" else 1)
             x3, y3 = seed.add_noise(case3)
             z3 = np.zeros((case3.nel, case3.lx1 - 2, case3.lx1 - 2))
             n3 = 2

@@ -207,7 +207,12 @@ int nsk_group_set_orbit(nsk_ctx** shards, int n, nsk_vec* q0, double spng_str, n
  * preconditioner factors, state, work arrays and ALL vectors allocated on the parent -- their handles become invalid).  The 1-D
  * bases and the replicated coarse operator stay.  The parent then only answers nsk_info / nsk_get_stats / nsk_finalize
  * (finalize it after its shards).  Option "shard_graph" (nsk_set_option on a shard): the sharded step runs as one hipGraph per
- * step class; -1 (default) = yes unless an RCCL communicator is attached, 0 = eager, 1 = yes, RCCL calls captured too. */
+ * step class; -1 (default) = yes unless an RCCL communicator is attached, 0 = eager, 1 = yes, RCCL calls captured too.
+ * Option "shard_hostcheck": eager sharded steps read the device's convergence flags on the host (one 4-128 byte copy and a stream
+ * synchronisation, from the iteration where the previous solve of the step class ended) and stop ISSUING iterations -- a launch
+ * that finds its solve converged costs 2 us, its halo exchange and all-reduce do not; the flags follow from all-reduced sums, so
+ * every rank takes the same decision without talking.  -1 (default) = yes once a transport is attached (RCCL or host-staged),
+ * 0 = never (launch budgets, as the captured graphs), 1 = always (also virtual ranks: no graphs then).  Bit-identical maps. */
 int nsk_shard_release_parent(nsk_ctx* parent);
 /* ---- rank-local set-up (what Nek5000 does by construction: every MPI rank sets up its own elements) ------------
  * Instead of the whole mesh, a rank hands over ITS sub-mesh: the elements it owns plus two rings of node-sharing
