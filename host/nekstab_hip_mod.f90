@@ -292,6 +292,11 @@ module nekstab_hip
       integer(c_int), value :: nranks
       type(c_ptr), intent(out) :: shard
     end function
+    integer(c_int) function nsk_shard_elems(shard, elems) bind(c, name='nsk_shard_elems')
+      import
+      type(c_ptr), value :: shard
+      integer(c_long_long), dimension(*) :: elems
+    end function
     integer(c_int) function nsk_shard_share_stream(shard, leader) bind(c, name='nsk_shard_share_stream')
       import
       type(c_ptr), value :: shard

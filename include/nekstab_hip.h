@@ -188,11 +188,16 @@ int nsk_get_stats(nsk_ctx* ctx, nsk_stats* s);
 /* ---- element sharding: one shard per rank, cut out of a full-mesh context --------
  * part[e] = owning rank of global element e.  The parent's set-up (geometry, Jacobi diagonal,
  * Schwarz patches, coarse inverse) is replicated; state, halos and reductions are per rank.
- * Vectors of a shard hold its own elements only ([vx | vy | pr], local element order = ascending
- * global element id).  Ranks that live in one process ("virtual ranks", what the single-GPU tests
+ * Vectors of a shard hold its own elements only ([vx | vy | pr], local element order: nsk_shard_elems).  Ranks that live in one process ("virtual ranks", what the single-GPU tests
  * use) advance in lock-step through nsk_group_matvec with loop-back copies as transport; ranks in
  * separate processes use RCCL (build with -DNSK_WITH_RCCL, nsk_comm_init_rccl). */
 int nsk_shard_create(nsk_ctx* parent, const int* part, int rank, int nranks, nsk_ctx** out);
+/* Local element order of a shard: its BOUNDARY elements (a node shared with another rank) first, the interior behind, each
+ * group by ascending global id; out[le] = global id of local element le (nsk_vec_upload / _download of a shard move element
+ * blocks in this order).  Option "halo_overlap" (nsk_set_option on the shard, quadrilaterals, eager steps): the velocity solve
+ * launches the boundary workgroups first and sends their halo on a second stream while the interior workgroups run; the
+ * all-reduce of the dot products waits for both (events).  Bit-identical to the serial order of the same shard. */
+int nsk_shard_elems(nsk_ctx* shard, long long* out);
 int nsk_group_matvec(nsk_ctx** shards, int n, int mode, nsk_vec* f, nsk_vec* q);    /* every mode of nsk_matvec */
 /* The rest of the operator interface on shards, for the ranks living in this process (the reference runs all of it under MPI):
  *   nsk_group_nonlinear_map  nonlinear_forward_map, core/newton_krylov.f:336-378 (subtract_q != 0: Phi_T(q) - q)

@@ -58,6 +58,7 @@ SYMBOLS = {
     "nsk_local_finish": (C.c_int, [_vp, C.c_double, C.c_double, C.c_double, C.c_longlong, C.c_longlong, C.POINTER(C.c_int), C.POINTER(C.c_int), _dp]),
     "nsk_shard_create_local": (C.c_int, [_vp, C.POINTER(C.c_int), _lp, C.c_int, C.c_int, _vpp]),
     "nsk_shard_share_stream": (C.c_int, [_vp, _vp]),
+    "nsk_shard_elems": (C.c_int, [_vp, _lp]),
     "nsk_last_error": (C.c_char_p, []),
     "nsk_get_info": (C.c_int, [_vp, _dp, C.POINTER(C.c_int), _lp, _lp, _lp]),
     "nsk_set_nsteps": (C.c_int, [_vp, C.c_int]),

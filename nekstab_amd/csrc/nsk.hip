@@ -108,6 +108,16 @@ struct nsk_ctx {
   // "shard_hostcheck" the host reads the device's convergence flags (identical on every rank: they come from all-reduced
   // sums) and stops issuing iterations: -1 = yes with a communicator / host transport, 0 = never, 1 = always.
   int shard_hostcheck = -1;
+  // The same on a full-mesh context (option "hostcheck"): eager steps, no launch budgets, no redone maps.  -1 = yes for large
+  // hexahedral meshes (>= 8192 elements: a launch that only finds its solve converged costs 25-140 us there and a map redone
+  // with larger budgets tens of seconds), 0 = never, 1 = always.
+  int hostcheck = -1;
+  // Halo / interior overlap of the velocity solve on shards (quadrilaterals): a shard keeps its BOUNDARY elements (those with a
+  // node another rank shares) first; k_helm is launched for the boundary workgroups, their halo travels on a second stream
+  // while the interior workgroups run, and the reduction that follows waits for both.  Option "halo_overlap" (0 / 1).
+  int halo_overlap = 0, nbb = 0;                        // nbb: workgroups that hold boundary elements
+  hipEvent_t ov_ev[2] = {nullptr, nullptr};
+  std::vector<long long> elems_glob;                    // global ids of the owned elements in LOCAL order (nsk_shard_elems)
   int hc_helm[NCLS] = {}, hc_pres[NCLS] = {};           // iterations the last solve of the class used: where the next one is first checked
   long long hc_checks = 0;                              // flag reads since init (diagnostics)
   double* scratch = nullptr;            // one state vector
@@ -793,7 +803,35 @@ static void launch_update_coarse(nsk_ctx* c, const Dev& d, int j, double scale, 
   else hipLaunchKernelGGL(k_update_coarse<12>, dim3(cgrid), dim3(256), sh, c->stream, d, j, scale, min_iter, ord);
 }
 
-static int pres_solve_launch(nsk_ctx* c, double h2, int ord, int np, double tol_mul = 1.0, bool allow_cap = false) {
+static bool stream_capturing(hipStream_t s) {
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  return hipStreamIsCapturing(s, &st) == hipSuccess && st == hipStreamCaptureStatusActive;
+}
+// host-checked convergence (options "hostcheck" / "shard_hostcheck"): the device's convergence flags, read by the host --
+// which = 0: every component of the velocity solve after launch `it`; which = 1: the pressure GMRES
+static int flags_done(nsk_ctx* c, int which, int it, bool* done) {
+  c->hc_checks++;
+  if (which == 0) {
+    HIPCHK(hipMemcpyAsync(c->hpin, c->d.hscal + (size_t)(it & 1) * c->hstride, c->hstride * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    bool all = true;
+    for (int cc = 0; cc < c->ndim; ++cc) all = all && c->hpin[cc * 4 + 2] != 0.0;
+    *done = all;
+  } else {
+    int* flag = (int*)c->hpin;
+    HIPCHK(hipMemcpyAsync(flag, &c->d.gsc->done, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    *done = *flag != 0;
+  }
+  return 0;
+}
+static bool hostcheck_on(const nsk_ctx* c) {
+  if (c->parent || c->fused || c->in_test) return false;
+  if (c->hostcheck >= 0) return c->hostcheck != 0;
+  return c->ndim == 3 && c->nel >= 8192;
+}
+
+static int pres_solve_launch(nsk_ctx* c, double h2, int ord, int np, double tol_mul = 1.0, bool allow_cap = false, bool hc = false) {
   Dev d = c->d;                                            // by value: the early steps of a map run with a tighter tolerance
   d.tol_pres = early_tol(d, tol_mul);
   // time steps >= 4: optionally a bounded solve (min_pres_iter .. pres_cap iterations): nothing is launched beyond the cap
@@ -812,8 +850,14 @@ static int pres_solve_launch(nsk_ctx* c, double h2, int ord, int np, double tol_
     // Only the first `merged_iters` (12) iterations of a solve: x_c(v_j) by linearity is a recurrence, its rounding error grows by
     // ~|h_jj / h_{j+1,j}| per iteration (harmless in a preconditioner for a dozen iterations, a stalled solve after forty:
     // measured on the 1e-8 solves of test_newton_gpu); later iterations take the classic four kernels.
-    const bool merged = c->merged_update && c->ndim == 2 && d.coarse_lda <= 3072 && !d.use_tot && d.nranks <= 1 && d.rch;
+    const bool merged = c->merged_update && c->ndim == 2 && d.coarse_lda <= 3072 && !d.use_tot && d.nranks <= 1 && d.rch && !hc;
     const int nm = merged ? std::min(np, std::min(c->merged_iters, c->gmres_cycle)) : 0;
+    if (hc && c->hc_pres[ord] <= 1) {                     // the projection space may have solved this right-hand side alone
+      bool done = false;
+      int rc2 = flags_done(c, 1, 0, &done);
+      if (rc2) return rc2;
+      if (done) { c->hc_pres[ord] = 0; np = 0; }
+    }
     for (int j = 0; j < nm; ++j) {
       launch_update_coarse(c, d, j, scale, c->min_pres, ord);
       hipLaunchKernelGGL(k_schwarz<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, (const double*)(d.V + (size_t)j * d.ps), d.Z + (size_t)j * d.npr, 1, 1);
@@ -849,6 +893,12 @@ static int pres_solve_launch(nsk_ctx* c, double h2, int ord, int np, double tol_
       }
       Dev d2 = d; d2.gs2 = two ? 1 : 0;
       hipLaunchKernelGGL(k_gmres_update<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d2, j, scale, c->min_pres, ord);
+      if (hc && jt + 1 < np && jt + 2 >= c->hc_pres[ord]) {
+        bool done = false;
+        int rc2 = flags_done(c, 1, 0, &done);
+        if (rc2) return rc2;
+        if (done) { c->hc_pres[ord] = jt + 1; break; }
+      }
     }
   });
   return 0;
@@ -884,7 +934,8 @@ static int fused_possible(nsk_ctx* c) {
 static int step(nsk_ctx* c, int istep, int adjoint) {
   Dev& d = c->d;
   const StepCoef sc = make_coef(c, istep, adjoint);
-  const int nh = c->cur_helm[sc.cls];
+  const bool hc = hostcheck_on(c) && !stream_capturing(c->stream);
+  int nh = hc ? c->max_helm : c->cur_helm[sc.cls];
   DISPATCH_N(c->key, {
     constexpr int NT = Cfg<N>::NT;
     if (c->key == 108 && adjoint != 2 && c->mfma_convect)
@@ -900,13 +951,19 @@ static int step(nsk_ctx* c, int istep, int adjoint) {
       for (int it = 0; it < nh; ++it) {
         hipLaunchKernelGGL(k_helm<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, sc, it, (const double*)d.rloc);
         tot_rows(c, d.hpart + (size_t)(it & 1) * c->hrows * c->nblk, c->hrows, d.htot + (it & 1) * c->hstride);
+        if (hc && it >= 1 && it >= c->hc_helm[sc.cls] && ((it - c->hc_helm[sc.cls]) % 2 == 0)) {
+          bool done = false;
+          int rc2 = flags_done(c, 0, it, &done);
+          if (rc2) return rc2;
+          if (done) { c->hc_helm[sc.cls] = std::max(1, it - 1); nh = it + 1; break; }
+        }
       }
       hipLaunchKernelGGL(k_pres_rhs<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, sc, (nh - 1) & 1, nh - 1);
     }
   });
   // The first steps of a map project out whatever divergence the input vector has (a noise seed is far from
   // solenoidal): an error there survives to the end of the map, so those solves are converged further.
-  int rc = pres_solve_launch(c, sc.h2, sc.cls, c->cur_pres[sc.cls], istep <= 3 ? c->early_pres_mul : 1.0, adjoint != 2);
+  int rc = pres_solve_launch(c, sc.h2, sc.cls, hc ? c->max_pres : c->cur_pres[sc.cls], istep <= 3 ? c->early_pres_mul : 1.0, adjoint != 2, hc);
   if (rc) return rc;
   DISPATCH_N(c->key, {
     hipLaunchKernelGGL(k_pres_update<N>, dim3(c->nblk), dim3(Cfg<N>::NT), 0, c->stream, d, sc);
@@ -948,7 +1005,7 @@ static int run_map(nsk_ctx* c, int adjoint, double* f, const double* q) {
   Dev& d = c->d;
   // one- and two-step maps (newton.py: time derivative of the orbit) run eagerly: capturing six step-class graphs for them
   // costs more than the steps, and their iteration counts say nothing about the budgets of the real maps
-  const bool use_graph = c->use_graph && c->nsteps > 2;
+  const bool use_graph = c->use_graph && c->nsteps > 2 && !hostcheck_on(c);
   if (use_graph)
     for (int k = 0; k < NCLS; ++k) { int rc = ensure_graph(c, k, adjoint); if (rc) return rc; }
   for (int cc = 0; cc < c->ndim; ++cc)
@@ -1532,6 +1589,14 @@ int nsk_shard_create_local(nsk_ctx* P, const int* part_sub, const long long* ele
   return shard_create(P, part_sub, rank, nranks, out, elem_glob);
 }
 
+// Global ids of a shard's elements in its LOCAL order (boundary elements first, each group ascending): the order of the
+// element blocks inside its vectors, i.e. what nsk_vec_upload / nsk_vec_download of a shard expect and return.
+int nsk_shard_elems(nsk_ctx* shard, long long* out) {
+  if (!shard || !shard->parent || !out) return fail(NSK_EINVAL, "needs a shard context");
+  std::copy(shard->elems_glob.begin(), shard->elems_glob.end(), out);
+  return 0;
+}
+
 // Virtual ranks (several shards in one process) advance in stream order on ONE stream.  Shards cut from one parent share its
 // stream; shards of separate rank-local parents are moved onto the first one's stream with this call.
 int nsk_shard_share_stream(nsk_ctx* shard, nsk_ctx* leader) {
@@ -1551,6 +1616,7 @@ int nsk_finalize(nsk_ctx* c) {
   if (c->hs_send) (void)hipHostFree(c->hs_send);
   if (c->hs_recv) (void)hipHostFree(c->hs_recv);
   if (c->comm_stream) { (void)hipStreamSynchronize(c->comm_stream); for (auto& e : c->orth_ev) if (e) (void)hipEventDestroy(e); (void)hipStreamDestroy(c->comm_stream); }
+  for (auto& e : c->ov_ev) if (e) (void)hipEventDestroy(e);
   if (c->comm && rccl_rt::CommDestroy) (void)rccl_rt::CommDestroy(c->comm);
   if (c->stream && !c->parent) (void)hipStreamDestroy(c->stream);      // shards share the parent's stream (clones have their own)
   delete c;
@@ -1588,6 +1654,8 @@ int nsk_set_option(nsk_ctx* c, const char* name, double value) {
   if (n == "use_graph") c->use_graph = (int)value;
   else if (n == "shard_graph") c->shard_graph = (int)value;
   else if (n == "shard_hostcheck") c->shard_hostcheck = (int)value;
+  else if (n == "hostcheck") c->hostcheck = (int)value;
+  else if (n == "halo_overlap") c->halo_overlap = value != 0.0;
   else if (n == "orth_overlap") c->orth_overlap = (int)value;
   else if (n == "nscal") {
     // krylov_vector%theta (core/krylov_subspace.f:13): carried by every vector operation and by the inner product; the time

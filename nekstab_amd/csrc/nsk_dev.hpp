@@ -63,6 +63,7 @@ struct Stats {
 
 struct Dev {
   int nel, nblk, nvert;
+  int boff;                      // set per launch: first workgroup of this launch (k_helm on shards: boundary elements first, interior behind)
   int gs2;                       // set per launch: the GMRES column of this k_gmres_update had a second Gram-Schmidt pass (k_gmres_reorth)
   long long nloc, npr;
   long long cs, ps;              // component stride of velocity-mesh arrays / stride of the GMRES basis V

@@ -619,13 +619,14 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_rhs(Dev d, StepCoef sc) {
 // ---------------------------------------------------------------------------
 template <int N>
 __global__ __launch_bounds__(Cfg<N>::NT) void k_helm(Dev d, StepCoef sc, int it, const double* rhs) {
+  const int bid = blockIdx.x + d.boff;       // (shards with halo / interior overlap launch the boundary workgroups first, the rest with an offset)
   using C = Cfg<N>;
   constexpr int NN = C::NN, EPB = C::EPB, NT = C::NT;
   __shared__ double sD[NN], sDt[NN];
   __shared__ double sz[2 * EPB * NN], st1[2 * EPB * NN], st2[2 * EPB * NN];
   __shared__ double sred[8 * 16];
   const int tid = threadIdx.x, el = tid / NN, nd = tid % NN;
-  const long long e = (long long)blockIdx.x * EPB + el;
+  const long long e = (long long)bid * EPB + el;
   const bool act = (el < EPB) && (e < d.nel);
   const int j = nd / N, i = nd % N;
   const long long l = e * NN + nd, nl = d.cs;
@@ -642,7 +643,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_helm(Dev d, StepCoef sc, int it,
   }
   if (act) tab = d.gs_tab[l];
   if (it > 2 && o[2] != 0.0 && o[6] != 0.0) {   // finished earlier: cheapest exit
-    if (blockIdx.x == 0 && tid < 8) d.hscal[par * 8 + tid] = o[tid & 7];
+    if (bid == 0 && tid < 8) d.hscal[par * 8 + tid] = o[tid & 7];
     return;
   }
   // ---- phase A: issue every independent global load before anything waits
@@ -678,7 +679,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_helm(Dev d, StepCoef sc, int it,
   }
   const double dreg = (tid < NN) ? d.D[tid] : 0.0;
   if (it > 1 && o[2] != 0.0 && o[6] != 0.0) {        // both components finished earlier
-    if (blockIdx.x == 0 && tid < 8) d.hscal[par * 8 + tid] = o[tid];
+    if (bid == 0 && tid < 8) d.hscal[par * 8 + tid] = o[tid];
     return;
   }
   NSK_STAMP(1);
@@ -718,7 +719,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_helm(Dev d, StepCoef sc, int it,
         if (it == 1) { beta[c] = 0.0; alpha[c] = g / del; }
         else { beta[c] = g / o[c * 4 + 0]; alpha[c] = g / (del - beta[c] * g / o[c * 4 + 1]); }
       }
-      if (blockIdx.x == 0 && tid == 0) {
+      if (bid == 0 && tid == 0) {
         double* cur = d.hscal + par * 8 + c * 4;
         cur[0] = g; cur[1] = alpha[c]; cur[2] = done[c] ? 1.0 : 0.0;
         cur[3] = was ? o[c * 4 + 3] : res;
@@ -778,7 +779,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_helm(Dev d, StepCoef sc, int it,
   }
   block_reduce<8>(v, sred, tid, NT);
   NSK_STAMP(6);
-  if (tid < 8) d.hpart[((size_t)par * 8 + tid) * d.nblk + blockIdx.x] = v[tid];
+  if (tid < 8) d.hpart[((size_t)par * 8 + tid) * d.nblk + bid] = v[tid];
   NSK_STAMP(7);
 }
 

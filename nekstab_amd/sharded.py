@@ -147,6 +147,14 @@ def local_parents(case, nranks: int, part=None, **kw):
     return P, part
 
 
+def _shard_elems(lib, ctx, n):
+    out = np.empty(n, dtype=np.int64)
+    rc = lib.nsk_shard_elems(ctx, out.ctypes.data_as(C.POINTER(C.c_longlong)))
+    if rc != 0:
+        raise NskError(rc, lib.nsk_last_error().decode())
+    return out
+
+
 class ShardVec:
     def __init__(self, parts):
         self.parts = parts            # one device handle per rank
@@ -180,6 +188,7 @@ class ShardGroup:
                 if r:
                     self._chk(self.lib.nsk_shard_share_stream(out, self.ctx[0]))     # virtual ranks run in stream order
             self.ctx.append(out)
+            self.elems[r] = _shard_elems(self.lib, out, len(self.elems[r]))      # the shard's own order: boundary elements first
         self._arr = (C.c_void_p * nranks)(*[c.value for c in self.ctx])
 
     def _chk(self, rc):
@@ -392,6 +401,7 @@ class ShardRank:
                                                       full.sub.ctypes.data_as(C.POINTER(C.c_longlong)), rank, nranks, C.byref(self.ctx)))
         else:
             self._chk(self.lib.nsk_shard_create(full.ctx, self.part.ctypes.data_as(C.POINTER(C.c_int)), rank, nranks, C.byref(self.ctx)))
+        self.elems = _shard_elems(self.lib, self.ctx, self.nel)        # the shard's own order: boundary elements first
         if unique_id is not None:
             buf = C.create_string_buffer(bytes(unique_id), 128)
             self._chk(self.lib.nsk_comm_init_rccl(self.ctx, C.cast(buf, C.c_void_p)))

@@ -34,6 +34,8 @@ def main_r3(kind):
     from nekstab_amd.sharded import LocalParent, ShardRank, attach_host_transport, partition_rcb
     golden = os.path.join(ROOT, "tests", "golden")
     errs = []
+    overlap = kind.endswith("-overlap")     # halo of the boundary workgroups on a second stream while the interior workgroups run
+    kind = kind.replace("-overlap", "")
     local = kind.endswith("-local")         # rank-local set-up: this rank's sub-mesh only, global facts through dist (LocalParent.finish_dist)
     kind = kind.replace("-local", "")
     if kind in ("adjoint", "proj"):
@@ -52,6 +54,8 @@ def main_r3(kind):
         else:
             sh = ShardRank(full, case, rank, world, None, part)
         tr = attach_host_transport(sh, dist)
+        if overlap:
+            sh.set_option("halo_overlap", 1)
         ns = 5 if adj else 12
         sh.set_nsteps(ns); full.set_nsteps(ns)
         vq, vf = sh.alloc(2)

@@ -233,6 +233,43 @@ def test_ifbf2d_forces_the_third_base_flow_component_to_zero():
         ha.close(); hb.close(); hc.close()
 
 
+def test_host_checked_convergence_full_mesh_context():
+    """Option hostcheck (default on hexahedral meshes of >= 8192 elements, where a launch that only finds its solve converged
+    costs 25-140 us and a map redone with larger launch budgets tens of seconds): eager steps, the host reads the device's
+    convergence flags and stops issuing iterations.  Bit-identical to the budgeted launches (captured or eager), same counts,
+    and no launch budget to exceed."""
+    c = _case(8, True)
+    x, y, z = c.x, c.y, c.z
+    q = [np.sin(1.3 * x + z) * np.cos(2.0 * y) * c.mask, np.cos(0.7 * x + 0.2) * np.sin(3.0 * y - z) * c.mask,
+         np.sin(x + y) * np.cos(2.0 * z) * c.mask, np.zeros((c.nel, 6, 6, 6))]
+    out, its = {}, {}
+    for name, opts in (("graph", {}), ("eager", {"use_graph": 0}), ("hostcheck", {"hostcheck": 1})):
+        h = _hip(c, nproj=4)
+        try:
+            for k, v in opts.items():
+                h.set_option(k, v)
+            a, b = h.alloc(2)
+            h.upload3(a, *q)
+            h.set_nsteps(5)
+            res = []
+            for rep in range(2):
+                h.matvec(b, a, 0)
+                res.append(h.download3(b))
+                h.copy(a, b)
+            out[name] = res
+            st = h.stats()
+            its[name] = (st["helm_iters"], st["pres_iters"], st["retries"])
+        finally:
+            h.close()
+    print("iterations of the last map (velocity, pressure, redone maps):", its)
+    for name in ("eager", "hostcheck"):
+        for rep in range(2):
+            for x0, x1 in zip(out["graph"][rep], out[name][rep]):
+                assert np.array_equal(x0, x1), (name, rep)
+        assert its[name][:2] == its["graph"][:2]
+    assert its["hostcheck"][2] == 0
+
+
 def test_arnoldi_3d_matches_oracle():
     """Short Arnoldi factorisation on the hexahedral path (full-length maps, host loop of krylov.py) against
     the oracle's Arnoldi (reference algorithm: core/krylov_decomposition.f:7-202)."""
