@@ -95,7 +95,10 @@ int nsk_set_tolerances(nsk_ctx* ctx, double tol_helm, double tol_pres, int relat
  * "mfma_convect" (hexahedra, lx1 = 8: convection contractions on v_mfma_f64_16x16x4_f64, default 1),
  * "merged_update" / "merged_iters" (quadrilaterals with the dense in-LDS coarse solve: the GMRES column bookkeeping runs inside
  * the coarse-solve kernel for the first `merged_iters` iterations of a solve, default 1 / 12; same iteration counts and results to
- * rounding as the classic four-kernel iteration), "shard_graph" (shard contexts, see nsk_shard_release_parent below),
+ * rounding as the classic four-kernel iteration), "shard_graph" / "shard_hostcheck" / "halo_overlap" (shard contexts, see
+ * nsk_shard_release_parent and nsk_shard_elems below), "hostcheck" (full-mesh contexts: eager time steps in which the host reads
+ * the device's convergence flags and stops issuing solver iterations -- no launch budgets, no redone maps; -1 = default: yes on
+ * hexahedral meshes of >= 8192 elements, where a launch that only finds its solve converged costs 25-140 us; 0 / 1; bit-identical),
  * "proj_restart" (1, default: a full projection space restarts on the latest total solution -- Fischer's / Nek5000's rule; 0: the
  * rounds-1-2 policy of merging into the oldest slot, kept for A/B runs), "gs2_from" (quadrilaterals: GMRES columns from this
  * iteration of a cycle on get a second Gram-Schmidt pass, default 48 = never; hexahedra always), "orth_overlap" (RCCL ranks: nsk_orth
