@@ -893,7 +893,9 @@ static int pres_solve_launch(nsk_ctx* c, double h2, int ord, int np, double tol_
       }
       Dev d2 = d; d2.gs2 = two ? 1 : 0;
       hipLaunchKernelGGL(k_gmres_update<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d2, j, scale, c->min_pres, ord);
-      if (hc && jt + 1 < np && jt + 2 >= c->hc_pres[ord]) {
+      // large meshes: an iteration takes milliseconds, a flag read microseconds -> after every iteration; otherwise from three
+      // iterations before the previous solve's count on
+      if (hc && jt + 1 < np && (c->nel >= 8192 || jt + 4 >= c->hc_pres[ord])) {
         bool done = false;
         int rc2 = flags_done(c, 1, 0, &done);
         if (rc2) return rc2;
