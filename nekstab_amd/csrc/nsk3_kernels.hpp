@@ -609,7 +609,7 @@ __global__ __launch_bounds__(Cfg<N>::NT, 4) void k_helm(Dev d, StepCoef sc, int 
   __shared__ double sred[4 * 16];
   __shared__ int sW[NT * 8];
   const int tid = threadIdx.x;
-  const long long e = xcd_element(blockIdx.x, gridDim.x);
+  const long long e = d.boff + xcd_element(blockIdx.x, gridDim.x);      // (boff: shards launch their boundary elements first, the interior behind)
   const bool act = tid < NN;
   const int k = tid / (N * N), j = (tid / N) % N, i = tid % N;
   const long long l = e * NN + tid, nl = d.cs;
@@ -631,7 +631,7 @@ __global__ __launch_bounds__(Cfg<N>::NT, 4) void k_helm(Dev d, StepCoef sc, int 
         if (it == 1) { beta[c] = 0.0; alpha[c] = gg / del; }
         else { beta[c] = gg / o[c * 4 + 0]; alpha[c] = gg / (del - beta[c] * gg / o[c * 4 + 1]); }
       }
-      if (blockIdx.x == 0 && tid == 0) {
+      if (blockIdx.x == 0 && d.boff == 0 && tid == 0) {
         double* cur = d.hscal + par * 16 + c * 4;
         const double keep = was ? o[c * 4 + 3] : res;
         cur[0] = gg; cur[1] = alpha[c]; cur[2] = done[c] ? 1.0 : 0.0; cur[3] = keep;

@@ -394,3 +394,35 @@ def test_halo_interior_overlap_equals_serial_order(case6, oracle6_nosolve, modes
         assert _rel(oracle6_nosolve.bm1, out["overlap"], ref) < 1e-8
     finally:
         h.close()
+
+
+def test_halo_interior_overlap_hexahedra():
+    """The same on hexahedral shards (three velocity components per halo message, workgroup -> element map with the XCD
+    de-interleave inside each of the two launches): bit-identical to the serial order, two ranks and three."""
+    from nekstab_amd import mesh3d
+    from nekstab_amd.capi import NekStabHip
+    from nekstab_amd.sharded import ShardGroup
+    ubf = lambda x, y, z: np.stack([1.0 - 0.3 * y * y + 0.1 * np.sin(x + z), 0.2 * np.cos(x) * y + 0.1 * z, 0.15 * np.sin(y + 0.5 * z)])
+    c = mesh3d.box_case_3d(6, 4, 3, 6, lengths=(3.0, 1.5, 1.0), outflow_xmax=True, re=40.0, endtime=0.05, ub_func=ubf, warp=0.05)
+    x, y, z = c.x, c.y, c.z
+    q = (np.sin(1.3 * x + z) * np.cos(2.0 * y) * c.mask, np.cos(0.7 * x + 0.2) * np.sin(3.0 * y - z) * c.mask,
+         np.sin(x + y) * np.cos(2.0 * z) * c.mask, np.zeros((c.nel, 4, 4, 4)))
+    h = NekStabHip(c, c.meta["vert"], c.meta["nvert"], tol_helm=1e-12, tol_pres=1e-7, tol_relative=1, max_helm_iter=200, max_pres_iter=48)
+    try:
+        for R in (2, 3):
+            out = {}
+            for name, opts in (("serial", {"shard_graph": 0}), ("overlap", {"shard_graph": 0, "halo_overlap": 1}), ("overlap + host check", {"shard_hostcheck": 1, "halo_overlap": 1})):
+                g = ShardGroup(h, c, R)
+                for k, v in opts.items():
+                    g.set_option(k, v)
+                g.set_nsteps(4)
+                a, b = g.alloc(2)
+                g.upload3(a, *q)
+                g.matvec(b, a, 0)
+                out[name] = g.download3(b)
+                g.free([a, b]); g.close()
+            for name in ("overlap", "overlap + host check"):
+                for x0, x1 in zip(out["serial"], out[name]):
+                    assert np.array_equal(x0, x1), (R, name)
+    finally:
+        h.close()
