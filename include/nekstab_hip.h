@@ -197,9 +197,9 @@ int nsk_get_stats(nsk_ctx* ctx, nsk_stats* s);
 int nsk_shard_create(nsk_ctx* parent, const int* part, int rank, int nranks, nsk_ctx** out);
 /* Local element order of a shard: its BOUNDARY elements (a node shared with another rank) first, the interior behind, each
  * group by ascending global id; out[le] = global id of local element le (nsk_vec_upload / _download of a shard move element
- * blocks in this order).  Option "halo_overlap" (nsk_set_option on the shard, quadrilaterals, eager steps): the velocity solve
- * launches the boundary workgroups first and sends their halo on a second stream while the interior workgroups run; the
- * all-reduce of the dot products waits for both (events).  Bit-identical to the serial order of the same shard. */
+ * blocks in this order).  Option "halo_overlap" (nsk_set_option on the shard, eager steps): the velocity solve and the
+ * pressure iteration launch the boundary workgroups apart from the interior ones and move the halos on a second stream while
+ * the interior workgroups run; the all-reduces wait for both (events).  Bit-identical to the serial order of the same shard. */
 int nsk_shard_elems(nsk_ctx* shard, long long* out);
 int nsk_group_matvec(nsk_ctx** shards, int n, int mode, nsk_vec* f, nsk_vec* q);    /* every mode of nsk_matvec */
 /* The rest of the operator interface on shards, for the ranks living in this process (the reference runs all of it under MPI):

@@ -981,7 +981,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_schwarz(Dev d, const double* __r
   __shared__ double sa[NN], sb[NN];
   __shared__ double sP[3 * MM], sC[3 * NMM], sE[2 * NNM];
   const int tid = threadIdx.x;
-  const long long e = blockIdx.x;
+  const long long e = (blockIdx.x + d.boff);
   const bool act = tid < NN;
   const int k = tid / (N * N), j = (tid / N) % N, i = tid % N;
   if (check_done && d.gsc->done) return;
@@ -1068,7 +1068,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_divgs(Dev d, const double* __res
   __shared__ double su[3 * NN], sA[2 * NNM], sB[3 * NMM];
   __shared__ double sdot[(MAXMR + 2) * 16];
   const int tid = threadIdx.x;
-  const long long e = blockIdx.x;
+  const long long e = (blockIdx.x + d.boff);
   const bool act = tid < NN;
   if (check_done && d.gsc->done) return;
   const long long l = e * NN + tid;
@@ -1096,7 +1096,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_divgs(Dev d, const double* __res
       double t = 0.0;
 #pragma unroll
       for (int ww = 0; ww < (MM + 63) / 64; ++ww) t += sdot[tid * 16 + ww];
-      d.gpart[(size_t)tid * d.nblk + blockIdx.x] = t;
+      d.gpart[(size_t)tid * d.nblk + (blockIdx.x + d.boff)] = t;
     }
   }
 }

@@ -1490,7 +1490,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_schwarz(Dev d, const double* __r
   __shared__ double sP[4 * EPB * MM], sB[4 * EPB * NM];
   __shared__ double sr[EPB * MAXP];
   const int tid = threadIdx.x, el = tid / NN, nd = tid % NN;
-  const long long e = (long long)blockIdx.x * EPB + el;
+  const long long e = (long long)(blockIdx.x + d.boff) * EPB + el;
   const bool act = (el < EPB) && (e < d.nel);
   if (check_done && d.gsc->done) return;
   const int PS = d.p_stride;
@@ -1592,7 +1592,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_divgs(Dev d, const double* __res
   __shared__ double su[2 * EPB * NN], sA[4 * EPB * NM];
   __shared__ double sdot[(MAXMR + 2) * 4];
   const int tid = threadIdx.x, el = tid / NN, nd = tid % NN;
-  const long long e = (long long)blockIdx.x * EPB + el;
+  const long long e = (long long)(blockIdx.x + d.boff) * EPB + el;
   const bool act = (el < EPB) && (e < d.nel);
   NSK_STAMP(0);
   if (check_done && d.gsc->done) return;
@@ -1644,7 +1644,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_divgs(Dev d, const double* __res
       double t = 0.0;
 #pragma unroll
       for (int ww = 0; ww < NW; ++ww) t += sdot[tid * 4 + ww];
-      d.gpart[(size_t)tid * d.nblk + blockIdx.x] = t;
+      d.gpart[(size_t)tid * d.nblk + (blockIdx.x + d.boff)] = t;
     }
     NSK_STAMP(4);
   }
