@@ -303,6 +303,8 @@ def main():
         if backend != "nccl":
             from nekstab_amd.sharded import attach_host_transport
             attach_host_transport(sh, dist)
+            if os.environ.get("NSK_BENCH_HALO_OVERLAP") == "1":     # dry run: interior workgroups run while gloo moves the halos
+                sh.set_option("halo_overlap", 1)
         else:
             sh.set_option("shard_graph", 0)                # eager until the first exchanges have run (RCCL sets its peer connections up lazily: not inside a capture)
         return sh

@@ -40,9 +40,13 @@ for p in P:
 print("coarse rows of all ranks: %d entries (%.0f MB); finish (dt, Jacobi diagonals, replicated coarse solve) %.1f s per rank" % (len(a), 16e-6 * len(a), np.mean(tf)), flush=True)
 g = ShardGroup(P, c3, R, part)
 g.release_parent()
+for k, v in (("shard_hostcheck", os.environ.get("HOSTCHECK")), ("halo_overlap", os.environ.get("HALO_OVERLAP"))):
+    if v is not None:
+        g.set_option(k, int(v))
 g.set_nsteps(nst)
 sq, sf = g.alloc(2)
 g.upload3(sq, *q)
+g.matvec(sf, sq, 1)                                   # (first map: captures / settles)
 t0 = time.time(); g.matvec(sf, sq, 1); g.norm(sf); tm = time.time() - t0
 got = g.download3(sf)
 sl = g.stats()
