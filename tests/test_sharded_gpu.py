@@ -112,6 +112,15 @@ def test_rccl_transport_single_rank_plumbing(hip6, case6, oracle6_nosolve, modes
     got = s.download_local(b)
     for x, y in zip(got, ref):
         assert np.abs(x - y).max() <= 1e-12 * np.abs(y).max()
+    # the mode bench.py --gpus N tries first on a node: the sharded step as one captured graph per step class WITH the RCCL
+    # calls inside (here: the all-reduces of a one-rank communicator -- what one GPU can exercise of it); bit-identical to the
+    # eager, host-checked run above
+    s.set_option("shard_graph", 1)
+    s.set_option("shard_hostcheck", 0)
+    s.matvec(b, a, 0)
+    for x, y in zip(s.download_local(b), got):
+        assert np.array_equal(x, y)
+    assert s.stats()["recaptures"] > 0
     s.free([a, b]); s.close()
     hip6.free([vq, vf]); hip6.set_nsteps(100)
 
