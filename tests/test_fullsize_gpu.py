@@ -82,6 +82,62 @@ def test_config4_backstep_extruded_E50100_adjoint():
     h.close()
 
 
+def test_config4_rank_local_setup_and_shards_at_full_size():
+    """Config 4 is an 8-GPU case: at its full size, two ranks set up from THEIR sub-meshes (own elements + two rings:
+    sharded.LocalParent), exchange volume / CFL maximum / coarse rows, and run the sharded adjoint step with host-checked
+    convergence -- equal to the whole-mesh single-rank map, the block-circulant coarse solve found on the gathered rows."""
+    from nekstab_amd import mesh, mesh3d
+    from nekstab_amd.capi import NekStabHip
+    from nekstab_amd.sharded import ShardGroup, local_parents, partition_rcb
+    c2 = mesh.load_case_npz(os.path.join(GOLDEN, "backstep_case.npz"), 8, re=500.0, endtime=1.0, xlspg=5.0, xrspg=10.0, spng_str=2.0)
+    nz = 30
+    c3 = mesh3d.extrude_case(c2, nz, 6.0, periodic=True)
+    kw = dict(tol_helm=1e-10, tol_pres=1e-2, tol_relative=1, max_helm_iter=150, max_pres_iter=96)
+    tg = np.load(os.path.join(GOLDEN, "backstep_tg.npz"))
+    u2 = mesh.interp_field_2d(tg["pRe_u"].astype(np.float64), 8) * c2.mask
+    w = 1e-2 * np.sin(2 * np.pi * c3.z / 6.0) * c3.mask * np.abs(mesh3d.extrude_field(u2[0], nz))
+    q = (mesh3d.extrude_field(u2[0], nz), mesh3d.extrude_field(u2[1], nz), w, np.zeros((c3.nel, 6, 6, 6)))
+    R, nst = 2, 3
+    part = partition_rcb(c3, R)
+    t0 = time.perf_counter()
+    P, _ = local_parents(c3, R, part, **kw)
+    t_local = time.perf_counter() - t0
+    try:
+        assert all(p.nel < 0.62 * c3.nel for p in P)
+        g = ShardGroup(P, c3, R, part)
+        g.release_parent()
+        g.set_option("shard_hostcheck", 1)
+        g.set_nsteps(nst)
+        sq, sf = g.alloc(2)
+        g.upload3(sq, *q)
+        g.matvec(sf, sq, 1)
+        got = g.download3(sf)
+        its = g.stats()
+        g.close()
+    finally:
+        for p in P:
+            p.close()
+    t0 = time.perf_counter()
+    h = NekStabHip(c3, c3.meta["vert"], c3.meta["nvert"], **kw)
+    t_whole = time.perf_counter() - t0
+    try:
+        assert P[0].nsteps == h.nsteps and abs(P[0].dt - h.dt) < 1e-15
+        h.set_nsteps(nst)
+        vq, vf = h.alloc(2)
+        h.upload3(vq, *q)
+        h.matvec(vf, vq, 1)
+        ref = h.download3(vf)
+        st = h.stats()
+        sc = max(np.abs(ref[k]).max() for k in range(3))
+        err = max(np.abs(got[k] - ref[k]).max() for k in range(3)) / sc
+        print("config 4 on two rank-local shards: %d + %d elements of %d, set-up of both ranks %.0f s (whole mesh %.0f s), velocity difference %.1e, "
+              "pressure iterations %d / %d" % (P[0].nel, P[1].nel, c3.nel, t_local, t_whole, err, its["pres_iters"], st["pres_iters"]))
+        assert err < 1e-10
+        assert abs(its["pres_iters"] - st["pres_iters"]) <= 2 and its["unconverged"] == 0
+    finally:
+        h.close()
+
+
 def test_config5_lid_driven_cube_E99452_lx1_10():
     """lid-driven cube, 46 x 46 x 47 = 99 452 hexahedra with wall clustering as examples/lid_driven/cav.box, lx1 = 10
     (lxd = 15): 99.5 M points per field, 349 M unknowns (2.8 GB per state vector), ~150 GB of device memory on ONE GPU;
