@@ -38,7 +38,9 @@ tf = []
 for p in P:
     t1 = time.time(); p.finish(vol, ct, lm, npr, u, v, a); tf.append(time.time() - t1)
 print("coarse rows of all ranks: %d entries (%.0f MB); finish (dt, Jacobi diagonals, replicated coarse solve) %.1f s per rank" % (len(a), 16e-6 * len(a), np.mean(tf)), flush=True)
+t0 = time.time()
 g = ShardGroup(P, c3, R, part)
+print("cutting the %d shards (halo tables, slices of the parents' arrays, work arrays): %.1f s" % (R, time.time() - t0), flush=True)
 g.release_parent()
 for k, v in (("shard_hostcheck", os.environ.get("HOSTCHECK")), ("halo_overlap", os.environ.get("HALO_OVERLAP"))):
     if v is not None:
