@@ -426,3 +426,40 @@ def test_halo_interior_overlap_hexahedra():
                     assert np.array_equal(x0, x1), (R, name)
     finally:
         h.close()
+
+
+def test_shards_at_lx1_12_one_element_per_workgroup():
+    """BASELINE configs[2]'s order (lx1 = 12: one element per workgroup, the totals path of many workgroups) on three shards:
+    serial order, halo / interior overlap and host-checked convergence all equal to one another bit for bit and to the single
+    rank to the solver tolerance."""
+    from nekstab_amd import mesh
+    from nekstab_amd.capi import NekStabHip
+    from nekstab_amd.sharded import ShardGroup
+    case = mesh.load_case_npz(os.path.join(GOLDEN, "cylinder_case.npz"), 12)
+    modes = np.load(os.path.join(GOLDEN, "cylinder_modes.npz"))
+    u = mesh.interp_field_2d(modes["dRe_u"].astype(np.float64), 12) * case.mask
+    q = (u[0], u[1], np.zeros((case.nel, 10, 10)))
+    h = NekStabHip(case, case.meta["vert"], case.meta["nvert"], tol_helm=1e-11, tol_pres=1e-5, tol_relative=1, nproj=8, max_helm_iter=150, max_pres_iter=96)
+    try:
+        h.set_nsteps(4)
+        vq, vf = h.alloc(2)
+        h.upload(vq, *q); h.matvec(vf, vq, 0)
+        ref = h.download(vf)
+        out = {}
+        for name, opts in (("serial", {"shard_graph": 0}), ("overlap", {"shard_graph": 0, "halo_overlap": 1}), ("host check", {"shard_hostcheck": 1}), ("graph", {})):
+            g = ShardGroup(h, case, 3)
+            for k, v in opts.items():
+                g.set_option(k, v)
+            g.set_nsteps(4)
+            a, b = g.alloc(2)
+            g.upload(a, *q)
+            g.matvec(b, a, 0)
+            out[name] = g.download(b)
+            g.free([a, b]); g.close()
+        for name in ("overlap", "host check", "graph"):
+            for x0, x1 in zip(out["serial"], out[name]):
+                assert np.array_equal(x0, x1), name
+        sc = max(np.abs(ref[0]).max(), np.abs(ref[1]).max())
+        assert max(np.abs(out["serial"][k] - ref[k]).max() for k in range(2)) < 1e-8 * sc
+    finally:
+        h.close()
