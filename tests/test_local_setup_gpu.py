@@ -135,3 +135,20 @@ def test_local_setup_3d_extruded_cylinder(monkeypatch, coarse):
     env = np.exp(-0.05 * (x - 2.0) ** 2 - 0.2 * y ** 2) * c3.mask
     q = [env * np.sin(y + np.pi * z), env * np.cos(x) * np.cos(np.pi * z), env * np.sin(x + y) * np.sin(np.pi * z), np.zeros((c3.nel, 4, 4, 4))]
     _maps3(c3, 3, q, nst=3, tol=1e-7)
+
+
+def test_local_setup_3d_closed_cavity_singular_operator(monkeypatch):
+    """The lid-driven cavity extruded over 5 periodic layers (config 5's kind: closed, singular pressure operator): `ortho` over
+    the ranks' Gauss nodes with the gathered count, the shifted wavenumber-0 block of the block-circulant coarse solve built from
+    gathered rows, on two rank-local shards."""
+    from nekstab_amd import mesh3d
+    from tests.test_3d_gpu import _cavity_2d
+    monkeypatch.setenv("NSK_COARSE_ITER", "0")
+    monkeypatch.setenv("NSK_COARSE_CIRC", "1")
+    c2, _ = _cavity_2d(3600.0)
+    c3 = mesh3d.extrude_case(c2, 5, 1.0, periodic=True)
+    assert not c3.has_outflow
+    x, y, z = c3.x, c3.y, c3.z
+    q = [np.sin(np.pi * x) * np.cos(2 * np.pi * z) * c3.mask, np.sin(2 * np.pi * y / 1.2) * np.sin(2 * np.pi * z) * c3.mask,
+         np.sin(np.pi * x) * np.sin(np.pi * y / 1.2) * c3.mask, np.zeros((c3.nel, 4, 4, 4))]
+    _maps3(c3, 2, q, nst=3, tol=1e-7, nproj=4)
