@@ -25,14 +25,16 @@ def test_sharded_matvec_across_processes(world, port):
 
 
 @pytest.mark.parametrize("kind,world,port", [("adjoint", 2, 29641), ("proj", 3, 29643), ("nonlinear", 2, 29645),
-                                             ("proj-local", 3, 29647), ("adjoint-local", 2, 29649), ("proj-local-overlap", 3, 29651)])
+                                             ("proj-local", 3, 29647), ("adjoint-local", 2, 29649), ("proj-local-overlap", 3, 29651),
+                                             ("box3d-local-overlap", 2, 29653), ("box3d", 3, 29655)])
 def test_round3_shard_features_across_processes(kind, world, port):
     """VERDICT r2 item 2 across processes (host-staged transport, ranks share the GPU): adjoint cylinder at lx1 = 8 (singular
     pressure, `ortho` through the all-reduce), the pressure projection space in shards over two maps, and the closed cavity's
     nonlinear map + set_baseflow (CFL maximum over the ranks) + linearised map -- each equal to the single-rank result.
     "-local": the shard comes from the RANK-LOCAL set-up (sharded.LocalParent: this rank's sub-mesh, volume / CFL maximum /
     coarse rows exchanged through torch.distributed) instead of a whole-mesh parent.  "-overlap": option halo_overlap (the
-    boundary workgroups' halo travels while the interior workgroups run)."""
+    boundary workgroups' halo travels while the interior workgroups run).  "box3d": a closed hexahedral box (singular pressure
+    operator, three-component halos, Schwarz layers of face / edge / corner neighbours on other ranks)."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world,
                           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "mp_shard_worker.py"), "0", kind],
