@@ -344,7 +344,7 @@ def main():
             ns = h.nsteps
             h.set_nsteps(2)
             h.matvec(probe[1], probe[0], 0)                 # eager: every peer connection and the all-reduce ring exist after this
-            if shard_graph == 1 and backend == "nccl":
+            if (shard_graph == 1 and backend == "nccl") or os.environ.get("NSK_BENCH_FORCE_MODE_PROBE") == "1":      # (the override: dry runs exercise this code)
                 # Two ways to run the sharded step over RCCL, and no hardware to have measured them on before this run: (a) one
                 # captured graph per step class with the RCCL calls inside (no host work per step, but every BUDGETED iteration
                 # pays its exchange and all-reduce); (b) eager launches with the convergence flags read on the host (half to a
@@ -371,7 +371,7 @@ def main():
                     barrier(); tq = time.perf_counter()
                     h.matvec(probe[1], probe[0], 0)
                     barrier(); tq = time.perf_counter() - tq
-                    tt = torch.tensor([tq], device="cuda", dtype=torch.float64)
+                    tt = torch.tensor([tq], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
                     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                     times[name] = float(tt.item())
                 shard_mode.update(times, picked=min(times, key=times.get))

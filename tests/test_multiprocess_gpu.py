@@ -51,7 +51,7 @@ def test_bench_two_ranks_under_the_launcher_dry_run():
     rank-local set-up, a sharded probe map, the timed sharded Arnoldi steps, ONE JSON line from rank 0 that names the same
     workload as the N = 1 record and carries the one-GPU rate of the same steps."""
     import json
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", NSK_DIST_BACKEND="gloo")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", NSK_DIST_BACKEND="gloo", NSK_BENCH_FORCE_MODE_PROBE="1")   # (the comparison of the sharded modes runs too)
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
                           "--master-port", "29661", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cfg3-probe"],
                          capture_output=True, text=True, timeout=900, env=env)
@@ -64,3 +64,6 @@ def test_bench_two_ranks_under_the_launcher_dry_run():
     assert "BASELINE configs[1]" in r["config"]["workload"] and "E=1996, lx1=8" in r["config"]["workload"]
     assert r["setup"]["rank_local"] and r["setup"]["elements_rank0"] < 0.8 * r["setup"]["elements_mesh"]
     assert r["single_gpu_same_config"]["matvecs_per_s"] > 0
+    sm = r["shard_mode"]
+    assert sm["picked"] in ("graph", "hostcheck", "hostcheck_overlap") and all(sm[k] > 0 for k in ("graph", "hostcheck", "hostcheck_overlap"))
+    assert sm[sm["picked"]] == min(sm[k] for k in ("graph", "hostcheck", "hostcheck_overlap"))
