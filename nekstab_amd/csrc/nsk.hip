@@ -83,6 +83,7 @@ struct nsk_ctx {
   int in_test = 0;
   int helm_guess = 1;
   int budget_freeze = 0;
+  int gs_lag = -1;                      // hexahedra: lagged second Gram-Schmidt correction (k_gs_lag: two basis reads per GMRES column instead of four); -1 = yes on single-rank contexts
   int gs2_from = MAXMR;                 // quadrilaterals: GMRES columns from this iteration (of a cycle) on get a second Gram-Schmidt pass (default: never)
   int dbg_max_order = 3, dbg_ab2 = 0, dbg_pext = 1;      // time-scheme sensitivity switches (options of the same names)
   double early_pres_mul = 1e-2;         // pressure tolerance factor of time steps 1-3 of every map
@@ -848,6 +849,41 @@ static bool hostcheck_on(const nsk_ctx* c) {
   return c->ndim == 3 && c->nel >= 8192;
 }
 
+// hexahedral GMRES column j in the lagged form: streaming Gram-Schmidt pass (first-pass subtraction, second-pass dots, the
+// pending correction of v_j, corner restriction of w'), totals, Hessenberg column.  JB = compile-time bound of j, RB = rows
+// of 64 nodes in flight per wavefront.
+static bool gs_lag_on(const nsk_ctx* c) {
+  if (c->ndim != 3 || c->N > 10) return false;
+  if (c->gs_lag >= 0) return c->gs_lag != 0;
+  return c->d.nranks <= 1 && !c->parent;
+}
+template <int N>
+static void launch_gs_dots3(nsk_ctx* c, const Dev& d, int j) {         // first-pass dots as their own streaming pass (gs_lag = 2)
+  if constexpr (N <= 10) {
+    constexpr int ROWS = (nsk::k3::Cfg<N>::MM + 63) / 64;
+    constexpr int R4 = ROWS < 4 ? ROWS : 4, R2 = ROWS < 2 ? ROWS : 2;
+    const dim3 grid(std::min<unsigned>((unsigned)((c->nel + 3) / 4), 2048u)), blk(256);
+    if (j < 8) hipLaunchKernelGGL((nsk::k3::k_gs_dots<N, 8, R4>), grid, blk, 0, c->stream, d, j);
+    else if (j < 16) hipLaunchKernelGGL((nsk::k3::k_gs_dots<N, 16, R2>), grid, blk, 0, c->stream, d, j);
+    else if (j < 32) hipLaunchKernelGGL((nsk::k3::k_gs_dots<N, 32, 1>), grid, blk, 0, c->stream, d, j);
+    else hipLaunchKernelGGL((nsk::k3::k_gs_dots<N, MAXMR, 1>), grid, blk, 0, c->stream, d, j);
+  }
+}
+template <int N>
+static void launch_gs_lag3(nsk_ctx* c, const Dev& d, int j, double scale, int ord) {
+  if constexpr (N <= 10) {
+    constexpr int ROWS = (nsk::k3::Cfg<N>::MM + 63) / 64;
+    constexpr int R4 = ROWS < 4 ? ROWS : 4, R2 = ROWS < 2 ? ROWS : 2;
+    const dim3 grid(std::min<unsigned>((unsigned)((c->nel + 3) / 4), 2048u)), blk(256);
+    if (j <= 8) hipLaunchKernelGGL((nsk::k3::k_gs_lag<N, 8, R4>), grid, blk, 0, c->stream, d, j);
+    else if (j <= 16) hipLaunchKernelGGL((nsk::k3::k_gs_lag<N, 16, R2>), grid, blk, 0, c->stream, d, j);
+    else if (j <= 32) hipLaunchKernelGGL((nsk::k3::k_gs_lag<N, 32, 1>), grid, blk, 0, c->stream, d, j);
+    else hipLaunchKernelGGL((nsk::k3::k_gs_lag<N, MAXMR, 1>), grid, blk, 0, c->stream, d, j);
+    tot_rows(c, d.gpart2, j + 2, d.gtot2, &d.gsc->done);
+    hipLaunchKernelGGL(nsk::k3::k_gmres_col, dim3(1), dim3(64), 0, c->stream, d, j, scale, c->min_pres, ord);
+  }
+}
+
 static int pres_solve_launch(nsk_ctx* c, double h2, int ord, int np, double tol_mul = 1.0, bool allow_cap = false, bool hc = false) {
   Dev d = c->d;                                            // by value: the early steps of a map run with a tighter tolerance
   d.tol_pres = early_tol(d, tol_mul);
@@ -856,6 +892,8 @@ static int pres_solve_launch(nsk_ctx* c, double h2, int ord, int np, double tol_
     d.pres_cap = std::max(c->pres_cap, c->min_pres); np = std::min(np, d.pres_cap);
   }
   const double scale = 1.0 / (h2 * std::sqrt(d.vol));
+  const bool lag = gs_lag_on(c);
+  d.gs_lag = lag ? 1 : 0;
   DISPATCH_N(c->key, {
     constexpr int NT = Cfg<N>::NT;
     tot_rows(c, d.gpart, d.has_outflow ? 1 : 2, d.gtot);
@@ -900,16 +938,25 @@ static int pres_solve_launch(nsk_ctx* c, double h2, int ord, int np, double tol_
         hipLaunchKernelGGL(k_coarse_big, dim3((d.nvert + 3) / 4), dim3(256), 0, c->stream, d, (const double*)c->rc_big);
       }
       hipLaunchKernelGGL(k_schwarz<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, (const double*)(d.V + (size_t)j * d.ps), d.Z + (size_t)j * d.npr, 1, 1);
-      hipLaunchKernelGGL(k_divgs<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, (const double*)d.yl, d.V + (size_t)(j + 1) * d.ps, j, 1);
-      tot_rows(c, d.gpart, j + 2, d.gtot, &d.gsc->done);
-      // second Gram-Schmidt pass: always on hexahedra, on quadrilaterals from iteration gs2_from of a cycle on
-      const bool two = c->ndim == 3 || j >= c->gs2_from;
-      if (two) {
-        hipLaunchKernelGGL(k_gmres_reorth<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, j);
-        tot_rows(c, d.gpart2, j + 2, d.gtot2, &d.gsc->done);
+      if (lag && c->gs_lag == 2) {
+        hipLaunchKernelGGL(k_divgs<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, (const double*)d.yl, d.V + (size_t)(j + 1) * d.ps, -1, 1);
+        launch_gs_dots3<N>(c, d, j);
+      } else {
+        hipLaunchKernelGGL(k_divgs<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, (const double*)d.yl, d.V + (size_t)(j + 1) * d.ps, j, 1);
       }
-      Dev d2 = d; d2.gs2 = two ? 1 : 0;
-      hipLaunchKernelGGL(k_gmres_update<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d2, j, scale, c->min_pres, ord);
+      tot_rows(c, d.gpart, j + 2, d.gtot, &d.gsc->done);
+      if (lag) {
+        launch_gs_lag3<N>(c, d, j, scale, ord);
+      } else {
+        // second Gram-Schmidt pass: always on hexahedra, on quadrilaterals from iteration gs2_from of a cycle on
+        const bool two = c->ndim == 3 || j >= c->gs2_from;
+        if (two) {
+          hipLaunchKernelGGL(k_gmres_reorth<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, j);
+          tot_rows(c, d.gpart2, j + 2, d.gtot2, &d.gsc->done);
+        }
+        Dev d2 = d; d2.gs2 = two ? 1 : 0;
+        hipLaunchKernelGGL(k_gmres_update<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d2, j, scale, c->min_pres, ord);
+      }
       // large meshes: an iteration takes milliseconds, a flag read microseconds -> after every iteration; otherwise from three
       // iterations before the previous solve's count on
       if (hc && jt + 1 < np && (c->nel >= 8192 || jt + 4 >= c->hc_pres[ord])) {
@@ -1694,6 +1741,7 @@ int nsk_set_option(nsk_ctx* c, const char* name, double value) {
   }
   else if (n == "helm_guess") c->helm_guess = (int)value;
   else if (n == "gs2_from") c->gs2_from = std::max(0, (int)value);
+  else if (n == "gs_lag") c->gs_lag = (int)value;
   else if (n == "dbg_max_order") c->dbg_max_order = (int)value;
   else if (n == "dbg_ab2") c->dbg_ab2 = (int)value;
   else if (n == "dbg_pext") c->dbg_pext = (int)value;
@@ -2165,7 +2213,7 @@ int nsk_clone(nsk_ctx* P, nsk_ctx** out) {
   c->dt = P->dt; c->re = P->re; c->endtime = P->endtime; c->nsteps = P->nsteps;
   c->max_helm = P->max_helm; c->max_pres = P->max_pres; c->min_pres = P->min_pres; c->pres_cap = P->pres_cap; c->layers = P->layers;
   c->use_graph = P->use_graph; c->gmres_cycle = P->gmres_cycle; c->helm_guess = P->helm_guess; c->early_pres_mul = P->early_pres_mul;
-  c->merged_iters = P->merged_iters; c->merged_update = P->merged_update; c->gs2_from = P->gs2_from; c->debug = P->debug;
+  c->merged_iters = P->merged_iters; c->merged_update = P->merged_update; c->gs2_from = P->gs2_from; c->gs_lag = P->gs_lag; c->debug = P->debug;
   c->dbg_max_order = P->dbg_max_order; c->dbg_ab2 = P->dbg_ab2; c->dbg_pext = P->dbg_pext;
   c->PS = P->PS; c->coarse_lda = P->coarse_lda; c->cfl_target = P->cfl_target; c->xyz = P->xyz;
   c->clone_of = P;

@@ -905,9 +905,11 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_gmres_update(Dev d, int j, doubl
     if (restart) {
       G->nit_prev += G->nit;
       G->beta0 = hn; G->g[0] = hn; G->nit = 0; G->resid = hn * scale;
+      G->pending = 0;
       if (!(hn > 0.0)) G->done = 1;
     } else if (j < 0) {
       G->beta0 = hn; G->g[0] = hn; G->nit = 0; G->nit_prev = 0; G->resid = hn * scale;
+      G->pending = 0;
       if (d.nproj_max <= 0) G->gnorm0 = hn;
       const double tol0 = d.tol_relative ? fmax(d.tol_pres * G->gnorm0 * scale, d.tol_pres_floor) : d.tol_pres;
       const int dn = (!(hn > 0.0) || (min_iter <= 0 && hn * scale <= tol0)) ? 1 : 0;
@@ -965,6 +967,238 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_gmres_update(Dev d, int j, doubl
   }
 }
 
+// ---------------------------------------------------------------------------
+// Two-pass classical Gram-Schmidt of the hexahedral pressure GMRES with TWO reads of the basis per column instead of four
+// (option "gs_lag", the default on single-rank hexahedral contexts).
+//
+// The classic sequence (k_divgs dots, k_gmres_reorth subtract + dots, k_gmres_update subtract + normalise) reads V_0..j four
+// times per column, 86 MB per vector at config 4's size, with the 216 pressure nodes of an element on 512-thread workgroups
+// (42 % of the lanes, four loads in flight each): 0.25-0.3 of the HBM rate.  Here
+//   * k_divgs still emits the first-pass dots (read 1);
+//   * k_gs_lag streams the basis ONCE (read 2): every lane holds its node's V_0..j in registers, forms
+//     w' = w - V h1, stores it, and takes the second-pass dots h2 = V^T w', (w', w') from the same registers;
+//   * the second correction v_{j+1} = (w' - V h2) / h_{j+1,j} is NOT applied by a pass of its own: the vector stays
+//     stored as w' ("pending", coefficients in GmresScal::pc / phinv) and the NEXT k_gs_lag, which has V_0..j in registers
+//     anyway, forms v_{j+1} on the fly and writes it back.  Until then its only readers are the preconditioner
+//     (k_schwarz and the corner restriction, which take phinv * w' -- right-preconditioned GMRES is flexible in its
+//     z_j, the Arnoldi relation E z_j = V_{j+2} h holds with the FINAL vectors whatever z_j was made from; the
+//     difference is the size of the lost orthogonality, 1e-8) and k_divgs' first-pass dot against it, whose value
+//     (w, v_{j+1}) follows from (w, w') and the dots against V_0..j by linearity (gs_lag prologue below).
+// One wavefront per element (4 rows of 64 lanes over the 216 nodes at lx1 = 8), RB rows in flight together,
+// JB = compile-time bound of j: every basis load of a row block is issued before the first use.
+// ---------------------------------------------------------------------------
+// uniform base (scalar registers) + 32-bit byte offset (one vector register for every basis vector of a node): the
+// global_load saddr form; a 64-bit address per load costs two vector registers per load in flight
+__device__ inline double ld_boff(const double* __restrict__ base, unsigned boff) {
+  return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + boff);
+}
+__device__ inline void st_boff(double* __restrict__ base, unsigned boff, double v) {
+  *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + boff) = v;
+}
+template <int N, int JB, int RB>
+__global__ __launch_bounds__(256) void k_gs_lag(Dev d, int j) {
+  using C = Cfg<N>;
+  constexpr int MM = C::MM, ROWS = (MM + 63) / 64;
+  __shared__ double sh[MAXMR + 2], spc[MAXMR + 2];
+  __shared__ double shat[8 * MM];
+  GmresScal* G = d.gsc;
+  if (G->done) return;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int pend = G->pending;
+  const double phinv = pend ? G->phinv : 1.0;
+  if (tid < MAXMR + 2) {
+    sh[tid] = (tid <= j) ? d.gtot[tid] : 0.0;
+    spc[tid] = (pend && tid < j) ? G->pc[tid] : 0.0;
+  }
+  for (int p = tid; p < 8 * MM; p += 256) shat[p] = d.hat[p];
+  lds_barrier();
+  if (tid == 0 && pend) {                       // (w, v_j) from (w, w'_{j-1}) and the dots against V_0..j-1
+    double s = sh[j];
+    for (int k = 0; k < j; ++k) s -= spc[k] * sh[k];
+    sh[j] = s * phinv;
+  }
+  lds_barrier();
+  if (blockIdx.x == 0 && tid <= j) G->hcol[tid] = sh[tid];      // first-pass column for k_gmres_col
+  const double hj = sh[j];
+  const size_t ps = (size_t)d.ps;
+  double* __restrict__ Vj = d.V + (size_t)j * ps;
+  double* __restrict__ Vw = d.V + (size_t)(j + 1) * ps;
+  const long long nw = (long long)gridDim.x * 4;
+  for (long long e = (long long)blockIdx.x * 4 + wv; e < d.nel; e += nw) {
+    asm volatile("" ::: "memory");               // (the coefficients stay in LDS: hoisted out of this loop they cost 4 registers per basis vector)
+    double acc[JB], accj = 0.0, accw = 0.0, cr[8];
+#pragma unroll
+    for (int k = 0; k < JB; ++k) acc[k] = 0.0;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) cr[c] = 0.0;
+    const unsigned eb = (unsigned)e * (unsigned)MM;
+#pragma unroll 1
+    for (int r0 = 0; r0 < ROWS; r0 += RB) {
+      if (ROWS > RB) asm volatile("" ::: "memory");
+      double v[RB][JB], t[RB], x[RB];
+      unsigned bo[RB];
+      bool in[RB];
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) {
+        const int kk = lane + 64 * (r0 + rb);
+        in[rb] = (r0 + rb < ROWS) && kk < MM;
+        bo[rb] = (eb + (in[rb] ? kk : 0)) * 8u;
+      }
+#pragma unroll
+      for (int k = 0; k < JB; ++k) {
+        const double* __restrict__ Vk = d.V + (size_t)k * ps;
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) v[rb][k] = (in[rb] && k < j) ? ld_boff(Vk, bo[rb]) : 0.0;
+      }
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) {
+        t[rb] = in[rb] ? ld_boff(Vj, bo[rb]) : 0.0;
+        x[rb] = in[rb] ? ld_boff(Vw, bo[rb]) : 0.0;
+      }
+      if (pend) {                                // v_j = (w'_{j-1} - sum_k pc[k] v_k) * phinv, formed here and written back
+#pragma unroll
+        for (int k = 0; k < JB; ++k) {
+          const double ck = spc[k];
+#pragma unroll
+          for (int rb = 0; rb < RB; ++rb) t[rb] -= ck * v[rb][k];
+        }
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) { t[rb] *= phinv; if (in[rb]) st_boff(Vj, bo[rb], t[rb]); }
+      }
+#pragma unroll
+      for (int k = 0; k < JB; ++k) {             // first pass: w' = w - sum_k h1[k] v_k
+        const double ck = sh[k];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) x[rb] -= ck * v[rb][k];
+      }
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) { x[rb] -= hj * t[rb]; if (in[rb]) st_boff(Vw, bo[rb], x[rb]); }
+#pragma unroll
+      for (int k = 0; k < JB; ++k)               // second-pass dots from the same registers
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) acc[k] += x[rb] * v[rb][k];
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) {
+        accj += x[rb] * t[rb];
+        accw += x[rb] * x[rb];
+        const int kc = in[rb] ? lane + 64 * (r0 + rb) : 0;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) cr[c] += shat[c * MM + kc] * x[rb];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < JB; ++k) {
+      if (k < j) {
+        const double s = wave_sum63(acc[k]);
+        if (lane == 63) d.gpart2[(size_t)k * d.nblk + e] = s;
+      }
+    }
+    accj = wave_sum63(accj);
+    accw = wave_sum63(accw);
+    if (lane == 63) { d.gpart2[(size_t)j * d.nblk + e] = accj; d.gpart2[(size_t)(j + 1) * d.nblk + e] = accw; }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const double s = wave_sum63(cr[c]);
+      if (lane == 63) d.ec[e * 8 + c] = s;       // restriction of w' (k_coarse_restrict_csr applies phinv)
+    }
+  }
+}
+
+// First-pass dots (w, V_k), k <= j, and (w, w) as a streaming pass of their own (gs_lag = 2: k_divgs then runs without its
+// dots, whose loads come from 42 % of its lanes): same wavefront-per-element layout and partial sums as k_gs_lag.
+template <int N, int JB, int RB>
+__global__ __launch_bounds__(256) void k_gs_dots(Dev d, int j) {
+  using C = Cfg<N>;
+  constexpr int MM = C::MM, ROWS = (MM + 63) / 64;
+  if (d.gsc->done) return;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const size_t ps = (size_t)d.ps;
+  const double* __restrict__ Vw = d.V + (size_t)(j + 1) * ps;
+  const long long nw = (long long)gridDim.x * 4;
+  for (long long e = (long long)blockIdx.x * 4 + wv; e < d.nel; e += nw) {
+    double acc[JB], accw = 0.0;
+#pragma unroll
+    for (int k = 0; k < JB; ++k) acc[k] = 0.0;
+    const unsigned eb = (unsigned)e * (unsigned)MM;
+#pragma unroll 1
+    for (int r0 = 0; r0 < ROWS; r0 += RB) {
+      double v[RB][JB], x[RB];
+      unsigned bo[RB];
+      bool in[RB];
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) {
+        const int kk = lane + 64 * (r0 + rb);
+        in[rb] = (r0 + rb < ROWS) && kk < MM;
+        bo[rb] = (eb + (in[rb] ? kk : 0)) * 8u;
+      }
+#pragma unroll
+      for (int k = 0; k < JB; ++k) {
+        const double* __restrict__ Vk = d.V + (size_t)k * ps;
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) v[rb][k] = (in[rb] && k <= j) ? ld_boff(Vk, bo[rb]) : 0.0;
+      }
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) x[rb] = in[rb] ? ld_boff(Vw, bo[rb]) : 0.0;
+#pragma unroll
+      for (int k = 0; k < JB; ++k)
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) acc[k] += x[rb] * v[rb][k];
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) accw += x[rb] * x[rb];
+    }
+#pragma unroll
+    for (int k = 0; k < JB; ++k) {
+      if (k <= j) {
+        const double s = wave_sum63(acc[k]);
+        if (lane == 63) d.gpart[(size_t)k * d.nblk + e] = s;
+      }
+    }
+    accw = wave_sum63(accw);
+    if (lane == 63) d.gpart[(size_t)(j + 1) * d.nblk + e] = accw;
+  }
+}
+
+// Hessenberg column j of the lagged scheme: first-pass coefficients (GmresScal::hcol, written by k_gs_lag) + second-pass
+// dots (gtot2), h_{j+1,j} from the Pythagorean form, Givens rotation and convergence test as k_gmres_update; leaves the
+// pending correction of the new basis vector in GmresScal::pc / phinv.
+__global__ __launch_bounds__(64) void k_gmres_col(Dev d, int j, double scale, int min_iter, int ord) {
+  __shared__ double col[MAXMR + 2];
+  GmresScal* G = d.gsc;
+  if (G->done || threadIdx.x != 0) return;
+  double s2 = 0.0;
+  for (int q = 0; q <= j; ++q) { const double h2 = d.gtot2[q]; s2 += h2 * h2; G->pc[q] = h2; col[q] = G->hcol[q] + h2; }
+  const double hn2 = d.gtot2[j + 1] - s2;
+  const double hn = sqrt(hn2 > 0.0 ? hn2 : 0.0);
+  G->phinv = (hn > 0.0) ? 1.0 / hn : 0.0;
+  G->pending = 1;
+  col[j + 1] = hn;
+  for (int q = 0; q < j; ++q) {
+    const double cq = G->cs[q], sq = G->sn[q];
+    const double t = cq * col[q] + sq * col[q + 1];
+    col[q + 1] = -sq * col[q] + cq * col[q + 1];
+    col[q] = t;
+  }
+  const double rho = sqrt(col[j] * col[j] + col[j + 1] * col[j + 1]);
+  const double cj = (rho > 0.0) ? col[j] / rho : 1.0, sj = (rho > 0.0) ? col[j + 1] / rho : 0.0;
+  G->cs[j] = cj; G->sn[j] = sj;
+  col[j] = rho;
+  for (int q = 0; q <= j; ++q) G->R[j * MAXMR + q] = col[q];
+  const double gj = G->g[j];
+  G->g[j] = cj * gj;
+  G->g[j + 1] = -sj * gj;
+  G->nit = j + 1;
+  const double res = fabs(sj * gj) * scale;
+  G->resid = res;
+  const double tol = d.tol_relative ? fmax(d.tol_pres * G->gnorm0 * scale, d.tol_pres_floor) : d.tol_pres;
+  if ((res <= tol && (j + 1) >= min_iter) || !(hn > 0.0)) {
+    atomicAdd((unsigned long long*)&d.stats->pres_iters, (unsigned long long)(G->nit_prev + j + 1));
+    atomicMax((unsigned long long*)&d.stats->max_pres, (unsigned long long)(G->nit_prev + j + 1));
+    atomicMax((unsigned long long*)&d.stats->max_pres_k[ord], (unsigned long long)(G->nit_prev + j + 1));
+    d.stats->last_pres_res = res;
+    G->done = 1;
+  }
+}
+
 // z_j = restricted overlapping Schwarz (v_j) + R^T x_c ;  yl = D^T z_j (unassembled)
 // Patch = the element's Gauss nodes plus the adjacent Gauss layer of every face neighbour = an lx1^3 tensor grid
 // (GLL position n <-> patch position n; own Gauss index a <-> position a+1).  The neighbours' layers come through a
@@ -998,9 +1232,11 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_schwarz(Dev d, const double* __r
       for (int c = 0; c < 8; ++c) zc += d.hat[c * MM + tid] * d.xc[d.evert[e * 8 + c]];
     }
   }
+  // (gs_lag: the newest basis vector is stored un-normalised until the next k_gs_lag finalises it)
+  const double vsc = (d.gs_lag && d.gsc->pending) ? d.gsc->phinv : 1.0;
   if (act) {                                          // the patch, one thread per position
     const int id = d.p_idx[e * NN + tid];
-    sa[tid] = (id >= 0) ? vin[id] : 0.0;
+    sa[tid] = (id >= 0) ? vsc * vin[id] : 0.0;
   }
   lds_barrier();
   // forward: S^T along r, s, t

@@ -41,6 +41,11 @@ struct GmresScal {               // device-resident small state of one pressure 
   int nproj;                     // vectors currently in the projection space
   int nit_prev;                  // iterations of the completed GMRES cycles of this solve (restarts)
   double gpre[MAXMR + 1];        // g[j] BEFORE the rotation of column j (never rewritten: k_update_coarse reads it in every workgroup)
+  // lagged second Gram-Schmidt correction (hexahedral GMRES, k_gs_lag): the newest basis vector is stored as
+  // w' (first pass applied, not normalised); v = (w' - sum_k pc[k] v_k) * phinv is formed by the next k_gs_lag
+  double pc[MAXMR + 2];
+  double phinv;
+  int pending;
 };
 
 // Step classes: one captured hipGraph and one launch budget each.  Time steps 1, 2, 3 differ in BDF/EXT order and
@@ -65,6 +70,7 @@ struct Dev {
   int nel, nblk, nvert;
   int boff;                      // set per launch: first workgroup of this launch (k_helm on shards: boundary elements first, interior behind)
   int gs2;                       // set per launch: the GMRES column of this k_gmres_update had a second Gram-Schmidt pass (k_gmres_reorth)
+  int gs_lag;                    // set per launch: the basis vector read here may still carry its pending scale GmresScal::phinv (k_gs_lag)
   long long nloc, npr;
   long long cs, ps;              // component stride of velocity-mesh arrays / stride of the GMRES basis V
                                  // (= nloc, npr on one rank; + ghost slots when elements are sharded)

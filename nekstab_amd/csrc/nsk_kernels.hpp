@@ -1138,6 +1138,11 @@ __global__ __launch_bounds__(256) void k_gmres_restart(Dev d, int m) {
       ss[i] = scs[i] * a - ssn[i] * b;
       ss[i + 1] = ssn[i] * a + scs[i] * b;
     }
+    if (G->pending) {                            // V[m] is stored as w' (k_gs_lag): v_m = (w' - sum_k pc[k] v_k) * phinv
+      const double f = ss[m] * G->phinv;
+      for (int i = 0; i < m; ++i) ss[i] -= f * G->pc[i];
+      ss[m] = f;
+    }
   }
   __syncthreads();
   const bool first = (G->nit_prev == 0);

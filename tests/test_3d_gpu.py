@@ -520,3 +520,47 @@ def test_block_circulant_coarse_solve_equals_dense_inverse(monkeypatch):
         assert abs(itc - itd) <= 1, (itd, itc)
         sc = np.abs(xd - xd.mean()).max()
         assert np.abs((xc - xc.mean()) - (xd - xd.mean())).max() < 1e-5 * sc
+
+
+@pytest.mark.parametrize("lx1,outflow", [(6, True), (8, True), (8, False), (10, True)])
+def test_lagged_gram_schmidt_equals_classic_two_pass(lx1, outflow):
+    """Option gs_lag (default on single-rank hexahedral contexts): the second Gram-Schmidt correction of a GMRES basis vector
+    is applied by the NEXT column's streaming pass instead of a pass of its own (two basis reads per column instead of four).
+    Same Krylov method: a pressure solve to 1e-8 gives the classic sequence's solution and iteration count (+-1), short
+    restart cycles included; gs_lag = 2 (first-pass dots in their own streaming kernel) likewise; a 5-step map agrees to
+    solver tolerance."""
+    c = _case(lx1, outflow)
+    c.spng = np.zeros_like(c.x)
+    rng = np.random.default_rng(11)
+    g = rng.standard_normal((c.nel,) + (c.lx1 - 2,) * 3)
+    if not outflow:
+        g -= g.mean()
+    x, y, z = c.x, c.y, c.z
+    q = [np.sin(1.3 * x + z) * np.cos(2.0 * y) * c.mask, np.cos(0.7 * x + 0.2) * np.sin(3.0 * y - z) * c.mask,
+         np.sin(x + y) * np.cos(2.0 * z) * c.mask, np.zeros((c.nel,) + (c.lx1 - 2,) * 3)]
+    sol, its, maps = {}, {}, {}
+    for lag in (0, 1, 2):
+        for cyc in (48, 6):
+            h = _hip(c, max_pres_iter=96)
+            try:
+                h.set_option("gs_lag", lag)
+                h.set_option("gmres_cycle", cyc)
+                xs, it = h.t_pres_solve(g)
+                sol[lag, cyc], its[lag, cyc] = (xs if outflow else xs - xs.mean()), it
+                if cyc == 48:
+                    a, b = h.alloc(2)
+                    h.upload3(a, *q)
+                    h.set_nsteps(5)
+                    h.matvec(b, a, 1)
+                    maps[lag] = h.download3(b)
+                    assert h.stats()["unconverged"] == 0
+            finally:
+                h.close()
+    print("GMRES iterations (gs_lag, cycle):", its)
+    for lag in (1, 2):
+        for cyc in (48, 6):
+            assert _rel(sol[lag, cyc], sol[0, cyc]) < 2e-6, (lag, cyc)
+            assert abs(its[lag, cyc] - its[0, cyc]) <= (1 if cyc == 48 else 3), (lag, cyc, its)
+        sc = max(np.abs(maps[0][k]).max() for k in range(3))
+        for k in range(3):
+            assert np.abs(maps[lag][k] - maps[0][k]).max() < 1e-7 * sc
