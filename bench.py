@@ -69,7 +69,10 @@ def _free_port():
     return port
 
 
-NO_GPU_EXIT = 3
+NO_GPU_EXIT = 7            # a worker found no GPU: nothing a second attempt could change (unique: the supervisor stops on it)
+STALL_EXIT = 5             # a worker's watchdog fired (stalled exchange / a rank waiting for one that failed): the next attempt runs
+FAIL_EXIT = 4              # a worker failed and every rank agreed on it (all_ok)
+C3_PROBE_S = 600           # N > 1 only: the short sharded run of cfg3 behind the headline workload
 
 
 def supervise(a):
@@ -102,7 +105,7 @@ def supervise(a):
             rc = max(rc, abs(p.wait()))
         if rc == 0:
             return 0
-        if rc == NO_GPU_EXIT:                                   # nothing a second attempt could change
+        if rc == NO_GPU_EXIT:                                   # nothing a second attempt could change (a stall, STALL_EXIT, is what the retry is for)
             break
         print("bench.py supervisor: attempt %d (%s) failed with code %d%s" % (att, "captured step graphs" if mode else "eager launches", rc,
               ": retrying with eager launches in fresh processes" if att + 1 < len(modes) else ""), file=sys.stderr, flush=True)
@@ -222,6 +225,11 @@ def main():
     shard_graph = int(os.environ.get("NSK_BENCH_SHARD_GRAPH", "0"))
     if world > 1 and backend == "nccl":
         os.environ["HIP_VISIBLE_DEVICES"] = str(local)     # before anything touches the GPU
+    if world > 1 and os.environ.get("NSK_BENCH_TEST_STALL") == os.environ.get("NSK_BENCH_ATTEMPT", "0"):
+        # test hook (tests/test_host_cpu.py): this attempt's workers behave like a run whose first exchange never completes
+        import threading
+        threading.Timer(1.0, lambda: (print("bench.py rank %d: forced stall (test hook): giving up" % rank, file=sys.stderr, flush=True), os._exit(STALL_EXIT))).start()
+        time.sleep(3600)
     import numpy as np
     import torch
     if not torch.cuda.is_available():
@@ -236,7 +244,7 @@ def main():
 
         def _stalled(what, limit):
             print("bench.py rank %d: %s: no result after %d s: giving up" % (rank, what, limit), file=sys.stderr, flush=True)
-            os._exit(3)
+            os._exit(STALL_EXIT)
         wd = threading.Timer(WATCHDOG_S, _stalled, ("multi-rank run", WATCHDOG_S))
         wd.daemon = True
         wd.start()
@@ -326,7 +334,16 @@ def main():
             flag = torch.zeros(1)
         if float(flag.item()) == 0.0:
             print("bench.py rank %d: SHARDED RUN FAILED (%s; shard_graph = %d)" % (rank, err or "another rank failed", shard_graph), file=sys.stderr, flush=True)
-            os._exit(4)
+            os._exit(FAIL_EXIT)
+
+    def agree(ok):
+        """True when EVERY rank reports ok (a failed all-reduce counts as a failure); nobody exits."""
+        flag = torch.tensor([1.0 if ok else 0.0], device="cuda" if backend == "nccl" else "cpu")
+        try:
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            return float(flag.item()) != 0.0
+        except Exception:                                   # noqa: BLE001
+            return False
 
     h = full
     if sharded:
@@ -516,52 +533,84 @@ def main():
             out["single_gpu_same_config"] = {"matvecs_per_s": r1, "sample": "the same %d + %d Arnoldi steps of the same case on rank 0's full-mesh context (hipGraph path), timed after the sharded run" % (a.warmup, steps),
                                              "speedup_sharded": (steps / elapsed) / r1}
         dist.barrier()
-        # ---- BASELINE configs[2] next to the headline workload: where element sharding is meant to pay (1.15 M points per field)
+        # ---- BASELINE configs[2] next to the headline workload: where element sharding is meant to pay (1.15 M points per field).
+        # The headline record is complete at this point and must survive whatever happens here: the section runs under its own
+        # watchdog (a stall prints the headline record with config3_sharded = {error} and ends the worker with code 0), every
+        # rank catches its own exceptions and the ranks agree on the outcome before anyone goes on.
         if a.case == "cfg2" and not a.no_cfg3_probe:
-            if not local_setup:
-                h.close()
-                full.close()
-            elif rank == 0:
-                full.close()
-            case3 = build_case("cfg3")
-            t0 = time.perf_counter()
-            full = make_parent(case3)
-            setup3_s = time.perf_counter() - t0
-            h = make_shard(full, case3)
-            if shard_graph == 1 and backend == "nccl":     # (connections exist since the headline run; the mode that was faster there)
-                h.set_option("shard_graph", 1 if shard_mode.get("picked") == "graph" else 0)
-                h.set_option("shard_hostcheck", 0 if shard_mode.get("picked") == "graph" else 1)
-                h.set_option("halo_overlap", 1 if shard_mode.get("picked") == "hostcheck_overlap" else 0)
-            x3, y3 = seed.add_noise(case3)
-            z3 = np.zeros((case3.nel, case3.lx1 - 2, case3.lx1 - 2))
-            n3 = 2
-            Q3 = h.alloc(n3 + 2)
-            h.upload(Q3[0], x3, y3, z3)
-            h.scal(Q3[0], 1.0 / h.norm(Q3[0]))
-            H3 = np.zeros((n3 + 2, n3 + 1)); s3 = {}
-            krylov.arnoldi_factorization(h, Q3, H3, 1, 1, 0, stats=s3)
-            barrier(); t3 = time.perf_counter()
-            krylov.arnoldi_factorization(h, Q3, H3, 2, n3 + 1, 0, stats=s3)
-            barrier(); t3 = time.perf_counter() - t3
-            tt = torch.tensor([t3], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            rec3 = {"workload": "cylinder Re=50 direct Arnoldi (BASELINE configs[2]): E=%d, lx1=%d, nsteps=%d/matvec" % (case3.nel, case3.lx1, h.nsteps),
-                    "matvecs_per_s": n3 / float(tt.item()), "steps": n3, "warmup": 1,
-                    "setup": {"rank_local": bool(local_setup), "seconds_rank0": setup3_s, "elements_rank0": int(full.nel), "elements_mesh": int(case3.nel)}}
-            if local_setup:
-                h.close(); full.close()
+            def _cfg3_stalled():
+                print("bench.py rank %d: config3_sharded: no result after %d s: keeping the headline record" % (rank, C3_PROBE_S), file=sys.stderr, flush=True)
                 if rank == 0:
-                    t0 = time.perf_counter()
-                    full = make_context(case3)
-                    rec3["setup"]["whole_mesh_seconds_rank0"] = time.perf_counter() - t0
-            if rank == 0:
-                saved = a.warmup
-                a.warmup = 1
-                r13 = one_gpu_same_steps(full, case3, n3)
-                a.warmup = saved
-                rec3["single_gpu_same_config"] = {"matvecs_per_s": r13, "speedup_sharded": rec3["matvecs_per_s"] / r13}
-            out["config3_sharded"] = rec3
-            dist.barrier()
+                    out["config3_sharded"] = {"error": "stalled: no result after %d s" % C3_PROBE_S}
+                    print(json.dumps(out), flush=True)
+                os._exit(0)
+            c3w = threading.Timer(C3_PROBE_S, _cfg3_stalled)
+            c3w.daemon = True
+            c3w.start()
+            rec3, err3, case3 = None, None, None
+            try:
+                if not local_setup:
+                    h.close()
+                    full.close()
+                elif rank == 0:
+                    full.close()
+                h = full = None
+                case3 = build_case("cfg3")
+                t0 = time.perf_counter()
+                full = make_parent(case3)
+                setup3_s = time.perf_counter() - t0
+                h = make_shard(full, case3)                # (a NEW communicator: ncclCommInitRank inside ShardRank; eager so far)
+                x3, y3 = seed.add_noise(case3)
+                z3 = np.zeros((case3.nel, case3.lx1 - 2, case3.lx1 - 2))
+                n3 = 2
+                Q3 = h.alloc(n3 + 2)
+                h.upload(Q3[0], x3, y3, z3)
+                h.scal(Q3[0], 1.0 / h.norm(Q3[0]))
+                # peer connections are per communicator and RCCL sets them up lazily: the first exchanges of THIS communicator
+                # run eagerly (a two-step map), as for the headline shard, before captured graphs may be switched on
+                ns3 = h.nsteps
+                h.set_nsteps(2)
+                h.matvec(Q3[1], Q3[0], 0)
+                h.set_nsteps(ns3)
+                if shard_graph == 1 and backend == "nccl":     # the mode that was faster on the headline workload
+                    h.set_option("shard_graph", 1 if shard_mode.get("picked") == "graph" else 0)
+                    h.set_option("shard_hostcheck", 0 if shard_mode.get("picked") == "graph" else 1)
+                    h.set_option("halo_overlap", 1 if shard_mode.get("picked") == "hostcheck_overlap" else 0)
+                H3 = np.zeros((n3 + 2, n3 + 1)); s3 = {}
+                krylov.arnoldi_factorization(h, Q3, H3, 1, 1, 0, stats=s3)
+                barrier(); t3 = time.perf_counter()
+                krylov.arnoldi_factorization(h, Q3, H3, 2, n3 + 1, 0, stats=s3)
+                barrier(); t3 = time.perf_counter() - t3
+                tt = torch.tensor([t3], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                rec3 = {"workload": "cylinder Re=50 direct Arnoldi (BASELINE configs[2]): E=%d, lx1=%d, nsteps=%d/matvec" % (case3.nel, case3.lx1, h.nsteps),
+                        "matvecs_per_s": n3 / float(tt.item()), "steps": n3, "warmup": 1,
+                        "setup": {"rank_local": bool(local_setup), "seconds_rank0": setup3_s, "elements_rank0": int(full.nel), "elements_mesh": int(case3.nel)}}
+            except Exception as e:                              # noqa: BLE001
+                err3 = repr(e)[:400]
+                print("bench.py rank %d: config3_sharded failed: %s" % (rank, err3), file=sys.stderr, flush=True)
+            if agree(err3 is None):
+                try:
+                    if local_setup:
+                        h.close(); full.close()
+                        h = full = None
+                        if rank == 0:
+                            t0 = time.perf_counter()
+                            full = make_context(case3)
+                            rec3["setup"]["whole_mesh_seconds_rank0"] = time.perf_counter() - t0
+                    if rank == 0:
+                        saved = a.warmup
+                        a.warmup = 1
+                        r13 = one_gpu_same_steps(full, case3, n3)
+                        a.warmup = saved
+                        rec3["single_gpu_same_config"] = {"matvecs_per_s": r13, "speedup_sharded": rec3["matvecs_per_s"] / r13}
+                except Exception as e:                          # noqa: BLE001
+                    rec3["single_gpu_same_config"] = {"error": repr(e)[:400]}
+                out["config3_sharded"] = rec3
+                dist.barrier()
+            else:
+                out["config3_sharded"] = {"error": err3 or "another rank failed"}
+            c3w.cancel()
     if rank == 0 and headline and not a.no_kdim and not a.no_settings_comparison:
         # The same build at the inner-solver settings earlier records were quoted on (NOT part of `value`): the production
         # settings changed between rounds because the parity pins did, so a reader comparing records
@@ -614,9 +663,10 @@ def main():
         all_ok(True, None)                                 # nobody prints a record unless every rank got to the end
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if sharded:
+    if sharded and h is not None:
         h.close()
-    full.close()
+    if full is not None:
+        full.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -349,15 +349,23 @@ class NekStabHip:
         """add_noise (core/utils.f:344-408) on the device."""
         self._chk(self.lib.nsk_seed_noise(self.ctx, v))
 
+    # Lanes (nsk_clone) hold their solver settings BY VALUE: a setter called after lanes exist acts on every lane, so that
+    # matvec_batch / band_arnoldi never apply different operators on different lanes (ADVICE r3).
+    def _all_lanes(self):
+        return getattr(self, "_lanes", None) or [self.ctx]
+
     def set_nsteps(self, n):
-        self._chk(self.lib.nsk_set_nsteps(self.ctx, n))
+        for lane in self._all_lanes():
+            self._chk(self.lib.nsk_set_nsteps(lane, n))
         self.nsteps = n
 
     def set_tolerances(self, th, tp, relative=0):
-        self._chk(self.lib.nsk_set_tolerances(self.ctx, th, tp, relative))
+        for lane in self._all_lanes():
+            self._chk(self.lib.nsk_set_tolerances(lane, th, tp, relative))
 
     def set_option(self, name, value):
-        self._chk(self.lib.nsk_set_option(self.ctx, name.encode(), float(value)))
+        for lane in self._all_lanes():
+            self._chk(self.lib.nsk_set_option(lane, name.encode(), float(value)))
 
     def bench_kernel(self, name, reps=200):
         us = C.c_double()

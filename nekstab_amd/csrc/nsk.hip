@@ -938,7 +938,7 @@ static int pres_solve_launch(nsk_ctx* c, double h2, int ord, int np, double tol_
         hipLaunchKernelGGL(k_coarse_big, dim3((d.nvert + 3) / 4), dim3(256), 0, c->stream, d, (const double*)c->rc_big);
       }
       hipLaunchKernelGGL(k_schwarz<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, (const double*)(d.V + (size_t)j * d.ps), d.Z + (size_t)j * d.npr, 1, 1);
-      if (lag && c->gs_lag == 2) {
+      if (lag && c->gs_lag != 1) {                        // (default, and gs_lag = 2: the first-pass dots as their own streaming pass)
         hipLaunchKernelGGL(k_divgs<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, (const double*)d.yl, d.V + (size_t)(j + 1) * d.ps, -1, 1);
         launch_gs_dots3<N>(c, d, j);
       } else {
@@ -2185,8 +2185,12 @@ int nsk_debug_stamps(nsk_ctx* c, unsigned long long* out, int nblk_max) {
       const StepCoef sc = make_coef(c, 3, 0);
       for (int r = 0; r < 6; ++r) hipLaunchKernelGGL(k_helm<N>, dim3(c->nblk), dim3(Cfg<N>::NT), 0, c->stream, dd, sc, r, (const double*)d.rloc);
       nblk_max = -nblk_max;
-    } else
-    for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(k_divgs<N>, dim3(c->nblk), dim3(Cfg<N>::NT), 0, c->stream, d, (const double*)d.yl, c->wp2, 5, 0);
+    } else if (std::getenv("NSK_STAMP_KERNEL") && std::string(std::getenv("NSK_STAMP_KERNEL")) == "schwarz") {
+      for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(k_schwarz<N>, dim3(c->nblk), dim3(Cfg<N>::NT), 0, c->stream, d, (const double*)d.V, d.Z, 1, 0);
+    } else {
+      const int jd = std::getenv("NSK_STAMP_J") ? std::atoi(std::getenv("NSK_STAMP_J")) : 5;
+      for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(k_divgs<N>, dim3(c->nblk), dim3(Cfg<N>::NT), 0, c->stream, d, (const double*)d.yl, c->wp2, jd, 0);
+    }
   });
   HIPCHK(hipStreamSynchronize(c->stream));
   HIPCHK(hipMemcpy(out, d.dbg, (size_t)16 * std::min(nblk_max, c->nblk) * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -2334,6 +2338,42 @@ int nsk_bench_kernel(nsk_ctx* c, const char* name, int reps, double* avg_us) {
       for (int r = 0; r < 4; ++r) { HIPCHK(hipMemsetAsync(c->sync, 0, SYNC_WORDS * sizeof(unsigned), c->stream)); launch_fused<N>(c, sc, its, &d); }
       HIPCHK(hipEventRecord(e0, c->stream));
       for (int r = 0; r < reps; ++r) { HIPCHK(hipMemsetAsync(c->sync, 0, SYNC_WORDS * sizeof(unsigned), c->stream)); launch_fused<N>(c, sc, its, &d); }
+      HIPCHK(hipEventRecord(e1, c->stream));
+    });
+  } else if (c->ndim == 3 && (n == "divgs" || n == "schwarz" || n == "gradt" || n.rfind("gs_lag", 0) == 0 || n.rfind("gs_dots", 0) == 0 || n == "pres_update" || n == "vel_update_proj" || n == "pres_rhs" || n == "rhs")) {
+    // hexahedral pressure kernels back to back on the state the last map left: the E apply without its dots ("divgs"), the
+    // Schwarz preconditioner + D^T ("schwarz"), the streaming Gram-Schmidt passes at basis index j ("gs_lag<j>", "gs_dots<j>")
+    d.tol_pres = 0.0; d.tol_relative = 0; d.pres_cap = 0;
+    const StepCoef sc = make_coef(c, 17, 0);
+    const int jj = (n.rfind("gs_lag", 0) == 0) ? std::atoi(n.c_str() + 6) : ((n.rfind("gs_dots", 0) == 0) ? std::atoi(n.c_str() + 7) : 3);
+    if (jj < 0 || jj + 1 >= MAXMR) return fail(NSK_EINVAL, "basis index out of range");
+    HIPCHK(hipMemsetAsync((char*)d.gsc + offsetof(GmresScal, done), 0, sizeof(int), c->stream));
+    HIPCHK(hipMemsetAsync((char*)d.gsc + offsetof(GmresScal, pending), 0, sizeof(int), c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    DISPATCH_N(c->key, {
+      constexpr int NT = Cfg<N>::NT;
+      for (int r = -3; r < reps; ++r) {
+        if (r == 0) HIPCHK(hipEventRecord(e0, c->stream));
+        if (n == "divgs") hipLaunchKernelGGL(k_divgs<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, (const double*)d.yl, c->wp2, -1, 0);
+        else if (n == "schwarz") hipLaunchKernelGGL(k_schwarz<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, (const double*)(d.V + (size_t)jj * d.ps), d.Z + (size_t)jj * d.npr, 1, 0);
+        else if (n == "gradt") hipLaunchKernelGGL(k_gradt<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, (const double*)c->wp1, d.yl);
+        else if (n == "pres_update") hipLaunchKernelGGL(k_pres_update<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, sc);
+        else if (n == "vel_update_proj") hipLaunchKernelGGL(k_vel_update_proj<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, sc);
+        else if (n == "pres_rhs") hipLaunchKernelGGL(k_pres_rhs<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, sc, 1, 7);
+        else if (n == "rhs") hipLaunchKernelGGL(k_rhs<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, sc);
+        else if (n.rfind("gs_dots", 0) == 0) launch_gs_dots3<N>(c, d, jj);
+        else {                                               // gs_lag<j>: the streaming pass alone (its totals and the column kernel are microseconds)
+          if constexpr (N <= 10) {
+            constexpr int ROWS = (nsk::k3::Cfg<N>::MM + 63) / 64;
+            constexpr int R4 = ROWS < 4 ? ROWS : 4, R2 = ROWS < 2 ? ROWS : 2;
+            const dim3 grid(std::min<unsigned>((unsigned)((c->nel + 3) / 4), 2048u)), blk(256);
+            if (jj <= 8) hipLaunchKernelGGL((nsk::k3::k_gs_lag<N, 8, R4>), grid, blk, 0, c->stream, d, jj);
+            else if (jj <= 16) hipLaunchKernelGGL((nsk::k3::k_gs_lag<N, 16, R2>), grid, blk, 0, c->stream, d, jj);
+            else if (jj <= 32) hipLaunchKernelGGL((nsk::k3::k_gs_lag<N, 32, 1>), grid, blk, 0, c->stream, d, jj);
+            else hipLaunchKernelGGL((nsk::k3::k_gs_lag<N, MAXMR, 1>), grid, blk, 0, c->stream, d, jj);
+          }
+        }
+      }
       HIPCHK(hipEventRecord(e1, c->stream));
     });
   } else if (n == "coarse" || n == "schwarz" || n == "divgs" || n == "gmres_update" || n == "pres_chain" || n == "pres_chain3" || n == "pres_chain_merged" || n.rfind("update_coarse", 0) == 0 || n == "divgs2" ||

@@ -24,7 +24,15 @@ __device__ inline long long xcd_element(unsigned b, unsigned n) {
 // are the same for every component and iteration, so a launch stages them once in LDS (8 ints per
 // thread, private to the thread: no barrier) and every later gather issues its value loads at once
 // instead of walking offsets -> indices -> values.  Same left-to-right sum as gs_csr.
-__device__ inline void gs_wide_stage(const Dev& d, const int4 tab, long long l, int* sw) {
+__device__ inline void gs_wide_stage(const Dev& d, const int4 tab, long long l, int* sw, const int4* corner = nullptr) {
+  if (corner) {                                  // element corner: its list is addressed directly (issued before tab is known)
+    const int4 a = corner[0], b = corner[1];
+    if (a.x != -2) {
+      if (tab.x >= 0) return;
+      sw[0] = a.x; sw[1] = a.y; sw[2] = a.z; sw[3] = a.w; sw[4] = b.x; sw[5] = b.y; sw[6] = b.z; sw[7] = b.w;
+      return;
+    }
+  }
   if (tab.x >= 0) return;
   const int o0 = d.gs_off[l], o1 = d.gs_off[l + 1];
   if (o1 - o0 > 8) { sw[0] = -2; return; }
@@ -47,6 +55,39 @@ __device__ inline double gs_wide_sum(const double* __restrict__ f, const Dev& d,
   for (int q = 0; q < 8; ++q)
     if (id[q] >= 0) s += v[q];
   return s;
+}
+
+// Element corners are the nodes of valence 5..8 of a regular hexahedral mesh.  Their lists live in a table addressed by
+// (element, corner) -- known from the thread index -- so the index loads go out with the kernel's first loads instead of
+// behind gs_tab -> gs_off -> gs_idx (measured at config 4's size, k_divgs: the loading phase of a workgroup took 10.4 us = five
+// dependent round trips, all 512 threads waiting at the barrier for the 8 corner threads).  Same left-to-right sum as gs_csr.
+template <int N>
+__device__ inline int corner_id(int k, int j, int i) {
+  const bool c = (i == 0 || i == N - 1) && (j == 0 || j == N - 1) && (k == 0 || k == N - 1);
+  return c ? ((k ? 4 : 0) | (j ? 2 : 0) | (i ? 1 : 0)) : -1;
+}
+struct CornerList { int id[8]; };
+__device__ inline void corner_issue(const Dev& d, long long e, int c, CornerList& L) {
+  if (c < 0 || !d.gs_corner) { L.id[0] = -2; return; }
+  const int4* p = reinterpret_cast<const int4*>(d.gs_corner + ((size_t)e * 8 + c) * 8);
+  const int4 a = p[0], b = p[1];
+  L.id[0] = a.x; L.id[1] = a.y; L.id[2] = a.z; L.id[3] = a.w; L.id[4] = b.x; L.id[5] = b.y; L.id[6] = b.z; L.id[7] = b.w;
+}
+__device__ inline double corner_sum(const double* __restrict__ f, const Dev& d, long long l, const CornerList& L) {
+  if (L.id[0] == -2) return gs_csr(f, d, l);
+  double v[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) v[q] = (L.id[q] >= 0) ? f[L.id[q]] : 0.0;
+  double s = 0.0;
+#pragma unroll
+  for (int q = 0; q < 8; ++q)
+    if (L.id[q] >= 0) s += v[q];
+  return s;
+}
+// gs_sum with the corner lists for the wide nodes
+__device__ inline double gs_sum3(const GsVals& v, const double* __restrict__ f, const Dev& d, const int4 t, long long l, const CornerList& L) {
+  if (t.x < 0) return corner_sum(f, d, l, L);
+  return ((v.a + v.b) + v.c) + v.d;
 }
 
 template <int N>
@@ -656,7 +697,8 @@ __global__ __launch_bounds__(Cfg<N>::NT, 4) void k_helm(Dev d, StepCoef sc, int 
     bm = d.bm1[l]; mk = d.mask[l]; mi = d.minv[l];
     g[0] = d.g1[l]; g[1] = d.g2[l]; g[2] = d.g3[l]; g[3] = d.g4[l]; g[4] = d.g5[l]; g[5] = d.g6[l];
     di = d.dinv[(size_t)(sc.k - 1) * d.nloc + l];
-    gs_wide_stage(d, tab, l, sW + tid * 8);
+    const int cid = corner_id<N>(k, j, i);
+    gs_wide_stage(d, tab, l, sW + tid * 8, (cid >= 0 && d.gs_corner) ? reinterpret_cast<const int4*>(d.gs_corner + ((size_t)e * 8 + cid) * 8) : nullptr);
   }
 #pragma unroll 1
   for (int c = 0; c < 3; ++c) {
@@ -1215,10 +1257,11 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_schwarz(Dev d, const double* __r
   __shared__ double sa[NN], sb[NN];
   __shared__ double sP[3 * MM], sC[3 * NMM], sE[2 * NNM];
   const int tid = threadIdx.x;
-  const long long e = (blockIdx.x + d.boff);
+  const long long e = d.boff + xcd_element(blockIdx.x, gridDim.x);      // XCD-contiguous runs of elements: the neighbours' face lines hit the L2 that streams them
   const bool act = tid < NN;
   const int k = tid / (N * N), j = (tid / N) % N, i = tid % N;
   if (check_done && d.gsc->done) return;
+  NSK_STAMP(0);
   const bool pact = tid < MM;
   const long long q = e * MM + tid;
   load_basis3<N>(d, nullptr, nullptr, sJ12, sD12, tid, NT);
@@ -1238,7 +1281,9 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_schwarz(Dev d, const double* __r
     const int id = d.p_idx[e * NN + tid];
     sa[tid] = (id >= 0) ? vsc * vin[id] : 0.0;
   }
+  NSK_STAMP(1);
   lds_barrier();
+  NSK_STAMP(2);
   // forward: S^T along r, s, t
   if (act) { double s = 0; for (int m = 0; m < N; ++m) s += sS[0 * N * N + m * N + i] * sa[(k * N + j) * N + m]; sb[tid] = s; }
   lds_barrier();
@@ -1257,6 +1302,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_schwarz(Dev d, const double* __r
   lds_barrier();
   if (act) { double s = 0; for (int m = 0; m < N; ++m) s += sS[0 * N * N + i * N + m] * sb[(k * N + j) * N + m]; sa[tid] = s; }
   lds_barrier();
+  NSK_STAMP(3);
   double z = 0.0;
   if (pact) {
     const int a = tid % M, b = (tid / M) % M, cc = tid / (M * M);
@@ -1265,10 +1311,12 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_schwarz(Dev d, const double* __r
   }
   double gp[3];
   opgradt3<N>(sJ12, sD12, z, w2, sP, sC, sE, tid, NT, act, k, j, i, gp);
+  NSK_STAMP(4);
   if (act) {
     const long long l = e * NN + tid;
     d.yl[l] = gp[0]; d.yl[d.cs + l] = gp[1]; d.yl[2 * d.cs + l] = gp[2];
   }
+  NSK_STAMP(5);
 }
 
 // yl = D^T p for an arbitrary pressure vector
@@ -1304,25 +1352,31 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_divgs(Dev d, const double* __res
   __shared__ double su[3 * NN], sA[2 * NNM], sB[3 * NMM];
   __shared__ double sdot[(MAXMR + 2) * 16];
   const int tid = threadIdx.x;
-  const long long e = (blockIdx.x + d.boff);
+  const long long e = d.boff + xcd_element(blockIdx.x, gridDim.x);      // XCD-contiguous runs of elements: the neighbours' face lines hit the L2 that streams them
   const bool act = tid < NN;
   if (check_done && d.gsc->done) return;
+  NSK_STAMP(0);
   const long long l = e * NN + tid;
   load_basis3<N>(d, nullptr, nullptr, sJ12, sD12, tid, NT);
   if (act) {
+    CornerList CL;
+    corner_issue(d, e, corner_id<N>(tid / (N * N), (tid / N) % N, tid % N), CL);
     const int4 tab = d.gs_tab[l];
     const double bi = d.binv[l];
     GsVals g0 = gs_load(yl, tab, l), g1 = gs_load(yl + d.cs, tab, l), g2 = gs_load(yl + 2 * d.cs, tab, l);
-    su[tid] = bi * gs_sum(g0, yl, d, tab, l);
-    su[NN + tid] = bi * gs_sum(g1, yl + d.cs, d, tab, l);
-    su[2 * NN + tid] = bi * gs_sum(g2, yl + 2 * d.cs, d, tab, l);
+    su[tid] = bi * gs_sum3(g0, yl, d, tab, l, CL);
+    su[NN + tid] = bi * gs_sum3(g1, yl + d.cs, d, tab, l, CL);
+    su[2 * NN + tid] = bi * gs_sum3(g2, yl + 2 * d.cs, d, tab, l, CL);
   }
   const bool pact = tid < MM;
   const long long q = e * MM + tid;
   double w2[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   if (pact) load_w2(d, q, w2);
+  NSK_STAMP(1);
   lds_barrier();
+  NSK_STAMP(2);
   const double w = opdiv3<N>(sJ12, sD12, su, sA, sB, tid, NT, w2);
+  NSK_STAMP(3);
   if (pact) wout[q] = w;
   if (j >= 0) {
     const int lane = tid & 63, wv = tid >> 6;
@@ -1395,19 +1449,20 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_vel_update_proj(Dev d, StepCoef 
   __shared__ double sJ12[NM], sD12[NM];
   __shared__ double su[3 * NN], sA[2 * NNM], sB[3 * NMM];
   const int tid = threadIdx.x;
-  const long long e = blockIdx.x;
+  const long long e = xcd_element(blockIdx.x, gridDim.x);
   const bool act = tid < NN;
   const GmresScal* G = d.gsc;
   load_basis3<N>(d, nullptr, nullptr, sJ12, sD12, tid, NT);
   if (act) {
     const long long l = e * NN + tid;
+    CornerList CL;
+    corner_issue(d, e, corner_id<N>(tid / (N * N), (tid / N) % N, tid % N), CL);
+    const int4 tab = d.gs_tab[l];
     const double bi = d.binv[l];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const double v = bi * gs_gather(d.yl + c * d.cs, d, l);
-      d.u[c * d.cs + l] += v / sc.h2;
-      su[c * NN + tid] = v;
-    }
+    const GsVals g0 = gs_load(d.yl, tab, l), g1 = gs_load(d.yl + d.cs, tab, l), g2 = gs_load(d.yl + 2 * d.cs, tab, l);
+    const double v0 = bi * gs_sum3(g0, d.yl, d, tab, l, CL), v1 = bi * gs_sum3(g1, d.yl + d.cs, d, tab, l, CL), v2 = bi * gs_sum3(g2, d.yl + 2 * d.cs, d, tab, l, CL);
+    d.u[l] += v0 / sc.h2; d.u[d.cs + l] += v1 / sc.h2; d.u[2 * d.cs + l] += v2 / sc.h2;
+    su[tid] = v0; su[NN + tid] = v1; su[2 * NN + tid] = v2;
   }
   if (G->nit == 0) return;
   const bool pact = tid < MM;

@@ -97,6 +97,8 @@ struct Dev {
   // gather-scatter (dssum) as a gather: CSR of co-located local nodes, ascending
   const int *gs_off, *gs_idx;
   const int4* gs_tab;
+  const int* gs_corner;          // hexahedra: [nel][8 corners][8] co-located local nodes of the element corners (ascending, -1 padded;
+                                 // first entry -2: more than 8, use the CSR lists): addressable WITHOUT the gs_tab / gs_off round trips
   // time-stepper state
   double *u, *p, *plag, *pext, *ulag, *exlag, *bf, *rloc, *bloc, *dulag;
   // Helmholtz CG (both components advance together)

@@ -132,6 +132,23 @@ def test_bench_spawns_its_ranks(tmp_path):
     assert out.returncode != 0 and "launcher started 1 ranks" in out.stderr
 
 
+def test_bench_retries_after_a_stalled_attempt():
+    """A stalled first attempt (watchdog exit, STALL_EXIT) must lead to the eager retry in fresh processes; only the unique
+    'no GPU' code stops the attempts (both used exit code 3, so a stall ended the run without the retry)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: the retry would run the whole sharded bench")
+    env = dict(os.environ, NSK_BENCH_TEST_STALL="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode != 0
+    assert out.stderr.count("forced stall (test hook)") == 2, out.stderr[-1500:]
+    assert "attempt 0 (captured step graphs) failed with code 5: retrying with eager launches in fresh processes" in out.stderr, out.stderr[-1500:]
+    assert out.stderr.count("bench.py needs a GPU") == 2, out.stderr[-1500:]        # attempt 1 ran (and ended on the unique no-GPU code)
+    assert "attempt 1" not in out.stderr
+    rec = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(rec) == 1 and '"value": null' in rec[0]
+
+
 @pytest.mark.parametrize("nranks", [2, 3, 8])
 def test_partition_rcb(case6, nranks):
     """Element partition for sharded runs: every element owned once, balanced, deterministic, and
