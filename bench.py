@@ -39,9 +39,9 @@ PROBE_S = 420              # N > 1 only: communicator set-up + the two-step prob
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None, help="timed Arnoldi steps (default 128 at N=1 on cfg2, 8 otherwise)")
+    ap.add_argument("--steps", type=int, default=None, help="timed Arnoldi steps (default 128 at N=1 on cfg2, 2 on cfg4, 8 otherwise)")
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--case", choices=["cfg2", "cfg3"], default="cfg2", help="workload: BASELINE configs[1] (default, the metric's configuration) or configs[2], at any N")
+    ap.add_argument("--case", choices=["cfg2", "cfg3", "cfg4"], default="cfg2", help="workload: BASELINE configs[1] (default, the metric's configuration), configs[2] at any N, or configs[3] (backward-facing step extruded to E = 50 100 hexahedra, adjoint) on one GPU")
     ap.add_argument("--lx1", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kdim", action="store_true", help="do not continue the factorisation to k_dim = 128 after the timed steps")
@@ -205,6 +205,16 @@ def pmc_traffic(kernel_key):
 
 def build_case(name, lx1_override=None):
     from nekstab_amd import mesh
+    if name == "cfg4":
+        # BASELINE configs[3]: the reference's backward-facing step (examples/back_fstep, Re = 500) extruded over 30 periodic
+        # spanwise layers: E = 50 100 hexahedra, lx1 = 8, 25.65 M points per field, state vector 702 MB; adjoint Arnoldi
+        from nekstab_amd import mesh3d
+        nz = int(os.environ.get("NSK_BENCH_CFG4_LAYERS", "30"))      # (tests run a thin slab)
+        c2 = mesh.load_case_npz(os.path.join(ROOT, "tests", "golden", "backstep_case.npz"), lx1_override or 8, re=500.0, endtime=1.0, xlspg=5.0, xrspg=10.0, spng_str=2.0)
+        c3 = mesh3d.extrude_case(c2, nz, 0.2 * nz, periodic=True)
+        c3.meta["c2"] = c2
+        c3.meta["nz"] = nz
+        return c3
     lx1 = lx1_override or (12 if name == "cfg3" else 8)
     case = mesh.load_case_npz(os.path.join(ROOT, "tests", "golden", "cylinder_case.npz"), lx1)
     if name == "cfg3":
@@ -258,11 +268,19 @@ def main():
 
     sharded = world > 1 and not a.replicas
     headline = (a.case == "cfg2" and world == 1)
-    steps = a.steps if a.steps is not None else (K_DIM if headline else 8)
+    hexa = a.case == "cfg4"
+    if hexa and world > 1:
+        raise SystemExit("bench.py --case cfg4: one GPU (the sharded hexahedral path is exercised by tests/test_fullsize_gpu.py and scripts/local_setup_cfg4.py)")
+    steps = a.steps if a.steps is not None else (K_DIM if headline else (2 if hexa else 8))
+    if hexa and a.warmup == 2:
+        a.warmup = 1                                       # a matvec of this case is 315 time steps of ~60 ms
     case = build_case(a.case, a.lx1)
-    cfg_index = 2 if a.case == "cfg3" else 1
+    cfg_index = {"cfg2": 1, "cfg3": 2, "cfg4": 3}[a.case]
+    amode = 1 if hexa else 0                               # configs[3] is an ADJOINT Arnoldi run
 
     def make_context(cs):
+        if hexa:                                           # the settings of scripts/run_cfg4_arnoldi.py
+            return NekStabHip(cs, cs.meta["vert"], cs.meta["nvert"], tol_helm=1e-10, tol_pres=1e-2, tol_relative=1, max_helm_iter=150, max_pres_iter=96, nproj=a.nproj)
         # shards carry the parent's projection space (nsk_shard_create), so the sharded operator is the single-rank one
         hh = NekStabHip(cs, cs.meta["vert"], cs.meta["nvert"], tol_helm=a.tol_helm, tol_pres=a.tol_pres, tol_relative=1,
                         schwarz_layers=2, max_helm_iter=100, max_pres_iter=48, nproj=a.nproj)
@@ -297,8 +315,25 @@ def main():
         full.set_option("pres_cap", a.pres_cap)
     if a.fused >= 0:
         full.set_option("fused", a.fused)
-    qx, qy = seed.add_noise(case)
-    zp = np.zeros((case.nel, case.lx1 - 2, case.lx1 - 2))
+    if hexa:
+        # seed: the reference's committed optimal perturbation of the 2-D step (examples/back_fstep/transient_growth), extruded,
+        # plus a spanwise-periodic w component: a three-dimensional vector whose inner solves behave like a Krylov vector's
+        from nekstab_amd import mesh, mesh3d
+        c2, nz = case.meta["c2"], case.meta["nz"]
+        tg = np.load(os.path.join(ROOT, "tests", "golden", "backstep_tg.npz"))
+        u2 = mesh.interp_field_2d(tg["pRe_u"].astype(np.float64), case.lx1) * c2.mask
+        qx, qy = mesh3d.extrude_field(u2[0], nz), mesh3d.extrude_field(u2[1], nz)
+        qz = 1e-1 * np.sin(2 * np.pi * case.z / (0.2 * nz)) * case.mask * np.abs(qx)
+        zp = np.zeros(full.npres)
+    else:
+        qx, qy = seed.add_noise(case)
+        zp = np.zeros((case.nel, case.lx1 - 2, case.lx1 - 2))
+
+    def upload_seed(ctx, v):
+        if hexa:
+            ctx.upload3(v, qx, qy, qz, zp)
+        else:
+            ctx.upload(v, qx, qy, zp)
 
     def make_shard(parent, cs):
         from nekstab_amd.sharded import ShardRank
@@ -404,15 +439,15 @@ def main():
         pw.cancel()
     ktot = max(a.warmup + steps, K_DIM if (headline and not a.no_kdim) else 0)
     Q = h.alloc(ktot + 1)
-    h.upload(Q[0], qx, qy, zp)
+    upload_seed(h, Q[0])
     h.scal(Q[0], 1.0 / h.norm(Q[0]))
     H = np.zeros((ktot + 1, ktot))
     stats = {}
     # warm-up steps: also settle the adaptive launch budgets / graph captures
-    krylov.arnoldi_factorization(h, Q, H, 1, a.warmup, 0, stats=stats)
+    krylov.arnoldi_factorization(h, Q, H, 1, a.warmup, amode, stats=stats)
     barrier()
     t0 = time.perf_counter()
-    krylov.arnoldi_factorization(h, Q, H, a.warmup + 1, a.warmup + steps, 0, stats=stats)
+    krylov.arnoldi_factorization(h, Q, H, a.warmup + 1, a.warmup + steps, amode, stats=stats)
     barrier()
     elapsed = time.perf_counter() - t0
     print("[bench] rank %d: %d timed Arnoldi steps in %.2f s" % (rank, steps, elapsed), file=sys.stderr, flush=True)
@@ -428,10 +463,12 @@ def main():
     wall_kdim = float(step_s[:K_DIM].sum()) if kdone >= K_DIM else None
     kk = min(kdone, K_DIM) if kdone >= K_DIM else kdone
     vals, vecs = krylov.eig_sorted(H[:kk, :kk])
+    kdim_case = 256 if hexa else K_DIM
     # The reference's only lx1 = 8 table is the adjoint one (same spectrum up to discretisation): Spectre_Ha.dat row 1 = 0.7386891 -+ 0.6972319i;
     # the CPU oracle's converged direct spectrum at lx1 = 8 is in tests/golden/cylinder_oracle_spectra.npz (Hd8)
-    ritz = {"k": kk, "re": float(vals[0].real), "im": float(abs(vals[0].imag)), "residual": float(abs(H[kk, kk - 1] * vecs[kk - 1, 0])),
-            "reference_Spectre_Ha_lx1_8": [0.7386891, 0.6972319]}
+    ritz = {"k": kk, "re": float(vals[0].real), "im": float(abs(vals[0].imag)), "residual": float(abs(H[kk, kk - 1] * vecs[kk - 1, 0]))}
+    if not hexa:
+        ritz["reference_Spectre_Ha_lx1_8"] = [0.7386891, 0.6972319]
     par = "1 GPU"
     if world > 1:
         par = ("element-sharded x%d (%s, one eigenproblem, %s)" % (world, "RCCL halos" if backend == "nccl" else "host-staged halos over %s: protocol dry run" % backend,
@@ -441,10 +478,14 @@ def main():
         "value": (world if (world > 1 and not sharded) else 1) * steps / elapsed, "unit": "matvecs/s", "n_gpus": world, "steps": steps, "warmup": a.warmup,
         "ms_per_step": 1e3 * elapsed / steps, "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic seed vector (the reference's add_noise) on the reference's committed mesh and base flow (fixtures under tests/golden)",
-        "config": {"workload": "cylinder Re=50 direct Arnoldi (BASELINE configs[%d]): E=%d, lx1=%d, lxd=%d, nsteps=%d/matvec, k_dim=%d"
-                   % (cfg_index, case.nel, case.lx1, case.lxd, h.nsteps, K_DIM),
-                   "base_flow": "reference BF_1cyl0.f00001 (committed fixture), seed = add_noise",
-                   "tolerances": "Helmholtz |b-Hu|<=%g|b|, pressure |g-E dp|<=%g|g| with at least %d GMRES iterations per solve%s (time steps 1-3 of a map: pressure tolerance x0.01), projection space %d: DESIGN.md section 1"
+        "config": {"workload": ("backward-facing step Re=500 extruded over %d periodic layers, adjoint Arnoldi (BASELINE configs[3]): E=%d hexahedra, lx1=%d, lxd=%d, nsteps=%d/matvec, k_dim=256; state vector %.0f MB"
+                                % (case.meta["nz"], case.nel, case.lx1, case.lxd, h.nsteps, 8e-6 * h.nstate)) if hexa else
+                               "cylinder Re=50 direct Arnoldi (BASELINE configs[%d]): E=%d, lx1=%d, lxd=%d, nsteps=%d/matvec, k_dim=%d"
+                               % (cfg_index, case.nel, case.lx1, case.lxd, h.nsteps, K_DIM),
+                   "base_flow": "reference BF_bfs0.f00001 (committed fixture) extruded, w = 0; seed = the reference's optimal perturbation pRe extruded + a spanwise-periodic w" if hexa
+                                else "reference BF_1cyl0.f00001 (committed fixture), seed = add_noise",
+                   "tolerances": ("Helmholtz |b-Hu|<=1e-10|b|, pressure |g-E dp|<=1e-2|g| (time steps 1-3 of a map: x0.01), projection space %d, host-read convergence flags: DESIGN.md section 8" % a.nproj) if hexa else
+                                 "Helmholtz |b-Hu|<=%g|b|, pressure |g-E dp|<=%g|g| with at least %d GMRES iterations per solve%s (time steps 1-3 of a map: pressure tolerance x0.01), projection space %d: DESIGN.md section 1"
                                  % (a.tol_helm, a.tol_pres, a.min_pres, (" and at most %d after time step 3" % a.pres_cap) if a.pres_cap else "", a.nproj),
                    "parallelism": par},
         "setup_s": setup_s,
@@ -453,7 +494,7 @@ def main():
         "leading_ritz": ritz,
     }
     if wall_kdim is None:
-        out["wall_time_kdim_note"] = "only %d of the %d Arnoldi steps were run (--steps / --no-kdim); per-step time x %d = %.1f s projected" % (kdone, K_DIM, K_DIM, K_DIM * elapsed / steps)
+        out["wall_time_kdim_note"] = "only %d of the %d Arnoldi steps were run (--steps / --no-kdim); per-step time x %d = %.1f s projected" % (kdone, kdim_case, kdim_case, kdim_case * elapsed / steps)
     if not sharded:
         st = full.stats()
         tsteps = max(st["total_steps"], 1)
@@ -463,6 +504,8 @@ def main():
         # ---- SURVEY 8(d) accounting: algorithmic bytes per matvec from the logged iteration counts
         geom = dict(nel=case.nel, lx1=case.lx1, ndim=2, nvert=int(case.meta["nvert"]), coarse_lda=((int(case.meta["nvert"]) + 255) // 256) * 256,
                     patch_stride=(((case.lx1 - 2 + 4) ** 2 + 3) // 4) * 4, nproj=a.nproj)
+        if hexa:
+            geom = dict(nel=case.nel, lx1=case.lx1, ndim=3, nvert=int(case.meta["nvert"]), nproj=a.nproj)
         bpm, per = roofline.matvec_bytes(st, full.nsteps, **geom)
         jmean = a.warmup + (steps + 1) / 2.0
         bpm_k = roofline.krylov_bytes(full.nstate, jmean)
@@ -471,6 +514,17 @@ def main():
                                    "rule": "SURVEY 8(d): every distinct array once per kernel invocation, from the logged iteration counts (nekstab_amd/roofline.py)"}
         out["roofline_end_to_end"] = {"bound": "hbm", "achieved": e2e, "peak": 8000.0, "unit": "GB/s", "frac": e2e / 8000.0,
                                       "note": "algorithmic bytes of a whole Arnoldi step / its wall time"}
+        out["ms_per_time_step"] = 1e3 * float(np.mean(stats["matvec_s"][a.warmup:a.warmup + steps])) / full.nsteps
+        if hexa:
+            out["pres_basis_index_sum_per_step"] = st["total_pres_jsum"] / tsteps
+            out["coarse_bytes_per_solve"] = st["coarse_bytes_per_solve"]
+            # the SURVEY rule counts the arrays the three components of a CG launch share once PER COMPONENT; with every distinct array once per launch:
+            rule, distinct = roofline.helm_launch_bytes(nel=case.nel, lx1=case.lx1, ndim=3)
+            hit = st["total_helm_iters"] / tsteps
+            bpm_d = bpm - full.nsteps * (rule - distinct) * hit
+            out["bytes_per_matvec"]["time_stepper_shared_arrays_once"] = bpm_d
+            e2d = (bpm_d + bpm_k) / (elapsed / steps) / 1e9
+            out["roofline_end_to_end"].update({"achieved_shared_arrays_once": e2d, "frac_shared_arrays_once": e2d / 8000.0})
         # ---- dominant kernel, timed live with HIP events on the library's own stream
         P = full.nvel
         fused_on = False
@@ -490,6 +544,31 @@ def main():
                                "avg_launch_us": kern8["avg_us"], "us_per_cg_iteration": (kern8["avg_us"] - kern0["avg_us"]) / its,
                                "algorithmic_bytes_per_launch": alg,
                                "note": "CG state lives in registers across iterations, so the launch moves fewer bytes than its algorithmic figure; working set (~30 MB) is Infinity-Cache resident: DESIGN.md section 5"}
+        elif hexa:
+            # live HIP-event timings of the hot hexahedral kernels on the state the last map left (every launch does full work)
+            rule, distinct = roofline.helm_launch_bytes(nel=case.nel, lx1=case.lx1, ndim=3)
+            P2, nel_, N_ = full.npres, case.nel, case.lx1
+            one = roofline.per_step_bytes(nel=nel_, lx1=N_, ndim=3, nvert=int(case.meta["nvert"]), nproj=0, helm_iters=0.0, pres_iters=1.0, pres_jsum=0.0, coarse_bytes=0.0)
+            kb = {"helm": rule, "divgs": one["K7 divgs (x n_pres)"], "schwarz": one["K6 schwarz (x n_pres)"] - nel_ * 8 * 12.0}
+            for jq in (8, 24):
+                kb["gs_dots%d" % jq] = 8.0 * P2 * (jq + 2)
+                kb["gs_lag%d" % jq] = 8.0 * P2 * (jq + 3) + 64.0 * nel_        # (no pending correction in this timing: one store)
+            ktab = {}
+            for kn, byts in kb.items():
+                kr = full.bench_kernel(kn, 20)
+                ktab[kn] = {"avg_us": kr["avg_us"], "algorithmic_bytes": byts, "GBps": byts / kr["avg_us"] / 1e3, "frac": byts / kr["avg_us"] / 1e3 / 8000.0}
+            ktab["helm"]["algorithmic_bytes_shared_arrays_once"] = distinct
+            ktab["helm"]["frac_shared_arrays_once"] = distinct / ktab["helm"]["avg_us"] / 1e3 / 8000.0
+            for kn in ktab:
+                tr, _ = pmc_traffic("k3::" + kn if not kn.startswith("gs_") else "k3::" + kn)
+                ktab[kn]["traffic"] = tr
+            out["kernels"] = ktab
+            traffic, tnote = pmc_traffic("k3::helm")
+            out["roofline"] = {"bound": "hbm", "kernel": "k3::k_helm<%d> (one CG iteration of the three components; the largest share of the kernel time: profiles/r04_cfg4_kernel_table.md)" % case.lx1,
+                               "achieved": ktab["helm"]["GBps"], "peak": 8000.0, "unit": "GB/s", "frac": ktab["helm"]["frac"], "traffic": traffic, "traffic_source": tnote,
+                               "avg_launch_us": ktab["helm"]["avg_us"], "algorithmic_bytes_per_launch": rule,
+                               "frac_shared_arrays_once": ktab["helm"]["frac_shared_arrays_once"],
+                               "note": "SURVEY 8(d) counts 172 B per point and COMPONENT; the launch reads the arrays the components share once (frac_shared_arrays_once)"}
         else:
             kern = full.bench_kernel("helm", 200)
             alg = 148.0 * 2 * P
@@ -659,6 +738,9 @@ def main():
         out["lanes"] = lanes
     if rank == 0 and headline and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(case, a.cpu_threads, (a.tol_helm, a.tol_pres, a.min_pres))
+    if hexa:
+        out["cpu_baseline"] = None
+        out["cpu_baseline_note"] = "the C / OpenMP port of the step (oracle/cpu_step.c) covers quadrilaterals; the hexahedral oracle (oracle/linns3d.py) uses sparse direct solves and does not reach this size: the default record (BASELINE configs[1]) carries the CPU baseline"
     if sharded:
         all_ok(True, None)                                 # nobody prints a record unless every rank got to the end
     if rank == 0:

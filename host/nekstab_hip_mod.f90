@@ -29,6 +29,8 @@ module nekstab_hip
     real(c_double) :: total_worst_cap_ratio
     integer(c_long_long) :: total_helm_iters, total_pres_iters, total_steps
     real(c_double) :: recapture_seconds
+    integer(c_long_long) :: total_pres_jsum
+    real(c_double) :: coarse_bytes_per_solve
   end type
 
   interface

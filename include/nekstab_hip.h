@@ -185,6 +185,8 @@ typedef struct {
   double total_worst_cap_ratio;
   long long total_helm_iters, total_pres_iters, total_steps;   /* since nsk_init: what bytes_per_matvec is computed from */
   double recapture_seconds;                 /* host time spent (re)capturing and instantiating the step graphs since nsk_init */
+  long long total_pres_jsum;                /* since nsk_init: sum over all GMRES columns of their basis index j (Gram-Schmidt bytes) */
+  double coarse_bytes_per_solve;            /* operator bytes ONE coarse solve reads (dense / block-circulant inverse, or degree x sparse rows) */
 } nsk_stats;
 int nsk_get_stats(nsk_ctx* ctx, nsk_stats* s);
 

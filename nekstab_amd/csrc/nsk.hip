@@ -90,7 +90,8 @@ struct nsk_ctx {
   long long recaptures = 0, retries = 0;
   double recapture_s = 0.0;             // host time spent capturing + instantiating step graphs (since init)
   // since init (nsk_stats: the per-matvec fields are reset by every nsk_matvec, these are not)
-  long long tot_capped = 0, tot_helm_iters = 0, tot_pres_iters = 0, tot_steps = 0;
+  long long tot_capped = 0, tot_helm_iters = 0, tot_pres_iters = 0, tot_steps = 0, tot_pres_jsum = 0;
+  double coarse_bytes = 0.0;            // bytes one coarse solve reads (operator storage): nsk_stats::coarse_bytes_per_solve
   double tot_worst_cap = 0.0;
   int debug = 0;
   struct StepGraph { hipGraphExec_t exec = nullptr; int nh = -1, np = -1; } graphs[3][NCLS];
@@ -321,6 +322,7 @@ static int coarse_dense_inverse(nsk_ctx* c, std::vector<double>& Ac, bool has_ou
   HIPCHK(hipMemcpy(Ah.data(), dA, Ah.size() * sizeof(double), hipMemcpyDeviceToHost));
   std::vector<float> Af((size_t)nvert * lda, 0.0f);
   for (int r = 0; r < nvert; ++r) for (int q = 0; q < nvert; ++q) Af[(size_t)r * lda + q] = (float)Ah[(size_t)r * nvert + q];
+  c->coarse_bytes = 4.0 * nvert * lda + 16.0 * nvert;
   return dupload(c, &d.Acif, Af);
 }
 
@@ -1163,7 +1165,7 @@ static int map_finish(nsk_ctx* c) {
   c->hstats.last_helm_res = h.last_helm_res; c->hstats.last_pres_res = h.last_pres_res;
   c->hstats.capped_solves += h.capped_solves; c->hstats.worst_cap_ratio = std::max(c->hstats.worst_cap_ratio, h.worst_cap_ratio);
   c->tot_capped += h.capped_solves; c->tot_worst_cap = std::max(c->tot_worst_cap, h.worst_cap_ratio);
-  c->tot_helm_iters += h.helm_iters; c->tot_pres_iters += h.pres_iters; c->tot_steps += c->nsteps;
+  c->tot_helm_iters += h.helm_iters; c->tot_pres_iters += h.pres_iters; c->tot_steps += c->nsteps; c->tot_pres_jsum += h.pres_jsum;
   for (int k = 0; k < NCLS; ++k) {
     c->hstats.max_helm_k[k] = std::max(c->hstats.max_helm_k[k], h.max_helm_k[k]);
     c->hstats.max_pres_k[k] = std::max(c->hstats.max_pres_k[k], h.max_pres_k[k]);
@@ -1866,6 +1868,7 @@ int nsk_get_stats(nsk_ctx* c, nsk_stats* s) {
   s->total_capped_solves = c->tot_capped; s->total_worst_cap_ratio = c->tot_worst_cap;
   s->total_helm_iters = c->tot_helm_iters; s->total_pres_iters = c->tot_pres_iters; s->total_steps = c->tot_steps;
   s->recapture_seconds = c->recapture_s;
+  s->total_pres_jsum = c->tot_pres_jsum; s->coarse_bytes_per_solve = c->coarse_bytes;
   return 0;
 }
 

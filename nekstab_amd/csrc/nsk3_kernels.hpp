@@ -976,6 +976,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_gmres_update(Dev d, int j, doubl
       G->g[j] = cj * gj;
       G->g[j + 1] = -sj * gj;
       G->nit = j + 1;
+      d.stats->pres_jsum += j;
       const double res = fabs(sj * gj) * scale;
       G->resid = res;
       const double tol = d.tol_relative ? fmax(d.tol_pres * G->gnorm0 * scale, d.tol_pres_floor) : d.tol_pres;
@@ -1229,6 +1230,7 @@ __global__ __launch_bounds__(64) void k_gmres_col(Dev d, int j, double scale, in
   G->g[j] = cj * gj;
   G->g[j + 1] = -sj * gj;
   G->nit = j + 1;
+  d.stats->pres_jsum += j;
   const double res = fabs(sj * gj) * scale;
   G->resid = res;
   const double tol = d.tol_relative ? fmax(d.tol_pres * G->gnorm0 * scale, d.tol_pres_floor) : d.tol_pres;

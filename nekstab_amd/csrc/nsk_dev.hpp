@@ -64,6 +64,7 @@ struct Stats {
   long long capped_solves;                        // pressure solves ended by `pres_cap` above their tolerance
   double worst_cap_ratio;                         // largest residual / tolerance among them
   long long sync_timeouts;                        // grid barriers of the persistent kernels that gave up (never in a healthy run)
+  long long pres_jsum;                            // sum over the GMRES columns of their basis index j (the Gram-Schmidt bytes are proportional to it)
 };
 
 struct Dev {

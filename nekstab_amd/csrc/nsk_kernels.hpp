@@ -1072,6 +1072,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_gmres_update(Dev d, int j, doubl
       G->g[j] = cj * gj;
       G->g[j + 1] = -sj * gj; G->gpre[j + 1] = -sj * gj;
       G->nit = j + 1;
+      d.stats->pres_jsum += j;
       const double res = fabs(sj * gj) * scale;
       G->resid = res;
       const double tol = d.tol_relative ? fmax(d.tol_pres * G->gnorm0 * scale, d.tol_pres_floor) : d.tol_pres;
@@ -1388,6 +1389,7 @@ __global__ __launch_bounds__(256) void k_update_coarse(Dev d, int j, double scal
       G->g[jj + 1] = -sj * gj; G->gpre[jj + 1] = -sj * gj;
       G->nit = jj + 1;
       G->resid = res;
+      d.stats->pres_jsum += jj;
       if (conv) {
         atomicAdd((unsigned long long*)&d.stats->pres_iters, (unsigned long long)(G->nit_prev + jj + 1));
         atomicMax((unsigned long long*)&d.stats->max_pres, (unsigned long long)(G->nit_prev + jj + 1));

@@ -12,9 +12,13 @@ the *compulsory* traffic of the launch-per-kernel formulation, so a kernel that 
 from __future__ import annotations
 
 
-def per_step_bytes(*, nel, lx1, ndim=2, nvert=0, coarse_lda=0, patch_stride=0, nproj=0, helm_iters=0.0, pres_iters=0.0):
+def per_step_bytes(*, nel, lx1, ndim=2, nvert=0, coarse_lda=0, patch_stride=0, nproj=0, helm_iters=0.0, pres_iters=0.0,
+                   pres_jsum=None, coarse_bytes=None, gs_lag=1):
     """Algorithmic bytes of ONE time step, by kernel family.  ``helm_iters`` / ``pres_iters``: mean iterations per step
-    (both velocity components advance together in one CG iteration)."""
+    (all velocity components advance together in one CG iteration).  Hexahedra (``ndim = 3``): ``pres_jsum`` = mean per step of
+    the sum over the GMRES columns of their basis index j (nsk_stats.total_pres_jsum / total_steps; the Gram-Schmidt bytes
+    are proportional to it), ``coarse_bytes`` = nsk_stats.coarse_bytes_per_solve, ``gs_lag``: the lagged Gram-Schmidt
+    sequence (two basis reads per column) or the classic one (four)."""
     d = ndim
     N, M, ND = lx1, lx1 - 2, 3 * lx1 // 2
     P, P2, Pd = nel * N ** d, nel * M ** d, nel * ND ** d
@@ -30,24 +34,54 @@ def per_step_bytes(*, nel, lx1, ndim=2, nvert=0, coarse_lda=0, patch_stride=0, n
     out["K3 helm iteration (x n_helm x d)"] = (148.0 if d == 2 else 172.0) * P * d * helm_iters
     # K4' pressure rhs: hx (d), dulag rw (3d + 3d), u rw (2d); metrics, V0 out, PX reads on P2
     out["K4 pres_rhs"] = f * (P * (d + 6 * d + 2 * d) + P2 * (nmet2 + 1 + nproj))
-    # per GMRES iteration (mean basis index j ~ (n-1)/2)
+    # per GMRES iteration (mean basis index j ~ (n-1)/2 unless the sum of the basis indices was logged)
     jbar = max(pres_iters - 1.0, 0.0) / 2.0
-    coarse = 4.0 * nvert * coarse_lda + f * (nel * 2 ** d + 2 * nvert)                      # fp32 dense inverse + restriction + x_c
-    schwarz = 4.0 * nel * patch_stride * M ** d + 4.0 * nel * patch_stride + f * nel * patch_stride + f * P2 * (1 + nmet2) + f * P * d
-    if d == 3:                                                                              # fast-diagonalisation patches: 3 N^2 + 3 N factors per element
-        schwarz = f * nel * (3 * N * N + 3 * N) + f * nel * N ** 3 + f * P2 * (1 + nmet2) + f * P * d
-        coarse = 0.0                                                                        # sparse / polynomial coarse solve: not counted (problem dependent)
-    divgs = f * (P * (d + 1) + 2.0 * P) + f * P2 * (nmet2 + 1 + (jbar + 1))                # yl gather (d), binv, 16-B table; metrics, w out, V_0..j for the dots
-    gupd = f * P2 * (jbar + 3)                                                              # V_0..j, V_{j+1} read + write
-    out["K6 coarse (x n_pres)"] = coarse * pres_iters
-    out["K6 schwarz (x n_pres)"] = schwarz * pres_iters
-    out["K7 divgs (x n_pres)"] = divgs * pres_iters
-    out["K7 gmres_update (x n_pres)"] = gupd * (pres_iters + 1.0)
+    jsum = pres_jsum if pres_jsum is not None else jbar * pres_iters
+    if d == 2:
+        coarse = 4.0 * nvert * coarse_lda + f * (nel * 2 ** d + 2 * nvert)                  # fp32 dense inverse + restriction + x_c
+        schwarz = 4.0 * nel * patch_stride * M ** d + 4.0 * nel * patch_stride + f * nel * patch_stride + f * P2 * (1 + nmet2) + f * P * d
+        divgs = f * (P * (d + 1) + 2.0 * P) + f * P2 * (nmet2 + 1) + f * P2 * (jsum + pres_iters)   # yl gather (d), binv, 16-B table; metrics, w out; V_0..j for the dots
+        gupd = f * P2 * (jsum + 3.0 * (pres_iters + 1.0))                                  # V_0..j, V_{j+1} read + write
+        out["K6 coarse (x n_pres)"] = coarse * pres_iters
+        out["K6 schwarz (x n_pres)"] = schwarz * pres_iters
+        out["K7 divgs (x n_pres)"] = divgs if pres_jsum is not None else f * (P * (d + 1) + 2.0 * P) * pres_iters + f * P2 * (nmet2 + 1 + (jbar + 1)) * pres_iters
+        out["K7 gmres_update (x n_pres)"] = gupd if pres_jsum is not None else f * P2 * (jbar + 3) * (pres_iters + 1.0)
+    else:
+        # hexahedra.  coarse solve: its operator storage (block-circulant inverses / dense inverse / degree x sparse rows:
+        # nsk_stats.coarse_bytes_per_solve) + corner restrictions (8 per element, value + index) + two vertex vectors
+        coarse = (coarse_bytes or 0.0) + nel * 8 * (f + 4.0) + 2.0 * f * nvert
+        # Schwarz by fast diagonalisation + D^T: V_j (patch gather: the basis vector once), 4-B patch table on P, 3 N^2 + 3 N factors per
+        # element, nine metrics, corner prolongation (8 x (value + index) per element); Z_j and yl (d) out
+        schwarz = f * P2 + 4.0 * P + f * nel * (3 * N * N + 3 * N) + f * P2 * nmet2 + nel * 8 * (f + 4.0) + f * P2 + f * P * d
+        # E apply: yl (d) gathered through the 16-B table, B^-1, nine metrics, w out
+        divgs = f * P * d + 16.0 * P + f * P + f * P2 * nmet2 + f * P2
+        if gs_lag:
+            # k_gs_dots: V_0..j and w; k_gs_lag: V_0..j and w again, w' out, the pending v_j out, 8 corner restrictions per element
+            gs = f * P2 * ((jsum + 2.0 * pres_iters) + (jsum + 4.0 * pres_iters)) + f * nel * 8 * pres_iters
+        else:
+            # dots inside k_divgs (j + 1), k_gmres_reorth (w, V twice, w' out), k_gmres_update (w', V, v out) + corner restrictions
+            gs = f * P2 * (4.0 * jsum + 8.0 * pres_iters) + f * nel * 8 * pres_iters
+        out["K6 coarse (x n_pres)"] = coarse * pres_iters
+        out["K6 schwarz (x n_pres)"] = schwarz * pres_iters
+        out["K7 divgs (x n_pres)"] = divgs * pres_iters
+        out["K7 gram-schmidt (x n_pres)"] = gs + f * P2 * 2.0                              # + normalising V_0 once per solve
     # K10 pressure / velocity update + projection space
     out["K10 pres_update"] = f * (P2 * (pres_iters + nproj + 3 + nmet2) + P * d)
     out["K10 vel_update(+proj)"] = f * (P * (d + 1 + 2 * d + 2.0) + P2 * (nmet2 + 2 + 2 * nproj))
     out["projection apply/update"] = f * P2 * (2 + nproj + 4 * nproj + 2) if nproj else 0.0
     return out
+
+
+def helm_launch_bytes(*, nel, lx1, ndim):
+    """One Helmholtz CG launch (ALL components): (SURVEY 8(d) per-component rule, distinct arrays counted once).  The rule
+    counts the arrays the components share -- geometric factors, mass, mask, multiplicity, the 16-B gather table -- once per
+    component; the launch reads them once."""
+    P = nel * lx1 ** ndim
+    rule = (148.0 if ndim == 2 else 172.0) * P * ndim
+    ng = 3 if ndim == 2 else 6
+    per_comp = 8.0 * (4 * 2 + 2 + 1)                    # x, r, p, s read + write; A z of the last iteration in, of this one out; Jacobi diagonal
+    shared = 8.0 * (ng + 3) + 16.0                      # G factors, mass, mask, 1 / multiplicity; gather table
+    return rule, P * (per_comp * ndim + shared)
 
 
 def krylov_bytes(nstate, j):
@@ -59,5 +93,7 @@ def krylov_bytes(nstate, j):
 def matvec_bytes(stats_total, nsteps, **geom):
     """Bytes of one matvec from the accumulated solver statistics (``total_*`` fields of nsk_get_stats)."""
     steps = max(stats_total["total_steps"], 1)
+    if geom.get("ndim", 2) == 3:
+        geom = dict(geom, pres_jsum=stats_total.get("total_pres_jsum", 0) / steps, coarse_bytes=stats_total.get("coarse_bytes_per_solve", 0.0))
     per = per_step_bytes(helm_iters=stats_total["total_helm_iters"] / steps, pres_iters=stats_total["total_pres_iters"] / steps, **geom)
     return nsteps * sum(per.values()), per

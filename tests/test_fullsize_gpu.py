@@ -10,6 +10,8 @@ import pytest
 
 from tests.conftest import GOLDEN
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 pytestmark = pytest.mark.gpu
 
 
@@ -181,3 +183,27 @@ def test_config5_lid_driven_cube_E99452_lx1_10():
     print("config 5: E %d lx1 10, %d points/field, state %.2f GB, mesh %.0f s, set-up %.0f s; " % (c.nel, h.nvel, 8e-9 * h.nstate, tm, setup) +
           "; ".join("%s %.0f ms per time step (%.1f Helmholtz + %.1f pressure iterations)" % (k, v[0], v[1], v[2]) for k, v in out.items()))
     h.close()
+
+
+def test_bench_case_cfg4_record_shape():
+    """`bench.py --case cfg4` (BASELINE configs[3], the bandwidth-sized configuration) on a thin slab of the same mesh: one JSON
+    line with the hexahedral byte accounting (Gram-Schmidt bytes from the logged basis indices, coarse-solve bytes from the
+    context), the dominant-kernel and end-to-end rooflines and the live per-kernel table."""
+    import json, subprocess, sys
+    env = dict(os.environ, NSK_BENCH_CFG4_LAYERS="2")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--case", "cfg4", "--steps", "1", "--warmup", "1"], capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    assert "BASELINE configs[3]" in r["config"]["workload"] and "adjoint" in r["config"]["workload"] and r["dtype"] == "f64"
+    assert r["value"] > 0 and r["steps"] == 1 and r["n_gpus"] == 1 and r["capped_solves"] == 0      # (a thin slab runs captured graphs with launch budgets: a redone first map is normal there)
+    per = r["bytes_per_matvec"]["per_time_step_by_kernel"]
+    assert per["K7 gram-schmidt (x n_pres)"] > 0 and per["K6 coarse (x n_pres)"] > 0 and r["coarse_bytes_per_solve"] > 0
+    assert r["pres_basis_index_sum_per_step"] > 0
+    assert r["bytes_per_matvec"]["time_stepper_shared_arrays_once"] < r["bytes_per_matvec"]["time_stepper"]
+    rf = r["roofline"]
+    assert rf["bound"] == "hbm" and 0 < rf["frac"] < 1.5 and 0 < rf["frac_shared_arrays_once"] < rf["frac"] and rf["peak"] == 8000.0
+    assert 0 < r["roofline_end_to_end"]["frac_shared_arrays_once"] < r["roofline_end_to_end"]["frac"] < 1.0
+    assert set(r["kernels"]) >= {"helm", "divgs", "schwarz", "gs_dots8", "gs_lag8"} and all(v["avg_us"] > 0 for v in r["kernels"].values())
+    print({k: (round(v["avg_us"], 1), round(v["frac"], 2)) for k, v in r["kernels"].items()}, r["ms_per_time_step"])
