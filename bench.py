@@ -401,7 +401,7 @@ def main():
                 # captured graph per step class with the RCCL calls inside (no host work per step, but every BUDGETED iteration
                 # pays its exchange and all-reduce); (b) eager launches with the convergence flags read on the host (half to a
                 # third of the collectives, a stream synchronisation per solve).  Time 24 time steps each way, keep the faster.
-                h.set_nsteps(24)
+                h.set_nsteps(int(os.environ.get("NSK_BENCH_PROBE_STEPS", "24")))      # (dry runs over gloo shorten it)
                 times = {}
                 # (c): (b) + the boundary workgroups' halo in flight while the interior workgroups run.  The captured graphs come LAST and
                 # with SETTLED launch budgets (the largest iteration counts the host-checked maps just saw, + 3): at the start-up

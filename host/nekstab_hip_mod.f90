@@ -294,6 +294,11 @@ module nekstab_hip
       integer(c_int), value :: nranks
       type(c_ptr), intent(out) :: shard
     end function
+    integer(c_int) function nsk_shard_halo_counts(shard, vel, pres_send, pres_recv) bind(c, name='nsk_shard_halo_counts')
+      import
+      type(c_ptr), value :: shard
+      integer(c_int), dimension(*) :: vel, pres_send, pres_recv
+    end function
     integer(c_int) function nsk_shard_elems(shard, elems) bind(c, name='nsk_shard_elems')
       import
       type(c_ptr), value :: shard

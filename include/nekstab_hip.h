@@ -203,6 +203,12 @@ int nsk_shard_create(nsk_ctx* parent, const int* part, int rank, int nranks, nsk
  * pressure iteration launch the boundary workgroups apart from the interior ones and move the halos on a second stream while
  * the interior workgroups run; the all-reduces wait for both (events).  Bit-identical to the serial order of the same shard. */
 int nsk_shard_elems(nsk_ctx* shard, long long* out);
+/* The exchange plan of a shard, per peer rank p (arrays of nranks entries, 0 where p is no neighbour): vel[p] = global nodes
+ * whose partial sums travel in one dssum message to AND from p (one double per node and component); pres_send[p] / pres_recv[p]
+ * = pressure dofs of a GMRES basis vector sent to / received from p (the Schwarz patch layers).  Two ranks' plans must agree:
+ * vel is symmetric and pres_send[p] on rank r = pres_recv[r] on rank p (tests/test_local_setup_gpu.py checks it on 8 ranks
+ * against the host-side derivation nekstab_amd.sharded.velocity_halo_plan). */
+int nsk_shard_halo_counts(nsk_ctx* shard, int* vel, int* pres_send, int* pres_recv);
 int nsk_group_matvec(nsk_ctx** shards, int n, int mode, nsk_vec* f, nsk_vec* q);    /* every mode of nsk_matvec */
 /* The rest of the operator interface on shards, for the ranks living in this process (the reference runs all of it under MPI):
  *   nsk_group_nonlinear_map  nonlinear_forward_map, core/newton_krylov.f:336-378 (subtract_q != 0: Phi_T(q) - q)

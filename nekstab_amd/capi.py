@@ -18,6 +18,7 @@ NSK_DIRECT, NSK_ADJOINT, NSK_DIRECT_ADJOINT, NSK_NEWTON, NSK_FORCE_SENSITIVITY =
 
 _dp = C.POINTER(C.c_double)
 _lp = C.POINTER(C.c_longlong)
+_ip = C.POINTER(C.c_int)
 
 
 class NskCase(C.Structure):
@@ -59,6 +60,7 @@ SYMBOLS = {
     "nsk_shard_create_local": (C.c_int, [_vp, C.POINTER(C.c_int), _lp, C.c_int, C.c_int, _vpp]),
     "nsk_shard_share_stream": (C.c_int, [_vp, _vp]),
     "nsk_shard_elems": (C.c_int, [_vp, _lp]),
+    "nsk_shard_halo_counts": (C.c_int, [_vp, _ip, _ip, _ip]),
     "nsk_last_error": (C.c_char_p, []),
     "nsk_get_info": (C.c_int, [_vp, _dp, C.POINTER(C.c_int), _lp, _lp, _lp]),
     "nsk_set_nsteps": (C.c_int, [_vp, C.c_int]),

@@ -1665,6 +1665,17 @@ int nsk_shard_elems(nsk_ctx* shard, long long* out) {
   return 0;
 }
 
+int nsk_shard_halo_counts(nsk_ctx* shard, int* vel, int* pres_send, int* pres_recv) {
+  if (!shard || !shard->parent || !vel || !pres_send || !pres_recv) return fail(NSK_EINVAL, "needs a shard context");
+  for (int p = 0; p < shard->nranks; ++p) {
+    vel[p] = 0;
+    pres_send[p] = (p < (int)shard->ph_scnt.size()) ? shard->ph_scnt[p] : 0;
+    pres_recv[p] = (p < (int)shard->ph_gcnt.size()) ? shard->ph_gcnt[p] : 0;
+  }
+  for (size_t k = 0; k < shard->peers.size(); ++k) vel[shard->peers[k]] = shard->vh_pcnt[k];
+  return 0;
+}
+
 // Virtual ranks (several shards in one process) advance in stream order on ONE stream.  Shards cut from one parent share its
 // stream; shards of separate rank-local parents are moved onto the first one's stream with this call.
 int nsk_shard_share_stream(nsk_ctx* shard, nsk_ctx* leader) {

@@ -50,6 +50,24 @@ def rank_submesh(case, part, rank: int, rings: int = 2) -> np.ndarray:
     return np.where(sel)[0]
 
 
+def velocity_halo_plan(gid_rows, owner_rows, rank: int) -> dict:
+    """The dssum interface of ``rank`` as the library derives it (nsk_shard.inc: shard_fill): {peer: ascending global node ids
+    that elements of ``rank`` AND elements of ``peer`` touch}.  ``gid_rows`` [n, nodes] / ``owner_rows`` [n]: the elements this
+    rank knows -- the whole mesh, or its rank-local sub-mesh (own elements + rings), which must give the same plan.  One message
+    per peer carries one partial sum per listed node (per component), in this order on both sides."""
+    gid_rows = np.asarray(gid_rows).reshape(len(owner_rows), -1)
+    owner_rows = np.asarray(owner_rows)
+    mine = np.unique(gid_rows[owner_rows == rank])
+    plan = {}
+    for p in np.unique(owner_rows):
+        if p == rank:
+            continue
+        shared = np.intersect1d(mine, np.unique(gid_rows[owner_rows == p]), assume_unique=True)
+        if len(shared):
+            plan[int(p)] = shared
+    return plan
+
+
 def subset_case(case, sub):
     """The case restricted to the elements ``sub`` (global node / vertex ids and nglob / nvert kept)."""
     import dataclasses
@@ -153,6 +171,15 @@ def _shard_elems(lib, ctx, n):
     if rc != 0:
         raise NskError(rc, lib.nsk_last_error().decode())
     return out
+
+
+def shard_halo_counts(lib, ctx, nranks):
+    """(vel, pres_send, pres_recv) per peer rank of one shard context: nsk_shard_halo_counts."""
+    arrs = [np.zeros(nranks, dtype=np.int32) for _ in range(3)]
+    rc = lib.nsk_shard_halo_counts(ctx, *[a.ctypes.data_as(C.POINTER(C.c_int)) for a in arrs])
+    if rc != 0:
+        raise NskError(rc, lib.nsk_last_error().decode())
+    return arrs
 
 
 class ShardVec:

@@ -110,3 +110,51 @@ def test_fortran_krylov_schur_restart_and_modes(tmp_path, spectre):
     assert abs(nrest - res.schur_cnt) <= 1
     assert abs(lead - fv[j]) < 1e-6
     h.close()
+
+
+def test_reference_arnoldi_loop_drives_the_library_through_the_seam(tmp_path):
+    """The boundary in the reference's own shape: host/_ref/ref_seam_driver links the REFERENCE'S
+    core/krylov_decomposition.f -- compiled unchanged from /root/reference by `make -C host ref_seam` -- against
+    host/ref_seam/krylov_subspace_hip.f90 (module krylov_subspace: type(krylov_vector) = a device handle; krylov_inner_product /
+    norm / normalize / cmult / add2 / sub2 / zero / copy / matmul and matvec with the reference's argument lists).  Its
+    arnoldi_factorization + update_hessenberg_matrix (modified Gram-Schmidt, two passes, one krylov_* call per operation) must
+    produce the Hessenberg matrix of the Python host's loop (nsk_orth: batched two-pass classical Gram-Schmidt) on the same
+    seed, at inner-solver tolerances tight enough that the comparison sees the seam and not the solvers.  This is a test of the
+    BOUNDARY (stand-in SIZE / TOTAL declare nid, mstep, ifres only), not an oracle."""
+    exe = os.path.join(ROOT, "host", "_ref", "ref_seam_driver")
+    if not os.path.exists(exe):
+        if shutil.which("flang") is None or not os.path.exists("/root/reference/core/krylov_decomposition.f"):
+            pytest.skip("host/_ref/ref_seam_driver not prebuilt and the reference's source / flang are not here")
+        subprocess.run(["make", "-C", os.path.join(ROOT, "host"), "ref_seam"], check=True)
+    from nekstab_amd import casefile, krylov, mesh, seed
+    from nekstab_amd.capi import NekStabHip
+    case = mesh.load_case_npz(os.path.join(GOLDEN, "cylinder_case.npz"), 6)
+    qx, qy = seed.add_noise(case)
+    pr = np.zeros((case.nel, 4, 4))
+    tight = dict(tol_helm=1e-13, tol_pres=1e-9, min_pres_iter=2, nproj=8, max_helm_iter=200)
+    cb = str(tmp_path / "case.bin")
+    casefile.write_case_bin(cb, case, (qx, qy, pr), settings=tight)
+    k = 12
+    out = subprocess.run([exe, cb, str(k), str(tmp_path)], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "nsteps = 100" in out.stdout
+    assert out.stdout.count("iteration current and total:") == k and out.stdout.count("ALPHA REORTH") == k * (k + 1) // 2   # the reference's own prints
+    assert "live vectors before release: %d" % (k + 2) in out.stdout and "live vectors after release: 0" in out.stdout      # Q(1:k+1) + comb; f and wrk were finalised
+    Hf = np.array(open(str(tmp_path / "HES_seam.txt")).read().split(), dtype=float)[: (k + 1) * k].reshape(k + 1, k)
+    h = NekStabHip(case, case.meta["vert"], case.meta["nvert"], tol_helm=tight["tol_helm"], tol_pres=tight["tol_pres"], tol_relative=1,
+                   schwarz_layers=2, max_helm_iter=200, max_pres_iter=192, nproj=8)
+    h.set_option("min_pres_iter", 2)
+    Q = h.alloc(k + 1)
+    h.upload(Q[0], qx, qy, pr)
+    h.scal(Q[0], 1.0 / h.norm(Q[0]))
+    H = np.zeros((k + 1, k))
+    krylov.arnoldi_factorization(h, Q, H, 1, k, 0)
+    err = np.abs(Hf - H).max() / np.abs(H).max()
+    print("reference loop through the seam vs Python host: max |dH| / max |H| = %.2e" % err)
+    assert err < 1e-10
+    # krylov_matmul against the same combination through the Python binding
+    c = h.alloc(1)[0]
+    h.basis_gemv(Q[:3], np.array([0.6, -0.3, 0.2]), c)
+    nrm = float([l for l in out.stdout.splitlines() if "|Q(1:3) y|" in l][0].split("=")[1])
+    assert abs(nrm - h.norm(c)) < 1e-10
+    h.close()

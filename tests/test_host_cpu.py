@@ -333,6 +333,48 @@ def test_rank_submesh_and_subset_case():
     assert np.all(seen == 1)
 
 
+def test_eight_rank_submeshes_and_halo_plans_are_mutually_consistent():
+    """Eight ranks before the node arrives, host side, no GPU: on a small extruded hexahedral case every
+    rank's sub-mesh (own elements + two rings) gives (i) the SAME dssum interface as the whole mesh -- per peer, the ascending
+    list of shared global nodes, which is what fixes message sizes and entry order on both sides --, (ii) lists that agree
+    pairwise (what r sends to p is what p expects from r, node for node), (iii) the complete multiplicity / assembled-mass
+    stencil of every node of the own and ring-1 elements, which ONE ring does not give."""
+    from nekstab_amd import mesh, mesh3d
+    from nekstab_amd.sharded import partition_rcb, rank_submesh, velocity_halo_plan
+    c2 = mesh.load_case_npz(os.path.join(GOLDEN, "cylinder_case.npz"), 4)
+    case = mesh3d.extrude_case(c2, 3, 0.6, periodic=True)
+    R = 8
+    part = partition_rcb(case, R)
+    gid = np.asarray(case.gid).reshape(case.nel, -1)
+    mult = np.bincount(gid.ravel(), minlength=int(case.nglob))              # elements' node copies per global node (whole mesh)
+    plans, one_ring_short = {}, 0
+    for r in range(R):
+        sub = rank_submesh(case, part, r)
+        assert np.isin(np.where(part == r)[0], sub).all() and len(sub) < 0.7 * case.nel
+        whole = velocity_halo_plan(gid, part, r)
+        local = velocity_halo_plan(gid[sub], part[sub], r)
+        assert sorted(whole) == sorted(local) and all(np.array_equal(whole[p], local[p]) for p in whole), r
+        plans[r] = local
+        # two rings: multiplicity of every node of the own + ring-1 elements, counted inside the sub-mesh, is the whole-mesh one
+        own = np.where(part == r)[0]
+        ring1 = rank_submesh(case, part, r, rings=1)
+        m2 = np.bincount(gid[sub].ravel(), minlength=int(case.nglob))
+        nodes1 = np.unique(gid[ring1])
+        assert np.array_equal(m2[nodes1], mult[nodes1]), r
+        m1 = np.bincount(gid[ring1].ravel(), minlength=int(case.nglob))
+        one_ring_short += int((m1[nodes1] != mult[nodes1]).sum())
+        assert np.array_equal(m1[np.unique(gid[own])], mult[np.unique(gid[own])])      # (one ring is enough for the OWN nodes only)
+    assert one_ring_short > 0
+    npairs = 0
+    for r in range(R):
+        for p, nodes in plans[r].items():
+            assert r in plans[p] and np.array_equal(plans[p][r], nodes), (r, p)        # send list of r -> p == receive list of p <- r
+            npairs += 1
+    assert npairs >= 2 * (R - 1) and max(len(v) for pl in plans.values() for v in pl.values()) > 0
+    print("8 ranks: %d directed neighbour pairs, messages of %d .. %d nodes" % (npairs, min(len(v) for pl in plans.values() for v in pl.values()),
+                                                                                   max(len(v) for pl in plans.values() for v in pl.values())))
+
+
 def test_local_setup_exchange_over_gloo(tmp_path):
     """The exchange of the rank-local set-up (sharded.exchange_local) between two processes: sums, maxima, and every rank's
     coarse rows concatenated in rank order."""

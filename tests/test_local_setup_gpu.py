@@ -74,11 +74,31 @@ def test_local_setup_equals_whole_mesh_setup_2d(case6, oracle6_nosolve, modes, n
         h.close()
 
 
+def _check_halo_plans(g, c, part, nranks):
+    """The exchange plans the LIBRARY derived on every rank (nsk_shard_halo_counts) against the host-side derivation from the
+    global numbering (sharded.velocity_halo_plan), and against one another: what r sends to p is what p expects from r."""
+    from nekstab_amd.sharded import shard_halo_counts, velocity_halo_plan
+    gid = np.asarray(c.gid).reshape(c.nel, -1)
+    cnt = [shard_halo_counts(g.lib, g.ctx[r], nranks) for r in range(nranks)]
+    for r in range(nranks):
+        vel, ps, pr = cnt[r]
+        plan = velocity_halo_plan(gid, part, r)
+        assert {p: len(v) for p, v in plan.items()} == {p: int(vel[p]) for p in range(nranks) if vel[p]}, r
+        for p in range(nranks):
+            assert vel[p] == cnt[p][0][r] and ps[p] == cnt[p][2][r] and pr[p] == cnt[p][1][r], (r, p)
+        assert vel[r] == 0 and ps[r] == 0 and pr[r] == 0
+    print("halo plans of %d ranks agree: velocity messages %s nodes, pressure messages up to %d dofs" %
+          (nranks, sorted({int(v) for r in range(nranks) for v in cnt[r][0] if v})[::max(1, nranks // 2)], max(int(cnt[r][1].max()) for r in range(nranks))))
+
+
 def _maps3(c, nranks, q, nst=4, tol=1e-8, **kw):
     from nekstab_amd.capi import NekStabHip
     from nekstab_amd.sharded import ShardGroup, local_parents, partition_rcb
     part = partition_rcb(c, nranks)
+    check_plan = kw.pop("_check_plan", False)
     h = NekStabHip(c, c.meta["vert"], c.meta["nvert"], **dict(KW, **kw))
+    if check_plan:
+        kw = dict(kw)
     P = []
     try:
         ns0 = h.nsteps
@@ -91,6 +111,8 @@ def _maps3(c, nranks, q, nst=4, tol=1e-8, **kw):
         for p in P:
             assert p.nsteps == ns0 and abs(p.dt - h.dt) < 1e-15
         g = ShardGroup(P, c, nranks, part)
+        if check_plan:
+            _check_halo_plans(g, c, part, nranks)
         g.set_nsteps(nst)
         sq, sf = g.alloc(2)
         g.upload3(sq, *q)
@@ -152,3 +174,19 @@ def test_local_setup_3d_closed_cavity_singular_operator(monkeypatch):
     q = [np.sin(np.pi * x) * np.cos(2 * np.pi * z) * c3.mask, np.sin(2 * np.pi * y / 1.2) * np.sin(2 * np.pi * z) * c3.mask,
          np.sin(np.pi * x) * np.sin(np.pi * y / 1.2) * c3.mask, np.zeros((c3.nel, 4, 4, 4))]
     _maps3(c3, 2, q, nst=3, tol=1e-7, nproj=4)
+
+
+def test_eight_rank_local_shards_closed_hexahedral_box():
+    """Eight ranks before the node arrives: a closed hexahedral box (singular pressure operator, `ortho`
+    over all ranks) on EIGHT rank-local shards (16 elements each) with the pressure projection space: the exchange plans of
+    the eight ranks -- as the library built them from each rank's sub-mesh -- agree with one another and with the host-side
+    derivation, and the sharded map equals the single-rank one at solver tolerance."""
+    from nekstab_amd import mesh3d
+    ubf = lambda x, y, z: np.stack([np.sin(np.pi * x / 4.0) * np.cos(np.pi * y / 2.0) * 0.5 + 0.2, -np.cos(np.pi * x / 4.0) * np.sin(np.pi * y / 2.0) * 0.5, 0.1 * np.sin(np.pi * z / 2.0) + 0.0 * x])
+    c = mesh3d.box_case_3d(8, 4, 4, 6, lengths=(4.0, 2.0, 2.0), re=40.0, endtime=0.05, ub_func=ubf, warp=0.04)        # all walls: no outflow
+    c.ub = c.ub * c.mask
+    assert not c.has_outflow and c.nel == 128
+    x, y, z = c.x, c.y, c.z
+    q = [np.sin(1.3 * x + z) * np.cos(2.0 * y) * c.mask, np.cos(0.7 * x + 0.2) * np.sin(3.0 * y - z) * c.mask,
+         np.sin(x + y) * np.cos(2.0 * z) * c.mask, np.zeros((c.nel, 4, 4, 4))]
+    _maps3(c, 8, q, nst=4, tol=1e-7, nproj=4, _check_plan=True)

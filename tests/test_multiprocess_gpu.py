@@ -26,13 +26,14 @@ def test_sharded_matvec_across_processes(world, port):
 
 @pytest.mark.parametrize("kind,world,port", [("adjoint", 2, 29641), ("proj", 3, 29643), ("nonlinear", 2, 29645),
                                              ("proj-local", 3, 29647), ("adjoint-local", 2, 29649), ("proj-local-overlap", 3, 29651),
-                                             ("box3d-local-overlap", 2, 29653), ("box3d", 3, 29655)])
+                                             ("box3d-local-overlap", 2, 29653), ("box3d", 3, 29655), ("box3d-local", 8, 29657)])
 def test_round3_shard_features_across_processes(kind, world, port):
     """VERDICT r2 item 2 across processes (host-staged transport, ranks share the GPU): adjoint cylinder at lx1 = 8 (singular
     pressure, `ortho` through the all-reduce), the pressure projection space in shards over two maps, and the closed cavity's
     nonlinear map + set_baseflow (CFL maximum over the ranks) + linearised map -- each equal to the single-rank result.
     "-local": the shard comes from the RANK-LOCAL set-up (sharded.LocalParent: this rank's sub-mesh, volume / CFL maximum /
-    coarse rows exchanged through torch.distributed) instead of a whole-mesh parent.  "-overlap": option halo_overlap (the
+    coarse rows exchanged through torch.distributed) instead of a whole-mesh parent.  ("box3d-local", 8): EIGHT processes (9 elements per rank, rank-local set-up,
+    singular operator, projection space).  "-overlap": option halo_overlap (the
     boundary workgroups' halo travels while the interior workgroups run).  "box3d": a closed hexahedral box (singular pressure
     operator, three-component halos, Schwarz layers of face / edge / corner neighbours on other ranks)."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -67,3 +68,24 @@ def test_bench_two_ranks_under_the_launcher_dry_run():
     sm = r["shard_mode"]
     assert sm["picked"] in ("graph", "hostcheck", "hostcheck_overlap") and all(sm[k] > 0 for k in ("graph", "hostcheck", "hostcheck_overlap"))
     assert sm[sm["picked"]] == min(sm[k] for k in ("graph", "hostcheck", "hostcheck_overlap"))
+
+
+def test_bench_eight_ranks_gloo_dry_run():
+    """`python bench.py --gpus 8`: the script starts its own eight ranks; they share this GPU and every halo
+    travels over gloo (protocol dry run), on the cylinder at lx1 = 6 to keep it short.  The three-mode probe runs
+    (NSK_BENCH_FORCE_MODE_PROBE), the record has the shape the driver reads and names the headline workload."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", NSK_DIST_BACKEND="gloo", NSK_BENCH_FORCE_MODE_PROBE="1", NSK_BENCH_PROBE_STEPS="3")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "1", "--lx1", "6", "--no-cfg3-probe"],
+                         capture_output=True, text=True, timeout=1500, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    r = json.loads(lines[0])
+    print({k: r[k] for k in ("value", "n_gpus", "scaling", "setup", "shard_mode")}, r["config"]["parallelism"])
+    assert r["n_gpus"] == 8 and r["steps"] == 1 and r["value"] > 0 and r["scaling"] == "strong" and r["unit"] == "matvecs/s"
+    assert "BASELINE configs[1]" in r["config"]["workload"] and "E=1996, lx1=6" in r["config"]["workload"] and "x8" in r["config"]["parallelism"]
+    assert r["setup"]["rank_local"] and r["setup"]["elements_rank0"] < 0.4 * r["setup"]["elements_mesh"]
+    sm = r["shard_mode"]
+    assert sm["picked"] in ("graph", "hostcheck", "hostcheck_overlap") and all(sm[k] > 0 for k in ("graph", "hostcheck", "hostcheck_overlap"))
+    assert r["single_gpu_same_config"]["matvecs_per_s"] > 0 and r["roofline"]["peak"] == 8000.0
