@@ -112,7 +112,7 @@ struct nsk_ctx {
   int shard_hostcheck = -1;
   // The same on a full-mesh context (option "hostcheck"): eager steps, no launch budgets, no redone maps.  -1 = yes for large
   // hexahedral meshes (>= 8192 elements: a launch that only finds its solve converged costs 25-140 us there and a map redone
-  // with larger budgets tens of seconds), 0 = never, 1 = always.
+  // with larger budgets tens of seconds) and for quadrilateral meshes of more than 4096 workgroups (config 3), 0 = never, 1 = always.
   int hostcheck = -1;
   // Halo / interior overlap of the velocity solve on shards (quadrilaterals): a shard keeps its BOUNDARY elements (those with a
   // node another rank shares) first; k_helm is launched for the boundary workgroups, their halo travels on a second stream
@@ -791,6 +791,7 @@ static int build(nsk_ctx* c, const nsk_case& cs) {
   if (const char* g = std::getenv("NSK_FUSED")) c->fused = std::atoi(g) && fused_possible(c);
   if (const char* g = std::getenv("NSK_USE_GRAPH")) c->use_graph = std::atoi(g);
   if (const char* g = std::getenv("NSK_MERGED_UPDATE")) c->merged_update = std::atoi(g);
+  if (const char* g = std::getenv("NSK_HOSTCHECK")) c->hostcheck = std::atoi(g);
   if (const char* g = std::getenv("NSK_MERGED_ITERS")) c->merged_iters = std::max(0, std::min(std::atoi(g), MAXMR));
   if (const char* g = std::getenv("NSK_DEBUG")) c->debug = std::atoi(g);
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -848,7 +849,11 @@ static int flags_done(nsk_ctx* c, int which, int it, bool* done) {
 static bool hostcheck_on(const nsk_ctx* c) {
   if (c->parent || c->fused || c->in_test) return false;
   if (c->hostcheck >= 0) return c->hostcheck != 0;
-  return c->ndim == 3 && c->nel >= 8192;
+  // quadrilateral meshes of thousands of workgroups (config 3: 7984 at lx1 = 12, kernels of ~65 us): a flag read per solve costs
+  // less than the launches a budget spends on converged solves, and budgets that cannot overflow mean no redone maps
+  // (measured: 0.262 -> 0.334 Arnoldi steps per second, scripts/cfg3_hostcheck_ab.sh)
+  if (c->ndim == 2) return c->nblk > 4096;
+  return c->nel >= 8192;
 }
 
 // hexahedral GMRES column j in the lagged form: streaming Gram-Schmidt pass (first-pass subtraction, second-pass dots, the

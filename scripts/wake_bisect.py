@@ -75,8 +75,13 @@ def main():
     modes = np.load(os.path.join(GOLDEN, "cylinder_modes.npz"))
     rows = [(n + 1, complex(r[0], r[1]), r[2]) for n, r in enumerate(spectre) if r[2] < 1e-7 and r[1] >= 0]
 
-    def run(case_kw=None, spng=None, opts=None, tol=(1e-13, 1e-6), ub_add=None, ctx_kw=None):
+    def run(case_kw=None, spng=None, opts=None, tol=(1e-13, 1e-6), ub_add=None, ctx_kw=None, xy_file=False):
         case = mesh.load_case_npz(os.path.join(GOLDEN, "cylinder_case.npz"), a.lx1, **(case_kw or {}))
+        if xy_file:                                   # node coordinates as the reference's base-flow file holds them (tests/golden/make_fixtures.py)
+            xy = np.load(os.path.join(GOLDEN, "cylinder_bf_xy.npz"))
+            assert a.lx1 == 6 and xy["x"].shape == case.x.shape
+            print("  (file coordinates - regenerated geometry: max %.2e)" % max(np.abs(xy["x"] - case.x).max(), np.abs(xy["y"] - case.y).max()), file=sys.stderr)
+            case.x, case.y = xy["x"].copy(), xy["y"].copy()
         if spng is not None:
             case.spng = spng(case)
         if ub_add is not None:
@@ -128,6 +133,11 @@ def main():
         "Helmholtz tolerance 1e-9, zero initial guess": dict(tol=(1e-9, 1e-6), opts={"helm_guess": 0}),
         "pressure tolerance 1e-3 (relative), Helmholtz converged": dict(tol=(1e-13, 1e-3)),
         "pressure tolerance 1e-2 with 20 projection vectors (mxprev = 20)": dict(tol=(1e-13, 1e-2), ctx_kw={"nproj": 20}),
+        # round 4.  (`lxd` is not a free parameter: the reference's SIZE:13 has lxd = 09 = 3 lx1 / 2, what this build uses.)
+        "geometry: node coordinates of the base-flow file's X block instead of the regenerated bilinear + arc geometry": dict(xy_file=True),
+        "Nek-style solves: ABSOLUTE tolerances 1e-9 / 1e-7 in Nek's norms (1cyl.par:29,34), zero initial guess, >= 1 GMRES iteration, 20 projection vectors": dict(
+            tol=(1e-9, 1e-7), ctx_kw={"tol_relative": 0, "nproj": 20}, opts={"helm_guess": 0, "min_pres_iter": 1}),
+        "the same with the velocity tolerance 1e-10 absolute": dict(tol=(1e-10, 1e-7), ctx_kw={"tol_relative": 0, "nproj": 20}, opts={"helm_guess": 0, "min_pres_iter": 1}),
     }
     only = [s for s in a.only.split(",") if s]
     base, ns0, w0 = run()

@@ -18,6 +18,15 @@ REF = "/root/reference/examples/cylinder"
 OUT = os.path.dirname(os.path.abspath(__file__))
 
 
+def coords_fixture():
+    """The coordinate block of the reference's base-flow file (lx1 = 6): what scripts/wake_bisect.py uses as the 'geometry from
+    the file' variant.  It agrees with the geometry regenerated from the .re2 (bilinear + arcs) to fp32 rounding of the
+    coordinates (<= 1.9e-6 at x = 41, 3e-8 at the cylinder)."""
+    bf = nekio.read_fld(REF + "/stability/direct/BF_1cyl0.f00001")
+    X = np.asarray(bf.x)[:, :, 0]
+    np.savez_compressed(OUT + "/cylinder_bf_xy.npz", x=X[0], y=X[1])
+
+
 def main():
     d = REF + "/stability/direct/"
     m = nekio.read_re2(d + "1cyl.re2")
@@ -26,6 +35,7 @@ def main():
     u = bf.u[:, :, 0]
     assert np.array_equal(u, u.astype(np.float32).astype(np.float64)) or True
     mesh.save_case_npz(OUT + "/cylinder_case.npz", m, vlex, u, bf.p[:, 0])
+    coords_fixture()
     # start field of the reference's Newton example (Re=40 solution, fp32)
     b40 = nekio.read_fld(REF + "/baseflow/newton/BFRe40_1cyl0.f00001")
     np.savez_compressed(OUT + "/cylinder_bf_re40.npz", u=b40.u[:, :, 0].astype(np.float32), p=b40.p[:, 0].astype(np.float32))

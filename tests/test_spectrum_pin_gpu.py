@@ -67,6 +67,9 @@ def _own_bound(res_ref, res_run):
 # realisations of scripts/pin_noise.py give 3.4e-6 and 1.7e-6 on the worst row at the production settings (1.1e-5 and 2.7e-6 at
 # 1e-11 / 1e-1), so the 5e-6 of the better-resolved lx1 = 8 case would be a coin toss here: 1e-5.
 OWN_BOUND_LX1_6 = 1e-5
+# |this build - Spectre_Hd.dat| on the direct wake rows at lx1 = 6, recorded in round 3 (the CPU oracle's exact-solve spectrum
+# sits at the same distances to 1e-7: the deviation is the table's, or a detail of the un-vendored Nek5000 fork)
+WAKE_TABLE_OFFSET = {5: 2.9e-5, 7: 3.9e-5, 9: 2.9e-5, 11: 2.4e-5, 13: 1.2e-5, 17: 4.0e-5, 23: 4.6e-5}
 
 
 @pytest.fixture(scope="module")
@@ -101,9 +104,15 @@ def test_direct_lx1_6_every_row_of_spectre_Hd(spectre, converged):
         print("Hd row %2d  ref %.7f%+.7fi (%.0e)  ours %.9f%+.9fi (%.0e)  diff %.1e" % (n, z.real, z.imag, rr, v.real, v.imag, rs, d))
     assert len(rows) >= 9
     for n, z, v, rr, rs, d in rows:
-        # rows 1, 4: the reference-table pin (2e-7, as in round 1).  Wake rows: known deviation of the TABLE from both this build
-        # and the oracle (module docstring) -- 1e-4 is a regression guard here, the parity bound for them is the oracle one below
-        assert d < (2e-7 if n <= 4 else 1e-4), (n, z, v)
+        # rows 1, 4: the reference-table pin (2e-7, as in round 1).  Wake rows: the table sits a KNOWN distance from both this
+        # build and the CPU oracle's exact-solve spectrum (profiles/r03_spectrum_pin.txt, profiles/r04_wake_bisect.md); the guard
+        # holds every row to that recorded distance +- 5e-6 (1e-5 where the table's own residual is above 2e-8), so a change of
+        # the operator in EITHER direction shows -- the parity bound proper for these rows is the oracle one below
+        if n <= 4:
+            assert d < 2e-7, (n, z, v)
+        else:
+            assert n in WAKE_TABLE_OFFSET, n
+            assert abs(d - WAKE_TABLE_OFFSET[n]) < (5e-6 if rr <= 2e-8 else 1e-5), (n, z, v, d)
     own = _match(res, converged["Hd6"], 1e-8)
     for n, z, v, rr, rs, d in own:
         print("converged lx1=6 row %2d  %.9f%+.9fi  bench settings %.9f%+.9fi  diff %.1e" % (n, z.real, z.imag, v.real, v.imag, d))
