@@ -437,6 +437,10 @@ def main():
             err = repr(e)[:400]
         all_ok(err is None, err)
         pw.cancel()
+    if os.environ.get("NSK_BENCH_MAP_STEPS"):              # dry runs (tests): shorter maps; the record says so in config.workload through h.nsteps
+        h.set_nsteps(int(os.environ["NSK_BENCH_MAP_STEPS"]))
+        if sharded and rank == 0 and not local_setup:
+            full.set_nsteps(int(os.environ["NSK_BENCH_MAP_STEPS"]))
     ktot = max(a.warmup + steps, K_DIM if (headline and not a.no_kdim) else 0)
     Q = h.alloc(ktot + 1)
     upload_seed(h, Q[0])
@@ -576,6 +580,25 @@ def main():
             traffic, tnote = pmc_traffic("k_helm<%d>" % case.lx1)
             out["roofline"] = {"bound": "hbm", "kernel": "k_helm<%d>" % case.lx1, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                                "traffic": traffic, "traffic_source": tnote, "avg_launch_us": kern["avg_us"], "algorithmic_bytes_per_launch": alg}
+            # How much of a time step is kernel time at all ("latency-bound" as a number): the step's kernels timed back to back
+            # with HIP events (every launch doing full work) x the launches the logged iteration counts imply, against the wall
+            # time of a step.  The rest is kernel boundaries (a dependent chain: the next kernel starts after the last one's
+            # write-back), launches that find their solve converged (1.8 us each) and host gaps.
+            try:
+                hit, pit = st["total_helm_iters"] / tsteps, st["total_pres_iters"] / tsteps
+                kt = {kn: full.bench_kernel(kn, 100)["avg_us"] for kn in ("convect", "rhs", "pres_rhs", "proj_apply", "gmres_update", "schwarz", "divgs2", "pres_update", "vel_update_proj", "proj_update")}
+                kt["update_coarse"] = full.bench_kernel("update_coarse3", 100)["avg_us"]
+                merged = min(pit, 12.0)
+                per = {"velocity solve (k_helm x (iterations + 1))": kern["avg_us"] * (hit + 1.0),
+                       "pressure iterations (k_update_coarse + k_schwarz + k_divgs per iteration)": (kt["update_coarse"] + kt["schwarz"] + kt["divgs2"]) * merged,
+                       "once per step (convect, rhs, pres_rhs, proj_apply, 2 x gmres_update, pres_update, vel_update_proj, proj_update)":
+                           kt["convect"] + kt["rhs"] + kt["pres_rhs"] + kt["proj_apply"] + 2.0 * kt["gmres_update"] + kt["pres_update"] + kt["vel_update_proj"] + kt["proj_update"]}
+                wall_us = 1e6 * float(np.mean(stats["matvec_s"][a.warmup:a.warmup + steps])) / full.nsteps
+                out["step_time_budget"] = {"wall_us_per_time_step": wall_us, "kernel_us_back_to_back": per, "busy_fraction": sum(per.values()) / wall_us,
+                                           "budgeted_launches_per_step": {"helm": st["budget_helm"], "pres": st["budget_pres"]},
+                                           "note": "kernel durations from nsk_bench_kernel (HIP events, back to back, full-work launches); busy_fraction = their sum / wall time of a step"}
+            except Exception as e:                                  # noqa: BLE001  (diagnostic only)
+                out["step_time_budget"] = {"error": repr(e)[:200]}
     else:
         st = h.stats()
         out.update({"helm_iters_per_step_last_map": st["helm_iters"] / max(st["steps"], 1), "pres_iters_per_step_last_map": st["pres_iters"] / max(st["steps"], 1),

@@ -198,7 +198,12 @@ contains
       call eig(H(1:k_dim, 1:k_dim), vecs, vals, k_dim)                           ! :346
       residual = abs(H(k_dim + 1, k_dim) * vecs(k_dim, :))                       ! :349
       cnt = count(residual < eigen_tol)
-      if (schur_tgt <= 0 .or. cnt >= schur_tgt .or. schur_cnt >= 50) then        ! :354-371
+      if (schur_tgt > 0 .and. cnt < schur_tgt .and. schur_cnt >= 50) then         ! the reference has no such cap: say so, never report it as converged
+        write(*,'(a,i0,a,i0,a)') ' krylov_schur: 50 restarts without ', schur_tgt, ' converged eigenvalues (', cnt, ' so far): NOT CONVERGED, stopping'
+        converged = .false.
+        exit
+      endif
+      if (schur_tgt <= 0 .or. cnt >= schur_tgt) then        ! :354-371
         converged = .true.
       else
         schur_cnt = schur_cnt + 1

@@ -83,6 +83,7 @@ struct nsk_ctx {
   int in_test = 0;
   int helm_guess = 1;
   int budget_freeze = 0;
+  int flat_proj = -1;                   // hexahedra: once-per-step sums over the GMRES / projection bases as streaming kernels (k_pres_comb, k_proj_dots); -1 = yes on single-rank contexts
   int gs_lag = -1;                      // hexahedra: lagged second Gram-Schmidt correction (k_gs_lag: two basis reads per GMRES column instead of four); -1 = yes on single-rank contexts
   int gs2_from = MAXMR;                 // quadrilaterals: GMRES columns from this iteration (of a cycle) on get a second Gram-Schmidt pass (default: never)
   int dbg_max_order = 3, dbg_ab2 = 0, dbg_pext = 1;      // time-scheme sensitivity switches (options of the same names)
@@ -94,7 +95,10 @@ struct nsk_ctx {
   double coarse_bytes = 0.0;            // bytes one coarse solve reads (operator storage): nsk_stats::coarse_bytes_per_solve
   double tot_worst_cap = 0.0;
   int debug = 0;
-  struct StepGraph { hipGraphExec_t exec = nullptr; int nh = -1, np = -1; } graphs[3][NCLS];
+  // graphs[.][NCLS]: the last step class (time steps >= 17: 167 of the 183 steps of a config-2 map) also as ONE graph of
+  // `graph_steps` consecutive steps: fewer graph launches and graph-to-graph hand-overs per map (option "graph_steps", 1 = off)
+  struct StepGraph { hipGraphExec_t exec = nullptr; int nh = -1, np = -1; } graphs[3][NCLS + 1];
+  int graph_steps = 1;                  // (measured on config 2: 11.79 / 11.80 / 11.84 matvecs/s at 1 / 8 / 16 steps per graph: within noise, off)
   std::vector<nsk_ctx*> graph_members;  // sharded step graphs (held by the first rank of a process): the ranks they were captured for
   int merged_iters = 12;                // ... for the first merged_iters iterations of a solve (see pres_solve_launch)
   int merged_update = 1;                // GMRES column bookkeeping inside the coarse-solve kernel (k_update_coarse)
@@ -792,6 +796,7 @@ static int build(nsk_ctx* c, const nsk_case& cs) {
   if (const char* g = std::getenv("NSK_USE_GRAPH")) c->use_graph = std::atoi(g);
   if (const char* g = std::getenv("NSK_MERGED_UPDATE")) c->merged_update = std::atoi(g);
   if (const char* g = std::getenv("NSK_HOSTCHECK")) c->hostcheck = std::atoi(g);
+  if (const char* g = std::getenv("NSK_GRAPH_STEPS")) c->graph_steps = std::max(1, std::min(std::atoi(g), 64));
   if (const char* g = std::getenv("NSK_MERGED_ITERS")) c->merged_iters = std::max(0, std::min(std::atoi(g), MAXMR));
   if (const char* g = std::getenv("NSK_DEBUG")) c->debug = std::atoi(g);
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -888,6 +893,27 @@ static void launch_gs_lag3(nsk_ctx* c, const Dev& d, int j, double scale, int or
     else hipLaunchKernelGGL((nsk::k3::k_gs_lag<N, MAXMR, 1>), grid, blk, 0, c->stream, d, j);
     tot_rows(c, d.gpart2, j + 2, d.gtot2, &d.gsc->done);
     hipLaunchKernelGGL(nsk::k3::k_gmres_col, dim3(1), dim3(64), 0, c->stream, d, j, scale, c->min_pres, ord);
+  }
+}
+
+static bool flat_proj_on(const nsk_ctx* c) {
+  if (c->ndim != 3 || c->N > 10 || !c->d.dpw) return false;
+  if (c->flat_proj >= 0) return c->flat_proj != 0;
+  return c->d.nranks <= 1 && !c->parent;
+}
+template <int N>
+static void launch_pres_comb3(nsk_ctx* c, const Dev& d, const StepCoef& sc) {        // dp, p and PD in one streaming pass, then yl = D^T dp
+  if constexpr (N <= 10) {
+    const dim3 grid(std::min<unsigned>((unsigned)((c->nel + 3) / 4), 2048u)), blk(256);
+    hipLaunchKernelGGL(nsk::k3::k_pres_comb<N>, grid, blk, 0, c->stream, d, sc);
+    hipLaunchKernelGGL(nsk::k3::k_gradt<N>, dim3(c->nblk), dim3(nsk::k3::Cfg<N>::NT), 0, c->stream, d, (const double*)d.dpw, d.yl);
+  }
+}
+template <int N>
+static void launch_proj_dots3(nsk_ctx* c, const Dev& d) {
+  if constexpr (N <= 10) {
+    const dim3 grid(std::min<unsigned>((unsigned)((c->nel + 3) / 4), 2048u)), blk(256);
+    hipLaunchKernelGGL(nsk::k3::k_proj_dots<N>, grid, blk, 0, c->stream, d);
   }
 }
 
@@ -1038,12 +1064,16 @@ static int step(nsk_ctx* c, int istep, int adjoint) {
   // solenoidal): an error there survives to the end of the map, so those solves are converged further.
   int rc = pres_solve_launch(c, sc.h2, sc.cls, hc ? c->max_pres : c->cur_pres[sc.cls], istep <= 3 ? c->early_pres_mul : 1.0, adjoint != 2, hc);
   if (rc) return rc;
+  const bool flat = flat_proj_on(c);
+  Dev df = d; df.flat_proj = flat ? 1 : 0;
   DISPATCH_N(c->key, {
-    hipLaunchKernelGGL(k_pres_update<N>, dim3(c->nblk), dim3(Cfg<N>::NT), 0, c->stream, d, sc);
+    if (flat) launch_pres_comb3<N>(c, df, sc);
+    else hipLaunchKernelGGL(k_pres_update<N>, dim3(c->nblk), dim3(Cfg<N>::NT), 0, c->stream, d, sc);
   });
   if (d.nproj_max > 0) {
     DISPATCH_N(c->key, {
-      hipLaunchKernelGGL(k_vel_update_proj<N>, dim3(c->nblk), dim3(Cfg<N>::NT), 0, c->stream, d, sc);
+      hipLaunchKernelGGL(k_vel_update_proj<N>, dim3(c->nblk), dim3(Cfg<N>::NT), 0, c->stream, df, sc);
+      if (flat) launch_proj_dots3<N>(c, df);
     });
     tot_rows(c, d.ppart, MAXPROJ + 1, d.ptot);
     hipLaunchKernelGGL(k_proj_update, dim3(c->nblk), dim3(256), 0, c->stream, d);
@@ -1074,6 +1104,27 @@ static int ensure_graph(nsk_ctx* c, int cls, int adjoint) {
   return 0;
 }
 
+static int ensure_graph_multi(nsk_ctx* c, int adjoint) {
+  nsk_ctx::StepGraph& g = c->graphs[adjoint][NCLS];
+  const int cls = NCLS - 1;
+  if (g.exec && g.nh == c->cur_helm[cls] && g.np == c->cur_pres[cls]) return 0;
+  const auto t_cap0 = std::chrono::steady_clock::now();
+  if (g.exec) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }
+  hipGraph_t graph = nullptr;
+  HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+  int rc = 0;
+  for (int r = 0; r < c->graph_steps && !rc; ++r) rc = step(c, CLS_ISTEP[cls], adjoint);
+  hipError_t e = hipStreamEndCapture(c->stream, &graph);
+  if (rc) return rc;
+  if (e != hipSuccess) return fail(NSK_EHIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+  HIPCHK(hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0));
+  c->recaptures++;
+  HIPCHK(hipGraphDestroy(graph));
+  g.nh = c->cur_helm[cls]; g.np = c->cur_pres[cls];
+  c->recapture_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_cap0).count();
+  return 0;
+}
+
 static int run_map(nsk_ctx* c, int adjoint, double* f, const double* q) {
   Dev& d = c->d;
   // one- and two-step maps (newton.py: time derivative of the orbit) run eagerly: capturing six step-class graphs for them
@@ -1081,6 +1132,8 @@ static int run_map(nsk_ctx* c, int adjoint, double* f, const double* q) {
   const bool use_graph = c->use_graph && c->nsteps > 2 && !hostcheck_on(c);
   if (use_graph)
     for (int k = 0; k < NCLS; ++k) { int rc = ensure_graph(c, k, adjoint); if (rc) return rc; }
+  const int gsteps = (use_graph && c->graph_steps > 1 && c->nsteps >= CLS_ISTEP[NCLS - 1] + 2 * c->graph_steps) ? c->graph_steps : 1;
+  if (gsteps > 1) { int rc = ensure_graph_multi(c, adjoint); if (rc) return rc; }
   for (int cc = 0; cc < c->ndim; ++cc)
     HIPCHK(hipMemcpyAsync(d.u + cc * d.cs, q + cc * d.nloc, d.nloc * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(d.p, q + c->ndim * d.nloc, d.npr * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
@@ -1090,6 +1143,11 @@ static int run_map(nsk_ctx* c, int adjoint, double* f, const double* q) {
   }
   for (int istep = 1; istep <= c->nsteps; ++istep) {
     if (use_graph) {
+      if (gsteps > 1 && istep >= CLS_ISTEP[NCLS - 1] && istep + gsteps - 1 <= c->nsteps) {
+        HIPCHK(hipGraphLaunch(c->graphs[adjoint][NCLS].exec, c->stream));
+        istep += gsteps - 1;
+        continue;
+      }
       HIPCHK(hipGraphLaunch(c->graphs[adjoint][step_class(istep)].exec, c->stream));
     } else {
       int rc = step(c, istep, adjoint);
@@ -1760,6 +1818,8 @@ int nsk_set_option(nsk_ctx* c, const char* name, double value) {
   else if (n == "helm_guess") c->helm_guess = (int)value;
   else if (n == "gs2_from") c->gs2_from = std::max(0, (int)value);
   else if (n == "gs_lag") c->gs_lag = (int)value;
+  else if (n == "flat_proj") c->flat_proj = (int)value;
+  else if (n == "graph_steps") { c->graph_steps = std::max(1, std::min((int)value, 64)); for (auto& a : c->graphs) a[NCLS].nh = -1; }
   else if (n == "dbg_max_order") c->dbg_max_order = (int)value;
   else if (n == "dbg_ab2") c->dbg_ab2 = (int)value;
   else if (n == "dbg_pext") c->dbg_pext = (int)value;

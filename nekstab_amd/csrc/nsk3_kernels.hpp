@@ -10,16 +10,6 @@
 namespace nsk {
 namespace k3 {
 
-// Workgroup -> element map.  Workgroups are handed to the 8 XCDs round-robin (blockIdx % 8), each XCD
-// with its own L2; consecutive elements are almost always face neighbours (97 % of the r-faces of the
-// reference's cylinder mesh are e, e+1), and the dssum gather reads the neighbours' face nodes.  Giving
-// every XCD one contiguous run of elements makes those reads hit the L2 that streams the neighbour's
-// own tile at about the same time, instead of fetching the same lines again from memory.
-__device__ inline long long xcd_element(unsigned b, unsigned n) {
-  const unsigned x = b & 7u, q = b >> 3, base = n >> 3, rem = n & 7u;
-  return (long long)(x * base + (x < rem ? x : rem) + q);
-}
-
 // Nodes of valence 5..8 (hexahedral vertices) do not fit the 4-wide gather table.  Their index lists
 // are the same for every component and iteration, so a launch stages them once in LDS (8 ints per
 // thread, private to the thread: no barrier) and every later gather issues its value loads at once
@@ -1257,7 +1247,12 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_schwarz(Dev d, const double* __r
   __shared__ double sJ12[NM], sD12[NM];
   __shared__ double sS[3 * N * N], sL[3 * N];
   __shared__ double sa[NN], sb[NN];
-  __shared__ double sP[3 * MM], sC[3 * NMM], sE[2 * NNM];
+#ifdef NSK_NO_MFMA_OPS
+  constexpr bool PRE = false;
+#else
+  constexpr bool PRE = (N <= 8);                                       // all nine metric products in LDS up front (lx1 = 10: the LDS would halve the occupancy)
+#endif
+  __shared__ double sP[(PRE ? 9 : 3) * MM], sC[3 * NMM], sE[2 * NNM];
   const int tid = threadIdx.x;
   const long long e = d.boff + xcd_element(blockIdx.x, gridDim.x);      // XCD-contiguous runs of elements: the neighbours' face lines hit the L2 that streams them
   const bool act = tid < NN;
@@ -1310,9 +1305,18 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_schwarz(Dev d, const double* __r
     const int a = tid % M, b = (tid / M) % M, cc = tid / (M * M);
     z = sa[((cc + 1) * N + (b + 1)) * N + (a + 1)] + zc;       // restriction to the element's own nodes
     zout[q] = z;
+    if constexpr (PRE) {
+#pragma unroll
+      for (int m = 0; m < 9; ++m) sP[((m % 3) * 3 + m / 3) * MM + tid] = z * w2[m];    // [component c = m % 3][axis a = m / 3]
+    }
   }
+  if constexpr (PRE) lds_barrier();
   double gp[3];
+#ifdef NSK_NO_MFMA_OPS
   opgradt3<N>(sJ12, sD12, z, w2, sP, sC, sE, tid, NT, act, k, j, i, gp);
+#else
+  opgradt3_mfma<N, PRE>(sJ12, sD12, z, w2, sP, sC, sE, tid, NT, gp);
+#endif
   NSK_STAMP(4);
   if (act) {
     const long long l = e * NN + tid;
@@ -1388,7 +1392,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_divgs(Dev d, const double* __res
       double t = 0.0;
 #pragma unroll
       for (int ww = 0; ww < (MM + 63) / 64; ++ww) t += sdot[tid * 16 + ww];
-      d.gpart[(size_t)tid * d.nblk + (blockIdx.x + d.boff)] = t;
+      d.gpart[(size_t)tid * d.nblk + e] = t;               // slot = element: the order of the sums does not depend on how a launch is split or mapped
     }
   }
 }
@@ -1443,6 +1447,119 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_pres_update(Dev d, StepCoef sc) 
   if (blockIdx.x == 0 && tid == 0 && !G->done) atomicAdd((unsigned long long*)&d.stats->unconverged, 1ull);
 }
 
+// ---------------------------------------------------------------------------
+// The once-per-step linear algebra over the GMRES basis Z (<= 48 vectors) and the projection space PX / PEX (<= 32 vectors
+// each, 86 MB per vector at config 4's size) as STREAMING passes (option "flat_proj", default on single-rank hexahedral
+// contexts): inside the element kernels k_pres_update / k_vel_update_proj those loops ran on 216 of 512 lanes with one load
+// in flight (2.1 + 2.2 ms per step at config 4); here one wavefront per element walks its 216 nodes in rows of 64 with every
+// vector of a row loaded before the first use.
+//   k_pres_comb:  x = xacc + Z y,  PD = x,  x += PX a,  dp = h2 x,  p = p* + dp,  dpw = dp     (then k_gradt: yl = D^T dp)
+//   k_proj_dots:  E dp (raw, left in PED by k_vel_update_proj) -= PEX a;  (PD, PEX_k), (PD, E dp) partial sums
+// ---------------------------------------------------------------------------
+template <int N>
+__global__ __launch_bounds__(256) void k_pres_comb(Dev d, StepCoef sc) {
+  using C = Cfg<N>;
+  constexpr int MM = C::MM, ROWS = (MM + 63) / 64;
+  __shared__ double sy[MAXMR], sg[MAXMR], sR[MAXMR * MAXMR], spa[MAXPROJ];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const GmresScal* G = d.gsc;
+  const int nit = G->nit;
+  const int np = (d.nproj_max > 0) ? G->nproj : 0;
+  for (int p = tid; p < nit * nit; p += 256) { const int cc = p / nit, rr = p % nit; sR[cc * MAXMR + rr] = G->R[cc * MAXMR + rr]; }
+  if (tid < nit) sg[tid] = G->g[tid];
+  if (tid < MAXPROJ) spa[tid] = (tid < np) ? G->pa[tid] : 0.0;
+  if (tid < MAXMR && tid >= nit) sy[tid] = 0.0;
+  lds_barrier();
+  if (tid == 0) {
+    for (int q = nit - 1; q >= 0; --q) {
+      double s = sg[q];
+      for (int kk = q + 1; kk < nit; ++kk) s -= sR[kk * MAXMR + q] * sy[kk];
+      sy[q] = s / sR[q * MAXMR + q];
+    }
+  }
+  lds_barrier();
+  if (blockIdx.x == 0 && tid == 0 && !G->done) atomicAdd((unsigned long long*)&d.stats->unconverged, 1ull);
+  const bool acc0 = G->nit_prev > 0;
+  const size_t npr = (size_t)d.npr;
+  const long long nw = (long long)gridDim.x * 4;
+  for (long long e = (long long)blockIdx.x * 4 + wv; e < d.nel; e += nw) {
+    asm volatile("" ::: "memory");
+    const unsigned eb = (unsigned)e * (unsigned)MM;
+#pragma unroll 1
+    for (int r = 0; r < ROWS; ++r) {
+      if (ROWS > 1) asm volatile("" ::: "memory");
+      const int kk = lane + 64 * r;
+      const bool in = kk < MM;
+      const unsigned bo = (eb + (in ? kk : 0)) * 8u;
+      double z[MAXMR], px[MAXPROJ];
+#pragma unroll
+      for (int k = 0; k < MAXMR; ++k) z[k] = (in && k < nit) ? ld_boff(d.Z + (size_t)k * npr, bo) : 0.0;
+#pragma unroll
+      for (int k = 0; k < MAXPROJ; ++k) px[k] = (in && k < np) ? ld_boff(d.PX + (size_t)k * npr, bo) : 0.0;
+      const double pe = in ? ld_boff(d.pext, bo) : 0.0;
+      double x = (in && acc0) ? ld_boff(d.xacc, bo) : 0.0;
+#pragma unroll
+      for (int k = 0; k < MAXMR; ++k) x += sy[k] * z[k];
+      if (d.nproj_max > 0) {
+        if (in) st_boff(d.PD, bo, x);
+#pragma unroll
+        for (int k = 0; k < MAXPROJ; ++k) x += spa[k] * px[k];
+      }
+      const double dp = sc.h2 * x;
+      if (in) { st_boff(d.p, bo, pe + dp); st_boff(d.dpw, bo, dp); }
+    }
+  }
+}
+
+template <int N>
+__global__ __launch_bounds__(256) void k_proj_dots(Dev d) {
+  using C = Cfg<N>;
+  constexpr int MM = C::MM, ROWS = (MM + 63) / 64;
+  __shared__ double spa[MAXPROJ];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const GmresScal* G = d.gsc;
+  if (G->nit == 0) return;
+  const int np = G->nproj;
+  if (tid < MAXPROJ) spa[tid] = (tid < np) ? G->pa[tid] : 0.0;
+  lds_barrier();
+  const size_t npr = (size_t)d.npr;
+  const long long nw = (long long)gridDim.x * 4;
+  for (long long e = (long long)blockIdx.x * 4 + wv; e < d.nel; e += nw) {
+    asm volatile("" ::: "memory");
+    double acc[MAXPROJ], accn = 0.0;
+#pragma unroll
+    for (int k = 0; k < MAXPROJ; ++k) acc[k] = 0.0;
+    const unsigned eb = (unsigned)e * (unsigned)MM;
+#pragma unroll 1
+    for (int r = 0; r < ROWS; ++r) {
+      if (ROWS > 1) asm volatile("" ::: "memory");
+      const int kk = lane + 64 * r;
+      const bool in = kk < MM;
+      const unsigned bo = (eb + (in ? kk : 0)) * 8u;
+      double pex[MAXPROJ];
+#pragma unroll
+      for (int k = 0; k < MAXPROJ; ++k) pex[k] = (in && k < np) ? ld_boff(d.PEX + (size_t)k * npr, bo) : 0.0;
+      double edel = in ? ld_boff(d.PED, bo) : 0.0;
+      const double del = in ? ld_boff(d.PD, bo) : 0.0;
+#pragma unroll
+      for (int k = 0; k < MAXPROJ; ++k) edel -= spa[k] * pex[k];
+      if (in) st_boff(d.PED, bo, edel);
+#pragma unroll
+      for (int k = 0; k < MAXPROJ; ++k) acc[k] += del * pex[k];
+      accn += del * edel;
+    }
+#pragma unroll
+    for (int k = 0; k < MAXPROJ; ++k) {
+      if (k < np) {
+        const double s = wave_sum63(acc[k]);
+        if (lane == 63) d.ppart[(size_t)k * d.nblk + e] = s;
+      }
+    }
+    accn = wave_sum63(accn);
+    if (lane == 63) d.ppart[(size_t)np * d.nblk + e] = accn;
+  }
+}
+
 // velocity correction fused with E*dp for the projection space
 template <int N>
 __global__ __launch_bounds__(Cfg<N>::NT) void k_vel_update_proj(Dev d, StepCoef sc) {
@@ -1473,6 +1590,10 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_vel_update_proj(Dev d, StepCoef 
   if (pact) load_w2(d, q, w2);
   lds_barrier();
   const double w = opdiv3<N>(sJ12, sD12, su, sA, sB, tid, NT, w2);
+  if (d.flat_proj) {                         // E dp raw; k_proj_dots subtracts the projected part and takes the dots
+    if (pact) d.PED[q] = w / sc.h2;
+    return;
+  }
   const int np = G->nproj;
   double del = 0.0, edel = 0.0;
   if (pact) {
@@ -1493,7 +1614,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_vel_update_proj(Dev d, StepCoef 
   if (tid <= np) {
     double t = 0.0;
     for (int ww = 0; ww < NT / 64; ++ww) t += sdot[tid * 16 + ww];
-    d.ppart[(size_t)tid * d.nblk + blockIdx.x] = t;
+    d.ppart[(size_t)tid * d.nblk + e] = t;
   }
 }
 

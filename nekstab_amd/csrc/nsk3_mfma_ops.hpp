@@ -61,7 +61,9 @@ template <class C, int MS, int H, int SPLIT> struct StSplit {
 
 // D^T p: same contract as the thread-per-node opgradt3<N> (sP [3][M^3], sC [3][N M^2], sE [2][N^2 M] scratch; result g[3] for GLL
 // node tid; the last pass is staged through sC, free by then, which holds N^3 <= 3 N M^2 doubles)
-template <int N>
+// PRE: sP holds ALL nine products p * w2[a][c] ([c][a][M^3], filled by the caller before a barrier): the metrics are then dead
+// before the passes start (18 fewer live registers, two barriers fewer) at the price of 6 M^3 more doubles of LDS
+template <int N, bool PRE = false>
 __device__ inline void opgradt3_mfma(const double* sJ12, const double* sD12, double pval, const double (&w2)[9], double* sP,
                                      double* sC, double* sE, int tid, int nt, double (&g)[3]) {
   constexpr int M = N - 2, MM = M * M * M, NN = N * N * N, NNM = N * N * M, NMM = N * M * M, KQ = (M + 3) / 4;
@@ -83,16 +85,19 @@ __device__ inline void opgradt3_mfma(const double* sJ12, const double* sD12, dou
   typedef ColRow<N> CR_out;                    // [(k,j)][i]
 #pragma unroll 1
   for (int c = 0; c < 3; ++c) {
-    if (tid < MM) {
-      sP[tid] = pval * w2[0 * 3 + c];
-      sP[MM + tid] = pval * w2[1 * 3 + c];
-      sP[2 * MM + tid] = pval * w2[2 * 3 + c];
+    if constexpr (!PRE) {
+      if (tid < MM) {
+        sP[tid] = pval * w2[0 * 3 + c];
+        sP[MM + tid] = pval * w2[1 * 3 + c];
+        sP[2 * MM + tid] = pval * w2[2 * 3 + c];
+      }
+      lds_barrier();
     }
-    lds_barrier();
+    const double* sPc = PRE ? sP + c * 3 * MM : sP;
     // axis t: sC_a[kk][ba] = sum_cc A_a[kk][cc] sP_a[cc][ba],  A_0 = A_1 = J12^T, A_2 = D12^T
-    mo_pass<M, KQ, M * M, CT, StLin<CT, M * M, N>, false>(aJ, sP, aJ, sP, sC, wave, nw, lane);
-    mo_pass<M, KQ, M * M, CT, StLin<CT, M * M, N>, false>(aJ, sP + MM, aJ, sP, sC + NMM, wave, nw, lane);
-    mo_pass<M, KQ, M * M, CT, StLin<CT, M * M, N>, false>(aD, sP + 2 * MM, aD, sP, sC + 2 * NMM, wave, nw, lane);
+    mo_pass<M, KQ, M * M, CT, StLin<CT, M * M, N>, false>(aJ, sPc, aJ, sPc, sC, wave, nw, lane);
+    mo_pass<M, KQ, M * M, CT, StLin<CT, M * M, N>, false>(aJ, sPc + MM, aJ, sPc, sC + NMM, wave, nw, lane);
+    mo_pass<M, KQ, M * M, CT, StLin<CT, M * M, N>, false>(aD, sPc + 2 * MM, aD, sPc, sC + 2 * NMM, wave, nw, lane);
     lds_barrier();
     // axis s: sE_0[kk][jj][a] = J12^T sC_0,   sE_1 = D12^T sC_1 + J12^T sC_2
     mo_pass<M, KQ, N * M, CS_in, StLin<CS_out, M, N>, false>(aJ, sC, aJ, sC, sE, wave, nw, lane);

@@ -71,6 +71,7 @@ struct Dev {
   int nel, nblk, nvert;
   int boff;                      // set per launch: first workgroup of this launch (k_helm on shards: boundary elements first, interior behind)
   int gs2;                       // set per launch: the GMRES column of this k_gmres_update had a second Gram-Schmidt pass (k_gmres_reorth)
+  int flat_proj;                 // set per launch: the linear combinations / dots over the GMRES and projection bases run in the streaming kernels (k_pres_comb, k_proj_dots)
   int gs_lag;                    // set per launch: the basis vector read here may still carry its pending scale GmresScal::phinv (k_gs_lag)
   long long nloc, npr;
   long long cs, ps;              // component stride of velocity-mesh arrays / stride of the GMRES basis V
@@ -107,6 +108,7 @@ struct Dev {
   // pressure GMRES
   double *V, *Z, *yl, *ec, *xc, *gpart;
   double *xacc;                  // solution accumulated over the completed GMRES cycles (restarted solves)
+  double *dpw;                   // hexahedra: the pressure increment dp of the step (k_pres_comb -> k_gradt)
   double *rch;                   // [MAXMR][coarse_lda] coarse solutions x_c(v_i) of the GMRES basis vectors (k_update_coarse)
   GmresScal* gsc;
   // projection onto previous pressure solutions (E-orthonormal)

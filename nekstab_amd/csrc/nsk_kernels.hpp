@@ -46,6 +46,16 @@ __device__ inline void tile_barrier() {
   else { lds_barrier(); }
 }
 
+// Workgroup -> element map.  Workgroups are handed to the 8 XCDs round-robin (blockIdx % 8), each XCD
+// with its own L2; consecutive elements are almost always face neighbours (97 % of the r-faces of the
+// reference's cylinder mesh are e, e+1), and the dssum gather reads the neighbours' face nodes.  Giving
+// every XCD one contiguous run of elements makes those reads hit the L2 that streams the neighbour's
+// own tile at about the same time, instead of fetching the same lines again from memory.
+__device__ inline long long xcd_element(unsigned b, unsigned n) {
+  const unsigned x = b & 7u, q = b >> 3, base = n >> 3, rem = n & 7u;
+  return (long long)(x * base + (x < rem ? x : rem) + q);
+}
+
 // ---------------------------------------------------------------------------
 // wave64 sum with DPP row shifts / row broadcasts (total lands in lane 63): ~6 dependent
 // v_mov_dpp+v_add_f64 steps instead of 6 ds_bpermute round trips through the LDS crossbar.
@@ -619,7 +629,9 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_rhs(Dev d, StepCoef sc) {
 // ---------------------------------------------------------------------------
 template <int N>
 __global__ __launch_bounds__(Cfg<N>::NT) void k_helm(Dev d, StepCoef sc, int it, const double* rhs) {
-  const int bid = blockIdx.x + d.boff;       // (shards with halo / interior overlap launch the boundary workgroups first, the rest with an offset)
+  // (shards with halo / interior overlap launch the boundary workgroups first, the rest with an offset; XCD-contiguous runs of
+  //  element blocks: the neighbours' edge values are L2 hits where the grid is larger than the caches, config 3)
+  const int bid = d.boff + (int)xcd_element(blockIdx.x, gridDim.x);
   using C = Cfg<N>;
   constexpr int NN = C::NN, EPB = C::EPB, NT = C::NT;
   __shared__ double sD[NN], sDt[NN];
@@ -1497,7 +1509,8 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_schwarz(Dev d, const double* __r
   __shared__ double sP[4 * EPB * MM], sB[4 * EPB * NM];
   __shared__ double sr[EPB * MAXP];
   const int tid = threadIdx.x, el = tid / NN, nd = tid % NN;
-  const long long e = (long long)(blockIdx.x + d.boff) * EPB + el;
+  const int bid = d.boff + (int)xcd_element(blockIdx.x, gridDim.x);
+  const long long e = (long long)bid * EPB + el;
   const bool act = (el < EPB) && (e < d.nel);
   if (check_done && d.gsc->done) return;
   const int PS = d.p_stride;
@@ -1599,7 +1612,8 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_divgs(Dev d, const double* __res
   __shared__ double su[2 * EPB * NN], sA[4 * EPB * NM];
   __shared__ double sdot[(MAXMR + 2) * 4];
   const int tid = threadIdx.x, el = tid / NN, nd = tid % NN;
-  const long long e = (long long)(blockIdx.x + d.boff) * EPB + el;
+  const int bid = d.boff + (int)xcd_element(blockIdx.x, gridDim.x);
+  const long long e = (long long)bid * EPB + el;
   const bool act = (el < EPB) && (e < d.nel);
   NSK_STAMP(0);
   if (check_done && d.gsc->done) return;
@@ -1651,7 +1665,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_divgs(Dev d, const double* __res
       double t = 0.0;
 #pragma unroll
       for (int ww = 0; ww < NW; ++ww) t += sdot[tid * 4 + ww];
-      d.gpart[(size_t)tid * d.nblk + (blockIdx.x + d.boff)] = t;
+      d.gpart[(size_t)tid * d.nblk + bid] = t;
     }
     NSK_STAMP(4);
   }
@@ -1738,7 +1752,8 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_vel_update_proj(Dev d, StepCoef 
   __shared__ double su[2 * EPB * NN], sA[4 * EPB * NM];
   __shared__ double sred[16];
   const int tid = threadIdx.x, el = tid / NN, nd = tid % NN;
-  const long long e = (long long)blockIdx.x * EPB + el;
+  const int bid = (int)xcd_element(blockIdx.x, gridDim.x);             // (as k_helm: XCD-contiguous runs of element blocks)
+  const long long e = (long long)bid * EPB + el;
   const bool act = (el < EPB) && (e < d.nel);
   const GmresScal* G = d.gsc;
   // E-images of the stored solutions and the GMRES correction at this thread's Gauss node: used after the divergence below,
@@ -1808,7 +1823,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_vel_update_proj(Dev d, StepCoef 
   if (tid <= np) {
     double t = 0.0;
     for (int ww = 0; ww < NT / 64; ++ww) t += sdot[tid * 4 + ww];
-    d.ppart[(size_t)tid * d.nblk + blockIdx.x] = t;
+    d.ppart[(size_t)tid * d.nblk + bid] = t;
   }
 }
 

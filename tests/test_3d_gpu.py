@@ -301,7 +301,11 @@ def test_arnoldi_3d_matches_oracle():
 def test_nonlinear_map_and_relinearisation_3d(lx1):
     """Full-equation steps (newton_krylov's nonlinear map) and a new linearisation point on hexahedra (lx1 = 10: the
     convection kernel with its accumulators in LDS, both of its branches)."""
-    c = _case(lx1, True)
+    if lx1 == 10:          # (two sparse-LU oracles at this order: a 2 x 2 x 1 box keeps them at seconds instead of 2 x 20 s)
+        c = mesh3d.box_case_3d(2, 2, 1, lx1, lengths=(1.4, 1.0, 0.5), outflow_xmax=True, re=40.0, endtime=0.05, ub_func=_ubf, warp=0.06)
+        c.spng = 0.4 * np.clip(c.x - 0.9, 0.0, None) ** 2
+    else:
+        c = _case(lx1, True)
     o = _oracle(c)
     h = _hip(c)
     try:
@@ -564,3 +568,45 @@ def test_lagged_gram_schmidt_equals_classic_two_pass(lx1, outflow):
         sc = max(np.abs(maps[0][k]).max() for k in range(3))
         for k in range(3):
             assert np.abs(maps[lag][k] - maps[0][k]).max() < 1e-7 * sc
+
+
+@pytest.mark.parametrize("lx1,outflow", [(8, True), (6, False), (10, True)])
+def test_streaming_projection_kernels_equal_element_kernel_forms(lx1, outflow):
+    """Option flat_proj (default on single-rank hexahedral contexts): the once-per-step sums over the GMRES basis and the
+    pressure projection space run as streaming kernels (k_pres_comb + k_gradt, k_proj_dots) instead of inside the element
+    kernels k_pres_update / k_vel_update_proj.  Same arithmetic in another summation order: three consecutive maps with the
+    projection space filling up agree to rounding-level differences amplified by the solves, with the same iteration counts
+    (+-2), short GMRES restart cycles included."""
+    c = _case(lx1, outflow)
+    c.spng = np.zeros_like(c.x)
+    x, y, z = c.x, c.y, c.z
+    q = [np.sin(1.3 * x + z) * np.cos(2.0 * y) * c.mask, np.cos(0.7 * x + 0.2) * np.sin(3.0 * y - z) * c.mask,
+         np.sin(x + y) * np.cos(2.0 * z) * c.mask, np.zeros((c.nel,) + (c.lx1 - 2,) * 3)]
+    out, its = {}, {}
+    for flat in (0, 1):
+        for cyc in (48, 5):
+            h = _hip(c, nproj=6, max_pres_iter=96)
+            try:
+                h.set_option("flat_proj", flat)
+                h.set_option("gmres_cycle", cyc)
+                a, b = h.alloc(2)
+                h.upload3(a, *q)
+                h.set_nsteps(4)
+                res, cnt = [], []
+                for rep in range(3):
+                    h.matvec(b, a, 0)
+                    res.append(h.download3(b))
+                    st = h.stats()
+                    assert st["unconverged"] == 0
+                    cnt.append(st["pres_iters"])
+                    h.copy(a, b)
+                out[flat, cyc], its[flat, cyc] = res, cnt
+            finally:
+                h.close()
+    print("pressure iterations per map (flat_proj, cycle):", its)
+    for cyc in (48, 5):
+        for rep in range(3):
+            sc = max(np.abs(out[0, cyc][rep][k]).max() for k in range(3))
+            for k in range(3):
+                assert np.abs(out[1, cyc][rep][k] - out[0, cyc][rep][k]).max() < 2e-7 * sc, (cyc, rep, k)
+            assert abs(its[1, cyc][rep] - its[0, cyc][rep]) <= 2, its
