@@ -1181,7 +1181,8 @@ static int run_map(nsk_ctx* c, int adjoint, double* f, const double* q) {
 // 449 graph re-captures in 130 maps).  So: a window of the last BW maps; grow at once; shrink to the window
 // maximum + head-room only when the window is full, or when the budget is more than twice what the window asks
 // for (start-up budgets, doubled budgets after a redone map).
-constexpr int BW = 8, BHEAD = 3;
+constexpr int BW = 8;
+static int bhead() { static const int v = std::getenv("NSK_BHEAD") ? std::max(0, std::atoi(std::getenv("NSK_BHEAD"))) : 3; return v; }      // head-room above the window maximum (A/B switch)
 static void budgets_update(nsk_ctx* c, const Stats& h) {
   if (c->budget_freeze) return;                         // measurement switch (scripts/noop_cost.py): budgets stay where the caller put them
   const int slot = c->bh_n % BW;
@@ -1197,7 +1198,7 @@ static void budgets_update(nsk_ctx* c, const Stats& h) {
     const int xh = k <= 3 ? std::max(4, mh / 2) : (k == 4 ? 1 : 0), xp = k <= 3 ? std::max(4, mp) : (k == 4 ? 1 : 0);
     // the first maps of a run differ most from one another (noise seed, empty projection space): wider margin
     const int sh = nv < 4 ? std::max(2, mh / 4) : 0, sp = nv < 4 ? std::max(4, mp) : 0;
-    const int th = std::min(c->max_helm, mh + BHEAD + xh + sh), tp = std::min(c->max_pres, mp + BHEAD + xp + sp);
+    const int th = std::min(c->max_helm, mh + bhead() + xh + sh), tp = std::min(c->max_pres, mp + bhead() + xp + sp);
     // before the window is full only the long classes are cut (their spare launches are what costs); the classes of
     // steps 1-6 keep what they have: the second Krylov vector of a run can need 34 pressure iterations where the
     // noise seed needed 4
