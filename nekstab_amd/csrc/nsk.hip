@@ -83,6 +83,7 @@ struct nsk_ctx {
   int in_test = 0;
   int helm_guess = 1;
   int budget_freeze = 0;
+  int helm_fdm = -1;                    // hexahedra: element-block fast-diagonalisation preconditioner of the velocity solves (NSK_HELM_FDM=1 builds it; measured slower than Jacobi-CG, off)
   int flat_proj = -1;                   // hexahedra: once-per-step sums over the GMRES / projection bases as streaming kernels (k_pres_comb, k_proj_dots); -1 = yes on single-rank contexts
   int gs_lag = -1;                      // hexahedra: lagged second Gram-Schmidt correction (k_gs_lag: two basis reads per GMRES column instead of four); -1 = yes on single-rank contexts
   int gs2_from = MAXMR;                 // quadrilaterals: GMRES columns from this iteration (of a cycle) on get a second Gram-Schmidt pass (default: never)
@@ -896,6 +897,23 @@ static void launch_gs_lag3(nsk_ctx* c, const Dev& d, int j, double scale, int or
   }
 }
 
+// one CG iteration of the velocity solve: k_helm, or (hexahedra with Dev::helm_fdm) the two launches of the block-preconditioned form
+template <int N>
+static void launch_helm_iter(nsk_ctx* c, const Dev& d, const StepCoef& sc, int it, const double* rhs) {
+  if constexpr (N <= 10) {
+    if (c->ndim == 3 && d.helm_fdm) {
+      hipLaunchKernelGGL(nsk::k3::k_helm_fa<N>, dim3(c->nblk), dim3(nsk::k3::Cfg<N>::NT), 0, c->stream, d, sc, it, rhs);
+      hipLaunchKernelGGL(nsk::k3::k_helm_fb<N>, dim3(c->nblk), dim3(nsk::k3::Cfg<N>::NT), 0, c->stream, d, sc, it);
+      return;
+    }
+  }
+  if (c->ndim == 3) {
+    if constexpr (N <= 10) hipLaunchKernelGGL(nsk::k3::k_helm<N>, dim3(c->nblk), dim3(nsk::k3::Cfg<N>::NT), 0, c->stream, d, sc, it, rhs);
+  } else {
+    hipLaunchKernelGGL(nsk::k2::k_helm<N>, dim3(c->nblk), dim3(nsk::k2::Cfg<N>::NT), 0, c->stream, d, sc, it, rhs);
+  }
+}
+
 static bool flat_proj_on(const nsk_ctx* c) {
   if (c->ndim != 3 || c->N > 10 || !c->d.dpw) return false;
   if (c->flat_proj >= 0) return c->flat_proj != 0;
@@ -1048,7 +1066,7 @@ static int step(nsk_ctx* c, int istep, int adjoint) {
     } else {
       hipLaunchKernelGGL(k_rhs<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, sc);
       for (int it = 0; it < nh; ++it) {
-        hipLaunchKernelGGL(k_helm<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, sc, it, (const double*)d.rloc);
+        launch_helm_iter<N>(c, d, sc, it, (const double*)d.rloc);
         tot_rows(c, d.hpart + (size_t)(it & 1) * c->hrows * c->nblk, c->hrows, d.htot + (it & 1) * c->hstride);
         if (hc && it >= 1 && it >= c->hc_helm[sc.cls] && ((it - c->hc_helm[sc.cls]) % 2 == 0)) {
           bool done = false;
@@ -1820,6 +1838,11 @@ int nsk_set_option(nsk_ctx* c, const char* name, double value) {
   else if (n == "gs2_from") c->gs2_from = std::max(0, (int)value);
   else if (n == "gs_lag") c->gs_lag = (int)value;
   else if (n == "flat_proj") c->flat_proj = (int)value;
+  else if (n == "helm_fdm") {           // 0: back to Jacobi (the factors stay); 1: only if the set-up built them (NSK_HELM_FDM=1 or an anisotropic mesh)
+    if (value != 0.0 && !c->d.hfS) return fail(NSK_EINVAL, "helm_fdm: the fast-diagonalisation factors were not built at set-up (NSK_HELM_FDM=1)");
+    c->d.helm_fdm = value != 0.0 ? 1 : 0;
+    for (auto& a : c->graphs) for (auto& g : a) g.nh = -1;
+  }
   else if (n == "graph_steps") { c->graph_steps = std::max(1, std::min((int)value, 64)); for (auto& a : c->graphs) a[NCLS].nh = -1; }
   else if (n == "dbg_max_order") c->dbg_max_order = (int)value;
   else if (n == "dbg_ab2") c->dbg_ab2 = (int)value;
@@ -2599,7 +2622,7 @@ int nsk_test_op3(nsk_ctx* c, int which, const double* in, double* out, int a, in
     const StepCoef sc = make_coef(c, a, 0);
     DISPATCH_N(c->key, {
       for (int it = 0; it < c->max_helm; ++it) {
-        hipLaunchKernelGGL(k_helm<N>, dim3(c->nblk), dim3(Cfg<N>::NT), 0, c->stream, d, sc, it, (const double*)d.rloc);
+        launch_helm_iter<N>(c, d, sc, it, (const double*)d.rloc);
         tot_rows(c, d.hpart + (size_t)(it & 1) * c->hrows * c->nblk, c->hrows, d.htot + (it & 1) * c->hstride);
       }
     });

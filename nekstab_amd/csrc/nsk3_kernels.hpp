@@ -742,6 +742,212 @@ __global__ __launch_bounds__(Cfg<N>::NT, 4) void k_helm(Dev d, StepCoef sc, int 
   }
 }
 
+
+// ---------------------------------------------------------------------------
+// Velocity solve with an ELEMENT-BLOCK FAST-DIAGONALISATION preconditioner (option "helm_fdm"; config 5's wall cells have
+// aspect ratios of 29, where the Jacobi-preconditioned CG of k_helm needs 60-105 iterations per time step):
+//   M^-1 = sum_e R_e^T W (S_t x S_s x S_r) (h2 + nu (l_r + l_s + l_t))^-1 (S_t x S_s x S_r)^T W R_e,   W = mask / sqrt(multiplicity),
+// the exact inverse of the element's own Helmholtz block on an undeformed box (1-D pairs of its GLL lines scaled by its
+// lengths, Dirichlet ends at walls; mean lengths on deformed elements).  M^-1 r needs a dssum of its own, so one CG iteration
+// (same Chronopoulos-Gear single-reduction recurrences, same scalars, flags and statistics as k_helm) is TWO launches:
+//   k_helm_fa(it): sums of iteration it-1 -> alpha, beta, flags; gather A z;  p = z + beta p, s = A z + beta s, x += alpha p,
+//                  r -= alpha s;  y_e = W H_e^-1 W r  (six LDS passes), stored unassembled
+//   k_helm_fb(it): z = mask dssum(y);  A z (axhelm), stored unassembled;  (r, z), (z, A z), (r, r) partial sums
+// 1.4x the bytes of a Jacobi iteration for 3-4x fewer iterations where the cells are that anisotropic (scripts/helm_fdm_study.py).
+// ---------------------------------------------------------------------------
+template <int N>
+__global__ __launch_bounds__(Cfg<N>::NT, 4) void k_helm_fa(Dev d, StepCoef sc, int it, const double* rhs) {
+  using C = Cfg<N>;
+  constexpr int NN = C::NN, NT = C::NT;
+  __shared__ double sS[3 * N * N], sL[3 * N];
+  __shared__ double sa[NN], sb[NN];
+  __shared__ double sred[16];
+  __shared__ int sW[NT * 8];
+  const int tid = threadIdx.x;
+  const long long e = xcd_element(blockIdx.x, gridDim.x);
+  const bool act = tid < NN;
+  const int k = tid / (N * N), j = (tid / N) % N, i = tid % N;
+  const long long l = e * NN + tid, nl = d.cs;
+  const int par = it & 1, ppar = par ^ 1;
+  double alpha[3] = {0, 0, 0}, beta[3] = {0, 0, 0};
+  bool done[3] = {false, false, false};
+  if (it > 0) {                                        // (the same bookkeeping as k_helm)
+    const double* ps = d.htot + ppar * 16;
+    const double* o = d.hscal + ppar * 16;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const double gg = ps[c * 3 + 0], del = ps[c * 3 + 1], rr = ps[c * 3 + 2];
+      const double res = sqrt(rr / d.vol);
+      const double ref = (it == 1) ? sqrt(ps[9 + c] / d.vol) : d.hscal[32 + c];
+      const double tol = d.tol_relative ? d.tol_helm * ref : d.tol_helm;
+      const bool was = (it > 1 && o[c * 4 + 2] != 0.0);
+      done[c] = was || (res <= tol) || !(gg > 0.0);
+      if (!done[c]) {
+        if (it == 1) { beta[c] = 0.0; alpha[c] = gg / del; }
+        else { beta[c] = gg / o[c * 4 + 0]; alpha[c] = gg / (del - beta[c] * gg / o[c * 4 + 1]); }
+      }
+      if (blockIdx.x == 0 && tid == 0) {
+        double* cur = d.hscal + par * 16 + c * 4;
+        const double keep = was ? o[c * 4 + 3] : res;
+        cur[0] = gg; cur[1] = alpha[c]; cur[2] = done[c] ? 1.0 : 0.0; cur[3] = keep;
+        if (it == 1) d.hscal[32 + c] = ref;
+        if (done[c] && !was) {
+          if (c == 0) atomicAdd((unsigned long long*)&d.stats->helm_iters, (unsigned long long)(it - 1));
+          atomicMax((unsigned long long*)&d.stats->max_helm, (unsigned long long)(it - 1));
+          atomicMax((unsigned long long*)&d.stats->max_helm_k[sc.cls], (unsigned long long)(it - 1));
+        }
+      }
+    }
+    if (done[0] && done[1] && done[2]) return;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { alpha[c] = uniform_f64(alpha[c]); beta[c] = uniform_f64(beta[c]); done[c] = __builtin_amdgcn_readfirstlane((int)done[c]) != 0; }
+  } else if (blockIdx.x == 0 && tid < 3) {
+    d.hscal[par * 16 + tid * 4 + 2] = 0.0;            // launch 0: nothing is converged yet (k_helm_fb reads the flags of its own launch)
+  }
+  // hybrid: an element of moderate aspect ratio contributes the Jacobi diagonal (multiplicity-weighted, so that all-Jacobi nodes
+  // get exactly D^-1 r), an anisotropic one its fast-diagonalisation block; the sum of the pieces stays symmetric positive definite
+  const bool blk = d.hfT[e] != 0;
+  if (blk) {
+    for (int q = tid; q < 3 * N * N; q += NT) sS[q] = d.hfS[(size_t)e * 3 * N * N + q];
+    for (int q = tid; q < 3 * N; q += NT) sL[q] = d.hfL[(size_t)e * 3 * N + q];
+  }
+  int4 tab = make_int4(0, -1, -1, -1);
+  double mk = 0, mi = 0, wt = 0, dj = 0;
+  if (act) {
+    tab = d.gs_tab[l];
+    mk = d.mask[l]; mi = d.minv[l];
+    wt = mk * sqrt(mi);
+    if (!blk) dj = mk * mi * d.dinv[(size_t)(sc.k - 1) * d.nloc + l];
+    const int cid = corner_id<N>(k, j, i);
+    gs_wide_stage(d, tab, l, sW + tid * 8, (cid >= 0 && d.gs_corner) ? reinterpret_cast<const int4*>(d.gs_corner + ((size_t)e * 8 + cid) * 8) : nullptr);
+  }
+#pragma unroll 1
+  for (int c = 0; c < 3; ++c) {
+    if (it > 0 && done[c]) continue;
+    const long long lc = c * nl + l;
+    double r = 0.0, bbv = 0.0;
+    if (act) {
+      if (it == 0) {
+        const GsVals gv = gs_load(rhs + c * nl, tab, l), gb = gs_load(d.bloc + c * nl, tab, l);
+        r = mk * (tab.x < 0 ? gs_wide_sum(rhs + c * nl, d, l, sW + tid * 8) : gs_sum(gv, rhs + c * nl, d, tab, l));
+        const double bb = mk * (tab.x < 0 ? gs_wide_sum(d.bloc + c * nl, d, l, sW + tid * 8) : gs_sum(gb, d.bloc + c * nl, d, tab, l));
+        d.hx[lc] = 0.0; d.hp[lc] = 0.0; d.hs[lc] = 0.0; d.hr[lc] = r;
+        bbv = bb * bb * mi;                                              // (b, b): the reference of the relative tolerance
+      } else {
+        const double* wl = d.hwl + ((size_t)ppar * 3 + c) * nl;
+        const GsVals gv = gs_load(wl, tab, l);
+        const double rold = d.hr[lc], pold = d.hp[lc], sold = d.hs[lc], xold = d.hx[lc], zold = d.hz[lc];
+        const double w = mk * (tab.x < 0 ? gs_wide_sum(wl, d, l, sW + tid * 8) : gs_sum(gv, wl, d, tab, l));
+        const double pn = zold + beta[c] * pold;
+        const double sn = w + beta[c] * sold;
+        d.hp[lc] = pn; d.hs[lc] = sn;
+        d.hx[lc] = xold + alpha[c] * pn;
+        r = rold - alpha[c] * sn;
+        d.hr[lc] = r;
+      }
+      sa[tid] = wt * r;
+    }
+    if (it == 0) {
+      const double x = wave_sum63(bbv);
+      if ((tid & 63) == 63) sred[tid >> 6] = x;
+    }
+    lds_barrier();
+    if (it == 0 && tid == 0) {
+      double s = 0.0;
+      for (int w = 0; w < NT / 64; ++w) s += sred[w];
+      d.hpart[((size_t)par * 12 + 9 + c) * d.nblk + e] = s;
+    }
+    if (!blk) {                                        // Jacobi piece (uniform per workgroup)
+      if (act) d.hy[lc] = dj * r;
+      lds_barrier();
+      continue;
+    }
+    // forward: S^T along r, s, t; scale; back: S along t, s, r   (S: [pos][mode], B-orthonormal)
+    if (act) { double s = 0; for (int m = 0; m < N; ++m) s += sS[0 * N * N + m * N + i] * sa[(k * N + j) * N + m]; sb[tid] = s; }
+    lds_barrier();
+    if (act) { double s = 0; for (int m = 0; m < N; ++m) s += sS[1 * N * N + m * N + j] * sb[(k * N + m) * N + i]; sa[tid] = s; }
+    lds_barrier();
+    if (act) {
+      double s = 0; for (int m = 0; m < N; ++m) s += sS[2 * N * N + m * N + k] * sa[(m * N + j) * N + i];
+      sb[tid] = s / (sc.h2 + d.nu * (sL[i] + sL[N + j] + sL[2 * N + k]));
+    }
+    lds_barrier();
+    if (act) { double s = 0; for (int m = 0; m < N; ++m) s += sS[2 * N * N + k * N + m] * sb[(m * N + j) * N + i]; sa[tid] = s; }
+    lds_barrier();
+    if (act) { double s = 0; for (int m = 0; m < N; ++m) s += sS[1 * N * N + j * N + m] * sa[(k * N + m) * N + i]; sb[tid] = s; }
+    lds_barrier();
+    if (act) {
+      double s = 0; for (int m = 0; m < N; ++m) s += sS[0 * N * N + i * N + m] * sb[(k * N + j) * N + m];
+      d.hy[lc] = wt * s;
+    }
+    lds_barrier();
+  }
+}
+
+template <int N>
+__global__ __launch_bounds__(Cfg<N>::NT, 4) void k_helm_fb(Dev d, StepCoef sc, int it) {
+  using C = Cfg<N>;
+  constexpr int NN = C::NN, NT = C::NT;
+  __shared__ double sD[N * N], sDt[N * N];
+  __shared__ double sz[NN], st[3 * NN];
+  __shared__ double sred[3 * 16];
+  __shared__ int sW[NT * 8];
+  const int tid = threadIdx.x;
+  const long long e = xcd_element(blockIdx.x, gridDim.x);
+  const bool act = tid < NN;
+  const int k = tid / (N * N), j = (tid / N) % N, i = tid % N;
+  const long long l = e * NN + tid, nl = d.cs;
+  const int par = it & 1;
+  bool done[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) done[c] = __builtin_amdgcn_readfirstlane((int)(d.hscal[par * 16 + c * 4 + 2] != 0.0)) != 0;   // written by k_helm_fa(it)
+  if (done[0] && done[1] && done[2]) return;
+  for (int q = tid; q < N * N; q += NT) { const double v = d.D[q]; sD[q] = v; sDt[(q % N) * N + q / N] = v; }
+  int4 tab = make_int4(0, -1, -1, -1);
+  double bm = 0, g[6] = {0, 0, 0, 0, 0, 0}, mk = 0, mi = 0;
+  if (act) {
+    tab = d.gs_tab[l];
+    bm = d.bm1[l]; mk = d.mask[l]; mi = d.minv[l];
+    g[0] = d.g1[l]; g[1] = d.g2[l]; g[2] = d.g3[l]; g[3] = d.g4[l]; g[4] = d.g5[l]; g[5] = d.g6[l];
+    const int cid = corner_id<N>(k, j, i);
+    gs_wide_stage(d, tab, l, sW + tid * 8, (cid >= 0 && d.gs_corner) ? reinterpret_cast<const int4*>(d.gs_corner + ((size_t)e * 8 + cid) * 8) : nullptr);
+  }
+#pragma unroll 1
+  for (int c = 0; c < 3; ++c) {
+    if (done[c]) continue;
+    const long long lc = c * nl + l;
+    double r = 0.0, z = 0.0;
+    if (act) {
+      const double* yl = d.hy + c * nl;
+      const GsVals gv = gs_load(yl, tab, l);
+      r = d.hr[lc];
+      z = mk * (tab.x < 0 ? gs_wide_sum(yl, d, l, sW + tid * 8) : gs_sum(gv, yl, d, tab, l));
+      d.hz[lc] = z;
+      sz[tid] = z;
+    }
+    lds_barrier();
+    double au[1];
+    axhelm3<N, 1>(sD, sDt, sz, st, act, k, j, i, g, au);
+    double v[3] = {0, 0, 0};
+    if (act) {
+      const double wl = d.nu * au[0] + sc.h2 * bm * z;
+      d.hwl[((size_t)par * 3 + c) * nl + l] = wl;
+      v[0] = r * z * mi; v[1] = z * wl; v[2] = r * r * mi;
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const double x = wave_sum63(v[q]);
+      if ((tid & 63) == 63) sred[q * 16 + (tid >> 6)] = x;
+    }
+    lds_barrier();
+    if (tid < 3) {
+      double s = 0.0;
+      for (int w = 0; w < NT / 64; ++w) s += sred[tid * 16 + w];
+      d.hpart[((size_t)par * 12 + c * 3 + tid) * d.nblk + e] = s;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------
 // K4: u* = u + du ;  g = -D u*  -> V[0], |g|^2 partials; checks the Helmholtz solve  [UPSTREAM incomprp]
 // ---------------------------------------------------------------------------

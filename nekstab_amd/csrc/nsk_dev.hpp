@@ -109,6 +109,14 @@ struct Dev {
   double *V, *Z, *yl, *ec, *xc, *gpart;
   double *xacc;                  // solution accumulated over the completed GMRES cycles (restarted solves)
   double *dpw;                   // hexahedra: the pressure increment dp of the step (k_pres_comb -> k_gradt)
+  // hexahedra, option "helm_fdm": element-block fast-diagonalisation preconditioner of the velocity solves -- per element and
+  // direction the generalised eigenvectors / values of the 1-D pair (stiffness, mass) of its GLL line scaled by the element's
+  // length (Dirichlet ends at walls): hfS [nel][3][N*N], hfL [nel][3][N]; hz = z = M^-1 r (assembled), hy = its unassembled
+  // element contributions ([3][cs] each)
+  int helm_fdm;
+  const double *hfS, *hfL;
+  const int* hfT;                // [nel] 1: this element takes its fast-diagonalisation block, 0: it is isotropic enough for the Jacobi diagonal
+  double *hz, *hy;
   double *rch;                   // [MAXMR][coarse_lda] coarse solutions x_c(v_i) of the GMRES basis vectors (k_update_coarse)
   GmresScal* gsc;
   // projection onto previous pressure solutions (E-orthonormal)

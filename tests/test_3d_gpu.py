@@ -611,3 +611,49 @@ def test_streaming_projection_kernels_equal_element_kernel_forms(lx1, outflow):
             for k in range(3):
                 assert np.abs(out[1, cyc][rep][k] - out[0, cyc][rep][k]).max() < 2e-7 * sc, (cyc, rep, k)
             assert abs(its[1, cyc][rep] - its[0, cyc][rep]) <= 2, its
+
+
+@pytest.mark.parametrize("lx1", [6, 8])
+def test_block_fdm_velocity_preconditioner_on_a_stretched_box(lx1, monkeypatch):
+    """Option helm_fdm (built, measured, NOT a gain -- DESIGN.md section 7): velocity solves preconditioned by
+    element-block fast diagonalisation (k_helm_fa / k_helm_fb: two launches per CG iteration) instead of the Jacobi diagonal.
+    What is tested is that it is a correct preconditioned CG: on a closed box with Chebyshev-like clustering the solve reproduces
+    the oracle's direct solve and a 4-step map equals the Jacobi path's at solver tolerance; the iteration counts are printed.
+    The library never chooses it by itself."""
+    stretch = lambda t: 0.5 * (1.0 - np.cos(np.pi * t))
+    c = mesh3d.box_case_3d(10, 3, 3, lx1, lengths=(1.0, 0.6, 0.6), re=400.0, endtime=0.01, ub_func=_ubf, warp=0.0, stretch=stretch)
+    c.ub = c.ub * c.mask
+    c.spng = np.zeros_like(c.x)
+    o = _oracle(c)
+    rng = np.random.default_rng(5)
+    r = rng.standard_normal((3,) + c.x.shape)
+    h2 = (11.0 / 6.0) / o.dt
+    ref = np.stack([o.helm_solve(r[k], o.nu, h2) for k in range(3)])
+    x, y, z = c.x, c.y, c.z
+    q = [np.sin(3.0 * x + z) * np.cos(2.0 * y) * c.mask, np.cos(0.7 * x + 0.2) * np.sin(3.0 * y - z) * c.mask,
+         np.sin(x + y) * np.cos(2.0 * z) * c.mask, np.zeros((c.nel,) + (c.lx1 - 2,) * 3)]
+    its, maps = {}, {}
+    for fdm in (0, 1, -1):
+        if fdm >= 0:
+            monkeypatch.setenv("NSK_HELM_FDM", str(fdm))
+        else:
+            monkeypatch.delenv("NSK_HELM_FDM")
+        h = _hip(c, max_helm_iter=400)
+        try:
+            out, it1 = h.t_op3(5, r, 3)
+            assert _rel(out, ref) < 1e-8, fdm
+            a, b = h.alloc(2)
+            h.upload3(a, *q)
+            h.set_nsteps(4)
+            h.matvec(b, a, 0)
+            maps[fdm] = h.download3(b)
+            st = h.stats()
+            assert st["unconverged"] == 0
+            its[fdm] = (it1, st["helm_iters"] / 4.0)
+        finally:
+            h.close()
+    print("lx1 %d: Helmholtz iterations (random rhs, per step of the map): Jacobi %s, element-block FDM %s" % (lx1, its[0], its[1]))
+    sc = max(np.abs(maps[0][k]).max() for k in range(3))
+    for k in range(3):
+        assert np.abs(maps[1][k] - maps[0][k]).max() < 1e-7 * sc
+    assert its[-1] == its[0] and all(np.array_equal(m0, m1) for m0, m1 in zip(maps[-1], maps[0]))      # default = Jacobi
