@@ -283,7 +283,7 @@ def main():
             return NekStabHip(cs, cs.meta["vert"], cs.meta["nvert"], tol_helm=1e-10, tol_pres=1e-2, tol_relative=1, max_helm_iter=150, max_pres_iter=96, nproj=a.nproj)
         # shards carry the parent's projection space (nsk_shard_create), so the sharded operator is the single-rank one
         hh = NekStabHip(cs, cs.meta["vert"], cs.meta["nvert"], tol_helm=a.tol_helm, tol_pres=a.tol_pres, tol_relative=1,
-                        schwarz_layers=2, max_helm_iter=100, max_pres_iter=48, nproj=a.nproj)
+                        schwarz_layers=2, max_helm_iter=100 if cs.lx1 <= 8 else 250, max_pres_iter=48 if cs.lx1 <= 8 else 144, nproj=a.nproj)
         if a.min_pres > 0:
             hh.set_option("min_pres_iter", a.min_pres)
         return hh

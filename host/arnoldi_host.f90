@@ -1,13 +1,18 @@
 ! Fortran host of the eigensolver on top of libnekstab_hip.so: the driver the reference's `krylov_schur` call site
 ! (core/usr_extra.f:193-213) becomes.  The algorithms live in host/krylov_host.f90, the bindings in host/nekstab_hip_mod.f90.
-! Usage:  arnoldi_host <case.bin> <k_dim> <outdir> [schur_tgt] [mode: d | a]
+! Usage:  arnoldi_host <case.bin> <k_dim> <outdir> [schur_tgt] [mode: d | a] [ifres: 0 | 1] [restart_from]
+!   ifres = 1: the reference's checkpoint after every Arnoldi step (KRY / HES / Spectre files, core/eigensolvers.f:802-905);
+!   restart_from = m > 0: continue from the checkpoint of step m in <outdir> (uparam(2), core/eigensolvers.f:284-325)
 ! case.bin is written by nekstab_amd/casefile.py: mesh arrays, base flow, seed vector and the inner-solver settings
 ! (nekstab_amd/settings.py: the production settings, not a copy of them in this file).
 program arnoldi_host
   use iso_c_binding
   use nekstab_hip
   use krylov_host
+  use nek_fld
   implicit none
+  type(host_geom) :: geom
+  integer :: ifres_i, restart_from
   character(len=512) :: casefile, outdir, arg
   character(len=1) :: evop
   integer :: k_dim, u, i, j, schur_tgt, schur_cnt, matvecs, ios
@@ -32,6 +37,13 @@ program arnoldi_host
     call get_command_argument(4, arg); read(arg, *) schur_tgt
   endif
   if (command_argument_count() >= 5) call get_command_argument(5, evop)
+  ifres_i = 0; restart_from = 0
+  if (command_argument_count() >= 6) then
+    call get_command_argument(6, arg); read(arg, *) ifres_i
+  endif
+  if (command_argument_count() >= 7) then
+    call get_command_argument(7, arg); read(arg, *) restart_from
+  endif
   mode = merge(NSK_ADJOINT, NSK_DIRECT, evop == 'a')
 
   open(newunit=u, file=trim(casefile), access='stream', form='unformatted', status='old')
@@ -53,7 +65,7 @@ program arnoldi_host
   cs%ub = c_loc(ub); cs%vb = c_loc(vb); cs%spng = c_loc(spng); cs%vert = c_loc(vert); cs%nvert = hdr(5)
   cs%re = rpar(1); cs%endtime = rpar(2); cs%cfl = rpar(3); cs%has_outflow = hdr(6)
   cs%tol_helm = sett(1); cs%tol_pres = sett(2); cs%tol_relative = 1
-  cs%schwarz_layers = 2; cs%max_helm_iter = int(sett(8)); cs%max_pres_iter = 48; cs%nproj = int(sett(4))
+  cs%schwarz_layers = 2; cs%max_helm_iter = int(sett(8)); cs%max_pres_iter = 144; cs%nproj = int(sett(4))      ! (restarted 48-vector GMRES cycles)
   call nsk_check(nsk_init(cs, ctx), 'nsk_init')
   call nsk_option(ctx, 'min_pres_iter', sett(3))
   call nsk_check(nsk_get_info(ctx, dt, nsteps, nstate, nvel, npres), 'nsk_get_info')
@@ -67,11 +79,21 @@ program arnoldi_host
   call nsk_check(nsk_vec_upload(ctx, Q(1), sx, sy, sp), 'nsk_vec_upload')       ! seed, :263-282
 
   call cpu_time(t0)
-  call krylov_schur(ctx, Q, H, vals, vecs, residual, k_dim, mode, schur_tgt, sett(5), sett(6), schur_cnt, matvecs)
+  if (hdr(1) == 2) call geom_init(geom, int(hdr(2)), int(hdr(3)), x, y, '1cyl')
+  if (hdr(1) == 2 .and. (ifres_i /= 0 .or. restart_from > 0)) then
+    call krylov_schur(ctx, Q, H, vals, vecs, residual, k_dim, mode, schur_tgt, sett(5), sett(6), schur_cnt, matvecs, &
+                      geom, trim(outdir), evop, rpar(2), int(nsteps), ifres_i /= 0, restart_from)
+  else
+    call krylov_schur(ctx, Q, H, vals, vecs, residual, k_dim, mode, schur_tgt, sett(5), sett(6), schur_cnt, matvecs)
+  endif
   call cpu_time(t1)
   write(*,'(a,i0,a,i0,a,f8.3,a)') ' Krylov-Schur: ', matvecs, ' matvecs, ', schur_cnt, ' restarts in ', t1 - t0, ' s (cpu time of the host thread)'
 
-  call outpost_ks(ctx, vals, vecs, Q, residual, k_dim, trim(outdir), evop, rpar(2), sett(5), int(sett(7)), nvel, npres)
+  if (hdr(1) == 2) then
+    call outpost_ks(ctx, vals, vecs, Q, residual, k_dim, trim(outdir), evop, rpar(2), sett(5), int(sett(7)), nvel, npres, geom, int(nsteps))
+  else
+    call outpost_ks(ctx, vals, vecs, Q, residual, k_dim, trim(outdir), evop, rpar(2), sett(5), int(sett(7)), nvel, npres)
+  endif
   open(newunit=u, file=trim(outdir)//'/ritz_full.txt', status='replace')
   do i = 1, k_dim
     write(u, '(3ES26.17)') real(vals(i)), aimag(vals(i)), residual(i)

@@ -12,20 +12,28 @@
 module krylov_host
   use iso_c_binding
   use nekstab_hip
+  use nek_fld
   implicit none
   private
   public :: arnoldi_factorization, krylov_schur, schur_condensation, schur_restart_dense, select_eigenvalues, eig, schur, ordschur, outpost_ks
 
 contains
 
-  ! ---- core/krylov_decomposition.f:73-102
-  subroutine arnoldi_factorization(ctx, Q, H, mstart, mend, ksize, mode)
+  ! ---- core/krylov_decomposition.f:73-102.  With `geom` + `outdir` present and ifres set, every step writes the reference's
+  ! checkpoint (core/krylov_decomposition.f:88 -> arnoldi_checkpoint, core/eigensolvers.f:802-905: nek_fld.f90)
+  subroutine arnoldi_factorization(ctx, Q, H, mstart, mend, ksize, mode, geom, outdir, evop, sampling_period, nsteps, ifres)
     type(c_ptr), intent(in) :: ctx
     integer, intent(in) :: mstart, mend, ksize
     type(c_ptr), intent(inout) :: Q(ksize + 1)
     real(c_double), intent(inout) :: H(ksize + 1, ksize)
     integer(c_int), intent(in) :: mode
+    type(host_geom), intent(in), optional :: geom
+    character(*), intent(in), optional :: outdir, evop
+    real(c_double), intent(in), optional :: sampling_period
+    integer, intent(in), optional :: nsteps
+    logical, intent(in), optional :: ifres
     real(c_double) :: hcol(ksize), beta
+    complex(c_double_complex), allocatable :: cvals(:), cvecs(:, :)
     integer :: mstep
     if (ksize == 0) then                                   ! :64-67
       write(*,*) 'Krylov base dimension == 0! Increase it.. STOP'; stop 1
@@ -35,6 +43,14 @@ contains
       call nsk_check(nsk_orth(ctx, Q(mstep + 1), Q, int(mstep, c_int), hcol, beta), 'nsk_orth')    ! :83 update_hessenberg_matrix
       H(1:mstep, mstep) = hcol(1:mstep)
       H(mstep + 1, mstep) = beta
+      if (present(ifres) .and. present(geom) .and. present(outdir)) then
+        if (ifres) then
+          allocate(cvals(mstep), cvecs(mstep, mstep))
+          call eig(H(1:mstep, 1:mstep), cvecs, cvals, mstep)
+          call arnoldi_checkpoint(ctx, geom, Q, H, mstep, ksize, outdir, evop, sampling_period, nsteps, cvals, cvecs)
+          deallocate(cvals, cvecs)
+        endif
+      endif
     enddo
   end subroutine
 
@@ -175,9 +191,18 @@ contains
 
   ! ---- krylov_schur                                  core/eigensolvers.f:141-388
   ! Q(1) holds the seed on entry (un-normalised); on return vals / vecs / residual describe H(1:k,1:k)
-  subroutine krylov_schur(ctx, Q, H, vals, vecs, residual, k_dim, mode, schur_tgt, eigen_tol, schur_del, schur_cnt, matvecs)
+  ! geom / outdir / ifres: checkpoint after every Arnoldi step; restart_from > 0: continue from the checkpoint of that step
+  ! (uparam(2) of the reference, core/eigensolvers.f:284-325) instead of starting from Q(1)
+  subroutine krylov_schur(ctx, Q, H, vals, vecs, residual, k_dim, mode, schur_tgt, eigen_tol, schur_del, schur_cnt, matvecs, &
+                          geom, outdir, evop, sampling_period, nsteps, ifres, restart_from)
     type(c_ptr), intent(in) :: ctx
     integer, intent(in) :: k_dim, schur_tgt
+    type(host_geom), intent(in), optional :: geom
+    character(*), intent(in), optional :: outdir, evop
+    real(c_double), intent(in), optional :: sampling_period
+    integer, intent(in), optional :: nsteps, restart_from
+    logical, intent(in), optional :: ifres
+    logical :: okr
     type(c_ptr), intent(inout) :: Q(k_dim + 1)
     real(c_double), intent(inout) :: H(k_dim + 1, k_dim)
     complex(c_double_complex), intent(out) :: vals(k_dim), vecs(k_dim, k_dim)
@@ -192,8 +217,22 @@ contains
     call nsk_check(nsk_norm(ctx, Q(1), alpha), 'nsk_norm')                       ! krylov_normalize, :271-278
     call nsk_check(nsk_scal(ctx, Q(1), 1.0d0 / alpha), 'nsk_scal')
     mstart = 1; schur_cnt = 0; matvecs = 0; converged = .false.
+    if (present(restart_from) .and. present(geom) .and. present(outdir)) then
+      if (restart_from > 0) then                                                 ! :284-325
+        call load_checkpoint(ctx, geom, Q, H, restart_from, k_dim, outdir, okr)
+        if (.not. okr) then
+          write(*,*) 'krylov_schur: no usable checkpoint of step ', restart_from, ' in ', trim(outdir); stop 1
+        endif
+        mstart = restart_from + 1
+        write(*,'(a,i0)') ' restarted from the checkpoint of Arnoldi step ', restart_from
+      endif
+    endif
     do while (.not. converged)                                                   ! :335-373
-      call arnoldi_factorization(ctx, Q, H, mstart, k_dim, k_dim, mode)          ! :337
+      if (present(ifres) .and. present(geom) .and. present(outdir)) then
+        call arnoldi_factorization(ctx, Q, H, mstart, k_dim, k_dim, mode, geom, outdir, evop, sampling_period, nsteps, ifres)
+      else
+        call arnoldi_factorization(ctx, Q, H, mstart, k_dim, k_dim, mode)        ! :337
+      endif
       matvecs = matvecs + k_dim - mstart + 1
       call eig(H(1:k_dim, 1:k_dim), vecs, vals, k_dim)                           ! :346
       residual = abs(H(k_dim + 1, k_dim) * vecs(k_dim, :))                       ! :349
@@ -216,8 +255,11 @@ contains
   ! ---- outpost_ks                                    core/eigensolvers.f:508-721
   ! spectra tables in the reference's formats; converged eigenmodes Q y_i (at most maxmodes), normalised so that
   ! |Re|^2 + |Im|^2 = 1 in the bm1s norm (:619-627), written as raw fp64 [vx | vy | pr] records next to the tables
-  subroutine outpost_ks(ctx, vals, vecs, Q, residual, k_dim, outdir, evop, sampling_period, eigen_tol, maxmodes, nvel, npres)
+  subroutine outpost_ks(ctx, vals, vecs, Q, residual, k_dim, outdir, evop, sampling_period, eigen_tol, maxmodes, nvel, npres, geom, nsteps)
     type(c_ptr), intent(in) :: ctx
+    type(host_geom), intent(in), optional :: geom          ! present: the modes also as Nek field files <op>Re<session>0.f0000i / <op>Im... (:625-642)
+    integer, intent(in), optional :: nsteps
+    character(len=256) :: fn
     integer, intent(in) :: k_dim, maxmodes
     complex(c_double_complex), intent(in) :: vals(k_dim), vecs(k_dim, k_dim)
     type(c_ptr), intent(in) :: Q(k_dim + 1)
@@ -257,6 +299,12 @@ contains
         call nsk_check(nsk_vec_download(ctx, w(2), vx, vy, pr), 'nsk_vec_download')
         open(newunit=um, file=trim(outdir)//'/'//trim(evop)//'Im'//trim(tag)//'.bin', access='stream', form='unformatted', status='replace')
         write(um) vx, vy, pr; close(um)
+        if (present(geom)) then                                                  ! outpost(vx, vy, vz, pr, t, nRe / nIm), :625-642
+          write(fn, '(a,a,a,a,a,a,i5.5)') trim(outdir), '/', trim(evop), 'Re', trim(geom%session), '0.f', outposted
+          call state_write(ctx, geom, w(1), trim(fn), dble(outposted), nsteps + 1)
+          write(fn, '(a,a,a,a,a,a,i5.5)') trim(outdir), '/', trim(evop), 'Im', trim(geom%session), '0.f', outposted
+          call state_write(ctx, geom, w(2), trim(fn), dble(outposted), nsteps + 1)
+        endif
       endif
     enddo
     close(u1); close(u2); close(u3)

@@ -15,7 +15,9 @@ k_dim = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 tgt = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 t0 = time.time()
 case = mesh.refine_case_2x2(mesh.load_case_npz(os.path.join(ROOT, "tests", "golden", "cylinder_case.npz"), 12))
-h = production_context(case)
+h = production_context(case, max_helm_iter=250, max_pres_iter=144)      # (lx1 = 12: the first time steps of a map can need more than the 100 iterations config 2 is capped at;
+                                                        #  and the tightened pressure solves of steps 1-3 more than one 48-vector GMRES cycle; with host-read convergence flags a
+                                                        #  high cap costs nothing, a cap that is hit costs a redone map: the '5 redone maps' of round 3 were cap hits)
 print("E %d lx1 %d: %d points per field, state %d, nsteps %d, set-up %.0f s" % (case.nel, case.lx1, h.nvel, h.nstate, h.nsteps, time.time() - t0), flush=True)
 qx, qy = seed.add_noise(case)
 v0, v1 = h.alloc(2)

@@ -158,3 +158,69 @@ def test_reference_arnoldi_loop_drives_the_library_through_the_seam(tmp_path):
     nrm = float([l for l in out.stdout.splitlines() if "|Q(1:3) y|" in l][0].split("=")[1])
     assert abs(nrm - h.norm(c)) < 1e-10
     h.close()
+
+
+def test_fortran_host_checkpoint_restart_and_nek_mode_files(tmp_path):
+    """Fortran-host parity with the Python host: host/nek_fld.f90 restates the reference's
+    `arnoldi_checkpoint` (KRY<session>0.f<k+1>, HES<session><k>, Spectre_H/NS<op><k>.dat: core/eigensolvers.f:802-905), the restart
+    from those files (:284-325) and `outpost` of the converged modes as Nek field files (:625-642), in the formats
+    nekstab_amd/checkpoint.py / nekio.py use.  An interrupted-and-restarted Fortran run reproduces the uninterrupted one, the
+    PYTHON host restarts from the Fortran host's files, and the written mode files are unit-norm eigenmodes."""
+    exe = os.path.join(ROOT, "host", "arnoldi_host")
+    if not os.path.exists(exe):
+        if shutil.which("flang") is None:
+            pytest.skip("flang not available and host/arnoldi_host not prebuilt")
+        subprocess.run(["make", "-C", os.path.join(ROOT, "host")], check=True)
+    from nekstab_amd import casefile, checkpoint, krylov, mesh, nekio, seed
+    from nekstab_amd.capi import NekStabHip
+    case = mesh.load_case_npz(os.path.join(GOLDEN, "cylinder_case.npz"), 6)
+    qx, qy = seed.add_noise(case)
+    pr = np.zeros((case.nel, 4, 4))
+    tight = dict(tol_helm=1e-13, tol_pres=1e-9, min_pres_iter=2, nproj=8, max_helm_iter=200)
+    cb = str(tmp_path / "case.bin")
+    casefile.write_case_bin(cb, case, (qx, qy, pr), settings=tight, eigen_tol=1.0, maxmodes=2)      # (eigen_tol 1: a 10-step run has "converged" modes to write)
+    k = 10
+    full, part = tmp_path / "full", tmp_path / "part"
+    full.mkdir(); part.mkdir()
+    out = subprocess.run([exe, cb, str(k), str(full), "0", "d", "1"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    for i in range(1, k + 2):
+        assert (full / ("KRY1cyl0.f%05d" % i)).exists()
+    for i in range(1, k + 1):
+        assert (full / ("HES1cyl%04d" % i)).exists() and (full / ("Spectre_Hd%04d.dat" % i)).exists() and (full / ("Spectre_NSd%04d.dat" % i)).exists()
+    Hf = np.array(open(str(full / "HES.txt")).read().split(), dtype=float)[: (k + 1) * k].reshape(k + 1, k)
+    Hc = np.array(open(str(full / ("HES1cyl%04d" % k))).read().split(), dtype=float).reshape(k + 1, k)
+    assert np.array_equal(Hf, Hc)
+    # interrupted after 5 steps (a 5-step run with checkpoints), then restarted to k = 10 in the same directory
+    out5 = subprocess.run([exe, cb, "5", str(part), "0", "d", "1"], capture_output=True, text=True, timeout=600)
+    assert out5.returncode == 0, out5.stdout[-2000:] + out5.stderr[-2000:]
+    outr = subprocess.run([exe, cb, str(k), str(part), "0", "d", "1", "5"], capture_output=True, text=True, timeout=600)
+    assert outr.returncode == 0 and "restarted from the checkpoint of Arnoldi step 5" in outr.stdout, outr.stdout[-2000:] + outr.stderr[-2000:]
+    Hr = np.array(open(str(part / "HES.txt")).read().split(), dtype=float)[: (k + 1) * k].reshape(k + 1, k)
+    err = np.abs(Hr - Hf).max() / np.abs(Hf).max()
+    print("Fortran run restarted at step 5 vs uninterrupted: max |dH| / max |H| = %.1e" % err)
+    assert err < 1e-8
+    # the Python host restarts from the Fortran host's files
+    h = NekStabHip(case, case.meta["vert"], case.meta["nvert"], tol_helm=tight["tol_helm"], tol_pres=tight["tol_pres"], tol_relative=1,
+                   schwarz_layers=2, max_helm_iter=200, max_pres_iter=144, nproj=8)
+    h.set_option("min_pres_iter", 2)
+    Q, H, m1 = checkpoint.load_checkpoint(h, case, str(full), k, 5, session="1cyl")
+    assert m1 == 6 and np.abs(H[:6, :5] - Hf[:6, :5]).max() == 0.0
+    krylov.arnoldi_factorization(h, Q, H, m1, k, 0)
+    errp = np.abs(H - Hf).max() / np.abs(Hf).max()
+    print("Python host restarted from the Fortran host's checkpoint: max |dH| / max |H| = %.1e" % errp)
+    assert errp < 1e-8
+    # Krylov vector files: what the Fortran host wrote for vector k+1 is the Python host's vector k+1 (same sequence)
+    f = nekio.read_fld(str(full / ("KRY1cyl0.f%05d" % (k + 1))))
+    assert f.wdsize == 8 and f.nx == 6 and f.nel == case.nel and f.istep == h.nsteps + 1
+    vx, vy, _ = h.download(Q[k])
+    sc = max(np.abs(vx).max(), np.abs(vy).max())
+    assert max(np.abs(f.u[0][:, 0] - vx).max(), np.abs(f.u[1][:, 0] - vy).max()) < 1e-7 * sc
+    assert np.abs(f.x[0][:, 0] - case.x).max() == 0.0
+    # mode files in Nek format: |Re|^2 + |Im|^2 = 1 in the bm1s norm (core/eigensolvers.f:619-622)
+    re, im = nekio.read_fld(str(full / "dRe1cyl0.f00001")), nekio.read_fld(str(full / "dIm1cyl0.f00001"))
+    a, b = h.alloc(2)
+    checkpoint.fields_to_state(h, case, a, re)
+    checkpoint.fields_to_state(h, case, b, im)
+    assert abs(h.dot(a, a) + h.dot(b, b) - 1.0) < 1e-12
+    h.close()
