@@ -132,7 +132,8 @@ int nsk_matvec(nsk_ctx* ctx, int mode, nsk_vec f, nsk_vec q);
 int nsk_nonlinear_map(nsk_ctx* ctx, nsk_vec f, nsk_vec q, int subtract_q);
 int nsk_set_baseflow(nsk_ctx* ctx, nsk_vec q);
 /* Floquet (uparam(1)=3.11): time-periodic base flow over one period T = endtime, stored per step on the
- * device; `end` (optional) receives Phi_T(q0) for a periodicity check. */
+ * device (quadrilaterals: six arrays per step; hexahedra: the twelve dealiasing-mesh constants per step, 12 * nel * lxd^3 doubles);
+ * `end` (optional) receives Phi_T(q0) for a periodicity check. */
 int nsk_set_orbit(nsk_ctx* ctx, nsk_vec q0, double spng_str, nsk_vec end);
 
 /* krylov_inner_product / norm / cmult / add2,sub2 / copy / zero

@@ -1463,50 +1463,57 @@ int nsk_group_set_baseflow(nsk_ctx** shards, int n, nsk_vec* q) {
 int nsk_group_set_orbit(nsk_ctx** shards, int n, nsk_vec* q0, double spng_str, nsk_vec* end) {
   if (!shards || n < 1 || !q0) return fail(NSK_EINVAL, "bad argument");
   std::vector<nsk_ctx*> G(shards, shards + n);
-  for (int r = 0; r < n; ++r) {
+  for (int r = 0; r < n; ++r)
     if (!G[r] || !q0[r] || !G[r]->parent) return fail(NSK_EINVAL, "needs shard contexts");
-    if (G[r]->ndim != 2) return fail(NSK_EINVAL, "time-periodic base flows: 2-D only in this build");
-  }
-  int rc;
-  for (nsk_ctx* c : G) {
+  const int nd = G[0]->ndim;
+  // quadrilaterals: six arrays of nel*lxd^2 per step; hexahedra: one array of 12*nel*lxd^3 per step behind Dev::bfc (= cUr)
+  const int narr = nd == 3 ? 1 : 6;
+  auto steady_back = [&](nsk_ctx* c) {
     Dev& d = c->d;
-    if (d.bf_stride) {                                            // back to the steady arrays first
-      d.cUr = c->steady[0]; d.cUs = c->steady[1]; d.GUx = c->steady[2]; d.GUy = c->steady[3]; d.GVx = c->steady[4]; d.GVy = c->steady[5];
-      d.bf_stride = 0;
-    }
-  }
+    if (!d.bf_stride) return;
+    if (nd == 3) { d.bfc = c->steady[0]; d.cUr = c->steady[0]; }
+    else { d.cUr = c->steady[0]; d.cUs = c->steady[1]; d.GUx = c->steady[2]; d.GUy = c->steady[3]; d.GVx = c->steady[4]; d.GVy = c->steady[5]; }
+    d.bf_stride = 0;
+  };
+  int rc;
+  for (nsk_ctx* c : G) steady_back(c);
   if ((rc = group_set_baseflow(G, (const double* const*)q0))) return rc;
   for (size_t r = 0; r < G.size(); ++r) {
     nsk_ctx* c = G[r]; Dev& d = c->d;
-    const long long nfine = (long long)c->nel * c->NDD;
-    for (int k = 0; k < 6; ++k) {
+    const long long per_step = nd == 3 ? 12 * d.nfine : (long long)c->nel * c->NDD;
+    for (int k = 0; k < narr; ++k) {
       if (c->orbit[k]) { nsk_vec v = c->orbit[k]; nsk_vec_free(c, 1, &v); c->orbit[k] = nullptr; }
-      if ((rc = dalloc(c, &c->orbit[k], (size_t)c->nsteps * nfine))) return rc;
+      if ((rc = dalloc(c, &c->orbit[k], (size_t)c->nsteps * per_step))) return rc;
     }
     double* vr = const_cast<double*>(d.spng_vr);
-    if (!vr && (rc = dalloc(c, &vr, 2 * d.cs))) return rc;
+    if (!vr && (rc = dalloc(c, &vr, nd * d.cs))) return rc;
     const double* q = (const double*)q0[r];
-    HIPCHK(hipMemcpyAsync(vr, q, d.nloc * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(vr + d.cs, q + d.nloc, d.nloc * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    for (int cc = 0; cc < nd; ++cc) HIPCHK(hipMemcpyAsync(vr + cc * d.cs, q + cc * d.nloc, d.nloc * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     d.spng_vr = vr; d.nl_spng_str = spng_str;
     if (!d.bstep && (rc = dalloc(c, &d.bstep, 4))) return rc;
     HIPCHK(hipMemsetAsync(d.stats, 0, sizeof(Stats), c->stream));
-    HIPCHK(hipMemcpyAsync(d.u, q, d.nloc * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(d.u + d.cs, q + d.nloc, d.nloc * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(d.p, q + 2 * d.nloc, d.npr * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    for (int cc = 0; cc < nd; ++cc) HIPCHK(hipMemcpyAsync(d.u + cc * d.cs, q + cc * d.nloc, d.nloc * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(d.p, q + nd * d.nloc, d.npr * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
   }
   const int nsteps = G[0]->nsteps;
   for (int istep = 1; istep <= nsteps; ++istep) {
     for (nsk_ctx* c : G) {
       Dev& d = c->d;
-      const long long off = (long long)(istep - 1) * c->nel * c->NDD;
+      const long long off = (long long)(istep - 1) * (nd == 3 ? 12 * d.nfine : (long long)c->nel * c->NDD);
       // k_baseflow reads a state vector (component stride nloc); the stepper's field has stride cs = nloc + ghost slots
-      for (int cc = 0; cc < 2; ++cc)
+      for (int cc = 0; cc < nd; ++cc)
         HIPCHK(hipMemcpyAsync(c->scratch + cc * d.nloc, d.u + cc * d.cs, d.nloc * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-      DISPATCH_N(c->key, {
-        hipLaunchKernelGGL(k_baseflow<N>, dim3(c->nel), dim3(Cfg<N>::NTD), 0, c->stream, d, (const double*)c->scratch, c->orbit[0] + off, c->orbit[1] + off,
-                           c->orbit[2] + off, c->orbit[3] + off, c->orbit[4] + off, c->orbit[5] + off);
-      });
+      if (nd == 3) {
+        DISPATCH_N(c->key, {
+          hipLaunchKernelGGL(k_baseflow<N>, dim3(c->nel), dim3(Cfg<N>::NTD), 0, c->stream, d, (const double*)c->scratch, c->orbit[0] + off,
+                             (double*)nullptr, (double*)nullptr, (double*)nullptr, (double*)nullptr, (double*)nullptr);
+        });
+      } else {
+        DISPATCH_N(c->key, {
+          hipLaunchKernelGGL(k_baseflow<N>, dim3(c->nel), dim3(Cfg<N>::NTD), 0, c->stream, d, (const double*)c->scratch, c->orbit[0] + off, c->orbit[1] + off,
+                             c->orbit[2] + off, c->orbit[3] + off, c->orbit[4] + off, c->orbit[5] + off);
+        });
+      }
     }
     if ((rc = group_step(G, istep, 2))) return rc;
   }
@@ -1516,18 +1523,24 @@ int nsk_group_set_orbit(nsk_ctx** shards, int n, nsk_vec* q0, double spng_str, n
     nsk_ctx* c = G[r]; Dev& d = c->d;
     if (end && end[r]) {
       double* f = (double*)end[r];
-      HIPCHK(hipMemcpyAsync(f, d.u, d.nloc * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-      HIPCHK(hipMemcpyAsync(f + d.nloc, d.u + d.cs, d.nloc * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-      HIPCHK(hipMemcpyAsync(f + 2 * d.nloc, d.p, d.npr * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+      for (int cc = 0; cc < nd; ++cc) HIPCHK(hipMemcpyAsync(f + cc * d.nloc, d.u + cc * d.cs, d.nloc * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+      HIPCHK(hipMemcpyAsync(f + nd * d.nloc, d.p, d.npr * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     }
   }
-  HIPCHK(hipStreamSynchronize(G[0]->stream));
+  for (nsk_ctx* c : G) HIPCHK(hipStreamSynchronize(c->stream));
   if (h.unconverged > 0) return fail(NSK_ENOCONV, "inner solve hit its iteration cap while integrating the base-flow orbit (sharded)");
   for (nsk_ctx* c : G) {
     Dev& d = c->d;
-    c->steady[0] = d.cUr; c->steady[1] = d.cUs; c->steady[2] = d.GUx; c->steady[3] = d.GUy; c->steady[4] = d.GVx; c->steady[5] = d.GVy;
-    d.cUr = c->orbit[0]; d.cUs = c->orbit[1]; d.GUx = c->orbit[2]; d.GUy = c->orbit[3]; d.GVx = c->orbit[4]; d.GVy = c->orbit[5];
-    d.bf_stride = (long long)c->nel * c->NDD; c->orbit_steps = c->nsteps;
+    if (nd == 3) {
+      c->steady[0] = d.bfc;
+      d.bfc = c->orbit[0]; d.cUr = c->orbit[0];
+      d.bf_stride = 12 * d.nfine;
+    } else {
+      c->steady[0] = d.cUr; c->steady[1] = d.cUs; c->steady[2] = d.GUx; c->steady[3] = d.GUy; c->steady[4] = d.GVx; c->steady[5] = d.GVy;
+      d.cUr = c->orbit[0]; d.cUs = c->orbit[1]; d.GUx = c->orbit[2]; d.GUy = c->orbit[3]; d.GVx = c->orbit[4]; d.GVy = c->orbit[5];
+      d.bf_stride = (long long)c->nel * c->NDD;
+    }
+    c->orbit_steps = c->nsteps;
     for (auto& a : c->graphs) for (auto& g : a) g.nh = -1;
   }
   return 0;
@@ -2048,9 +2061,49 @@ int nsk_set_orbit(nsk_ctx* c, nsk_vec q0v, double spng_str, nsk_vec end) {
   if (!c || !q0v) return fail(NSK_EINVAL, "bad argument");
   if (c->parent) return fail(NSK_EINVAL, "shards: use nsk_group_set_orbit");
   if (c->clone_of) return fail(NSK_EINVAL, "not on a lane (nsk_clone)");
-  if (c->ndim != 2) return fail(NSK_EINVAL, "time-periodic base flows: 2-D only in this build");
   Dev& d = c->d;
   const double* q0 = (const double*)q0v;
+  if (c->ndim == 3) {
+    // hexahedra: the twelve dealiasing-mesh constants of every time step of the orbit, [nsteps][12][nfine] behind Dev::bfc
+    if (d.bf_stride) { d.bfc = c->steady[0]; d.cUr = c->steady[0]; d.bf_stride = 0; }
+    int rc = nsk_set_baseflow(c, q0v);                          // dt, nsteps from the CFL of the initial field
+    if (rc) return rc;
+    const long long nfine = d.nfine;
+    if (c->orbit[0]) { nsk_vec v = c->orbit[0]; nsk_vec_free(c, 1, &v); c->orbit[0] = nullptr; }
+    if ((rc = dalloc(c, &c->orbit[0], (size_t)c->nsteps * 12 * nfine))) return rc;
+    double* vr = const_cast<double*>(d.spng_vr);
+    if (!vr && (rc = dalloc(c, &vr, 3 * d.cs))) return rc;
+    for (int cc = 0; cc < 3; ++cc) HIPCHK(hipMemcpyAsync(vr + cc * d.cs, q0 + cc * d.nloc, d.nloc * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    d.spng_vr = vr; d.nl_spng_str = spng_str;
+    if (!d.bstep && (rc = dalloc(c, &d.bstep, 4))) return rc;
+    for (auto& a : c->graphs) for (auto& g : a) g.nh = -1;
+    for (int k = 0; k < NCLS; ++k) { c->cur_helm[k] = c->max_helm; c->cur_pres[k] = c->max_pres; }
+    c->bh_n = 0;
+    HIPCHK(hipMemsetAsync(d.stats, 0, sizeof(Stats), c->stream));
+    for (int cc = 0; cc < 3; ++cc) HIPCHK(hipMemcpyAsync(d.u + cc * d.cs, q0 + cc * d.nloc, d.nloc * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(d.p, q0 + 3 * d.nloc, d.npr * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    for (int istep = 1; istep <= c->nsteps; ++istep) {
+      DISPATCH_N(c->key, {
+        hipLaunchKernelGGL(k_baseflow<N>, dim3(c->nel), dim3(Cfg<N>::NTD), 0, c->stream, d, (const double*)d.u, c->orbit[0] + (size_t)(istep - 1) * 12 * nfine,
+                           (double*)nullptr, (double*)nullptr, (double*)nullptr, (double*)nullptr, (double*)nullptr);
+      });
+      if ((rc = step(c, istep, 2))) return rc;
+    }
+    Stats h;
+    HIPCHK(hipMemcpyAsync(&h, d.stats, sizeof(Stats), hipMemcpyDeviceToHost, c->stream));
+    if (end) {
+      double* f = (double*)end;
+      for (int cc = 0; cc < 3; ++cc) HIPCHK(hipMemcpyAsync(f + cc * d.nloc, d.u + cc * d.cs, d.nloc * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+      HIPCHK(hipMemcpyAsync(f + 3 * d.nloc, d.p, d.npr * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (h.unconverged > 0) return fail(NSK_ENOCONV, "inner solve hit its iteration cap while integrating the base-flow orbit");
+    c->steady[0] = d.bfc;
+    d.bfc = c->orbit[0]; d.cUr = c->orbit[0];
+    d.bf_stride = 12 * nfine; c->orbit_steps = c->nsteps;
+    for (auto& a : c->graphs) for (auto& g : a) g.nh = -1;
+    return 0;
+  }
   if (d.bf_stride) {                                            // back to the steady arrays first
     d.cUr = c->steady[0]; d.cUs = c->steady[1]; d.GUx = c->steady[2]; d.GUy = c->steady[3]; d.GVx = c->steady[4]; d.GVy = c->steady[5];
     d.bf_stride = 0;

@@ -334,6 +334,8 @@ __device__ inline void fine_grad(const double* sDd, const double* f, int a, int 
 // to the 60 KB of tiles, one workgroup per CU either way -- and walks a lane's points one at a time: no scratch.
 template <int N>
 __device__ inline void convect_lds(const Dev& d, const double* __restrict__ uin, double* __restrict__ bf, int adjoint) {
+  // base-flow constants: the steady set, or slot `*bstep` of the stored periodic orbit (Floquet, core/matvec.f:200-236)
+  const double* __restrict__ bfc = d.bfc + (d.bf_stride ? (size_t)(*d.bstep) * (size_t)d.bf_stride : (size_t)0);
   using C = Cfg<N>;
   constexpr int NN = C::NN, ND = C::ND, NDD = C::NDD, NT = C::NT;
   __shared__ double sJ[ND * N], sDd[ND * ND];
@@ -386,12 +388,12 @@ __device__ inline void convect_lds(const Dev& d, const double* __restrict__ uin,
       fine_grad<N>(sDd, sf, a, b, cc, g);
       const double uf = sf[p];
       const size_t q = (size_t)e * NDD + p;
-      const double conv = d.bfc[0 * nf + q] * g[0] + d.bfc[1 * nf + q] * g[1] + d.bfc[2 * nf + q] * g[2];   // (U.grad) u'_c
+      const double conv = bfc[0 * nf + q] * g[0] + bfc[1 * nf + q] * g[1] + bfc[2 * nf + q] * g[2];   // (U.grad) u'_c
       so[c * NDD + p] += adjoint ? -conv : conv;
 #pragma unroll
       for (int x = 0; x < 3; ++x) {
         // direct:  + u'_c dU_x/dx_c   (u'.grad) U ;   adjoint:  + u'_c dU_c/dx_x   (grad U)^T u'
-        const double G = adjoint ? d.bfc[(3 + 3 * c + x) * nf + q] : d.bfc[(3 + 3 * x + c) * nf + q];
+        const double G = adjoint ? bfc[(3 + 3 * c + x) * nf + q] : bfc[(3 + 3 * x + c) * nf + q];
         so[x * NDD + p] += uf * G;
       }
     }
@@ -407,6 +409,8 @@ __device__ inline void convect_lds(const Dev& d, const double* __restrict__ uin,
 template <int N>
 __global__ __launch_bounds__(Cfg<N>::NT) void k_convect(Dev d, const double* __restrict__ uin,
                                                         double* __restrict__ bf, int adjoint) {
+  // base-flow constants: the steady set, or slot `*bstep` of the stored periodic orbit (Floquet, core/matvec.f:200-236)
+  const double* __restrict__ bfc = d.bfc + (d.bf_stride ? (size_t)(*d.bstep) * (size_t)d.bf_stride : (size_t)0);
   if constexpr (N >= 10) { convect_lds<N>(d, uin, bf, adjoint); return; }
   using C = Cfg<N>;
   constexpr int NN = C::NN, ND = C::ND, NDD = C::NDD, NT = C::NT;
@@ -456,13 +460,13 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_convect(Dev d, const double* __r
           const double v = ca[r][0] * g[0] + ca[r][1] * g[1] + ca[r][2] * g[2];
           if (c == 0) o[r][0] = v; else if (c == 1) o[r][1] = v; else o[r][2] = v;
         } else {
-          const double conv = d.bfc[0 * nf + q] * g[0] + d.bfc[1 * nf + q] * g[1] + d.bfc[2 * nf + q] * g[2];   // (U.grad) u'_c
+          const double conv = bfc[0 * nf + q] * g[0] + bfc[1 * nf + q] * g[1] + bfc[2 * nf + q] * g[2];   // (U.grad) u'_c
           const double sg = adjoint ? -conv : conv;
           if (c == 0) o[r][0] += sg; else if (c == 1) o[r][1] += sg; else o[r][2] += sg;
 #pragma unroll
           for (int x = 0; x < 3; ++x) {
             // direct:  + u'_c dU_x/dx_c   (u'.grad) U ;   adjoint:  + u'_c dU_c/dx_x   (grad U)^T u'
-            const double G = adjoint ? d.bfc[(3 + 3 * c + x) * nf + q] : d.bfc[(3 + 3 * x + c) * nf + q];
+            const double G = adjoint ? bfc[(3 + 3 * c + x) * nf + q] : bfc[(3 + 3 * x + c) * nf + q];
             o[r][x] += uf * G;
           }
         }
@@ -546,6 +550,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_rhs(Dev d, StepCoef sc) {
   double* sP = reg; double* sC = reg + 3 * MM; double* sE = sC + 3 * NMM;
   double* su = reg; double* st = reg + NN;
   const int tid = threadIdx.x;
+  if (d.bf_stride && sc.adjoint != 2 && blockIdx.x == 0 && tid == 0) *d.bstep += 1;     // next step reads the next orbit slot (as the 2-D k_rhs)
   const long long e = blockIdx.x;
   const bool act = tid < NN;
   const int k = tid / (N * N), j = (tid / N) % N, i = tid % N;

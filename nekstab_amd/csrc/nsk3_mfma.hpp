@@ -46,6 +46,7 @@ template <int CS, int MS> struct OutLin : ColLin<CS, MS> { static __device__ inl
 template <int DIV, int HI, int MS> struct OutSplit : ColSplit<DIV, HI, MS> { static __device__ inline constexpr int ms_() { return MS; } };
 
 __global__ __launch_bounds__(512) void k_convect_mfma8(Dev d, const double* __restrict__ uin, double* __restrict__ bf, int adjoint) {
+  const double* __restrict__ bfc = d.bfc + (d.bf_stride ? (size_t)(*d.bstep) * (size_t)d.bf_stride : (size_t)0);      // steady set or orbit slot
   constexpr int N = 8, ND = 12, NN = 512, NDD = 1728, NT = 512, PPT = 4, NW = 8;
   __shared__ double su[NN], t1[N * N * ND], t2[N * ND * ND], sf[NDD], gr[NDD], gs[NDD], gt[NDD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -86,12 +87,12 @@ __global__ __launch_bounds__(512) void k_convect_mfma8(Dev d, const double* __re
       if (p < NDD) {
         const double g0 = gr[p], g1 = gs[p], g2 = gt[p], uf = sf[p];
         const size_t q = (size_t)e * NDD + p;
-        const double conv = d.bfc[0 * nf + q] * g0 + d.bfc[1 * nf + q] * g1 + d.bfc[2 * nf + q] * g2;   // (U.grad) u'_c
+        const double conv = bfc[0 * nf + q] * g0 + bfc[1 * nf + q] * g1 + bfc[2 * nf + q] * g2;   // (U.grad) u'_c
         const double sg = adjoint ? -conv : conv;
         if (c == 0) o[r][0] += sg; else if (c == 1) o[r][1] += sg; else o[r][2] += sg;
 #pragma unroll
         for (int x = 0; x < 3; ++x) {
-          const double G = adjoint ? d.bfc[(3 + 3 * c + x) * nf + q] : d.bfc[(3 + 3 * x + c) * nf + q];
+          const double G = adjoint ? bfc[(3 + 3 * c + x) * nf + q] : bfc[(3 + 3 * x + c) * nf + q];
           o[r][x] += uf * G;
         }
       }

@@ -78,3 +78,60 @@ def test_adjoint_floquet_lx1_8():
     print("reference", ref, "ours", res.vals[j], "residual", res.residual[j])
     assert abs(res.vals[j] - ref) < 2e-5
     h.close()
+
+
+@pytest.mark.parametrize("lx1", [6, 8])
+def test_time_periodic_base_flow_on_hexahedra_equals_the_quadrilateral_path(lx1):
+    """Time-periodic base flows on hexahedra (core/matvec.f:191-236; missing until round 4): `nsk_set_orbit` on a hexahedral context
+    integrates the full equations from the given state and stores the twelve dealiasing-mesh base-flow constants of every time
+    step; direct and adjoint maps then read slot `istep`.  Pinned through the 2-D path (itself pinned on the reference's Floquet
+    multipliers above): on the cylinder mesh extruded over two periodic layers, with the z-invariant vortex-shedding state as the
+    initial base flow and a z-invariant perturbation, the hexahedral orbit and maps reproduce the quadrilateral ones plane by
+    plane -- over a 40-step stretch of the orbit, which exercises every slot.  lx1 = 6 runs the LDS convection kernels, lx1 = 8 the
+    matrix-core one (the shedding state interpolated to the finer points: both paths start from the same field)."""
+    from nekstab_amd import mesh, mesh3d, seed
+    from nekstab_amd.capi import NekStabHip
+    from nekstab_amd.quadrature import gauss_legendre, gauss_lobatto_legendre, interp_matrix
+    z = np.load(os.path.join(GOLDEN, "cylinder_upo.npz"))
+    kw = dict(tol_helm=1e-12, tol_pres=1e-7, tol_relative=1, nproj=0, max_helm_iter=400, max_pres_iter=192)
+    c2 = mesh.load_case_npz(os.path.join(GOLDEN, "cylinder_case.npz"), lx1, endtime=0.4)
+    Ju = interp_matrix(gauss_lobatto_legendre(6)[0], gauss_lobatto_legendre(lx1)[0])
+    uo = np.stack([Ju @ z["u"][k] @ Ju.T for k in range(2)]) if lx1 != 6 else z["u"]
+    c2.ub[:] = uo
+    nz = 2
+    c3 = mesh3d.extrude_case(c2, nz, 0.5, periodic=True)
+    J = interp_matrix(gauss_lobatto_legendre(6)[0], gauss_legendre(lx1 - 2)[0])
+    p2 = J @ z["p"] @ J.T
+    h2 = NekStabHip(c2, c2.meta["vert"], c2.meta["nvert"], **kw)
+    h3 = NekStabHip(c3, c3.meta["vert"], c3.meta["nvert"], **kw)
+    try:
+        a2, e2 = h2.alloc(2)
+        h2.upload(a2, uo[0], uo[1], p2)
+        h2.set_orbit(a2, spng_str=1.7, end=e2)
+        a3, e3 = h3.alloc(2)
+        h3.upload3(a3, mesh3d.extrude_field(uo[0], nz), mesh3d.extrude_field(uo[1], nz), np.zeros(c3.x.shape),
+                   mesh3d.extrude_pressure(p2, nz))
+        h3.set_orbit(a3, spng_str=1.7, end=e3)
+        assert h3.nsteps == h2.nsteps and abs(h3.dt - h2.dt) < 1e-15 and h2.nsteps >= 30
+        u2 = h2.download(e2); u3 = h3.download3(e3)
+        sc = max(np.abs(u2[0]).max(), np.abs(u2[1]).max())
+        for k in range(2):
+            assert np.abs(u3[k] - mesh3d.extrude_field(u2[k], nz)).max() < 1e-8 * sc          # the orbit itself
+        assert np.abs(u3[2]).max() < 1e-8 * sc
+        qx, qy = seed.add_noise(c2)
+        for mode in (0, 1):
+            v2, f2 = h2.alloc(2); v3, f3 = h3.alloc(2)
+            h2.upload(v2, qx, qy, np.zeros(h2.npres))
+            h3.upload3(v3, mesh3d.extrude_field(qx, nz), mesh3d.extrude_field(qy, nz), np.zeros(c3.x.shape), np.zeros(h3.npres))
+            h2.matvec(f2, v2, mode); h3.matvec(f3, v3, mode)
+            r2 = h2.download(f2); r3 = h3.download3(f3)
+            sc = max(np.abs(r2[0]).max(), np.abs(r2[1]).max())
+            err = max(np.abs(r3[k] - mesh3d.extrude_field(r2[k], nz)).max() for k in range(2)) / sc
+            print("mode", mode, "hexahedral vs quadrilateral map over the stored orbit:", err)
+            assert err < 1e-6 and np.abs(r3[2]).max() < 1e-7 * sc
+        # a map longer than the stored orbit is refused, as in 2-D
+        h3.set_nsteps(h3.nsteps + 5)
+        with pytest.raises(Exception):
+            h3.matvec(f3, v3, 0)
+    finally:
+        h2.close(); h3.close()

@@ -184,6 +184,58 @@ def test_time_periodic_base_flow_on_shards(case6):
         h.close()
 
 
+def test_time_periodic_base_flow_on_hexahedral_shards():
+    """The same on hexahedra (round 4: `nsk_set_orbit` / `nsk_group_set_orbit` store the twelve dealiasing-mesh constants per step):
+    extruded cylinder, the shedding state as the initial base flow, 2 and 3 shards against the single rank -- orbit end state, then a
+    direct and an adjoint map over the stored orbit."""
+    from nekstab_amd import mesh, mesh3d, seed
+    from nekstab_amd.capi import NekStabHip
+    from nekstab_amd.quadrature import gauss_legendre, gauss_lobatto_legendre, interp_matrix
+    from nekstab_amd.sharded import ShardGroup
+    z = np.load(os.path.join(GOLDEN, "cylinder_upo.npz"))
+    c2 = mesh.load_case_npz(os.path.join(GOLDEN, "cylinder_case.npz"), 6, endtime=0.15)
+    c2.ub[:] = z["u"]
+    c3 = mesh3d.extrude_case(c2, 2, 1.0, periodic=True)
+    h = NekStabHip(c3, c3.meta["vert"], c3.meta["nvert"], tol_helm=1e-12, tol_pres=1e-7, tol_relative=1, nproj=0,
+                   max_helm_iter=400, max_pres_iter=192)
+    try:
+        J = interp_matrix(gauss_lobatto_legendre(6)[0], gauss_legendre(4)[0])
+        q0 = (mesh3d.extrude_field(z["u"][0], 2), mesh3d.extrude_field(z["u"][1], 2), np.zeros(c3.x.shape), mesh3d.extrude_pressure(J @ z["p"] @ J.T, 2))
+        a0, ae, vq, vf = h.alloc(4)
+        h.upload3(a0, *q0)
+        h.set_orbit(a0, spng_str=1.7, end=ae)
+        ref_end = h.download3(ae)
+        qx, qy = seed.add_noise(c2)
+        q = (mesh3d.extrude_field(qx, 2) * np.cos(2 * np.pi * c3.z), mesh3d.extrude_field(qy, 2), mesh3d.extrude_field(qx, 2) * np.sin(2 * np.pi * c3.z) * c3.mask,
+             np.zeros(h.npres))
+        h.upload3(vq, *q)
+        refs = []
+        for mode in (0, 1):
+            h.matvec(vf, vq, mode); refs.append(h.download3(vf))
+        for nranks in (2, 3):
+            g = ShardGroup(h, c3, nranks)
+            b0, be, sq, sf = g.alloc(4)
+            g.upload3(b0, *q0)
+            g.set_orbit(b0, spng_str=1.7, end=be)
+            assert g.nsteps == h.nsteps
+            got = g.download3(be)
+            sc = max(np.abs(ref_end[k]).max() for k in range(2))
+            err = max(np.abs(got[k] - ref_end[k]).max() for k in range(3)) / sc
+            print("hexahedral orbit end state,", nranks, "shards: max diff", err)
+            assert err < 1e-8
+            g.upload3(sq, *q)
+            for mode in (0, 1):
+                g.matvec(sf, sq, mode)
+                got = g.download3(sf)
+                sc = max(np.abs(refs[mode][k]).max() for k in range(3))
+                err = max(np.abs(got[k] - refs[mode][k]).max() for k in range(3)) / sc
+                print("mode", mode, "map over the stored orbit,", nranks, "hexahedral shards: max diff", err)
+                assert err < 1e-6
+            g.free([b0, be, sq, sf]); g.close()
+    finally:
+        h.close()
+
+
 def test_backstep_adjoint_hexahedra_chebyshev_coarse_on_shards(monkeypatch):
     """BASELINE config 4's case in small: backward-facing step extruded in z, ADJOINT map (all-Dirichlet: singular pressure),
     hexahedral kernels, sparse coarse operator with the Chebyshev polynomial forced (what 5e4 vertices need), 2 and 3 shards."""
