@@ -84,6 +84,8 @@ struct nsk_ctx {
   int helm_guess = 1;
   int budget_freeze = 0;
   int helm_fdm = -1;                    // hexahedra: element-block fast-diagonalisation preconditioner of the velocity solves (NSK_HELM_FDM=1 builds it; measured slower than Jacobi-CG, off)
+  int eapply_pipe = 2;                  // hexahedra, the E-apply kernels: 0 = one workgroup per element, 1 = resident workgroups with the next element's loads in flight (k_schwarz_p), 2 = one wavefront per element (k_schwarz_w)
+  int eapply_grid[2] = {0, 0};          // their grid sizes (workgroups that fit the device at once; 0 = not yet asked)
   int flat_proj = -1;                   // hexahedra: once-per-step sums over the GMRES / projection bases as streaming kernels (k_pres_comb, k_proj_dots); -1 = yes on single-rank contexts
   int gs_lag = -1;                      // hexahedra: lagged second Gram-Schmidt correction (k_gs_lag: two basis reads per GMRES column instead of four); -1 = yes on single-rank contexts
   int gs2_from = MAXMR;                 // quadrilaterals: GMRES columns from this iteration (of a cycle) on get a second Gram-Schmidt pass (default: never)
@@ -870,6 +872,54 @@ static bool gs_lag_on(const nsk_ctx* c) {
   if (c->gs_lag >= 0) return c->gs_lag != 0;
   return c->d.nranks <= 1 && !c->parent;
 }
+// E-apply kernels of the hexahedral pressure iteration as resident workgroups (nsk3_kernels.hpp: k_schwarz_p): as many
+// workgroups as the device holds at once, a multiple of 8 so that a workgroup's stride stays inside its XCD's run of elements.
+template <int N>
+static unsigned eapply_grid(nsk_ctx* c, int which, int count) {
+  if constexpr (N <= 10) {
+    if (!c->eapply_grid[which]) {
+      int per_cu = 0, ncu = 0, dev = 0;
+      (void)hipGetDevice(&dev);
+      (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+      if (which == 0) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, nsk::k3::k_schwarz_p<N>, nsk::k3::Cfg<N>::NT, 0);
+      if (const char* g = std::getenv("NSK_EAPPLY_WGS")) per_cu = std::atoi(g);
+      c->eapply_grid[which] = std::max(8, (std::max(1, per_cu) * std::max(1, ncu)) / 8 * 8);
+    }
+  }
+  return (unsigned)std::min(count, c->eapply_grid[which]);
+}
+template <int N>
+static void launch_schwarz3(nsk_ctx* c, const Dev& d, int count, const double* vin, double* zout, int use_coarse, int check_done, int mode = -1) {
+  if constexpr (N <= 10) {
+    if (mode < 0) mode = c->eapply_pipe;
+    if (mode == 3) mode = 2;                             // (3 = 2 + the divergence kernel in wavefront form: launch_divgs3)
+    if (mode == 2 && N > 8 && !std::getenv("NSK_WAVE_LX10")) mode = 0;      // lx1 = 10: 16 nodes per lane, 234 registers: not measured faster
+    if (mode == 2)            // one wavefront per element
+      hipLaunchKernelGGL(nsk::k3::k_schwarz_w<N>, dim3(count), dim3(64), 0, c->stream, d, vin, zout, use_coarse, check_done);
+    else if (mode == 1)       // resident workgroups, next element's loads in flight
+      hipLaunchKernelGGL(nsk::k3::k_schwarz_p<N>, dim3(eapply_grid<N>(c, 0, count)), dim3(nsk::k3::Cfg<N>::NT), 0, c->stream, d, vin, zout,
+                         use_coarse, check_done, count);
+    else
+      hipLaunchKernelGGL(nsk::k3::k_schwarz<N>, dim3(count), dim3(nsk::k3::Cfg<N>::NT), 0, c->stream, d, vin, zout, use_coarse, check_done);
+  }
+}
+// E apply without the Gram-Schmidt dots (j < 0): one wavefront per element where that form exists (lx1 <= 8), else k_divgs
+template <int N>
+static void launch_divgs3(nsk_ctx* c, const Dev& d, int count, const double* yl, double* wout, int j, int check_done, int mode = -1) {
+  if constexpr (N <= 10) {
+    if (mode < 0) mode = c->eapply_pipe;
+    if constexpr (N <= 8) {
+      // (measured slower than k_divgs at config 4's size, 997 against 682 us: eight nodes per lane make the gather a chain of seven
+      //  dependent round trips where the 512-thread form has two; kept for the record, reachable with mode 3 / NSK_DIVGS_WAVE=1)
+      static const bool dv_wave = std::getenv("NSK_DIVGS_WAVE") && std::atoi(std::getenv("NSK_DIVGS_WAVE")) != 0;
+      if ((mode == 3 || (mode == 2 && dv_wave)) && j < 0) {
+        hipLaunchKernelGGL(nsk::k3::k_divgs_w<N>, dim3(count), dim3(64), 0, c->stream, d, yl, wout, check_done);
+        return;
+      }
+    }
+    hipLaunchKernelGGL(nsk::k3::k_divgs<N>, dim3(count), dim3(nsk::k3::Cfg<N>::NT), 0, c->stream, d, yl, wout, j, check_done);
+  }
+}
 template <int N>
 static void launch_gs_dots3(nsk_ctx* c, const Dev& d, int j) {         // first-pass dots as their own streaming pass (gs_lag = 2)
   if constexpr (N <= 10) {
@@ -988,9 +1038,10 @@ static int pres_solve_launch(nsk_ctx* c, double h2, int ord, int np, double tol_
         hipLaunchKernelGGL(k_coarse_restrict, dim3(d.coarse_lda / 256), dim3(256), 0, c->stream, d, c->rc_big);
         hipLaunchKernelGGL(k_coarse_big, dim3((d.nvert + 3) / 4), dim3(256), 0, c->stream, d, (const double*)c->rc_big);
       }
-      hipLaunchKernelGGL(k_schwarz<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, (const double*)(d.V + (size_t)j * d.ps), d.Z + (size_t)j * d.npr, 1, 1);
+      if (c->ndim == 3) launch_schwarz3<N>(c, d, c->nblk, (const double*)(d.V + (size_t)j * d.ps), d.Z + (size_t)j * d.npr, 1, 1);
+      else hipLaunchKernelGGL(k_schwarz<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, (const double*)(d.V + (size_t)j * d.ps), d.Z + (size_t)j * d.npr, 1, 1);
       if (lag && c->gs_lag != 1) {                        // (default, and gs_lag = 2: the first-pass dots as their own streaming pass)
-        hipLaunchKernelGGL(k_divgs<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, (const double*)d.yl, d.V + (size_t)(j + 1) * d.ps, -1, 1);
+        launch_divgs3<N>(c, d, c->nblk, (const double*)d.yl, d.V + (size_t)(j + 1) * d.ps, -1, 1);
         launch_gs_dots3<N>(c, d, j);
       } else {
         hipLaunchKernelGGL(k_divgs<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, (const double*)d.yl, d.V + (size_t)(j + 1) * d.ps, j, 1);
@@ -1851,6 +1902,7 @@ int nsk_set_option(nsk_ctx* c, const char* name, double value) {
   else if (n == "gs2_from") c->gs2_from = std::max(0, (int)value);
   else if (n == "gs_lag") c->gs_lag = (int)value;
   else if (n == "flat_proj") c->flat_proj = (int)value;
+  else if (n == "eapply_pipe") { c->eapply_pipe = (int)value; for (auto& a : c->graphs) for (auto& g : a) g.nh = -1; }
   else if (n == "helm_fdm") {           // 0: back to Jacobi (the factors stay); 1: only if the set-up built them (NSK_HELM_FDM=1 or an anisotropic mesh)
     if (value != 0.0 && !c->d.hfS) return fail(NSK_EINVAL, "helm_fdm: the fast-diagonalisation factors were not built at set-up (NSK_HELM_FDM=1)");
     c->d.helm_fdm = value != 0.0 ? 1 : 0;
@@ -2341,6 +2393,12 @@ int nsk_debug_stamps(nsk_ctx* c, unsigned long long* out, int nblk_max) {
       const StepCoef sc = make_coef(c, 3, 0);
       for (int r = 0; r < 6; ++r) hipLaunchKernelGGL(k_helm<N>, dim3(c->nblk), dim3(Cfg<N>::NT), 0, c->stream, dd, sc, r, (const double*)d.rloc);
       nblk_max = -nblk_max;
+    } else if (std::getenv("NSK_STAMP_KERNEL") && std::string(std::getenv("NSK_STAMP_KERNEL")) == "divgs_w") {
+      for (int r = 0; r < 5; ++r) launch_divgs3<N>(c, d, c->nblk, (const double*)d.yl, c->wp2, -1, 0, 3);
+    } else if (std::getenv("NSK_STAMP_KERNEL") && std::string(std::getenv("NSK_STAMP_KERNEL")) == "schwarz_w") {
+      for (int r = 0; r < 5; ++r) launch_schwarz3<N>(c, d, c->nblk, (const double*)d.V, d.Z, 1, 0, 2);
+    } else if (std::getenv("NSK_STAMP_KERNEL") && std::string(std::getenv("NSK_STAMP_KERNEL")) == "schwarz_p") {
+      for (int r = 0; r < 5; ++r) launch_schwarz3<N>(c, d, c->nblk, (const double*)d.V, d.Z, 1, 0, 1);
     } else if (std::getenv("NSK_STAMP_KERNEL") && std::string(std::getenv("NSK_STAMP_KERNEL")) == "schwarz") {
       for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(k_schwarz<N>, dim3(c->nblk), dim3(Cfg<N>::NT), 0, c->stream, d, (const double*)d.V, d.Z, 1, 0);
     } else {
@@ -2496,7 +2554,7 @@ int nsk_bench_kernel(nsk_ctx* c, const char* name, int reps, double* avg_us) {
       for (int r = 0; r < reps; ++r) { HIPCHK(hipMemsetAsync(c->sync, 0, SYNC_WORDS * sizeof(unsigned), c->stream)); launch_fused<N>(c, sc, its, &d); }
       HIPCHK(hipEventRecord(e1, c->stream));
     });
-  } else if (c->ndim == 3 && (n == "divgs" || n == "schwarz" || n == "gradt" || n.rfind("gs_lag", 0) == 0 || n.rfind("gs_dots", 0) == 0 || n == "pres_update" || n == "vel_update_proj" || n == "pres_rhs" || n == "rhs")) {
+  } else if (c->ndim == 3 && (n == "divgs" || n == "divgs_p" || n == "divgs_w" || n == "schwarz" || n == "schwarz_p" || n == "schwarz_w" || n == "gradt" || n.rfind("gs_lag", 0) == 0 || n.rfind("gs_dots", 0) == 0 || n == "pres_update" || n == "vel_update_proj" || n == "pres_rhs" || n == "rhs")) {
     // hexahedral pressure kernels back to back on the state the last map left: the E apply without its dots ("divgs"), the
     // Schwarz preconditioner + D^T ("schwarz"), the streaming Gram-Schmidt passes at basis index j ("gs_lag<j>", "gs_dots<j>")
     d.tol_pres = 0.0; d.tol_relative = 0; d.pres_cap = 0;
@@ -2511,7 +2569,10 @@ int nsk_bench_kernel(nsk_ctx* c, const char* name, int reps, double* avg_us) {
       for (int r = -3; r < reps; ++r) {
         if (r == 0) HIPCHK(hipEventRecord(e0, c->stream));
         if (n == "divgs") hipLaunchKernelGGL(k_divgs<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, (const double*)d.yl, c->wp2, -1, 0);
+        else if (n == "divgs_w") launch_divgs3<N>(c, d, c->nblk, (const double*)d.yl, c->wp2, -1, 0, 3);
         else if (n == "schwarz") hipLaunchKernelGGL(k_schwarz<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, (const double*)(d.V + (size_t)jj * d.ps), d.Z + (size_t)jj * d.npr, 1, 0);
+        else if (n == "schwarz_p") launch_schwarz3<N>(c, d, c->nblk, (const double*)(d.V + (size_t)jj * d.ps), d.Z + (size_t)jj * d.npr, 1, 0, 1);
+        else if (n == "schwarz_w") launch_schwarz3<N>(c, d, c->nblk, (const double*)(d.V + (size_t)jj * d.ps), d.Z + (size_t)jj * d.npr, 1, 0, 2);
         else if (n == "gradt") hipLaunchKernelGGL(k_gradt<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, (const double*)c->wp1, d.yl);
         else if (n == "pres_update") hipLaunchKernelGGL(k_pres_update<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, sc);
         else if (n == "vel_update_proj") hipLaunchKernelGGL(k_vel_update_proj<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, sc);

@@ -80,6 +80,24 @@ __device__ inline double gs_sum3(const GsVals& v, const double* __restrict__ f, 
   return ((v.a + v.b) + v.c) + v.d;
 }
 
+// uniform base (scalar registers) + 32-bit byte offset (one vector register for every basis vector of a node): the
+// global_load saddr form; a 64-bit address per load costs two vector registers per load in flight
+__device__ inline double ld_boff(const double* __restrict__ base, unsigned boff) {
+  return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + boff);
+}
+__device__ inline void st_boff(double* __restrict__ base, unsigned boff, double v) {
+  *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + boff) = v;
+}
+// gs_load with the uniform field base in scalar registers and 32-bit byte offsets (node indices * 8 fit 32 bits up to 5e8 nodes):
+// half the address registers of the 64-bit form when eight nodes per lane are in flight
+__device__ inline GsVals gs_load_o(const double* __restrict__ f, const int4 t, unsigned l) {
+  GsVals v;
+  v.a = ld_boff(f, (unsigned)(t.x >= 0 ? t.x : (int)l) * 8u);
+  v.b = (t.y >= 0) ? ld_boff(f, (unsigned)t.y * 8u) : 0.0;
+  v.c = (t.z >= 0) ? ld_boff(f, (unsigned)t.z * 8u) : 0.0;
+  v.d = (t.w >= 0) ? ld_boff(f, (unsigned)t.w * 8u) : 0.0;
+  return v;
+}
 template <int N>
 struct Cfg {
   static constexpr int NN = N * N * N, M = N - 2, MM = M * M * M, ND = 3 * N / 2, NDD = ND * ND * ND;
@@ -1231,14 +1249,6 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_gmres_update(Dev d, int j, doubl
 // One wavefront per element (4 rows of 64 lanes over the 216 nodes at lx1 = 8), RB rows in flight together,
 // JB = compile-time bound of j: every basis load of a row block is issued before the first use.
 // ---------------------------------------------------------------------------
-// uniform base (scalar registers) + 32-bit byte offset (one vector register for every basis vector of a node): the
-// global_load saddr form; a 64-bit address per load costs two vector registers per load in flight
-__device__ inline double ld_boff(const double* __restrict__ base, unsigned boff) {
-  return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + boff);
-}
-__device__ inline void st_boff(double* __restrict__ base, unsigned boff, double v) {
-  *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + boff) = v;
-}
 template <int N, int JB, int RB>
 __global__ __launch_bounds__(256) void k_gs_lag(Dev d, int j) {
   using C = Cfg<N>;
@@ -1536,6 +1546,242 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_schwarz(Dev d, const double* __r
   NSK_STAMP(5);
 }
 
+// k_schwarz as a resident workgroup that walks its share of the elements (b, b + gridDim.x, ...) with the NEXT element's inputs
+// in flight while the current one is solved.  One element of k_schwarz<8> at config 4's size: 4.2 us waiting for the patch values
+// (gather table -> values, two dependent round trips), 2.9 us in the six fast-diagonalisation passes, 4.9 us in D^T; four
+// workgroups per CU is the hardware maximum for 512 threads, so the waiting can only be hidden inside the workgroup.  Here:
+//   - the gather-table entry of the element after next, the patch value / S, Lambda entry / coarse-vertex value of the next
+//     element are loads issued at the top of an iteration and consumed at its bottom (7 registers);
+//   - the six passes run on the matrix cores (fd_forward_mfma, fd_back_mfma);
+//   - the D^T p stores go out after the next element's tile is in LDS, so that nothing waits for them.
+// `count` elements from d.boff on, XCD-contiguous as in k_schwarz (a step of gridDim.x, a multiple of 8, stays in the XCD's run).
+template <int N>
+__device__ __forceinline__ void schwarz_p_body(const Dev& d, const double* __restrict__ vin, double* __restrict__ zout,
+                                               int use_coarse, int check_done, int count) {
+  using C = Cfg<N>;
+  constexpr int NN = C::NN, M = C::M, MM = C::MM, NT = C::NT, NM = N * M, NNM = C::NNM, NMM = C::NMM;
+  constexpr int NS = 3 * N * N, NSL = NS + 3 * N;
+  static_assert(NSL <= NT, "one S / Lambda entry per thread");
+  __shared__ double sJ12[NM], sD12[NM];
+  using L = PadLay<N>;                                 // bank-conflict-free tile strides (nsk3_mfma_ops.hpp)
+  __shared__ double sSL[NSL], sH[2 * M];
+  __shared__ double sa[L::FEXT], sb[L::FEXT];
+  constexpr bool PRE = (N <= 8);
+  __shared__ double sP[(PRE ? 9 : 3) * MM], sC[3 * L::CEXT], sE[2 * L::EEXT];
+  const int tid = threadIdx.x;
+  if (check_done && d.gsc->done) return;
+  const bool act = tid < NN, pact = tid < MM;
+  load_basis3<N>(d, nullptr, nullptr, sJ12, sD12, tid, NT);
+  const double vsc = (d.gs_lag && d.gsc->pending) ? d.gsc->phinv : 1.0;
+  const unsigned G = gridDim.x;
+  unsigned b = blockIdx.x;
+  long long e = d.boff + xcd_element(b, count);
+  // pipeline registers: idn = gather-table entry (element after next); pv / svS, svL / xl = patch value, S and Lambda entry, coarse
+  // value of vertex (tid & 7) (next element), evl = that vertex' index (element after next).  The loads are unconditional
+  // (clamped addresses) and their values are not touched before the bottom of the iteration: a select or a scale at issue
+  // time would be a use, and the wait for it would sit right behind the load.
+  int idn = 0, evl = 0;
+  bool pok = false;
+  double pv = 0.0, svS = 0.0, svL = 0.0, xl = 0.0;
+  const unsigned tS = min((unsigned)tid, (unsigned)(NS - 1)), tL = min((unsigned)max(tid - NS, 0), (unsigned)(3 * N - 1)), tA = min((unsigned)tid, (unsigned)(NN - 1));
+  {
+    const int id = d.p_idx[e * NN + tA];
+    pv = (act && id >= 0) ? vsc * vin[id < 0 ? 0 : id] : 0.0;
+    svS = d.fdS[(size_t)e * NS + tS]; svL = d.fdL[(size_t)e * 3 * N + tL];
+    if (use_coarse) xl = d.xc[d.evert[e * 8 + (tid & 7)]];
+    const long long e1 = d.boff + xcd_element((b + G < (unsigned)count) ? b + G : b, count);
+    idn = d.p_idx[e1 * NN + tA];
+    if (use_coarse) evl = d.evert[e1 * 8 + (tid & 7)];
+  }
+  if (act) sa[(tid / (N * N)) * L::F[0][0] + ((tid / N) % N) * L::F[0][1] + (tid % N) * L::F[0][2]] = pv;
+  if (tid < NSL) sSL[tid] = (tid < NS) ? svS : svL;
+  double xcur = xl;
+  if (tid < 2 * M) sH[tid] = d.hat[8 * MM + tid];      // [2][M]: the 1-D factors of the eight vertex functions
+  int it = 0;
+  for (;; ++it) {
+#define SW_STAMP(i) do { if (it == 2) NSK_STAMP(i); } while (0)
+    SW_STAMP(0);
+    // (the lane index is made opaque per iteration: otherwise every lane-dependent address and LDS offset of the passes below is
+    //  hoisted out of the loop and the kernel needs twice the registers -- half the workgroups per CU)
+    unsigned tl = tid;
+    asm volatile("" : "+v"(tl));
+    const bool pactl = tl < MM, actl = tl < NN;
+    lds_barrier();                                     // tile, S / Lambda (and sH) of this element are in LDS
+    // uniform base + 32-bit lane offset (global_load saddr form): one address register for the nine metric loads
+    double w2[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (pactl) {
+#pragma unroll
+      for (int m = 0; m < 9; ++m) w2[m] = ld_boff(d.w2m + (size_t)m * d.npr + e * MM, tl * 8u);      // parked in sP after the forward passes
+    }
+    double zc = 0.0;
+    if (use_coarse) {                                  // R^T x_c: the eight vertex values sit in lanes 0..7 of every wave
+      const unsigned a = tl % M, bb = (tl / M) % M, cc = (tl / (M * M)) % M;
+      const double hr[2] = {sH[a], sH[M + a]}, hs[2] = {sH[bb], sH[M + bb]}, ht[2] = {sH[cc], sH[M + cc]};
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const double xv = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(xcur), c), __builtin_amdgcn_readlane(__double2loint(xcur), c));
+        zc += ((hr[c & 1] * hs[(c >> 1) & 1]) * ht[c >> 2]) * xv;         // = hat[c][tl] * xv, same products as the table
+      }
+    }
+    SW_STAMP(1);
+    fd_forward_mfma<N, L>(sSL, sSL + NS, sa, sb, d.fd_eps, (int)tl, NT);
+    SW_STAMP(2);
+    if constexpr (PRE) {
+      if (pactl) {
+#pragma unroll
+        for (int m = 0; m < 9; ++m) sP[((m % 3) * 3 + m / 3) * MM + tl] = w2[m];      // [component c = m % 3][axis a = m / 3]
+      }
+    }
+    SW_STAMP(3);
+    // next element (the last iteration re-reads its own: harmless).  Issued here, behind the only wait of the iteration (the
+    // metrics above), and consumed at the bottom: in flight under the backward passes and D^T.
+    const unsigned bn = b + G;
+    const bool more = bn < (unsigned)count;
+    const long long en = d.boff + xcd_element(more ? bn : b, count);
+    {
+      const unsigned tSl = min(tl, (unsigned)(NS - 1)), tLl = min((unsigned)max((int)tl - NS, 0), (unsigned)(3 * N - 1)), tAl = min(tl, (unsigned)(NN - 1));
+      pok = idn >= 0;
+      pv = ld_boff(vin, (unsigned)max(idn, 0) * 8u);
+      svS = ld_boff(d.fdS + (size_t)en * NS, tSl * 8u);
+      svL = ld_boff(d.fdL + (size_t)en * 3 * N, tLl * 8u);
+      if (use_coarse) xl = ld_boff(d.xc, (unsigned)evl * 8u);
+      const long long e2 = d.boff + xcd_element((bn + G < (unsigned)count) ? bn + G : (more ? bn : b), count);
+      idn = *reinterpret_cast<const int*>(reinterpret_cast<const char*>(d.p_idx + e2 * NN) + tAl * 4u);
+      if (use_coarse) evl = d.evert[e2 * 8 + (tl & 7)];
+    }
+    fd_back_mfma<N, L>(sSL, sa, sb, (int)tl, NT);
+    SW_STAMP(4);
+    double z = 0.0;
+    if (pactl) {
+      const unsigned a = tl % M, bb = (tl / M) % M, cc = tl / (M * M);
+      z = sa[(cc + 1) * L::F[6][0] + (bb + 1) * L::F[6][1] + (a + 1) * L::F[6][2]] + zc;       // restriction to the element's own nodes
+      st_boff(zout + e * MM, tl * 8u, z);
+      if constexpr (PRE) {
+#pragma unroll
+        for (int m = 0; m < 9; ++m) sP[m * MM + tl] *= z;
+      }
+    }
+    if constexpr (PRE) lds_barrier();
+    SW_STAMP(5);
+    double gp[3];
+    opgradt3_mfma<N, PRE, L>(sJ12, sD12, z, w2, sP, sC, sE, (int)tl, NT, gp);       // (ends with a barrier: sa / sSL are free)
+    SW_STAMP(6);
+    if (more) {
+      if (actl) sa[(tl / (N * N)) * L::F[0][0] + ((tl / N) % N) * L::F[0][1] + (tl % N) * L::F[0][2]] = pok ? vsc * pv : 0.0;
+      if (tl < NSL) sSL[tl] = (tl < NS) ? svS : svL;
+      xcur = xl;
+    }
+    SW_STAMP(7);
+    if (actl) {
+      double* __restrict__ y = d.yl + e * NN;
+      st_boff(y, tl * 8u, gp[0]); st_boff(y + d.cs, tl * 8u, gp[1]); st_boff(y + 2 * d.cs, tl * 8u, gp[2]);
+    }
+    SW_STAMP(8);
+    if (!more) break;
+    e = en; b = bn;
+  }
+#undef SW_STAMP
+}
+
+template <int N>
+__global__ __launch_bounds__(Cfg<N>::NT) void k_schwarz_p(Dev d, const double* __restrict__ vin, double* __restrict__ zout,
+                                                          int use_coarse, int check_done, int count) {
+  schwarz_p_body<N>(d, vin, zout, use_coarse, check_done, count);
+}
+// lx1 = 8: three workgroups per CU (<= 80 registers; left alone the scheduler takes 92 and two workgroups fit)
+#ifndef NSK_SWP_WAVES
+#define NSK_SWP_WAVES 6
+#endif
+template <>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NSK_SWP_WAVES, 8))) void k_schwarz_p<8>(
+    Dev d, const double* __restrict__ vin, double* __restrict__ zout, int use_coarse, int check_done, int count) {
+  schwarz_p_body<8>(d, vin, zout, use_coarse, check_done, count);
+}
+
+// k_schwarz with ONE WAVEFRONT PER ELEMENT (lx1 = 8: 512 nodes = 8 per lane).  What the counters said about the workgroup-per-element
+// forms above at config 4's size (scripts/pmc_sq_summary.py): waves parked at barriers / waits for 65-75 % of their cycles, instruction
+// issue the rest -- every one of the eight waves walks through all fourteen passes, most of them with no tile to compute, and the
+// per-pass time (~0.5 us) is the same whether the LDS banks conflict or not.  Here a wave owns its element: no workgroup barrier
+// at all (the LDS serves a wave's accesses in order), every tile of a pass is this wave's work and is unrolled with constant LDS
+// offsets, the linear phases handle eight nodes per lane.  Twelve elements per CU are in flight (LDS: 12.4 KB per wave), so
+// one wave's waiting for its loads is another wave's compute, and the registers of a CU are shared by 8-9 waves instead of 32.
+template <int N>
+__global__ __launch_bounds__(64) void k_schwarz_w(Dev d, const double* __restrict__ vin, double* __restrict__ zout,
+                                                  int use_coarse, int check_done) {
+  using C = Cfg<N>;
+  using L = PadLay<N>;
+  constexpr int NN = C::NN, M = C::M, MM = C::MM, NM = N * M, NS = 3 * N * N, NSL = NS + 3 * N;
+  constexpr int RN = (NN + 63) / 64, RM = (MM + 63) / 64, RS = (NSL + 63) / 64;
+  constexpr int GBUF = GtWave<N, L>::BUF, FBUF = 2 * L::FEXT, BUF = GBUF > FBUF ? GBUF : FBUF;
+  __shared__ double sJ12[NM], sD12[NM], sSL[NSL], sH[2 * M];
+  __shared__ double buf[BUF];
+  double* sa = buf; double* sb = buf + L::FEXT;                    // fast-diagonalisation tiles; afterwards the D^T intermediates (GtWave)
+  const int lane = threadIdx.x;
+  if (check_done && d.gsc->done) return;
+  const long long e = d.boff + xcd_element(blockIdx.x, gridDim.x);
+  NSK_STAMP(0);
+  // ---- every load of the element, issued together
+  int id[RN];
+#pragma unroll
+  for (int r = 0; r < RN; ++r) { const int idx = r * 64 + lane; id[r] = (idx < NN) ? d.p_idx[e * NN + idx] : -1; }
+  double sv[RS];
+#pragma unroll
+  for (int r = 0; r < RS; ++r) {
+    const int idx = r * 64 + lane;
+    sv[r] = (idx < NS) ? d.fdS[(size_t)e * NS + idx] : ((idx < NSL) ? d.fdL[(size_t)e * 3 * N + (idx - NS)] : 0.0);
+  }
+  double w2[9][RM];
+#pragma unroll
+  for (int m = 0; m < 9; ++m)
+#pragma unroll
+    for (int r = 0; r < RM; ++r) { const int idx = r * 64 + lane; w2[m][r] = (idx < MM) ? d.w2m[(size_t)m * d.npr + e * MM + idx] : 0.0; }
+  const double xl = use_coarse ? d.xc[d.evert[e * 8 + (lane & 7)]] : 0.0;
+  load_basis3<N>(d, nullptr, nullptr, sJ12, sD12, lane, 64);
+  if (lane < 2 * M) sH[lane] = d.hat[8 * MM + lane];
+  const double vsc = (d.gs_lag && d.gsc->pending) ? d.gsc->phinv : 1.0;
+  double pv[RN];
+#pragma unroll
+  for (int r = 0; r < RN; ++r) pv[r] = (id[r] >= 0) ? vsc * vin[id[r]] : 0.0;
+#pragma unroll
+  for (int r = 0; r < RS; ++r) { const int idx = r * 64 + lane; if (idx < NSL) sSL[idx] = sv[r]; }
+#pragma unroll
+  for (int r = 0; r < RN; ++r) {
+    const int idx = r * 64 + lane;
+    if (idx < NN) sa[(idx / (N * N)) * L::F[0][0] + ((idx / N) % N) * L::F[0][1] + (idx % N) * L::F[0][2]] = pv[r];
+  }
+  wave_sync();
+  NSK_STAMP(1);
+  fd_forward_mfma<N, L, true>(sSL, sSL + NS, sa, sb, d.fd_eps, lane, 64);
+  NSK_STAMP(2);
+  fd_back_mfma<N, L, true>(sSL, sa, sb, lane, 64);
+  NSK_STAMP(3);
+  // ---- restriction to the element's own nodes + R^T x_c (the eight vertex values sit in lanes 0..7)
+  double xv[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) xv[c] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(xl), c), __builtin_amdgcn_readlane(__double2loint(xl), c));
+  double z[RM];
+#pragma unroll
+  for (int r = 0; r < RM; ++r) {
+    const int idx = r * 64 + lane;
+    z[r] = 0.0;
+    if (idx < MM) {
+      const int a = idx % M, bb = (idx / M) % M, cc = idx / (M * M);
+      double zc = 0.0;
+      if (use_coarse) {
+        const double hr[2] = {sH[a], sH[M + a]}, hs[2] = {sH[bb], sH[M + bb]}, ht[2] = {sH[cc], sH[M + cc]};
+#pragma unroll
+        for (int c = 0; c < 8; ++c) zc += ((hr[c & 1] * hs[(c >> 1) & 1]) * ht[c >> 2]) * xv[c];       // = hat[c][idx] * x_c
+      }
+      z[r] = sa[(cc + 1) * L::F[6][0] + (bb + 1) * L::F[6][1] + (a + 1) * L::F[6][2]] + zc;
+      zout[e * MM + idx] = z[r];
+    }
+  }
+  wave_sync();
+  NSK_STAMP(4);
+  opgradt3_wave<N, L, RM>(sJ12, sD12, z, w2, buf, lane, d.yl + e * NN, d.cs);
+  NSK_STAMP(5);
+}
+
 // yl = D^T p for an arbitrary pressure vector
 template <int N>
 __global__ __launch_bounds__(Cfg<N>::NT) void k_gradt(Dev d, const double* __restrict__ pin, double* __restrict__ yl) {
@@ -1606,6 +1852,96 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_divgs(Dev d, const double* __res
       d.gpart[(size_t)tid * d.nblk + e] = t;               // slot = element: the order of the sums does not depend on how a launch is split or mapped
     }
   }
+}
+
+// k_divgs (without the Gram-Schmidt dots: the lagged Gram-Schmidt has them in k_gs_dots) with ONE WAVEFRONT PER ELEMENT, as
+// k_schwarz_w: no workgroup barrier, eight nodes per lane in the gather, the three passes of a component unrolled with constant
+// LDS offsets, the last pass combined with the metrics in the matrix-core accumulators (no staging tile), 11-12 elements per CU.
+#ifndef NSK_DVW_WAVES
+#define NSK_DVW_WAVES 3
+#endif
+template <int N>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NSK_DVW_WAVES))) void k_divgs_w(Dev d, const double* __restrict__ yl, double* __restrict__ wout, int check_done) {
+  using C = Cfg<N>;
+  using W = DvWave<N>;
+  constexpr int NN = C::NN, M = C::M, MM = C::MM, NM = N * M, KQ = (N + 3) / 4, RN = (NN + 63) / 64;
+  __shared__ double sJ12[NM], sD12[NM];
+  __shared__ double buf[W::BUF];
+  const int lane = threadIdx.x;
+  if (check_done && d.gsc->done) return;
+  const long long e = d.boff + xcd_element(blockIdx.x, gridDim.x);
+  int4 tab[RN];
+#pragma unroll
+  for (int r = 0; r < RN; ++r) {
+    const int idx = r * 64 + lane;
+    const unsigned lo = (unsigned)(idx < NN ? idx : 0);
+    tab[r] = *reinterpret_cast<const int4*>(reinterpret_cast<const char*>(d.gs_tab + e * NN) + lo * 16u);
+  }
+  // element corners (wide nodes): planes k = 0 and k = N - 1, lanes (j, i) in the corners of the 8 x 8 lane grid (N = 8; other
+  // orders: found by corner_id)
+  static_assert(N * N <= 64 || N == 10, "corner planes");
+  CornerList CL0, CL1;                                 // planes k = 0 and k = N - 1 (r = 0 and r = RN - 1 at N = 8)
+  {
+    const int i0 = lane, i1 = (RN - 1) * 64 + lane;
+    if (i0 < N * N) corner_issue(d, e, corner_id<N>(0, (i0 / N) % N, i0 % N), CL0); else CL0.id[0] = -2;
+    if (i1 < NN && i1 / (N * N) == N - 1) corner_issue(d, e, corner_id<N>(N - 1, (i1 / N) % N, i1 % N), CL1); else CL1.id[0] = -2;
+  }
+  CornerList CLx; CLx.id[0] = -2;                      // every other node: the general list walk if its table entry says "wide"
+  load_basis3<N>(d, nullptr, nullptr, sJ12, sD12, lane, 64);
+  wave_sync();
+  const int m16 = lane & 15, kq = lane >> 4;
+  double aDJ[KQ], aJ[KQ], aD[KQ];
+#pragma unroll
+  for (int q = 0; q < KQ; ++q) {
+    const int k = 4 * q + kq;
+    const bool kok = k < N;
+    aJ[q] = (m16 < M && kok) ? sJ12[m16 * N + k] : 0.0;
+    aD[q] = (m16 < M && kok) ? sD12[m16 * N + k] : 0.0;
+    aDJ[q] = !kok ? 0.0 : ((m16 < M) ? sD12[m16 * N + k] : ((m16 < 2 * M) ? sJ12[(m16 - M) * N + k] : 0.0));
+  }
+  double div[W::NT3][W::RQ];
+#pragma unroll
+  for (int t = 0; t < W::NT3; ++t)
+#pragma unroll
+    for (int r = 0; r < W::RQ; ++r) div[t][r] = 0.0;
+#pragma unroll 1
+  for (int c = 0; c < 3; ++c) {
+    // (lane index opaque per component: otherwise every lane-dependent offset below is hoisted out of this loop and spills)
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const double* __restrict__ f = yl + c * d.cs;
+    // (two half-batches of RN / 2 planes: eight nodes per lane in flight at once is 64 registers of values alone)
+    constexpr int RH = (RN + 1) / 2;
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) {
+      GsVals g[RH];
+      double bi[RH];                                     // (B^-1 mask: re-read per component, from the caches, rather than held)
+#pragma unroll
+      for (int rr = 0; rr < RH; ++rr) {
+        const int r = hb * RH + rr, idx = r * 64 + ln;
+        if (r < RN) {
+          g[rr] = gs_load_o(f, tab[r], (unsigned)(e * NN) + (unsigned)(idx < NN ? idx : 0));
+          bi[rr] = ld_boff(d.binv + e * NN, (unsigned)(idx < NN ? idx : 0) * 8u);
+        }
+      }
+#pragma unroll
+      for (int rr = 0; rr < RH; ++rr) {
+        const int r = hb * RH + rr, idx = r * 64 + ln;
+        if (r < RN && idx < NN) buf[W::oU + idx] = bi[rr] * gs_sum3(g[rr], f, d, tab[r], e * NN + idx, (r == 0) ? CL0 : ((r == RN - 1) ? CL1 : CLx));
+      }
+      asm volatile("" ::: "memory");
+    }
+    wave_sync();
+    opdiv3_wave_comp<N>(aDJ, aJ, aD, buf, ln, d.w2m + (size_t)(0 * 3 + c) * d.npr + e * MM, d.w2m + (size_t)(1 * 3 + c) * d.npr + e * MM,
+                        d.w2m + (size_t)(2 * 3 + c) * d.npr + e * MM, div);
+  }
+#pragma unroll
+  for (int t = 0; t < W::NT3; ++t)
+#pragma unroll
+    for (int r = 0; r < W::RQ; ++r) {
+      const int n = t * 16 + m16, cc = kq + 4 * r;
+      if (n < M * M && cc < M) wout[e * MM + cc * M * M + n] = div[t][r];
+    }
 }
 
 // after GMRES: dp = h2 * sum_i y_i Z_i (+ projected part) ; p = p* + dp ; yl = D^T dp

@@ -59,16 +59,44 @@ template <class C, int MS, int H, int SPLIT> struct StSplit {
   }
 };
 
+// general column map: columns n = p * Q + q over two tensor indices with strides SP, SQ; the contracted / produced index has stride KS
+template <int Q, int SP, int SQ, int KS> struct Col2 { static constexpr int ks = KS; static __device__ inline int col(int n) { return (n / Q) * SP + (n % Q) * SQ; } };
+
+// LDS layouts of the tiles the passes write and read: strides of the three tensor indices, slowest first.  Compact by default.
+// At lx1 = 8 the compact strides (64, 8, 1) put whole 16-lane groups of a matrix-core store on one or two banks (ds_write_b64:
+// 16 contiguous lanes per LDS cycle, bank = double index mod 16): counters at config 4's size gave 52 % of k_schwarz's LDS cycles as
+// bank conflicts, and the LDS array busy for 60 % of the kernel.  Every tile stage has ONE writer pattern and ONE reader pattern, so
+// each gets its own strides (searched with the bank rules of the CDNA4 guide: all passes below conflict-free or within one cycle):
+//   F[s]: the N^3 tile of the fast-diagonalisation solve after stage s (0: filled, 1..3: forward r, s, t; 4..6: back t, s, r);
+//   C: D^T intermediates [N][M][M] (written along t, read along s), E: [N][N][M] (written along s, read along r), G: the N^3 result.
+template <int N> struct CompactLay {
+  static constexpr int M = N - 2;
+  static constexpr int F[7][3] = {{N * N, N, 1}, {N * N, N, 1}, {N * N, N, 1}, {N * N, N, 1}, {N * N, N, 1}, {N * N, N, 1}, {N * N, N, 1}};
+  static constexpr int FEXT = N * N * N;
+  static constexpr int C[3] = {M * M, M, 1}, CEXT = N * M * M;
+  static constexpr int E[3] = {N * M, M, 1}, EEXT = N * N * M;
+  static constexpr int G[3] = {N * N, N, 1};
+};
+template <int N> struct PadLay : CompactLay<N> {};
+template <> struct PadLay<8> {
+  static constexpr int F[7][3] = {{66, 8, 1}, {8, 65, 1}, {65, 16, 2}, {16, 65, 2}, {16, 65, 2}, {9, 76, 2}, {8, 71, 1}};
+  static constexpr int FEXT = 616;
+  static constexpr int C[3] = {38, 6, 1}, CEXT = 304;
+  static constexpr int E[3] = {6, 52, 1}, EEXT = 416;
+  static constexpr int G[3] = {8, 69, 1};
+};
+
 // D^T p: same contract as the thread-per-node opgradt3<N> (sP [3][M^3], sC [3][N M^2], sE [2][N^2 M] scratch; result g[3] for GLL
 // node tid; the last pass is staged through sC, free by then, which holds N^3 <= 3 N M^2 doubles)
 // PRE: sP holds ALL nine products p * w2[a][c] ([c][a][M^3], filled by the caller before a barrier): the metrics are then dead
 // before the passes start (18 fewer live registers, two barriers fewer) at the price of 6 M^3 more doubles of LDS
-template <int N, bool PRE = false>
+// L: layout of sC (three arrays of L::CEXT) and sE (two of L::EEXT); the result is staged through sC with strides L::G
+template <int N, bool PRE = false, class L = CompactLay<N>>
 __device__ inline void opgradt3_mfma(const double* sJ12, const double* sD12, double pval, const double (&w2)[9], double* sP,
                                      double* sC, double* sE, int tid, int nt, double (&g)[3]) {
-  constexpr int M = N - 2, MM = M * M * M, NN = N * N * N, NNM = N * N * M, NMM = N * M * M, KQ = (M + 3) / 4;
-  static_assert(NN <= 3 * NMM && N <= 16, "staging through sC");
-  const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6, m16 = lane & 15, kq = lane >> 4;
+  constexpr int M = N - 2, MM = M * M * M, NN = N * N * N, NNM = L::EEXT, NMM = L::CEXT, KQ = (M + 3) / 4;
+  static_assert((N - 1) * (L::G[0] + L::G[1] + L::G[2]) < 3 * NMM && N <= 16, "staging through sC");
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = nt >> 6, m16 = lane & 15, kq = lane >> 4;
   // fragments of J12^T and D12^T (N x M, zero padded): A[m][k] = J12[k][m]
   double aJ[KQ], aD[KQ];
 #pragma unroll
@@ -78,11 +106,13 @@ __device__ inline void opgradt3_mfma(const double* sJ12, const double* sD12, dou
     aJ[q] = ok ? sJ12[k * N + m16] : 0.0;
     aD[q] = ok ? sD12[k * N + m16] : 0.0;
   }
-  typedef ColLinear<M * M> CT;                 // [cc | kk][(b,a)]
-  typedef ColPlane<M, M * M, M> CS_in;         // [kk][b][a]   -> contract b
-  typedef ColPlane<M, N * M, M> CS_out;        // [kk][jj][a]
-  typedef ColRow<M> CR_in;                     // [(k,j)][a]   -> contract a
-  typedef ColRow<N> CR_out;                    // [(k,j)][i]
+  typedef ColLinear<M * M> CT;                                   // sP [cc][(b,a)]            -> contract cc
+  typedef Col2<M, L::C[1], L::C[2], L::C[0]> CT_out;             // sC [kk][b][a], columns (b,a): produce kk
+  typedef Col2<M, L::C[0], L::C[2], L::C[1]> CS_in;              // sC, columns (kk,a)        -> contract b
+  typedef Col2<M, L::E[0], L::E[2], L::E[1]> CS_out;             // sE [kk][jj][a], columns (kk,a): produce jj
+  typedef Col2<N, L::E[0], L::E[1], L::E[2]> CR_in;              // sE, columns (kk,jj)       -> contract a
+  typedef Col2<N, L::G[0], L::G[1], L::G[2]> CR_out;             // result [k][j][i], columns (k,j): produce i
+  const int gk = tid / (N * N), gj = (tid / N) % N, gi = tid % N;
 #pragma unroll 1
   for (int c = 0; c < 3; ++c) {
     if constexpr (!PRE) {
@@ -95,18 +125,18 @@ __device__ inline void opgradt3_mfma(const double* sJ12, const double* sD12, dou
     }
     const double* sPc = PRE ? sP + c * 3 * MM : sP;
     // axis t: sC_a[kk][ba] = sum_cc A_a[kk][cc] sP_a[cc][ba],  A_0 = A_1 = J12^T, A_2 = D12^T
-    mo_pass<M, KQ, M * M, CT, StLin<CT, M * M, N>, false>(aJ, sPc, aJ, sPc, sC, wave, nw, lane);
-    mo_pass<M, KQ, M * M, CT, StLin<CT, M * M, N>, false>(aJ, sPc + MM, aJ, sPc, sC + NMM, wave, nw, lane);
-    mo_pass<M, KQ, M * M, CT, StLin<CT, M * M, N>, false>(aD, sPc + 2 * MM, aD, sPc, sC + 2 * NMM, wave, nw, lane);
+    mo_pass<M, KQ, M * M, CT, StLin<CT_out, CT_out::ks, N>, false>(aJ, sPc, aJ, sPc, sC, wave, nw, lane);
+    mo_pass<M, KQ, M * M, CT, StLin<CT_out, CT_out::ks, N>, false>(aJ, sPc + MM, aJ, sPc, sC + NMM, wave, nw, lane);
+    mo_pass<M, KQ, M * M, CT, StLin<CT_out, CT_out::ks, N>, false>(aD, sPc + 2 * MM, aD, sPc, sC + 2 * NMM, wave, nw, lane);
     lds_barrier();
     // axis s: sE_0[kk][jj][a] = J12^T sC_0,   sE_1 = D12^T sC_1 + J12^T sC_2
-    mo_pass<M, KQ, N * M, CS_in, StLin<CS_out, M, N>, false>(aJ, sC, aJ, sC, sE, wave, nw, lane);
-    mo_pass<M, KQ, N * M, CS_in, StLin<CS_out, M, N>, true>(aD, sC + NMM, aJ, sC + 2 * NMM, sE + NNM, wave, nw, lane);
+    mo_pass<M, KQ, N * M, CS_in, StLin<CS_out, CS_out::ks, N>, false>(aJ, sC, aJ, sC, sE, wave, nw, lane);
+    mo_pass<M, KQ, N * M, CS_in, StLin<CS_out, CS_out::ks, N>, true>(aD, sC + NMM, aJ, sC + 2 * NMM, sE + NNM, wave, nw, lane);
     lds_barrier();
     // axis r: g[(k,j)][i] = D12^T sE_0 + J12^T sE_1   -> staged in sC, one value per GLL node
-    mo_pass<M, KQ, N * N, CR_in, StLin<CR_out, 1, N>, true>(aD, sE, aJ, sE + NNM, sC, wave, nw, lane);
+    mo_pass<M, KQ, N * N, CR_in, StLin<CR_out, CR_out::ks, N>, true>(aD, sE, aJ, sE + NNM, sC, wave, nw, lane);
     lds_barrier();
-    g[c] = (tid < NN) ? sC[tid] : 0.0;
+    g[c] = (tid < NN) ? sC[gk * L::G[0] + gj * L::G[1] + gi * L::G[2]] : 0.0;
     lds_barrier();
   }
 }
@@ -118,7 +148,7 @@ __device__ inline double opdiv3_mfma(const double* sJ12, const double* sD12, con
                                      int tid, int nt, const double (&w2)[9]) {
   constexpr int M = N - 2, MM = M * M * M, NN = N * N * N, NNM = N * N * M, NMM = N * M * M, KQ = (N + 3) / 4;
   static_assert(3 * MM <= 2 * NNM && 2 * M <= 16, "staging through sA, stacked operator in one tile");
-  const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6, m16 = lane & 15, kq = lane >> 4;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = nt >> 6, m16 = lane & 15, kq = lane >> 4;
   // A[m][k]: rows 0..M-1 = D12[m][k], rows M..2M-1 = J12[m-M][k] (stacked), and the two M-row operators alone
   double aDJ[KQ], aJ[KQ], aD[KQ];
 #pragma unroll
@@ -154,6 +184,209 @@ __device__ inline double opdiv3_mfma(const double* sJ12, const double* sD12, con
     lds_barrier();
   }
   return div;
+}
+
+// Fast-diagonalisation solve of one Schwarz patch (k_schwarz): six N x N passes over an N^3 tile,
+//   z = (S_t x S_s x S_r) diag(1/(lr+ls+lt)) (S_t x S_s x S_r)^T w,
+// each OUT(m, n) = sum_k A(m,k) X(k,n) with N^2 columns.  sS = [3][N*N] (S_d[pos][mode]), sL = [3][N]; in: sa, out: sa, scratch sb.
+// The thread-per-node form read two LDS operands per multiply-add (96 reads per thread and solve); here the operator is a register
+// fragment and the tile is read once per 16-column block (2-3 reads per lane and pass).  Ends with a barrier.
+template <int N, class XC, class OC, bool FWD, class F>
+__device__ inline void fd_pass(const double* sSd, const double* X, int wave, int nwaves, int lane, F&& store) {
+  constexpr int KQ = (N + 3) / 4, NCOL = N * N, NT16 = (NCOL + 15) / 16;
+  const int n16 = lane & 15, kq = lane >> 4;
+  double a[KQ];
+#pragma unroll
+  for (int q = 0; q < KQ; ++q) {
+    const int k = 4 * q + kq;
+    // forward: A(m, k) = S[k][m] (S^T);  back: A(m, k) = S[m][k]
+    a[q] = (n16 < N && k < N) ? (FWD ? sSd[k * N + n16] : sSd[n16 * N + k]) : 0.0;
+  }
+  for (int tile = wave; tile < NT16; tile += nwaves) {
+    const int n = tile * 16 + n16;
+    const bool nok = n < NCOL;
+    const int cb = nok ? XC::col(n) : 0, ob = nok ? OC::col(n) : 0;
+    mo_d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) {
+      const int k = 4 * q + kq;
+      const double b = (nok && k < N) ? X[cb + k * XC::ks] : 0.0;
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b, acc, 0, 0, 0);
+    }
+    if (nok) {
+#pragma unroll
+      for (int r = 0; r < (N + 3) / 4; ++r)
+        if (kq + 4 * r < N) store(ob + (kq + 4 * r) * OC::ks, n, kq + 4 * r, acc[r]);
+    }
+  }
+}
+// column maps of stage ST of the tile (strides L::F[ST] of (k, j, i)): contract / produce i, j or k
+template <int N, class L, int ST> using FdR = Col2<N, L::F[ST][0], L::F[ST][1], L::F[ST][2]>;      // columns (k, j)
+template <int N, class L, int ST> using FdS = Col2<N, L::F[ST][0], L::F[ST][2], L::F[ST][1]>;      // columns (k, i)
+template <int N, class L, int ST> using FdT = Col2<N, L::F[ST][1], L::F[ST][2], L::F[ST][0]>;      // columns (j, i)
+// pass boundary: workgroup barrier, or -- one wavefront per element -- only the wait for the wave's own LDS traffic (the LDS
+// serves a wavefront's instructions in order; the "memory" clobber keeps the compiler from moving accesses across)
+__device__ inline void wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+template <bool WAVE> __device__ inline void pass_sync() { if constexpr (WAVE) wave_sync(); else lds_barrier(); }
+
+template <int N, class L, bool WAVE = false>
+__device__ inline void fd_forward_mfma(const double* sS, const double* sL, double* sa, double* sb, double eps, int tid, int nt) {
+  const int lane = tid & 63, wave = WAVE ? 0 : __builtin_amdgcn_readfirstlane(tid >> 6), nw = WAVE ? 1 : nt >> 6;
+  fd_pass<N, FdR<N, L, 0>, FdR<N, L, 1>, true>(sS, sa, wave, nw, lane, [&](int o, int, int, double v) { sb[o] = v; });
+  pass_sync<WAVE>();
+  fd_pass<N, FdS<N, L, 1>, FdS<N, L, 2>, true>(sS + N * N, sb, wave, nw, lane, [&](int o, int, int, double v) { sa[o] = v; });
+  pass_sync<WAVE>();
+  fd_pass<N, FdT<N, L, 2>, FdT<N, L, 3>, true>(sS + 2 * N * N, sa, wave, nw, lane, [&](int o, int n, int m, double v) {
+    const double lam = sL[n % N] + sL[N + n / N] + sL[2 * N + m];
+    sb[o] = (lam > eps) ? v / lam : 0.0;
+  });
+  pass_sync<WAVE>();
+}
+template <int N, class L, bool WAVE = false>
+__device__ inline void fd_back_mfma(const double* sS, double* sa, double* sb, int tid, int nt) {
+  const int lane = tid & 63, wave = WAVE ? 0 : __builtin_amdgcn_readfirstlane(tid >> 6), nw = WAVE ? 1 : nt >> 6;
+  fd_pass<N, FdT<N, L, 3>, FdT<N, L, 4>, false>(sS + 2 * N * N, sb, wave, nw, lane, [&](int o, int, int, double v) { sa[o] = v; });
+  pass_sync<WAVE>();
+  fd_pass<N, FdS<N, L, 4>, FdS<N, L, 5>, false>(sS + N * N, sa, wave, nw, lane, [&](int o, int, int, double v) { sb[o] = v; });
+  pass_sync<WAVE>();
+  fd_pass<N, FdR<N, L, 5>, FdR<N, L, 6>, false>(sS, sb, wave, nw, lane, [&](int o, int, int, double v) { sa[o] = v; });
+  pass_sync<WAVE>();
+}
+
+// D^T p by ONE wavefront (k_schwarz_w): z[r], w2[m][r] = value / metrics of Gauss node r * 64 + lane; the three components go
+// straight from the accumulators of the last pass to yl (element base `y`, component stride cs; a tile's two stores cover whole
+// 64-byte lines).  One buffer of GT_BUF doubles, regions reused in the order the passes allow (what is live together: the two
+// intermediates of the D-along-s / D-along-t terms + their sum's tile, then the three tiles of the last two passes):
+//   sC1 [0, C) sC2 [C, 2C) | products P1, P2 and later sE1 [C+E, ...) | then P0 [C, ..) -> sC0 [0, C) -> sE0 [C, C+E)
+template <int N, class L> struct GtWave {
+  static constexpr int M = N - 2, MM = M * M * M, C = L::CEXT, E = L::EEXT;
+  static constexpr int oC1 = 0, oC2 = C, oE1 = C + E, oP12 = C + E, oP0 = C, oC0 = 0, oE0 = C;
+  static constexpr int BUF = (oE1 + E > oP12 + 2 * MM) ? oE1 + E : oP12 + 2 * MM;
+  static_assert(2 * C <= oP12 && oP0 + MM <= oE1 && oE0 + E <= oE1, "regions");
+};
+template <int N, class L, int RM>
+__device__ inline void opgradt3_wave(const double* sJ12, const double* sD12, const double (&z)[RM], const double (&w2)[9][RM],
+                                     double* buf, int lane, double* __restrict__ y, long long cs) {
+  using G = GtWave<N, L>;
+  constexpr int M = N - 2, MM = M * M * M, KQ = (M + 3) / 4;
+  const int m16 = lane & 15, kq = lane >> 4;
+  double aJ[KQ], aD[KQ];
+#pragma unroll
+  for (int q = 0; q < KQ; ++q) {
+    const int k = 4 * q + kq;
+    const bool ok = m16 < N && k < M;
+    aJ[q] = ok ? sJ12[k * N + m16] : 0.0;
+    aD[q] = ok ? sD12[k * N + m16] : 0.0;
+  }
+  typedef ColLinear<M * M> CT;
+  typedef Col2<M, L::C[1], L::C[2], L::C[0]> CT_out;
+  typedef Col2<M, L::C[0], L::C[2], L::C[1]> CS_in;
+  typedef Col2<M, L::E[0], L::E[2], L::E[1]> CS_out;
+  typedef Col2<N, L::E[0], L::E[1], L::E[2]> CR_in;
+  typedef ColRow<N> CR_out;                                  // the element's own [(k,j)][i] order in global memory
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {                          // (unrolled: w2 stays in registers)
+    // terms with the derivative along s (axis 1) and along t (axis 2): products, t-axis passes, s-axis pass
+#pragma unroll
+    for (int r = 0; r < RM; ++r) {
+      const int idx = r * 64 + lane;
+      if (idx < MM) { buf[G::oP12 + idx] = z[r] * w2[1 * 3 + c][r]; buf[G::oP12 + MM + idx] = z[r] * w2[2 * 3 + c][r]; }
+    }
+    wave_sync();
+    mo_pass<M, KQ, M * M, CT, StLin<CT_out, CT_out::ks, N>, false>(aJ, buf + G::oP12, aJ, buf, buf + G::oC1, 0, 1, lane);
+    mo_pass<M, KQ, M * M, CT, StLin<CT_out, CT_out::ks, N>, false>(aD, buf + G::oP12 + MM, aD, buf, buf + G::oC2, 0, 1, lane);
+    wave_sync();
+    mo_pass<M, KQ, N * M, CS_in, StLin<CS_out, CS_out::ks, N>, true>(aD, buf + G::oC1, aJ, buf + G::oC2, buf + G::oE1, 0, 1, lane);
+    wave_sync();
+    // term with the derivative along r (axis 0)
+#pragma unroll
+    for (int r = 0; r < RM; ++r) {
+      const int idx = r * 64 + lane;
+      if (idx < MM) buf[G::oP0 + idx] = z[r] * w2[0 * 3 + c][r];
+    }
+    wave_sync();
+    mo_pass<M, KQ, M * M, CT, StLin<CT_out, CT_out::ks, N>, false>(aJ, buf + G::oP0, aJ, buf, buf + G::oC0, 0, 1, lane);
+    wave_sync();
+    mo_pass<M, KQ, N * M, CS_in, StLin<CS_out, CS_out::ks, N>, false>(aJ, buf + G::oC0, aJ, buf, buf + G::oE0, 0, 1, lane);
+    wave_sync();
+    // axis r: g[(k,j)][i] = D12^T sE_0 + J12^T sE_1  -> global
+    mo_pass<M, KQ, N * N, CR_in, StLin<CR_out, 1, N>, true>(aD, buf + G::oE0, aJ, buf + G::oE1, y + c * cs, 0, 1, lane);
+    wave_sync();
+  }
+}
+
+// Weak divergence by ONE wavefront (k_divgs_w), component by component: `su` (the gathered, mass-scaled component c, [k][j][i])
+// -> r-axis (stacked [D12; J12]) -> s-axis -> t-axis, whose three products stay in the accumulators and are combined with the
+// metrics there (w2 is loaded in the accumulator's own node order: rows cc = kq + 4 r, columns (b, a) = 16 tile + n16).
+// One buffer, regions reused as the passes allow:  sA0 [0, A) sA1 [A, 2A) | su [2A, 2A + N^3) -> sB0 [2A, ..) sB2 [2A + B, ..) | sB1 [0, B)
+template <int N> struct DvWave {
+  static constexpr int M = N - 2, A = N * N * M, B = N * M * M, NN = N * N * N;
+  static constexpr int oA0 = 0, oA1 = A, oU = 2 * A, oB0 = 2 * A, oB2 = 2 * A + B, oB1 = 0;
+  static constexpr int BUF = (2 * A + NN > 2 * A + 2 * B) ? 2 * A + NN : 2 * A + 2 * B;
+  static constexpr int NT3 = (M * M + 15) / 16, RQ = (M + 3) / 4;
+  static_assert(B <= A && 2 * M <= 16, "sB1 in sA0's place; stacked operator in one tile");
+};
+template <int K, int KQ, class XC>
+__device__ inline mo_d4 mo_tile(const double (&a)[KQ], const double* X, int tile, int ncol, int lane) {
+  const int n = tile * 16 + (lane & 15), kq = lane >> 4;
+  const bool nok = n < ncol;
+  const int cb = nok ? XC::col(n) : 0;
+  mo_d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int q = 0; q < KQ; ++q) {
+    const int k = 4 * q + kq;
+    const double b = (nok && k < K) ? X[cb + k * XC::ks] : 0.0;
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b, acc, 0, 0, 0);
+  }
+  return acc;
+}
+// one component: buf + oU holds it; div[t][r] += the component's three terms.  wa / wb / wc -> the element's w2[0*3+c], w2[1*3+c],
+// w2[2*3+c]; they are read in accumulator order, issued after the first pass (the gather's registers are free by then) and
+// consumed after the last.
+template <int N>
+__device__ inline void opdiv3_wave_comp(const double (&aDJ)[(N + 3) / 4], const double (&aJ)[(N + 3) / 4], const double (&aD)[(N + 3) / 4],
+                                        double* buf, int lane, const double* __restrict__ wa, const double* __restrict__ wb,
+                                        const double* __restrict__ wc, double (&div)[DvWave<N>::NT3][DvWave<N>::RQ]) {
+  using W = DvWave<N>;
+  constexpr int M = N - 2, KQ = (N + 3) / 4;
+  typedef ColRow<N> CR_in;                     // [(k,j)][i]   -> contract i
+  typedef ColRow<M> CR_out;                    // [(k,j)][a]
+  typedef ColPlane<M, N * M, M> CS_in;         // [k][j][a]    -> contract j
+  typedef ColPlane<M, M * M, M> CS_out;        // [k][b][a]
+  typedef ColLinear<M * M> CT;                 // [k][(b,a)]   -> contract k
+  // axis r: sA_0[(k,j)][a] = D12 u, sA_1 = J12 u   (stacked)
+  mo_pass<N, KQ, N * N, CR_in, StSplit<CR_out, 1, M, W::oA1 - W::oA0>, false>(aDJ, buf + W::oU, aDJ, buf, buf + W::oA0, 0, 1, lane);
+  wave_sync();
+  double ma[W::NT3][W::RQ], mb[W::NT3][W::RQ], mc[W::NT3][W::RQ];
+  {
+    const int m16 = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int t = 0; t < W::NT3; ++t)
+#pragma unroll
+      for (int r = 0; r < W::RQ; ++r) {
+        const int n = t * 16 + m16, cc = kq + 4 * r;
+        const bool ok = n < M * M && cc < M;
+        const unsigned qo = (unsigned)(ok ? cc * M * M + n : 0) * 8u;
+        ma[t][r] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(wa) + qo);
+        mb[t][r] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(wb) + qo);
+        mc[t][r] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(wc) + qo);
+      }
+  }
+  // axis s: sB_0[k][b][a] = J12 sA_0;  sB_1 = D12 sA_1, sB_2 = J12 sA_1 (stacked)
+  mo_pass<N, KQ, N * M, CS_in, StLin<CS_out, M, M>, false>(aJ, buf + W::oA0, aJ, buf, buf + W::oB0, 0, 1, lane);
+  mo_pass<N, KQ, N * M, CS_in, StSplit<CS_out, M, M, W::oB2 - W::oB1>, false>(aDJ, buf + W::oA1, aDJ, buf, buf + W::oB1, 0, 1, lane);
+  wave_sync();
+  // axis t: ur = J12 sB_0, us = J12 sB_1, ut = D12 sB_2, combined with the metrics in the accumulators (rows / columns outside
+  // the tile carry zeros in the accumulators: whatever metric value was read there does not count)
+#pragma unroll
+  for (int t = 0; t < W::NT3; ++t) {
+    const mo_d4 ur = mo_tile<N, KQ, CT>(aJ, buf + W::oB0, t, M * M, lane);
+    const mo_d4 us = mo_tile<N, KQ, CT>(aJ, buf + W::oB1, t, M * M, lane);
+    const mo_d4 ut = mo_tile<N, KQ, CT>(aD, buf + W::oB2, t, M * M, lane);
+#pragma unroll
+    for (int r = 0; r < W::RQ; ++r) div[t][r] += ma[t][r] * ur[r] + mb[t][r] * us[r] + mc[t][r] * ut[r];
+  }
+  wave_sync();
 }
 
 }  // namespace k3
