@@ -2554,7 +2554,7 @@ int nsk_bench_kernel(nsk_ctx* c, const char* name, int reps, double* avg_us) {
       for (int r = 0; r < reps; ++r) { HIPCHK(hipMemsetAsync(c->sync, 0, SYNC_WORDS * sizeof(unsigned), c->stream)); launch_fused<N>(c, sc, its, &d); }
       HIPCHK(hipEventRecord(e1, c->stream));
     });
-  } else if (c->ndim == 3 && (n == "divgs" || n == "divgs_p" || n == "divgs_w" || n == "schwarz" || n == "schwarz_p" || n == "schwarz_w" || n == "gradt" || n.rfind("gs_lag", 0) == 0 || n.rfind("gs_dots", 0) == 0 || n == "pres_update" || n == "vel_update_proj" || n == "pres_rhs" || n == "rhs")) {
+  } else if (c->ndim == 3 && (n == "divgs" || n == "divgs_w" || n == "schwarz" || n == "schwarz_wg" || n == "schwarz_p" || n == "schwarz_w" || n == "gradt" || n.rfind("gs_lag", 0) == 0 || n.rfind("gs_dots", 0) == 0 || n == "pres_update" || n == "vel_update_proj" || n == "pres_rhs" || n == "rhs")) {
     // hexahedral pressure kernels back to back on the state the last map left: the E apply without its dots ("divgs"), the
     // Schwarz preconditioner + D^T ("schwarz"), the streaming Gram-Schmidt passes at basis index j ("gs_lag<j>", "gs_dots<j>")
     d.tol_pres = 0.0; d.tol_relative = 0; d.pres_cap = 0;
@@ -2570,7 +2570,8 @@ int nsk_bench_kernel(nsk_ctx* c, const char* name, int reps, double* avg_us) {
         if (r == 0) HIPCHK(hipEventRecord(e0, c->stream));
         if (n == "divgs") hipLaunchKernelGGL(k_divgs<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, (const double*)d.yl, c->wp2, -1, 0);
         else if (n == "divgs_w") launch_divgs3<N>(c, d, c->nblk, (const double*)d.yl, c->wp2, -1, 0, 3);
-        else if (n == "schwarz") hipLaunchKernelGGL(k_schwarz<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, (const double*)(d.V + (size_t)jj * d.ps), d.Z + (size_t)jj * d.npr, 1, 0);
+        else if (n == "schwarz") launch_schwarz3<N>(c, d, c->nblk, (const double*)(d.V + (size_t)jj * d.ps), d.Z + (size_t)jj * d.npr, 1, 0);      // the form the context runs
+        else if (n == "schwarz_wg") launch_schwarz3<N>(c, d, c->nblk, (const double*)(d.V + (size_t)jj * d.ps), d.Z + (size_t)jj * d.npr, 1, 0, 0);
         else if (n == "schwarz_p") launch_schwarz3<N>(c, d, c->nblk, (const double*)(d.V + (size_t)jj * d.ps), d.Z + (size_t)jj * d.npr, 1, 0, 1);
         else if (n == "schwarz_w") launch_schwarz3<N>(c, d, c->nblk, (const double*)(d.V + (size_t)jj * d.ps), d.Z + (size_t)jj * d.npr, 1, 0, 2);
         else if (n == "gradt") hipLaunchKernelGGL(k_gradt<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, (const double*)c->wp1, d.yl);

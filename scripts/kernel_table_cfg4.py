@@ -26,7 +26,8 @@ rule, distinct = roofline.helm_launch_bytes(nel=nel, lx1=N, ndim=3)
 stepb = roofline.per_step_bytes(nel=nel, lx1=N, ndim=3, nvert=nvert, nproj=32, helm_iters=0.0, pres_iters=0.0, pres_jsum=0.0, coarse_bytes=0.0)
 alg = {"helm": (distinct, "k3::k_helm<8>", "all arrays of the three components once (SURVEY rule, 172 B/pt and component: %.2f GB)" % (rule / 1e9)),
        "divgs": (one["K7 divgs (x n_pres)"], "k3::k_divgs<8>", "E apply without dots"),
-       "schwarz": (one["K6 schwarz (x n_pres)"] - nel * 8 * 12.0, "k3::k_schwarz<8>", "fast-diagonalisation Schwarz + D^T"),
+       "schwarz": (one["K6 schwarz (x n_pres)"] - nel * 8 * 12.0, "k3::k_schwarz_w<8>", "fast-diagonalisation Schwarz + D^T, one wavefront per element"),
+       "schwarz_wg": (one["K6 schwarz (x n_pres)"] - nel * 8 * 12.0, "k3::k_schwarz<8>", "the same as one workgroup per element (round 3's form; option eapply_pipe = 0)"),
        "pres_rhs": (stepb["K4 pres_rhs"], "k3::k_pres_rhs<8>", "nproj = 32"), "rhs": (stepb["K2 rhs"], "k3::k_rhs<8>", ""),
        "convect_mfma": (stepb["K1 convect"], "k3::k_convect_mfma8", "")}
 for j in (3, 8, 16, 24, 32):
@@ -42,7 +43,7 @@ def pmc_of(key):
 print("| kernel (launch) | HIP-event us | algorithmic GB / launch | TB/s | frac of 8 TB/s | counter GB / launch (2 x FETCH + WRITE) | frac by counter bytes | note |")
 print("|---|---|---|---|---|---|---|---|")
 out = {}
-for kn in ("helm", "divgs", "schwarz", "gs_dots3", "gs_lag3", "gs_dots8", "gs_lag8", "gs_dots16", "gs_lag16", "gs_dots24", "gs_lag24", "gs_dots32", "gs_lag32", "pres_rhs", "rhs", "convect_mfma"):
+for kn in ("helm", "divgs", "schwarz", "schwarz_wg", "gs_dots3", "gs_lag3", "gs_dots8", "gs_lag8", "gs_dots16", "gs_lag16", "gs_dots24", "gs_lag24", "gs_dots32", "gs_lag32", "pres_rhs", "rhs", "convect_mfma"):
     if kn not in t or kn not in alg:
         continue
     a, key, note = alg[kn]

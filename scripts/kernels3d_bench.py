@@ -7,7 +7,7 @@ import numpy as np
 from nekstab_amd import mesh, mesh3d, capi
 from nekstab_amd.capi import NekStabHip
 nz = int(sys.argv[1]) if len(sys.argv) > 1 else 30
-names = sys.argv[2:] or ["helm", "divgs", "schwarz", "gs_dots3", "gs_lag3", "gs_dots8", "gs_lag8", "gs_dots16", "gs_lag16", "gs_dots32", "gs_lag32", "pres_update", "vel_update_proj", "pres_rhs", "rhs", "convect_mfma"]
+names = sys.argv[2:] or ["helm", "divgs", "schwarz", "schwarz_wg", "gs_dots3", "gs_lag3", "gs_dots8", "gs_lag8", "gs_dots16", "gs_lag16", "gs_dots32", "gs_lag32", "pres_update", "vel_update_proj", "pres_rhs", "rhs", "convect_mfma"]
 G = os.path.join(ROOT, "tests", "golden")
 c2 = mesh.load_case_npz(os.path.join(G, "backstep_case.npz"), 8, re=500.0, endtime=1.0, xlspg=5.0, xrspg=10.0, spng_str=2.0)
 c3 = mesh3d.extrude_case(c2, nz, 0.2 * nz, periodic=True)

@@ -27,7 +27,7 @@ rm -rf $OUT/p_eager $OUT/p_fetch $OUT/p_write $OUT/p_graph
 NPROJ=32 rocprofv3 --kernel-trace --stats -d $OUT/p_cfg4 --output-format csv -- python3 $R/scripts/prof_cfg4.py 30 40 4 > $OUT/${T}_cfg4_run.txt 2> $OUT/${T}_cfg4_run.err
 python3 $R/scripts/trace_summary.py $OUT/p_cfg4 --last 0.22 > $OUT/${T}_cfg4_trace_summary.txt
 cat $OUT/${T}_cfg4_run.txt >> $OUT/${T}_cfg4_trace_summary.txt
-K3="helm divgs schwarz gs_dots8 gs_lag8 gs_dots24 gs_lag24 pres_rhs rhs convect_mfma"
+K3="helm divgs schwarz schwarz_wg gs_dots8 gs_lag8 gs_dots24 gs_lag24 pres_rhs rhs convect_mfma"
 REPS=6 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/p_c4f --output-format csv -- python3 $R/scripts/kernels3d_bench.py 30 $K3 > $OUT/${T}_cfg4_kernels_under_pmc.txt 2> $OUT/${T}_cfg4_fetch.err
 REPS=6 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/p_c4w --output-format csv -- python3 $R/scripts/kernels3d_bench.py 30 $K3 > /dev/null 2> $OUT/${T}_cfg4_write.err
 python3 $R/scripts/pmc_summary.py $OUT/p_c4f $OUT/p_c4w $OUT/${T}_cfg4_pmc_fetch_write_per_kernel.json > $OUT/${T}_cfg4_pmc_summary.txt 2>&1
