@@ -84,7 +84,7 @@ struct nsk_ctx {
   int helm_guess = 1;
   int budget_freeze = 0;
   int helm_fdm = -1;                    // hexahedra: element-block fast-diagonalisation preconditioner of the velocity solves (NSK_HELM_FDM=1 builds it; measured slower than Jacobi-CG, off)
-  int eapply_pipe = 2;                  // hexahedra, the E-apply kernels: 0 = one workgroup per element, 1 = resident workgroups with the next element's loads in flight (k_schwarz_p), 2 = one wavefront per element (k_schwarz_w)
+  int eapply_pipe = 4;                  // hexahedra, the Schwarz + D^T kernel: 0 = one workgroup per element, 1 = resident workgroups with the next element's loads in flight (k_schwarz_p), 2 = one wavefront per element (k_schwarz_w), 3 = 2 + k_divgs_w, 4 = one wavefront per element, sixteen per CU (k_schwarz_w16; default, lx1 <= 8)
   int eapply_grid[2] = {0, 0};          // their grid sizes (workgroups that fit the device at once; 0 = not yet asked)
   int flat_proj = -1;                   // hexahedra: once-per-step sums over the GMRES / projection bases as streaming kernels (k_pres_comb, k_proj_dots); -1 = yes on single-rank contexts
   int gs_lag = -1;                      // hexahedra: lagged second Gram-Schmidt correction (k_gs_lag: two basis reads per GMRES column instead of four); -1 = yes on single-rank contexts
@@ -894,7 +894,10 @@ static void launch_schwarz3(nsk_ctx* c, const Dev& d, int count, const double* v
     if (mode < 0) mode = c->eapply_pipe;
     if (mode == 3) mode = 2;                             // (3 = 2 + the divergence kernel in wavefront form: launch_divgs3)
     if (mode == 2 && N > 8 && !std::getenv("NSK_WAVE_LX10")) mode = 0;      // lx1 = 10: 16 nodes per lane, 234 registers: not measured faster
-    if (mode == 2)            // one wavefront per element
+    if (mode == 4 && N > 8) mode = 0;
+    if (mode == 4) {          // one wavefront per element, sixteen per CU (in-place solve, metrics per component)
+      if constexpr (N <= 8) hipLaunchKernelGGL(nsk::k3::k_schwarz_w16<N>, dim3(count), dim3(64), 0, c->stream, d, vin, zout, use_coarse, check_done);
+    } else if (mode == 2)     // one wavefront per element
       hipLaunchKernelGGL(nsk::k3::k_schwarz_w<N>, dim3(count), dim3(64), 0, c->stream, d, vin, zout, use_coarse, check_done);
     else if (mode == 1)       // resident workgroups, next element's loads in flight
       hipLaunchKernelGGL(nsk::k3::k_schwarz_p<N>, dim3(eapply_grid<N>(c, 0, count)), dim3(nsk::k3::Cfg<N>::NT), 0, c->stream, d, vin, zout,
@@ -2554,7 +2557,7 @@ int nsk_bench_kernel(nsk_ctx* c, const char* name, int reps, double* avg_us) {
       for (int r = 0; r < reps; ++r) { HIPCHK(hipMemsetAsync(c->sync, 0, SYNC_WORDS * sizeof(unsigned), c->stream)); launch_fused<N>(c, sc, its, &d); }
       HIPCHK(hipEventRecord(e1, c->stream));
     });
-  } else if (c->ndim == 3 && (n == "divgs" || n == "divgs_w" || n == "schwarz" || n == "schwarz_wg" || n == "schwarz_p" || n == "schwarz_w" || n == "gradt" || n.rfind("gs_lag", 0) == 0 || n.rfind("gs_dots", 0) == 0 || n == "pres_update" || n == "vel_update_proj" || n == "pres_rhs" || n == "rhs")) {
+  } else if (c->ndim == 3 && (n == "divgs" || n == "divgs_w" || n == "schwarz" || n == "schwarz_wg" || n == "schwarz_p" || n == "schwarz_w" || n == "schwarz_w16" || n == "gradt" || n.rfind("gs_lag", 0) == 0 || n.rfind("gs_dots", 0) == 0 || n == "pres_update" || n == "vel_update_proj" || n == "pres_rhs" || n == "rhs")) {
     // hexahedral pressure kernels back to back on the state the last map left: the E apply without its dots ("divgs"), the
     // Schwarz preconditioner + D^T ("schwarz"), the streaming Gram-Schmidt passes at basis index j ("gs_lag<j>", "gs_dots<j>")
     d.tol_pres = 0.0; d.tol_relative = 0; d.pres_cap = 0;
@@ -2574,6 +2577,7 @@ int nsk_bench_kernel(nsk_ctx* c, const char* name, int reps, double* avg_us) {
         else if (n == "schwarz_wg") launch_schwarz3<N>(c, d, c->nblk, (const double*)(d.V + (size_t)jj * d.ps), d.Z + (size_t)jj * d.npr, 1, 0, 0);
         else if (n == "schwarz_p") launch_schwarz3<N>(c, d, c->nblk, (const double*)(d.V + (size_t)jj * d.ps), d.Z + (size_t)jj * d.npr, 1, 0, 1);
         else if (n == "schwarz_w") launch_schwarz3<N>(c, d, c->nblk, (const double*)(d.V + (size_t)jj * d.ps), d.Z + (size_t)jj * d.npr, 1, 0, 2);
+        else if (n == "schwarz_w16") launch_schwarz3<N>(c, d, c->nblk, (const double*)(d.V + (size_t)jj * d.ps), d.Z + (size_t)jj * d.npr, 1, 0, 4);
         else if (n == "gradt") hipLaunchKernelGGL(k_gradt<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, (const double*)c->wp1, d.yl);
         else if (n == "pres_update") hipLaunchKernelGGL(k_pres_update<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, sc);
         else if (n == "vel_update_proj") hipLaunchKernelGGL(k_vel_update_proj<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, sc);

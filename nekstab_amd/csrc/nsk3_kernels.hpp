@@ -1782,6 +1782,72 @@ __global__ __launch_bounds__(64) void k_schwarz_w(Dev d, const double* __restric
   NSK_STAMP(5);
 }
 
+// k_schwarz_w with sixteen elements per CU in flight instead of twelve: the fast-diagonalisation solve in place in ONE tile
+// (fd_solve_inplace_wave), its factors inside the D^T buffer, the metrics loaded per component -> 10 KB of LDS and <= 128 registers.
+template <int N>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_schwarz_w16(Dev d, const double* __restrict__ vin, double* __restrict__ zout,
+                                                                                            int use_coarse, int check_done) {
+  using C = Cfg<N>;
+  using L = PadLay<N>;
+  using S = SlimLay<N>;
+  constexpr int NN = C::NN, M = C::M, MM = C::MM, NM = N * M, NS = 3 * N * N, NSL = NS + 3 * N;
+  constexpr int RN = (NN + 63) / 64, RM = (MM + 63) / 64, RS = (NSL + 63) / 64;
+  constexpr int GBUF = GtWave<N, L>::BUF, FBUF = S::EXT + NSL, BUF = GBUF > FBUF ? GBUF : FBUF;
+  __shared__ double sJ12[NM], sD12[NM], sH[2 * M];
+  __shared__ double buf[BUF];
+  double* sa = buf; double* sSL = buf + S::EXT;                    // tile + factors; afterwards the D^T intermediates (GtWave)
+  const int lane = threadIdx.x;
+  if (check_done && d.gsc->done) return;
+  const long long e = d.boff + xcd_element(blockIdx.x, gridDim.x);
+  int id[RN];
+#pragma unroll
+  for (int r = 0; r < RN; ++r) { const int idx = r * 64 + lane; id[r] = (idx < NN) ? d.p_idx[e * NN + idx] : -1; }
+  double sv[RS];
+#pragma unroll
+  for (int r = 0; r < RS; ++r) {
+    const int idx = r * 64 + lane;
+    sv[r] = (idx < NS) ? d.fdS[(size_t)e * NS + idx] : ((idx < NSL) ? d.fdL[(size_t)e * 3 * N + (idx - NS)] : 0.0);
+  }
+  const double xl = use_coarse ? d.xc[d.evert[e * 8 + (lane & 7)]] : 0.0;
+  load_basis3<N>(d, nullptr, nullptr, sJ12, sD12, lane, 64);
+  if (lane < 2 * M) sH[lane] = d.hat[8 * MM + lane];
+  const double vsc = (d.gs_lag && d.gsc->pending) ? d.gsc->phinv : 1.0;
+  double pv[RN];
+#pragma unroll
+  for (int r = 0; r < RN; ++r) pv[r] = (id[r] >= 0) ? vsc * vin[id[r]] : 0.0;
+#pragma unroll
+  for (int r = 0; r < RS; ++r) { const int idx = r * 64 + lane; if (idx < NSL) sSL[idx] = sv[r]; }
+#pragma unroll
+  for (int r = 0; r < RN; ++r) {
+    const int idx = r * 64 + lane;
+    if (idx < NN) sa[(idx / (N * N)) * S::PS + ((idx / N) % N) * S::RS + (idx % N)] = pv[r];
+  }
+  wave_sync();
+  fd_solve_inplace_wave<N>(sSL, sSL + NS, sa, d.fd_eps, lane);
+  double xv[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) xv[c] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(xl), c), __builtin_amdgcn_readlane(__double2loint(xl), c));
+  double z[RM];
+#pragma unroll
+  for (int r = 0; r < RM; ++r) {
+    const int idx = r * 64 + lane;
+    z[r] = 0.0;
+    if (idx < MM) {
+      const int a = idx % M, bb = (idx / M) % M, cc = idx / (M * M);
+      double zc = 0.0;
+      if (use_coarse) {
+        const double hr[2] = {sH[a], sH[M + a]}, hs[2] = {sH[bb], sH[M + bb]}, ht[2] = {sH[cc], sH[M + cc]};
+#pragma unroll
+        for (int c = 0; c < 8; ++c) zc += ((hr[c & 1] * hs[(c >> 1) & 1]) * ht[c >> 2]) * xv[c];
+      }
+      z[r] = sa[(cc + 1) * S::PS + (bb + 1) * S::RS + (a + 1)] + zc;
+      zout[e * MM + idx] = z[r];
+    }
+  }
+  wave_sync();
+  opgradt3_wave_ld<N, L, RM>(sJ12, sD12, z, d.w2m + e * MM, d.npr, buf, lane, d.yl + e * NN, d.cs);
+}
+
 // yl = D^T p for an arbitrary pressure vector
 template <int N>
 __global__ __launch_bounds__(Cfg<N>::NT) void k_gradt(Dev d, const double* __restrict__ pin, double* __restrict__ yl) {

@@ -389,5 +389,131 @@ __device__ inline void opdiv3_wave_comp(const double (&aDJ)[(N + 3) / 4], const 
   wave_sync();
 }
 
+// ---- slim forms for k_schwarz_w<N, true>: sixteen elements in flight per CU instead of twelve --------------------------------
+// One tile buffer for the fast-diagonalisation solve: a wavefront that owns the tile can run a pass IN PLACE -- every operand read of
+// all tiles is issued before the first store, and the LDS serves a wavefront in order.  One layout for all six passes then
+// (strides (k, j, i) = (PS, RS, 1); at lx1 = 8 (72, 9, 1): 224 LDS cycles per three passes in the bank model against 144 with the
+// per-stage strides of PadLay and 480 compact).
+template <int N> struct SlimLay { static constexpr int PS = N * N, RS = N, EXT = N * N * N; };
+template <> struct SlimLay<8> { static constexpr int PS = 72, RS = 9, EXT = 576; };
+template <int N, class XC, bool FWD, class F>
+__device__ inline void fd_pass_inplace(const double* sSd, double* X, int lane, F&& xform) {
+  constexpr int KQ = (N + 3) / 4, NCOL = N * N, NT16 = (NCOL + 15) / 16, RQ = (N + 3) / 4;
+  const int n16 = lane & 15, kq = lane >> 4;
+  double a[KQ];
+#pragma unroll
+  for (int q = 0; q < KQ; ++q) {
+    const int k = 4 * q + kq;
+    a[q] = (n16 < N && k < N) ? (FWD ? sSd[k * N + n16] : sSd[n16 * N + k]) : 0.0;
+  }
+  double b[NT16][KQ];
+#pragma unroll
+  for (int t = 0; t < NT16; ++t) {
+    const int n = t * 16 + n16;
+    const int cb = (n < NCOL) ? XC::col(n) : 0;
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) {
+      const int k = 4 * q + kq;
+      b[t][q] = (n < NCOL && k < N) ? X[cb + k * XC::ks] : 0.0;
+    }
+  }
+  wave_sync();                                   // every read of the pass has returned before the first store is issued
+#pragma unroll
+  for (int t = 0; t < NT16; ++t) {
+    const int n = t * 16 + n16;
+    mo_d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b[t][q], acc, 0, 0, 0);
+    if (n < NCOL) {
+      const int cb = XC::col(n);
+#pragma unroll
+      for (int r = 0; r < RQ; ++r)
+        if (kq + 4 * r < N) X[cb + (kq + 4 * r) * XC::ks] = xform(acc[r], n, kq + 4 * r);
+    }
+  }
+  wave_sync();
+}
+template <int N>
+__device__ inline void fd_solve_inplace_wave(const double* sS, const double* sL, double* X, double eps, int lane) {
+  using S = SlimLay<N>;
+  typedef Col2<N, S::PS, S::RS, 1> CR;           // columns (k, j): contract i
+  typedef Col2<N, S::PS, 1, S::RS> CS;           // columns (k, i): contract j
+  typedef Col2<N, S::RS, 1, S::PS> CT;           // columns (j, i): contract k
+  auto same = [](double v, int, int) { return v; };
+  fd_pass_inplace<N, CR, true>(sS, X, lane, same);
+  fd_pass_inplace<N, CS, true>(sS + N * N, X, lane, same);
+  fd_pass_inplace<N, CT, true>(sS + 2 * N * N, X, lane, [&](double v, int n, int m) {
+    const double lam = sL[n % N] + sL[N + n / N] + sL[2 * N + m];
+    return (lam > eps) ? v / lam : 0.0;
+  });
+  fd_pass_inplace<N, CT, false>(sS + 2 * N * N, X, lane, same);
+  fd_pass_inplace<N, CS, false>(sS + N * N, X, lane, same);
+  fd_pass_inplace<N, CR, false>(sS, X, lane, same);
+}
+// opgradt3_wave with the metrics of a component loaded when its turn comes (the next component's are in flight under the current
+// one's passes): 24 registers of metrics instead of 72.  wm = the element's first metric, npr = stride between the nine.
+template <int N, class L, int RM>
+__device__ inline void opgradt3_wave_ld(const double* sJ12, const double* sD12, const double (&z)[RM], const double* __restrict__ wm,
+                                        long long npr, double* buf, int lane, double* __restrict__ y, long long cs) {
+  using G = GtWave<N, L>;
+  constexpr int M = N - 2, MM = M * M * M, KQ = (M + 3) / 4;
+  const int m16 = lane & 15, kq = lane >> 4;
+  double aJ[KQ], aD[KQ];
+#pragma unroll
+  for (int q = 0; q < KQ; ++q) {
+    const int k = 4 * q + kq;
+    const bool ok = m16 < N && k < M;
+    aJ[q] = ok ? sJ12[k * N + m16] : 0.0;
+    aD[q] = ok ? sD12[k * N + m16] : 0.0;
+  }
+  typedef ColLinear<M * M> CT;
+  typedef Col2<M, L::C[1], L::C[2], L::C[0]> CT_out;
+  typedef Col2<M, L::C[0], L::C[2], L::C[1]> CS_in;
+  typedef Col2<M, L::E[0], L::E[2], L::E[1]> CS_out;
+  typedef Col2<N, L::E[0], L::E[1], L::E[2]> CR_in;
+  typedef ColRow<N> CR_out;
+  double wn[3][RM];                                      // metrics (axis a, this component) of the component in turn
+  auto load_w = [&](int c) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int r = 0; r < RM; ++r) {
+        const int idx = r * 64 + lane;
+        wn[a][r] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(wm + (size_t)(a * 3 + c) * npr) + (unsigned)(idx < MM ? idx : 0) * 8u);
+      }
+  };
+  load_w(0);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    double p0[RM], p1[RM], p2[RM];
+#pragma unroll
+    for (int r = 0; r < RM; ++r) { p0[r] = z[r] * wn[0][r]; p1[r] = z[r] * wn[1][r]; p2[r] = z[r] * wn[2][r]; }
+    if (c < 2) load_w(c + 1);                              // in flight under this component's passes
+#pragma unroll
+    for (int r = 0; r < RM; ++r) {
+      const int idx = r * 64 + lane;
+      if (idx < MM) { buf[G::oP12 + idx] = p1[r]; buf[G::oP12 + MM + idx] = p2[r]; }
+    }
+    wave_sync();
+    mo_pass<M, KQ, M * M, CT, StLin<CT_out, CT_out::ks, N>, false>(aJ, buf + G::oP12, aJ, buf, buf + G::oC1, 0, 1, lane);
+    mo_pass<M, KQ, M * M, CT, StLin<CT_out, CT_out::ks, N>, false>(aD, buf + G::oP12 + MM, aD, buf, buf + G::oC2, 0, 1, lane);
+    wave_sync();
+    mo_pass<M, KQ, N * M, CS_in, StLin<CS_out, CS_out::ks, N>, true>(aD, buf + G::oC1, aJ, buf + G::oC2, buf + G::oE1, 0, 1, lane);
+    wave_sync();
+#pragma unroll
+    for (int r = 0; r < RM; ++r) {
+      const int idx = r * 64 + lane;
+      if (idx < MM) buf[G::oP0 + idx] = p0[r];
+    }
+    wave_sync();
+    mo_pass<M, KQ, M * M, CT, StLin<CT_out, CT_out::ks, N>, false>(aJ, buf + G::oP0, aJ, buf, buf + G::oC0, 0, 1, lane);
+    wave_sync();
+    mo_pass<M, KQ, N * M, CS_in, StLin<CS_out, CS_out::ks, N>, false>(aJ, buf + G::oC0, aJ, buf, buf + G::oE0, 0, 1, lane);
+    wave_sync();
+    mo_pass<M, KQ, N * N, CR_in, StLin<CR_out, 1, N>, true>(aD, buf + G::oE0, aJ, buf + G::oE1, y + c * cs, 0, 1, lane);
+    wave_sync();
+  }
+}
+
 }  // namespace k3
 }  // namespace nsk

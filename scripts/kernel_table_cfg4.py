@@ -26,7 +26,7 @@ rule, distinct = roofline.helm_launch_bytes(nel=nel, lx1=N, ndim=3)
 stepb = roofline.per_step_bytes(nel=nel, lx1=N, ndim=3, nvert=nvert, nproj=32, helm_iters=0.0, pres_iters=0.0, pres_jsum=0.0, coarse_bytes=0.0)
 alg = {"helm": (distinct, "k3::k_helm<8>", "all arrays of the three components once (SURVEY rule, 172 B/pt and component: %.2f GB)" % (rule / 1e9)),
        "divgs": (one["K7 divgs (x n_pres)"], "k3::k_divgs<8>", "E apply without dots"),
-       "schwarz": (one["K6 schwarz (x n_pres)"] - nel * 8 * 12.0, "k3::k_schwarz_w<8>", "fast-diagonalisation Schwarz + D^T, one wavefront per element"),
+       "schwarz": (one["K6 schwarz (x n_pres)"] - nel * 8 * 12.0, "k3::k_schwarz_w16<8>", "fast-diagonalisation Schwarz + D^T, one wavefront per element, sixteen per CU"),
        "schwarz_wg": (one["K6 schwarz (x n_pres)"] - nel * 8 * 12.0, "k3::k_schwarz<8>", "the same as one workgroup per element (round 3's form; option eapply_pipe = 0)"),
        "pres_rhs": (stepb["K4 pres_rhs"], "k3::k_pres_rhs<8>", "nproj = 32"), "rhs": (stepb["K2 rhs"], "k3::k_rhs<8>", ""),
        "convect_mfma": (stepb["K1 convect"], "k3::k_convect_mfma8", "")}
