@@ -85,6 +85,7 @@ struct nsk_ctx {
   int budget_freeze = 0;
   int helm_fdm = -1;                    // hexahedra: element-block fast-diagonalisation preconditioner of the velocity solves (NSK_HELM_FDM=1 builds it; measured slower than Jacobi-CG, off)
   int eapply_pipe = 4;                  // hexahedra, the Schwarz + D^T kernel: 0 = one workgroup per element, 1 = resident workgroups with the next element's loads in flight (k_schwarz_p), 2 = one wavefront per element (k_schwarz_w), 3 = 2 + k_divgs_w, 4 = one wavefront per element, sixteen per CU (k_schwarz_w16; default, lx1 <= 8)
+  int divgs_c3 = 0;                     // hexahedra: k_divgs with the three components' pass chains side by side (k_divgs_c3: 5 barriers instead of 12; measured 6 % SLOWER at config 4's size, 718 against 678 us: the gather, not the passes, is what a workgroup waits for; kept as an option)
   int eapply_grid[2] = {0, 0};          // their grid sizes (workgroups that fit the device at once; 0 = not yet asked)
   int flat_proj = -1;                   // hexahedra: once-per-step sums over the GMRES / projection bases as streaming kernels (k_pres_comb, k_proj_dots); -1 = yes on single-rank contexts
   int gs_lag = -1;                      // hexahedra: lagged second Gram-Schmidt correction (k_gs_lag: two basis reads per GMRES column instead of four); -1 = yes on single-rank contexts
@@ -908,7 +909,7 @@ static void launch_schwarz3(nsk_ctx* c, const Dev& d, int count, const double* v
 }
 // E apply without the Gram-Schmidt dots (j < 0): one wavefront per element where that form exists (lx1 <= 8), else k_divgs
 template <int N>
-static void launch_divgs3(nsk_ctx* c, const Dev& d, int count, const double* yl, double* wout, int j, int check_done, int mode = -1) {
+static void launch_divgs3(nsk_ctx* c, const Dev& d, int count, const double* yl, double* wout, int j, int check_done, int mode = -1, int c3 = -1) {
   if constexpr (N <= 10) {
     if (mode < 0) mode = c->eapply_pipe;
     if constexpr (N <= 8) {
@@ -920,7 +921,9 @@ static void launch_divgs3(nsk_ctx* c, const Dev& d, int count, const double* yl,
         return;
       }
     }
-    hipLaunchKernelGGL(nsk::k3::k_divgs<N>, dim3(count), dim3(nsk::k3::Cfg<N>::NT), 0, c->stream, d, yl, wout, j, check_done);
+    if (c3 < 0) c3 = c->divgs_c3;
+    if (c3) hipLaunchKernelGGL(nsk::k3::k_divgs_c3<N>, dim3(count), dim3(nsk::k3::Cfg<N>::NT), 0, c->stream, d, yl, wout, j, check_done);
+    else hipLaunchKernelGGL(nsk::k3::k_divgs<N>, dim3(count), dim3(nsk::k3::Cfg<N>::NT), 0, c->stream, d, yl, wout, j, check_done);
   }
 }
 template <int N>
@@ -1047,7 +1050,8 @@ static int pres_solve_launch(nsk_ctx* c, double h2, int ord, int np, double tol_
         launch_divgs3<N>(c, d, c->nblk, (const double*)d.yl, d.V + (size_t)(j + 1) * d.ps, -1, 1);
         launch_gs_dots3<N>(c, d, j);
       } else {
-        hipLaunchKernelGGL(k_divgs<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, (const double*)d.yl, d.V + (size_t)(j + 1) * d.ps, j, 1);
+        if (c->ndim == 3) launch_divgs3<N>(c, d, c->nblk, (const double*)d.yl, d.V + (size_t)(j + 1) * d.ps, j, 1);
+        else hipLaunchKernelGGL(k_divgs<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, (const double*)d.yl, d.V + (size_t)(j + 1) * d.ps, j, 1);
       }
       tot_rows(c, d.gpart, j + 2, d.gtot, &d.gsc->done);
       if (lag) {
@@ -1905,6 +1909,7 @@ int nsk_set_option(nsk_ctx* c, const char* name, double value) {
   else if (n == "gs2_from") c->gs2_from = std::max(0, (int)value);
   else if (n == "gs_lag") c->gs_lag = (int)value;
   else if (n == "flat_proj") c->flat_proj = (int)value;
+  else if (n == "divgs_c3") { c->divgs_c3 = (int)value; for (auto& a : c->graphs) for (auto& g : a) g.nh = -1; }
   else if (n == "eapply_pipe") { c->eapply_pipe = (int)value; for (auto& a : c->graphs) for (auto& g : a) g.nh = -1; }
   else if (n == "helm_fdm") {           // 0: back to Jacobi (the factors stay); 1: only if the set-up built them (NSK_HELM_FDM=1 or an anisotropic mesh)
     if (value != 0.0 && !c->d.hfS) return fail(NSK_EINVAL, "helm_fdm: the fast-diagonalisation factors were not built at set-up (NSK_HELM_FDM=1)");
@@ -2557,7 +2562,7 @@ int nsk_bench_kernel(nsk_ctx* c, const char* name, int reps, double* avg_us) {
       for (int r = 0; r < reps; ++r) { HIPCHK(hipMemsetAsync(c->sync, 0, SYNC_WORDS * sizeof(unsigned), c->stream)); launch_fused<N>(c, sc, its, &d); }
       HIPCHK(hipEventRecord(e1, c->stream));
     });
-  } else if (c->ndim == 3 && (n == "divgs" || n == "divgs_w" || n == "schwarz" || n == "schwarz_wg" || n == "schwarz_p" || n == "schwarz_w" || n == "schwarz_w16" || n == "gradt" || n.rfind("gs_lag", 0) == 0 || n.rfind("gs_dots", 0) == 0 || n == "pres_update" || n == "vel_update_proj" || n == "pres_rhs" || n == "rhs")) {
+  } else if (c->ndim == 3 && (n == "divgs" || n == "divgs_wg" || n == "divgs_w" || n == "divgs_c3" || n == "schwarz" || n == "schwarz_wg" || n == "schwarz_p" || n == "schwarz_w" || n == "schwarz_w16" || n == "gradt" || n.rfind("gs_lag", 0) == 0 || n.rfind("gs_dots", 0) == 0 || n == "pres_update" || n == "vel_update_proj" || n == "pres_rhs" || n == "rhs")) {
     // hexahedral pressure kernels back to back on the state the last map left: the E apply without its dots ("divgs"), the
     // Schwarz preconditioner + D^T ("schwarz"), the streaming Gram-Schmidt passes at basis index j ("gs_lag<j>", "gs_dots<j>")
     d.tol_pres = 0.0; d.tol_relative = 0; d.pres_cap = 0;
@@ -2571,8 +2576,10 @@ int nsk_bench_kernel(nsk_ctx* c, const char* name, int reps, double* avg_us) {
       constexpr int NT = Cfg<N>::NT;
       for (int r = -3; r < reps; ++r) {
         if (r == 0) HIPCHK(hipEventRecord(e0, c->stream));
-        if (n == "divgs") hipLaunchKernelGGL(k_divgs<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, (const double*)d.yl, c->wp2, -1, 0);
+        if (n == "divgs") launch_divgs3<N>(c, d, c->nblk, (const double*)d.yl, c->wp2, -1, 0, 0);                 // the form the context runs
+        else if (n == "divgs_wg") launch_divgs3<N>(c, d, c->nblk, (const double*)d.yl, c->wp2, -1, 0, 0, 0);
         else if (n == "divgs_w") launch_divgs3<N>(c, d, c->nblk, (const double*)d.yl, c->wp2, -1, 0, 3);
+        else if (n == "divgs_c3") launch_divgs3<N>(c, d, c->nblk, (const double*)d.yl, c->wp2, -1, 0, 0, 1);
         else if (n == "schwarz") launch_schwarz3<N>(c, d, c->nblk, (const double*)(d.V + (size_t)jj * d.ps), d.Z + (size_t)jj * d.npr, 1, 0);      // the form the context runs
         else if (n == "schwarz_wg") launch_schwarz3<N>(c, d, c->nblk, (const double*)(d.V + (size_t)jj * d.ps), d.Z + (size_t)jj * d.npr, 1, 0, 0);
         else if (n == "schwarz_p") launch_schwarz3<N>(c, d, c->nblk, (const double*)(d.V + (size_t)jj * d.ps), d.Z + (size_t)jj * d.npr, 1, 0, 1);

@@ -1920,6 +1920,53 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_divgs(Dev d, const double* __res
   }
 }
 
+// k_divgs with the three components' pass chains side by side (opdiv3_mfma_c3): 5 workgroup barriers after the gather instead of 12
+template <int N>
+__global__ __launch_bounds__(Cfg<N>::NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_divgs_c3(Dev d, const double* __restrict__ yl,
+                                                         double* __restrict__ wout, int j, int check_done) {
+  using C = Cfg<N>;
+  using W = DvWave<N>;
+  constexpr int NN = C::NN, M = C::M, MM = C::MM, NT = C::NT, NM = N * M;
+  __shared__ double sJ12[NM], sD12[NM];
+  __shared__ double buf[3 * W::BUF];
+  static_assert((MAXMR + 2) * 16 <= 3 * W::BUF, "the dot partials reuse the buffer");
+  double* sdot = buf;
+  const int tid = threadIdx.x;
+  const long long e = d.boff + xcd_element(blockIdx.x, gridDim.x);
+  const bool act = tid < NN;
+  if (check_done && d.gsc->done) return;
+  const long long l = e * NN + tid;
+  load_basis3<N>(d, nullptr, nullptr, sJ12, sD12, tid, NT);
+  if (act) {
+    CornerList CL;
+    corner_issue(d, e, corner_id<N>(tid / (N * N), (tid / N) % N, tid % N), CL);
+    const int4 tab = *reinterpret_cast<const int4*>(reinterpret_cast<const char*>(d.gs_tab + e * NN) + (unsigned)tid * 16u);
+    const double bi = ld_boff(d.binv + e * NN, (unsigned)tid * 8u);
+    const unsigned lu = (unsigned)l;
+    GsVals g0 = gs_load_o(yl, tab, lu), g1 = gs_load_o(yl + d.cs, tab, lu), g2 = gs_load_o(yl + 2 * d.cs, tab, lu);
+    buf[W::oU + tid] = bi * gs_sum3(g0, yl, d, tab, l, CL);
+    buf[W::BUF + W::oU + tid] = bi * gs_sum3(g1, yl + d.cs, d, tab, l, CL);
+    buf[2 * W::BUF + W::oU + tid] = bi * gs_sum3(g2, yl + 2 * d.cs, d, tab, l, CL);
+  }
+  const bool pact = tid < MM;
+  const long long q = e * MM + tid;
+  lds_barrier();
+  const double w = opdiv3_mfma_c3<N>(d, e, sJ12, sD12, buf, tid, NT);
+  if (pact) wout[q] = w;
+  if (j >= 0) {
+    const int lane = tid & 63, wv = tid >> 6;
+    lds_barrier();                                         // (the partial sums above are read; sdot reuses the buffer)
+    basis_dots<N>(d, w, pact, q, j, lane, wv, sdot);
+    lds_barrier();
+    if (tid <= j + 1) {
+      double t = 0.0;
+#pragma unroll
+      for (int ww = 0; ww < (MM + 63) / 64; ++ww) t += sdot[tid * 16 + ww];
+      d.gpart[(size_t)tid * d.nblk + e] = t;
+    }
+  }
+}
+
 // k_divgs (without the Gram-Schmidt dots: the lagged Gram-Schmidt has them in k_gs_dots) with ONE WAVEFRONT PER ELEMENT, as
 // k_schwarz_w: no workgroup barrier, eight nodes per lane in the gather, the three passes of a component unrolled with constant
 // LDS offsets, the last pass combined with the metrics in the matrix-core accumulators (no staging tile), 11-12 elements per CU.

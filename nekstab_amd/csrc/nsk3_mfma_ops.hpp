@@ -515,5 +515,73 @@ __device__ inline void opgradt3_wave_ld(const double* sJ12, const double* sD12, 
   }
 }
 
+// Weak divergence with the THREE COMPONENTS' pass chains running side by side (k_divgs_c3): waves w, w + 3, ... of the workgroup own
+// component w % 3 and its buffer region (DvWave's regions: 3 x 10.5 KB at lx1 = 8), so the workgroup meets at 5 barriers instead
+// of 12 and every pass has three times the tiles to spread over the waves.  The last pass stays in the accumulators and is
+// combined with the metrics there (read in accumulator order by the wave that owns the tile); the three components' partial sums
+// meet in LDS.  buf: 3 regions of DvWave<N>::BUF doubles, component c gathered at region c + oU.  Returns the value of Gauss node tid.
+template <int N> constexpr int nt_min_sub() { return ((((N * N * N + 63) / 64)) / 3) < 1 ? 1 : (((N * N * N + 63) / 64)) / 3; }   // fewest waves a component gets
+template <int N>
+__device__ inline double opdiv3_mfma_c3(const Dev& d, long long e, const double* sJ12, const double* sD12, double* buf, int tid, int nt) {
+  using W = DvWave<N>;
+  constexpr int M = N - 2, MM = M * M * M, KQ = (N + 3) / 4, oPart = W::B;      // partial sums: [B, B + M^3) of the region (free after the s-axis)
+  static_assert(W::B + MM <= 2 * W::A, "partial sums inside the dead sA tiles");
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = nt >> 6, m16 = lane & 15, kq = lane >> 4;
+  const int comp = wave % 3, sub = wave / 3, nsub = (nw - comp + 2) / 3;
+  double* rb = buf + comp * W::BUF;
+  double aDJ[KQ], aJ[KQ];
+#pragma unroll
+  for (int q = 0; q < KQ; ++q) {
+    const int k = 4 * q + kq;
+    const bool kok = k < N;
+    aJ[q] = (m16 < M && kok) ? sJ12[m16 * N + k] : 0.0;
+    aDJ[q] = !kok ? 0.0 : ((m16 < M) ? sD12[m16 * N + k] : ((m16 < 2 * M) ? sJ12[(m16 - M) * N + k] : 0.0));
+  }
+  typedef ColRow<N> CR_in;
+  typedef ColRow<M> CR_out;
+  typedef ColPlane<M, N * M, M> CS_in;
+  typedef ColPlane<M, M * M, M> CS_out;
+  typedef ColLinear<M * M> CT;
+  // metrics of this wave's tiles of the last pass, in accumulator order; issued now, consumed after the three passes
+  constexpr int TPW = (W::NT3 + (nt_min_sub<N>()) - 1) / nt_min_sub<N>();
+  double wa[TPW][W::RQ], wb[TPW][W::RQ], wc[TPW][W::RQ];
+#pragma unroll
+  for (int u = 0; u < TPW; ++u)
+#pragma unroll
+    for (int r = 0; r < W::RQ; ++r) {
+      const int t = sub + u * nsub, n = t * 16 + m16, cc = kq + 4 * r;
+      const bool ok = t < W::NT3 && n < M * M && cc < M;
+      const size_t q = (size_t)e * MM + (ok ? cc * M * M + n : 0);
+      wa[u][r] = d.w2m[(size_t)(0 * 3 + comp) * d.npr + q];
+      wb[u][r] = d.w2m[(size_t)(1 * 3 + comp) * d.npr + q];
+      wc[u][r] = d.w2m[(size_t)(2 * 3 + comp) * d.npr + q];
+    }
+  mo_pass<N, KQ, N * N, CR_in, StSplit<CR_out, 1, M, W::oA1 - W::oA0>, false>(aDJ, rb + W::oU, aDJ, rb, rb + W::oA0, sub, nsub, lane);
+  lds_barrier();
+  mo_pass<N, KQ, N * M, CS_in, StLin<CS_out, M, M>, false>(aJ, rb + W::oA0, aJ, rb, rb + W::oB0, sub, nsub, lane);
+  lds_barrier();                                 // (sB_1 lands where sA_0 was: every wave is done reading it)
+  mo_pass<N, KQ, N * M, CS_in, StSplit<CS_out, M, M, W::oB2 - W::oB1>, false>(aDJ, rb + W::oA1, aDJ, rb, rb + W::oB1, sub, nsub, lane);
+  lds_barrier();
+  double aD[KQ];                                 // D12 alone = the first M rows of the stacked fragment
+#pragma unroll
+  for (int q = 0; q < KQ; ++q) aD[q] = (m16 < M) ? aDJ[q] : 0.0;
+#pragma unroll
+  for (int u = 0; u < TPW; ++u) {
+    const int t = sub + u * nsub;
+    if (t < W::NT3) {
+      const mo_d4 ur = mo_tile<N, KQ, CT>(aJ, rb + W::oB0, t, M * M, lane);
+      const mo_d4 us = mo_tile<N, KQ, CT>(aJ, rb + W::oB1, t, M * M, lane);
+      const mo_d4 ut = mo_tile<N, KQ, CT>(aD, rb + W::oB2, t, M * M, lane);
+#pragma unroll
+      for (int r = 0; r < W::RQ; ++r) {
+        const int n = t * 16 + m16, cc = kq + 4 * r;
+        if (n < M * M && cc < M) rb[oPart + cc * M * M + n] = wa[u][r] * ur[r] + wb[u][r] * us[r] + wc[u][r] * ut[r];
+      }
+    }
+  }
+  lds_barrier();
+  return (tid < MM) ? (buf[oPart + tid] + buf[W::BUF + oPart + tid]) + buf[2 * W::BUF + oPart + tid] : 0.0;
+}
+
 }  // namespace k3
 }  // namespace nsk

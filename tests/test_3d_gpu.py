@@ -594,6 +594,7 @@ def test_schwarz_kernel_forms_agree(lx1, outflow):
         h = _hip(c, max_pres_iter=96)
         try:
             h.set_option("eapply_pipe", form)
+            h.set_option("divgs_c3", 1 if form == 1 else 0)          # (the divergence kernel with its components side by side rides along with form 1)
             xs, it = h.t_pres_solve(g)
             sol[form], its[form] = (xs if outflow else xs - xs.mean()), it
             a, b = h.alloc(2)
