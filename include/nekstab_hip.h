@@ -94,7 +94,7 @@ int nsk_set_tolerances(nsk_ctx* ctx, double tol_helm, double tol_pres, int relat
  * "gmres_cycle" (the pressure GMRES restarts after this many iterations, default and maximum 48; `max_pres_iter` may be up to 4 x 48),
  * "mfma_convect" (hexahedra, lx1 = 8: convection contractions on v_mfma_f64_16x16x4_f64, default 1),
  * "merged_update" / "merged_iters" (quadrilaterals with the dense in-LDS coarse solve: the GMRES column bookkeeping runs inside
- * the coarse-solve kernel for the first `merged_iters` iterations of a solve, default 1 / 12; same iteration counts and results to
+ * the coarse-solve kernel for the first `merged_iters` iterations of a solve, default 1 / 24; same iteration counts and results to
  * rounding as the classic four-kernel iteration), "shard_graph" / "shard_hostcheck" / "halo_overlap" (shard contexts, see
  * nsk_shard_release_parent and nsk_shard_elems below), "hostcheck" (full-mesh contexts: eager time steps in which the host reads
  * the device's convergence flags and stops issuing solver iterations -- no launch budgets, no redone maps; -1 = default: yes on
@@ -103,6 +103,14 @@ int nsk_set_tolerances(nsk_ctx* ctx, double tol_helm, double tol_pres, int relat
  * rounds-1-2 policy of merging into the oldest slot, kept for A/B runs), "gs2_from" (quadrilaterals: GMRES columns from this
  * iteration of a cycle on get a second Gram-Schmidt pass, default 48 = never; hexahedra always), "orth_overlap" (RCCL ranks: nsk_orth
  * all-reduces its coefficients in chunks on a second stream while the next chunk's dots are computed, default 1),
+ * "gs_lag" (hexahedra: lagged second Gram-Schmidt correction of the pressure GMRES, two basis reads per column instead of four;
+ * -1 = default: on for single-rank contexts; 0 / 1 / 2), "flat_proj" (hexahedra: once-per-step sums over the bases as streaming
+ * kernels; -1 = default: on for single-rank contexts), "eapply_pipe" (hexahedra, form of the Schwarz + D^T kernel: 0 = one
+ * workgroup per element, 1 = resident workgroups, 2 = one wavefront per element, 3 = 2 + the divergence kernel in that form,
+ * 4 = default at lx1 <= 8: one wavefront per element, sixteen per CU; same results to rounding: DESIGN.md section 4.3),
+ * "divgs_c3" (hexahedra: divergence kernel with its components side by side, default 0: measured slower), "helm_fdm" (hexahedra:
+ * element-block fast-diagonalisation preconditioner of the velocity solves, default 0: measured slower), "graph_steps" (time steps
+ * per captured graph of the last step class, default 1),
  * "budget_freeze" / "budget_add_helm" / "budget_add_pres" (measurement switches of scripts/noop_cost.py),
  * "dbg_max_order" / "dbg_ab2" / "dbg_pext" (time-scheme sensitivity switches of scripts/wake_bisect.py; defaults = SURVEY App. A),
  * "dbg" (developer ablation mask) */

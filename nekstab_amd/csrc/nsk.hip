@@ -104,7 +104,7 @@ struct nsk_ctx {
   struct StepGraph { hipGraphExec_t exec = nullptr; int nh = -1, np = -1; } graphs[3][NCLS + 1];
   int graph_steps = 1;                  // (measured on config 2: 11.79 / 11.80 / 11.84 matvecs/s at 1 / 8 / 16 steps per graph: within noise, off)
   std::vector<nsk_ctx*> graph_members;  // sharded step graphs (held by the first rank of a process): the ranks they were captured for
-  int merged_iters = 12;                // ... for the first merged_iters iterations of a solve (see pres_solve_launch)
+  int merged_iters = 24;                // ... for the first merged_iters iterations of a solve (see pres_solve_launch; 12 until round 4: 24 covers the tightened solves of time steps 1-3 too, +2 % on config 2 at identical iteration counts)
   int merged_update = 1;                // GMRES column bookkeeping inside the coarse-solve kernel (k_update_coarse)
   double* kacc = nullptr;               // nsk_orth: coefficients accumulated over the two passes + the squared norm (device)
   bool released = false;                // nsk_shard_release_parent: only the arrays shards share are left on the device
@@ -1009,7 +1009,7 @@ static int pres_solve_launch(nsk_ctx* c, double h2, int ord, int np, double tol_
     if (d.nproj_max > 0 && !c->in_test) { hipLaunchKernelGGL(k_proj_apply, dim3(c->nblk), dim3(256), 0, c->stream, d); tot_rows(c, d.gpart, 1, d.gtot); }
     hipLaunchKernelGGL(k_gmres_update<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, -1, scale, c->min_pres, ord);
     // merged bookkeeping (k_update_coarse): quadrilateral single-rank contexts with the dense in-LDS coarse solve.
-    // Only the first `merged_iters` (12) iterations of a solve: x_c(v_j) by linearity is a recurrence, its rounding error grows by
+    // Only the first `merged_iters` (24) iterations of a solve: x_c(v_j) by linearity is a recurrence, its rounding error grows by
     // ~|h_jj / h_{j+1,j}| per iteration (harmless in a preconditioner for a dozen iterations, a stalled solve after forty:
     // measured on the 1e-8 solves of test_newton_gpu); later iterations take the classic four kernels.
     const bool merged = c->merged_update && c->ndim == 2 && d.coarse_lda <= 3072 && !d.use_tot && d.nranks <= 1 && d.rch && !hc;
