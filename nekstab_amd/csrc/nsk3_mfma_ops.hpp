@@ -389,6 +389,59 @@ __device__ inline void opdiv3_wave_comp(const double (&aDJ)[(N + 3) / 4], const 
   wave_sync();
 }
 
+// ---- passes on v_mfma_f64_4x4x4_4b_f64 (four independent 4x4x4 blocks per instruction) ----------------------------------------
+// Timed on the MI355X (scripts/mfma_f64_rate.hip): 69 TFLOP/s against 49 for v_mfma_f64_16x16x4_f64 (and 54 for v_fma_f64) -- and a
+// 4-row block wastes nothing on an 8-row operator where the 16-row tile is half empty: 2.1x fewer flops issued at 1.4x the rate.
+// Operand layout, found by experiment (scripts/mfma_f64_4x4_layout.hip): A[b][i][k] in lane i + 4 b + 16 k, B[b][k][j] in lane
+// j + 4 b + 16 k, D[b][i][j] in lane j + 4 b + 16 i.  With the four blocks b = four groups of four columns and the SAME A in each,
+// B and D sit exactly where the 16x16x4 form has them (column lane & 15, k resp. row lane >> 4): one instruction per 4-row block
+// of the operator replaces one 16x16x4 instruction, the callers' column maps and stores do not change.
+// Used by the wavefront-per-element Schwarz kernel (k_schwarz_w16: 470 -> 422-434 us at config 4's size), which had reached 90 % of
+// the 16x16x4 rate.  NOT by the workgroup-per-element kernels (opgradt3_mfma, opdiv3_mfma, k_convect_mfma8): measured there, the
+// extra fragment registers cost a workgroup per CU (k_divgs<8> 61 -> 74 VGPRs, 675 -> 762 us; k_convect_mfma8 2.8 -> 4.1 ms).
+template <int KQ, int RB> struct Frag4 { double a[RB][KQ]; };
+template <int KQ, int RB, class F>
+__device__ inline Frag4<KQ, RB> make_frag4(int lane, F&& elem) {      // elem(row, k): the operator, zero outside its range
+  Frag4<KQ, RB> f;
+  const int i = lane & 3, kq = lane >> 4;
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) f.a[rb][q] = elem(rb * 4 + i, 4 * q + kq);
+  return f;
+}
+template <int K, int KQ, int RB, int NCOL, class XC, class ST, bool TWO>
+__device__ inline void mo_pass4(const Frag4<KQ, RB>& a1, const double* X1, const Frag4<KQ, RB>& a2, const double* X2, double* OUT,
+                                int wave, int nwaves, int lane) {
+  const int n16 = lane & 15, kq = lane >> 4;
+  constexpr int NT16 = (NCOL + 15) / 16;
+  for (int tile = wave; tile < NT16; tile += nwaves) {
+    const int n = tile * 16 + n16;
+    const bool nok = n < NCOL;
+    const int cb = nok ? XC::col(n) : 0;
+    double acc[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) acc[rb] = 0.0;
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) {
+      const int k = 4 * q + kq;
+      const bool ok = nok && k < K;
+      const double b1 = ok ? X1[cb + k * XC::ks] : 0.0;
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) acc[rb] = __builtin_amdgcn_mfma_f64_4x4x4f64(a1.a[rb][q], b1, acc[rb], 0, 0, 0);
+      if (TWO) {
+        const double b2 = ok ? X2[cb + k * XC::ks] : 0.0;
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) acc[rb] = __builtin_amdgcn_mfma_f64_4x4x4f64(a2.a[rb][q], b2, acc[rb], 0, 0, 0);
+      }
+    }
+    if (nok) {
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) ST::store(OUT, n, kq + 4 * rb, acc[rb]);
+    }
+  }
+}
+
 // ---- slim forms for k_schwarz_w<N, true>: sixteen elements in flight per CU instead of twelve --------------------------------
 // One tile buffer for the fast-diagonalisation solve: a wavefront that owns the tile can run a pass IN PLACE -- every operand read of
 // all tiles is issued before the first store, and the LDS serves a wavefront in order.  One layout for all six passes then
@@ -398,14 +451,10 @@ template <int N> struct SlimLay { static constexpr int PS = N * N, RS = N, EXT =
 template <> struct SlimLay<8> { static constexpr int PS = 72, RS = 9, EXT = 576; };
 template <int N, class XC, bool FWD, class F>
 __device__ inline void fd_pass_inplace(const double* sSd, double* X, int lane, F&& xform) {
-  constexpr int KQ = (N + 3) / 4, NCOL = N * N, NT16 = (NCOL + 15) / 16, RQ = (N + 3) / 4;
+  constexpr int KQ = (N + 3) / 4, NCOL = N * N, NT16 = (NCOL + 15) / 16, RB = (N + 3) / 4;
   const int n16 = lane & 15, kq = lane >> 4;
-  double a[KQ];
-#pragma unroll
-  for (int q = 0; q < KQ; ++q) {
-    const int k = 4 * q + kq;
-    a[q] = (n16 < N && k < N) ? (FWD ? sSd[k * N + n16] : sSd[n16 * N + k]) : 0.0;
-  }
+  // forward: A(m, k) = S[k][m] (S^T);  back: A(m, k) = S[m][k]
+  const Frag4<KQ, RB> a = make_frag4<KQ, RB>(lane, [&](int mrow, int k) { return (mrow < N && k < N) ? (FWD ? sSd[k * N + mrow] : sSd[mrow * N + k]) : 0.0; });
   double b[NT16][KQ];
 #pragma unroll
   for (int t = 0; t < NT16; ++t) {
@@ -421,14 +470,18 @@ __device__ inline void fd_pass_inplace(const double* sSd, double* X, int lane, F
 #pragma unroll
   for (int t = 0; t < NT16; ++t) {
     const int n = t * 16 + n16;
-    mo_d4 acc = {0.0, 0.0, 0.0, 0.0};
+    double acc[RB];
 #pragma unroll
-    for (int q = 0; q < KQ; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b[t][q], acc, 0, 0, 0);
+    for (int rb = 0; rb < RB; ++rb) acc[rb] = 0.0;
+#pragma unroll
+    for (int q = 0; q < KQ; ++q)
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) acc[rb] = __builtin_amdgcn_mfma_f64_4x4x4f64(a.a[rb][q], b[t][q], acc[rb], 0, 0, 0);
     if (n < NCOL) {
       const int cb = XC::col(n);
 #pragma unroll
-      for (int r = 0; r < RQ; ++r)
-        if (kq + 4 * r < N) X[cb + (kq + 4 * r) * XC::ks] = xform(acc[r], n, kq + 4 * r);
+      for (int rb = 0; rb < RB; ++rb)
+        if (kq + 4 * rb < N) X[cb + (kq + 4 * rb) * XC::ks] = xform(acc[rb], n, kq + 4 * rb);
     }
   }
   wave_sync();
@@ -457,15 +510,10 @@ __device__ inline void opgradt3_wave_ld(const double* sJ12, const double* sD12, 
                                         long long npr, double* buf, int lane, double* __restrict__ y, long long cs) {
   using G = GtWave<N, L>;
   constexpr int M = N - 2, MM = M * M * M, KQ = (M + 3) / 4;
-  const int m16 = lane & 15, kq = lane >> 4;
-  double aJ[KQ], aD[KQ];
-#pragma unroll
-  for (int q = 0; q < KQ; ++q) {
-    const int k = 4 * q + kq;
-    const bool ok = m16 < N && k < M;
-    aJ[q] = ok ? sJ12[k * N + m16] : 0.0;
-    aD[q] = ok ? sD12[k * N + m16] : 0.0;
-  }
+  constexpr int RB = (N + 3) / 4;
+  // fragments of J12^T and D12^T (N x M, zero padded): A[m][k] = J12[k][m]
+  const Frag4<KQ, RB> aJ = make_frag4<KQ, RB>(lane, [&](int mrow, int k) { return (mrow < N && k < M) ? sJ12[k * N + mrow] : 0.0; });
+  const Frag4<KQ, RB> aD = make_frag4<KQ, RB>(lane, [&](int mrow, int k) { return (mrow < N && k < M) ? sD12[k * N + mrow] : 0.0; });
   typedef ColLinear<M * M> CT;
   typedef Col2<M, L::C[1], L::C[2], L::C[0]> CT_out;
   typedef Col2<M, L::C[0], L::C[2], L::C[1]> CS_in;
@@ -495,10 +543,10 @@ __device__ inline void opgradt3_wave_ld(const double* sJ12, const double* sD12, 
       if (idx < MM) { buf[G::oP12 + idx] = p1[r]; buf[G::oP12 + MM + idx] = p2[r]; }
     }
     wave_sync();
-    mo_pass<M, KQ, M * M, CT, StLin<CT_out, CT_out::ks, N>, false>(aJ, buf + G::oP12, aJ, buf, buf + G::oC1, 0, 1, lane);
-    mo_pass<M, KQ, M * M, CT, StLin<CT_out, CT_out::ks, N>, false>(aD, buf + G::oP12 + MM, aD, buf, buf + G::oC2, 0, 1, lane);
+    mo_pass4<M, KQ, RB, M * M, CT, StLin<CT_out, CT_out::ks, N>, false>(aJ, buf + G::oP12, aJ, buf, buf + G::oC1, 0, 1, lane);
+    mo_pass4<M, KQ, RB, M * M, CT, StLin<CT_out, CT_out::ks, N>, false>(aD, buf + G::oP12 + MM, aD, buf, buf + G::oC2, 0, 1, lane);
     wave_sync();
-    mo_pass<M, KQ, N * M, CS_in, StLin<CS_out, CS_out::ks, N>, true>(aD, buf + G::oC1, aJ, buf + G::oC2, buf + G::oE1, 0, 1, lane);
+    mo_pass4<M, KQ, RB, N * M, CS_in, StLin<CS_out, CS_out::ks, N>, true>(aD, buf + G::oC1, aJ, buf + G::oC2, buf + G::oE1, 0, 1, lane);
     wave_sync();
 #pragma unroll
     for (int r = 0; r < RM; ++r) {
@@ -506,11 +554,11 @@ __device__ inline void opgradt3_wave_ld(const double* sJ12, const double* sD12, 
       if (idx < MM) buf[G::oP0 + idx] = p0[r];
     }
     wave_sync();
-    mo_pass<M, KQ, M * M, CT, StLin<CT_out, CT_out::ks, N>, false>(aJ, buf + G::oP0, aJ, buf, buf + G::oC0, 0, 1, lane);
+    mo_pass4<M, KQ, RB, M * M, CT, StLin<CT_out, CT_out::ks, N>, false>(aJ, buf + G::oP0, aJ, buf, buf + G::oC0, 0, 1, lane);
     wave_sync();
-    mo_pass<M, KQ, N * M, CS_in, StLin<CS_out, CS_out::ks, N>, false>(aJ, buf + G::oC0, aJ, buf, buf + G::oE0, 0, 1, lane);
+    mo_pass4<M, KQ, RB, N * M, CS_in, StLin<CS_out, CS_out::ks, N>, false>(aJ, buf + G::oC0, aJ, buf, buf + G::oE0, 0, 1, lane);
     wave_sync();
-    mo_pass<M, KQ, N * N, CR_in, StLin<CR_out, 1, N>, true>(aD, buf + G::oE0, aJ, buf + G::oE1, y + c * cs, 0, 1, lane);
+    mo_pass4<M, KQ, RB, N * N, CR_in, StLin<CR_out, 1, N>, true>(aD, buf + G::oE0, aJ, buf + G::oE1, y + c * cs, 0, 1, lane);
     wave_sync();
   }
 }
