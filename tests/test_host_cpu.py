@@ -399,3 +399,38 @@ def test_local_setup_exchange_over_gloo(tmp_path):
                          capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-2000:]
     assert out.stdout.count("ok") == 2
+
+
+def test_lds_stride_table_of_the_matrix_core_passes_is_conflict_free_in_the_bank_model():
+    """PadLay<8> (nekstab_amd/csrc/nsk3_mfma_ops.hpp): the per-stage LDS strides of the wavefront-per-element Schwarz kernel,
+    checked against the bank model they were searched with (scripts/lds_bank_search.py: ds_read_b64 in two 32-lane groups over
+    64 banks, ds_write_b64 in four 16-lane groups over 32 banks).  Every stage of the fast-diagonalisation tile costs its ideal
+    cycle count or one group more; the compact strides cost 2-4 times as much."""
+    import importlib.util, re
+    spec = importlib.util.spec_from_file_location("lds_bank_search", os.path.join(ROOT, "scripts", "lds_bank_search.py"))
+    bank = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bank)
+    src = open(os.path.join(ROOT, "nekstab_amd", "csrc", "nsk3_mfma_ops.hpp")).read()
+    blk = src[src.index("template <> struct PadLay<8>"):]
+    F = re.search(r"F\[7\]\[3\] = \{(.*?)\};", blk, re.S).group(1)
+    strides = [tuple(int(x) for x in t.split(",")) for t in re.findall(r"\{([^{}]+)\}", F)]
+    assert len(strides) == 7
+    T, M = (8, 8, 8), 6
+    def cost(s, wkind, rkind, sub=None):
+        c = 0
+        if wkind == "lin": c += bank.lin_w(bank.lin_addr(T, s))
+        else:
+            cols, ms, MR = bank.cols_for(wkind, T, s); c += bank.wr(MR, cols, ms)
+        if rkind == "lin": c += bank.lin_r(bank.lin_addr(T, s, sub))
+        else:
+            cols, ks, K = bank.cols_for(rkind, T, s); c += bank.rd(K, cols, ks)
+        return c
+    stages = [("lin", "r"), ("r", "s"), ("s", "t"), ("t", "t"), ("t", "s"), ("s", "r"), ("r", "lin")]
+    compact = (64, 8, 1)
+    tot_pad = tot_cmp = 0
+    for st, (w, r) in zip(strides, stages):
+        assert bank.injective(T, st, 640)
+        sub = (1, (M, M, M)) if r == "lin" else None
+        tot_pad += cost(st, w, r, sub); tot_cmp += cost(compact, w, r, sub)
+    print("LDS cycles of one fast-diagonalisation solve in the bank model: padded", tot_pad, "compact", tot_cmp)
+    assert tot_pad <= 370 and tot_cmp >= 2.5 * tot_pad
