@@ -32,13 +32,16 @@ contains
     real(c_double), intent(in), optional :: sampling_period
     integer, intent(in), optional :: nsteps
     logical, intent(in), optional :: ifres
-    real(c_double) :: hcol(ksize), beta
+    real(c_double) :: hcol(ksize), beta, telapsed, tmiss
     complex(c_double_complex), allocatable :: cvals(:), cvecs(:, :)
     integer :: mstep
+    integer(8) :: tick0, tick1, tickrate
     if (ksize == 0) then                                   ! :64-67
       write(*,*) 'Krylov base dimension == 0! Increase it.. STOP'; stop 1
     endif
     do mstep = mstart, mend
+      write(*,*) 'iteration current and total:', mstep, '/', mend                                  ! :75
+      call system_clock(tick0, tickrate)                                                           ! :77 eetime0 = dnekclock()
       call nsk_check(nsk_matvec(ctx, mode, Q(mstep + 1), Q(mstep)), 'nsk_matvec')                 ! :80
       call nsk_check(nsk_orth(ctx, Q(mstep + 1), Q, int(mstep, c_int), hcol, beta), 'nsk_orth')    ! :83 update_hessenberg_matrix
       H(1:mstep, mstep) = hcol(1:mstep)
@@ -51,6 +54,13 @@ contains
           deallocate(cvals, cvecs)
         endif
       endif
+      ! timing statistics, :92-98 (the reference prints hours and minutes; a step of this build takes a fraction of a second,
+      ! so the wall seconds of the step follow on the same line: what bench.py's Fortran-host leg parses)
+      call system_clock(tick1)
+      telapsed = real(tick1 - tick0, c_double) / real(tickrate, c_double) / 3600.0d0
+      tmiss = telapsed * (ksize - mstep)
+      write(*,"(' Time per iteration/remaining:',I3,'h ',I2,'min /',I3,'h ',I2,'min   step_wall_s=',ES13.6)") &
+        int(telapsed), ceiling((telapsed - int(telapsed)) * 60.), int(tmiss), ceiling((tmiss - int(tmiss)) * 60.), telapsed * 3600.0d0
     enddo
   end subroutine
 

@@ -137,6 +137,8 @@ struct nsk_ctx {
   Stats hstats{};
   hipStream_t stream = nullptr;
   std::vector<void*> allocs;
+  std::map<void*, size_t> alloc_bytes;  // size of every device allocation of this context (reset_solver_state)
+  bool state_dirty = false;             // the mutable solver state is not what a map left (nsk_bench_kernel ran on it): the next map starts from a reset state
   // krylov scratch
   double* kpart = nullptr; double* kout = nullptr; double** kptr = nullptr; int kblk = 0;
   double* hpin = nullptr;   // pinned host scratch
@@ -191,6 +193,7 @@ static int dalloc(nsk_ctx* c, T** p, size_t n) {
   if (e != hipSuccess) return fail(NSK_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
   (void)hipMemset(q, 0, std::max<size_t>(n, 1) * sizeof(T));
   c->allocs.push_back(q);
+  c->alloc_bytes[q] = std::max<size_t>(n, 1) * sizeof(T);
   *p = (T*)q;
   return 0;
 }
@@ -662,6 +665,7 @@ static int build(nsk_ctx* c, const nsk_case& cs) {
     HIPCHK(hipMemcpy(Eblk.data(), dE, Eblk.size() * sizeof(double), hipMemcpyDeviceToHost));
     HIPCHK(hipFree(dE));
     c->allocs.erase(std::find(c->allocs.begin(), c->allocs.end(), (void*)dE));
+    c->alloc_bytes.erase((void*)dE);
   }
   auto Eentry = [&](int a, int r, int b, int k) -> double {   // E[(a,r),(b,k)]
     const std::vector<int>& v = nb[b];
@@ -1290,7 +1294,29 @@ static void budgets_update(nsk_ctx* c, const Stats& h) {
 // One attempt of a map, asynchronous: everything is queued on the lane's stream, the device-side counters follow into pinned
 // host memory; map_finish waits, books the counters and says whether the attempt stands (0), must be redone with larger
 // launch budgets (1) or failed (< 0).  Split so that several lanes (nsk_matvec_batch) can have their maps in flight at once.
+// Everything a map may leave behind for the next one -- time-stepper lags, CG / GMRES work arrays, the pressure projection
+// space and its counters, partial sums -- back to what nsk_init left: zeros.  The immutable arrays (const members of Dev) and
+// the launch budgets stay.  Called (on the stream) before the next map when nsk_bench_kernel has run on the state, and by
+// map_finish after a map whose state went non-finite: a NaN / Inf in a lag array or in the projection space would otherwise
+// survive every later map (step 1 multiplies the lags by ZERO coefficients: 0 x Inf = NaN; the projection space is kept from
+// map to map by design).  This is what made BENCH_r04 fail: scripts/repro_r04_nan.py.
+static int reset_solver_state(nsk_ctx* c) {
+  Dev& d = c->d;
+  void* mut[] = {d.u, d.p, d.plag, d.pext, d.ulag, d.exlag, d.bf, d.rloc, d.bloc, d.dulag, d.hx, d.hr, d.hp, d.hs, d.hwl, d.hpart, d.hscal,
+                 d.V, d.Z, d.yl, d.ec, d.xc, d.gpart, d.xacc, d.dpw, d.hz, d.hy, d.rch, d.gsc, d.PX, d.PEX, d.PD, d.PED, d.ppart, d.stats,
+                 d.gpart2, d.gtot2, d.ptot, d.htot, d.gtot, c->rc_big, c->cw_d0, c->cw_d1, c->cw_r, c->circ_rh, c->circ_xh, c->rc_part, c->sync};
+  for (void* p : mut) {
+    if (!p) continue;
+    auto it = c->alloc_bytes.find(p);
+    if (it == c->alloc_bytes.end()) continue;            // (an array this context shares with its parent: the parent resets it)
+    HIPCHK(hipMemsetAsync(p, 0, it->second, c->stream));
+  }
+  c->state_dirty = false;
+  return 0;
+}
+
 static int map_launch(nsk_ctx* c, int adjoint, double* f, const double* src) {
+  if (c->state_dirty) { int rc0 = reset_solver_state(c); if (rc0) return rc0; }
   HIPCHK(hipMemsetAsync(c->d.stats, 0, sizeof(Stats), c->stream));
   int rc = run_map(c, adjoint, f, src);
   if (rc) return rc;
@@ -1318,6 +1344,10 @@ static int map_finish(nsk_ctx* c) {
     fprintf(stderr, "\n");
   }
   if (h.sync_timeouts) return fail(NSK_EHIP, "grid barrier of the persistent velocity solve timed out (workgroups not co-resident?): set option fused = 0");
+  if (h.nonfinite) {                    // the MAP says so (the reference's only guard is the NaN check of the next inner product, core/krylov_subspace.f:52-55)
+    (void)reset_solver_state(c);        // ... and the next map of this context starts clean
+    return fail(NSK_ENAN, "non-finite state inside the map: " + std::to_string((long long)h.nonfinite) + " time steps with a NaN / Inf pressure right-hand side (input vector not finite?)");
+  }
   if (h.unconverged == 0) {
     if (c->nsteps > 2) budgets_update(c, h);
     return 0;
@@ -1384,7 +1414,7 @@ int nsk_shard_release_parent(nsk_ctx* P) {
   for (void* p : P->allocs) {
     bool k = false;
     for (const void* q : keep) k = k || (q && q == p);
-    if (k) left.push_back(p); else (void)hipFree(p);
+    if (k) left.push_back(p); else { (void)hipFree(p); P->alloc_bytes.erase(p); }
   }
   P->allocs.swap(left);
   for (auto& a : P->graphs) for (auto& g : a) if (g.exec) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; g.nh = -1; }
@@ -1965,6 +1995,7 @@ int nsk_vec_free(nsk_ctx* c, int n, nsk_vec* v) {
     if (it == c->allocs.end()) return fail(NSK_EINVAL, "unknown vector handle");
     (void)hipFree(v[k]);
     c->allocs.erase(it);
+    c->alloc_bytes.erase((void*)v[k]);
     v[k] = nullptr;
   }
   return 0;
@@ -2661,6 +2692,9 @@ int nsk_bench_kernel(nsk_ctx* c, const char* name, int reps, double* avg_us) {
   *avg_us = 1e3 * ms / reps;
   HIPCHK(hipEventDestroy(e0)); HIPCHK(hipEventDestroy(e1));
   HIPCHK(hipMemsetAsync(c->d.stats, 0, sizeof(Stats), c->stream));
+  // the kernels above ran hundreds of times on the live solver state (lags shifted, the projection space fed with itself):
+  // not a state any map left.  The next map of this context starts from the state nsk_init left (reset_solver_state).
+  c->state_dirty = true;
   return 0;
 }
 

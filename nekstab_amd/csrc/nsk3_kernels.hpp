@@ -1175,6 +1175,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_gmres_update(Dev d, int j, doubl
       const double tol0 = d.tol_relative ? fmax(d.tol_pres * G->gnorm0 * scale, d.tol_pres_floor) : d.tol_pres;
       const int dn = (!(hn > 0.0) || (min_iter <= 0 && hn * scale <= tol0)) ? 1 : 0;
       if (dn) d.stats->last_pres_res = hn * scale;
+      if (!(hn * 0.0 == 0.0)) d.stats->nonfinite += 1;      // |g| is NaN or Inf: nothing below can repair it (map_finish returns NSK_ENAN)
       G->done = dn;
     } else {
       double* col = scol;

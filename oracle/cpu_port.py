@@ -31,7 +31,7 @@ _ip = C.POINTER(C.c_int)
 
 class CpuCase(C.Structure):
     _fields_ = ([(n, C.c_int) for n in ("nel", "N", "M", "ND", "nvert", "PS", "max_helm", "max_pres", "min_pres",
-                                        "tol_relative", "helm_guess", "pad0")] +
+                                        "tol_relative", "helm_guess", "nproj")] +
                 [(n, _dp) for n in ("D", "J12", "D12", "Jd", "Dd", "hat", "g1", "g2", "g4", "bm1", "mask", "minv", "binv",
                                     "spng", "dinv", "w2rx", "w2sx", "w2ry", "w2sy", "cUr", "cUs", "GUx", "GUy", "GVx", "GVy")] +
                 [("gs_off", _ip), ("gs_idx", _ip), ("p_idx", _ip), ("p_inv", _fp), ("Aci", _fp),
@@ -41,7 +41,8 @@ class CpuCase(C.Structure):
 
 class CpuStats(C.Structure):
     _fields_ = [("steps", C.c_longlong), ("helm_iters", C.c_longlong), ("pres_iters", C.c_longlong),
-                ("unconverged", C.c_longlong), ("last_helm_res", C.c_double), ("last_pres_res", C.c_double)]
+                ("unconverged", C.c_longlong), ("last_helm_res", C.c_double), ("last_pres_res", C.c_double),
+                ("last_pres_iters", C.c_longlong)]
 
 
 CFLAGS = ["-O3", "-mavx2", "-mfma", "-ffp-contract=off", "-fopenmp", "-fPIC", "-shared"]
@@ -69,12 +70,13 @@ def _load():
     lib.cpu_matvec.argtypes = [C.POINTER(CpuCase), _dp, _dp, C.c_int, C.POINTER(CpuStats)]
     lib.cpu_set_threads.argtypes = [C.c_int]
     lib.cpu_max_threads.restype = C.c_int
+    lib.cpu_proj_reset.restype = None
     return lib
 
 
 class CpuPort:
     def __init__(self, o, vert, nvert, *, tol_helm=1e-9, tol_pres=1e-7, tol_relative=0, min_pres=0, layers=2,
-                 max_helm=120, max_pres=48, early_pres_mul=1e-2, helm_guess=1):
+                 max_helm=120, max_pres=48, early_pres_mul=1e-2, helm_guess=1, nproj=0):
         """``o``: a LinNS2D oracle with its pressure matrix built; ``vert``: (nel,4) lexicographic vertex ids."""
         assert o.has_outflow, "the C port covers domains with an outflow boundary (configs 1 and 2)"
         self.lib = _load()
@@ -175,7 +177,7 @@ class CpuPort:
         ptr = {"gs_off": _ip, "gs_idx": _ip, "p_idx": _ip, "evert": _ip, "v_off": _ip, "v_ent": _ip, "p_inv": _fp, "Aci": _fp}
         args = {name: k[name].ctypes.data_as(ptr.get(name, _dp)) for name in k}
         self.case = CpuCase(nel=nel, N=n, M=m, ND=nd, nvert=int(nvert), PS=PS, max_helm=max_helm, max_pres=max_pres,
-                            min_pres=min_pres, tol_relative=tol_relative, helm_guess=helm_guess, pad0=0,
+                            min_pres=min_pres, tol_relative=tol_relative, helm_guess=helm_guess, nproj=int(nproj),
                             nu=o.nu, dt=o.dt, vol=float(o.volvm1), tol_helm=tol_helm, tol_pres=tol_pres,
                             early_pres_mul=early_pres_mul, **args)
         self.nsteps = o.nsteps
@@ -183,6 +185,11 @@ class CpuPort:
         self.shape_v, self.shape_p = (nel, n, n), (nel, m, m)
         self.setup_s = time.perf_counter() - t0
         self.stats = None
+        self.lib.cpu_proj_reset()
+
+    def proj_reset(self):
+        """empty the pressure projection space (it is kept from matvec to matvec, as the device's)"""
+        self.lib.cpu_proj_reset()
 
     def set_threads(self, nthreads):
         self.lib.cpu_set_threads(int(nthreads))

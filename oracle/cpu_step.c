@@ -13,6 +13,9 @@
  * The discretisation follows oracle/linns.py line by line; set-up data (geometry,
  * patch inverses, coarse inverse) come from oracle/cpu_port.py, which builds them from the oracle's
  * assembled operators.  Direct map, domains with an outflow boundary (configs 1 and 2).
+ * Pressure projection space ([UPSTREAM navier4.f setrhsp / gensolnp], Fischer 1998) as the HIP path builds it
+ * (nsk_kernels.hpp: k_proj_apply / k_proj_update): E-orthogonal solutions since the last restart, appended while there is
+ * room, restarted on the latest total solution when full; kept from matvec to matvec (cpu_proj_reset empties it).
  *
  * Threading: one `omp parallel for` over elements per phase, static schedule; dssum is a gather over
  * the CSR of co-located nodes (no atomics).
@@ -25,9 +28,10 @@
 #define MAXN 12
 #define MAXND 18
 #define MAXMR 48
+#define MAXPROJ 32
 
 typedef struct {
-  int nel, N, M, ND, nvert, PS, max_helm, max_pres, min_pres, tol_relative, helm_guess, pad0;
+  int nel, N, M, ND, nvert, PS, max_helm, max_pres, min_pres, tol_relative, helm_guess, nproj;   /* nproj: size of the pressure projection space (0 = none) */
   const double *D, *J12, *D12, *Jd, *Dd, *hat;
   const double *g1, *g2, *g4, *bm1, *mask, *minv, *binv, *spng, *dinv;
   const double *w2rx, *w2sx, *w2ry, *w2sy;
@@ -40,7 +44,7 @@ typedef struct {
   double nu, dt, vol, tol_helm, tol_pres, early_pres_mul;
 } cpu_case;
 
-typedef struct { long long steps, helm_iters, pres_iters, unconverged; double last_helm_res, last_pres_res; } cpu_stats;
+typedef struct { long long steps, helm_iters, pres_iters, unconverged; double last_helm_res, last_pres_res; long long last_pres_iters; } cpu_stats;
 
 static const double BD[3][4] = {{1.0, 1.0, 0.0, 0.0}, {1.5, 2.0, -0.5, 0.0}, {11.0 / 6.0, 3.0, -1.5, 1.0 / 3.0}};
 static const double AB[3][3] = {{1.0, 0.0, 0.0}, {2.0, -1.0, 0.0}, {3.0, -3.0, 1.0}};
@@ -185,7 +189,7 @@ typedef struct {
   long long nloc, npr;
   double *u, *p, *plag, *pext, *ulag, *exlag, *bf, *rloc, *bloc, *dulag;   /* velocity arrays [2][nloc] (lags [2 lags][2][nloc]) */
   double *hx, *hr, *hp, *hz, *hw, *tmp;                                   /* CG work [2][nloc] */
-  double *V, *Z, *yl, *vv, *ec, *rc, *xc, *wp;                            /* GMRES */
+  double *V, *Z, *yl, *vv, *ec, *rc, *xc, *wp, *pd, *ped;                 /* GMRES; projection space: correction and its E-image */
 } work_t;
 
 static double* dz(size_t n) { return (double*)calloc(n > 0 ? n : 1, sizeof(double)); }
@@ -299,7 +303,7 @@ static void eapply(const cpu_case* c, work_t* w, const double* z, double* wout) 
 }
 
 /* right-preconditioned GMRES for E0 y = g (E0 = D B^-1 D^T), g in V[0]; returns y in w->wp   [UPSTREAM navier1.f uzawa_gmres] */
-static int pres_solve(const cpu_case* c, work_t* w, double h2, double tol_mul, cpu_stats* st) {
+static int pres_solve(const cpu_case* c, work_t* w, double h2, double tol_mul, double gnorm0, cpu_stats* st) {
   const long long np = w->npr;
   double H[(MAXMR + 1) * MAXMR], cs[MAXMR], sn[MAXMR], g[MAXMR + 1], y[MAXMR];
   const double scale = 1.0 / (h2 * sqrt(c->vol));
@@ -310,8 +314,9 @@ static int pres_solve(const cpu_case* c, work_t* w, double h2, double tol_mul, c
   const double beta0 = sqrt(b2);
   double tp = c->tol_pres;
   if (c->tol_relative) { tp = c->tol_pres * tol_mul; const double lo = c->tol_pres < 1e-4 ? c->tol_pres : 1e-4; if (tp < lo) tp = lo; }
-  const double tol = c->tol_relative ? tp * beta0 * scale : c->tol_pres;
+  const double tol = c->tol_relative ? tp * (gnorm0 >= 0.0 ? gnorm0 : beta0) * scale : c->tol_pres;    /* relative to |g| BEFORE the projection */
   memset(w->wp, 0, np * sizeof(double));
+  st->last_pres_iters = 0;
   if (!(beta0 > 0.0) || (c->min_pres <= 0 && beta0 * scale <= tol)) { st->last_pres_res = beta0 * scale; return 0; }
 #pragma omp parallel for schedule(static)
   for (long long q = 0; q < np; ++q) V[q] /= beta0;
@@ -354,7 +359,7 @@ static int pres_solve(const cpu_case* c, work_t* w, double h2, double tol_mul, c
   }
   if (!conv) st->unconverged++;
   const int nit = j;
-  st->pres_iters += nit;
+  st->pres_iters += nit; st->last_pres_iters = nit;
   for (int q = nit - 1; q >= 0; --q) {
     double s = g[q];
     for (int k = q + 1; k < nit; ++k) s -= H[q * MAXMR + k] * y[k];
@@ -367,6 +372,66 @@ static int pres_solve(const cpu_case* c, work_t* w, double h2, double tol_mul, c
     w->wp[q] = s;
   }
   return 0;
+}
+
+/* ---- pressure projection space: X_i, E X_i, n_i = (X_i, E X_i); persists across cpu_matvec calls like the device's ---- */
+typedef struct { int n, pcnt, cap; long long np; double *X, *EX; double nn[MAXPROJ], a[MAXPROJ]; } proj_t;
+static proj_t g_proj;
+void cpu_proj_reset(void) { free(g_proj.X); free(g_proj.EX); memset(&g_proj, 0, sizeof(g_proj)); }
+static void proj_ensure(int cap, long long np) {
+  if (g_proj.cap == cap && g_proj.np == np && g_proj.X) return;
+  cpu_proj_reset();
+  g_proj.cap = cap; g_proj.np = np;
+  g_proj.X = (double*)calloc((size_t)cap * np, sizeof(double)); g_proj.EX = (double*)calloc((size_t)cap * np, sizeof(double));
+}
+/* g' = g - sum_i a_i E x_i,  a_i = (x_i, g) / n_i ; returns |g| */
+static double proj_apply(double* g, long long np) {
+  proj_t* P = &g_proj;
+  double gg = 0;
+#pragma omp parallel for schedule(static) reduction(+ : gg)
+  for (long long q = 0; q < np; ++q) gg += g[q] * g[q];
+  for (int i = 0; i < P->n; ++i) {
+    const double* x = P->X + (size_t)i * np;
+    double s = 0;
+#pragma omp parallel for schedule(static) reduction(+ : s)
+    for (long long q = 0; q < np; ++q) s += x[q] * g[q];
+    P->a[i] = s / P->nn[i];
+  }
+#pragma omp parallel for schedule(static)
+  for (long long q = 0; q < np; ++q) {
+    double t = g[q];
+    for (int i = 0; i < P->n; ++i) t -= P->a[i] * P->EX[(size_t)i * np + q];
+    g[q] = t;
+  }
+  return sqrt(gg);
+}
+/* absorb the GMRES correction delta (E-image edel) : nsk_kernels.hpp k_proj_update, proj_restart = 1 */
+static void proj_update(const double* delta, const double* edel, long long np) {
+  proj_t* P = &g_proj;
+  const int n = P->n, full = n >= P->cap, s = full ? 0 : n;
+  double c[MAXPROJ], cf[MAXPROJ], dd = 0;
+  for (int k = 0; k < n; ++k) {
+    const double* ex = P->EX + (size_t)k * np;
+    double t = 0;
+#pragma omp parallel for schedule(static) reduction(+ : t)
+    for (long long q = 0; q < np; ++q) t += delta[q] * ex[q];
+    c[k] = t;
+  }
+#pragma omp parallel for schedule(static) reduction(+ : dd)
+  for (long long q = 0; q < np; ++q) dd += delta[q] * edel[q];
+  double nn = dd;
+  for (int k = 0; k < n; ++k) { nn -= c[k] * c[k] / P->nn[k]; cf[k] = c[k] / P->nn[k] - (full ? P->a[k] : 0.0); }
+  if (full) for (int k = 0; k < n; ++k) nn += P->a[k] * P->a[k] * P->nn[k];
+  if (!(nn > 0.0)) { P->n = 0; P->pcnt = 0; return; }     /* degenerate direction: drop the space */
+  double* xs = P->X + (size_t)s * np; double* exs = P->EX + (size_t)s * np;
+#pragma omp parallel for schedule(static)
+  for (long long q = 0; q < np; ++q) {
+    double x = delta[q], ex = edel[q];
+    for (int k = 0; k < n; ++k) { x -= cf[k] * P->X[(size_t)k * np + q]; ex -= cf[k] * P->EX[(size_t)k * np + q]; }
+    xs[q] = x; exs[q] = ex;                                  /* (slot 0 on a restart: every thread has read its own entry of it above) */
+  }
+  if (full) { P->nn[0] = nn; P->n = 1; P->pcnt = 1; }
+  else { P->nn[s] = nn; P->n = n + 1; P->pcnt += 1; }
 }
 
 static int step(const cpu_case* c, work_t* w, int istep, cpu_stats* st) {
@@ -426,7 +491,19 @@ static int step(const cpu_case* c, work_t* w, int istep, cpu_stats* st) {
     opdiv_e(c, e, us[0], us[1], dv);
     for (int q = 0; q < MM; ++q) w->V[e * MM + q] = -dv[q];
   }
-  pres_solve(c, w, h2, istep <= 3 ? c->early_pres_mul : 1.0, st);
+  double gnorm0 = -1.0;
+  const int useproj = c->nproj > 0;
+  if (useproj) { proj_ensure(c->nproj < MAXPROJ ? c->nproj : MAXPROJ, w->npr); gnorm0 = proj_apply(w->V, w->npr); }
+  pres_solve(c, w, h2, istep <= 3 ? c->early_pres_mul : 1.0, gnorm0, st);
+  if (useproj) {                      /* delta = GMRES correction (kept in w->pd); total solution = delta + sum a_i x_i */
+    memcpy(w->pd, w->wp, w->npr * sizeof(double));
+#pragma omp parallel for schedule(static)
+    for (long long q = 0; q < w->npr; ++q) {
+      double t = w->wp[q];
+      for (int i = 0; i < g_proj.n; ++i) t += g_proj.a[i] * g_proj.X[(size_t)i * w->npr + q];
+      w->wp[q] = t;
+    }
+  }
   /* p = p* + h2 y ; u += (h2 B)^-1 mask dssum(D^T dp) */
 #pragma omp parallel for schedule(static)
   for (long long e = 0; e < nel; ++e) {
@@ -435,11 +512,25 @@ static int step(const cpu_case* c, work_t* w, int istep, cpu_stats* st) {
     opgradt_e(c, e, dp, w->yl + e * NN, w->yl + nl + e * NN);
   }
   dssum(c, w->yl, w->vv, nl); dssum(c, w->yl + nl, w->vv + nl, nl);
+  if (useproj) {                      /* E delta = D B^-1 dssum(D^T dp) / h2 - sum a_i E x_i, from the arrays of the velocity correction */
+#pragma omp parallel for schedule(static)
+    for (long long e = 0; e < nel; ++e) {
+      double a[MAXN * MAXN], b[MAXN * MAXN], dv[MAXN * MAXN];
+      for (int l = 0; l < NN; ++l) { a[l] = c->binv[e * NN + l] * w->vv[e * NN + l]; b[l] = c->binv[e * NN + l] * w->vv[nl + e * NN + l]; }
+      opdiv_e(c, e, a, b, dv);
+      for (int q = 0; q < MM; ++q) {
+        double t = dv[q] / h2;
+        for (int i = 0; i < g_proj.n; ++i) t -= g_proj.a[i] * g_proj.EX[(size_t)i * w->npr + e * MM + q];
+        w->ped[e * MM + q] = t;
+      }
+    }
+  }
 #pragma omp parallel for schedule(static)
   for (long long l = 0; l < nl; ++l) {
     const double f = c->binv[l] / h2;
     w->u[l] += f * w->vv[l]; w->u[nl + l] += f * w->vv[nl + l];
   }
+  if (useproj && st->last_pres_iters > 0) proj_update(w->pd, w->ped, w->npr);
   st->steps++;
   return 0;
 }
@@ -453,13 +544,13 @@ int cpu_matvec(const cpu_case* c, const double* q, double* f, int nsteps, cpu_st
   w.u = dz(2 * nl); w.p = dz(np); w.plag = dz(np); w.pext = dz(np); w.ulag = dz(4 * nl); w.exlag = dz(4 * nl); w.bf = dz(2 * nl);
   w.rloc = dz(2 * nl); w.bloc = dz(2 * nl); w.dulag = dz(6 * nl); w.hx = dz(2 * nl); w.hr = dz(2 * nl); w.hp = dz(2 * nl);
   w.hz = dz(2 * nl); w.hw = dz(2 * nl); w.tmp = dz(2 * nl); w.V = dz((size_t)(MAXMR + 1) * np); w.Z = dz((size_t)MAXMR * np);
-  w.yl = dz(2 * nl); w.vv = dz(2 * nl); w.ec = dz((size_t)c->nel * 4); w.rc = dz(c->nvert); w.xc = dz(c->nvert); w.wp = dz(np);
+  w.yl = dz(2 * nl); w.vv = dz(2 * nl); w.ec = dz((size_t)c->nel * 4); w.rc = dz(c->nvert); w.xc = dz(c->nvert); w.wp = dz(np); w.pd = dz(np); w.ped = dz(np);
   memcpy(w.u, q, 2 * nl * sizeof(double)); memcpy(w.p, q + 2 * nl, np * sizeof(double));
   cpu_stats local; memset(&local, 0, sizeof(local));
   for (int istep = 1; istep <= nsteps; ++istep) step(c, &w, istep, &local);
   memcpy(f, w.u, 2 * nl * sizeof(double)); memcpy(f + 2 * nl, w.p, np * sizeof(double));
   if (st) *st = local;
-  double* all[] = {w.u, w.p, w.plag, w.pext, w.ulag, w.exlag, w.bf, w.rloc, w.bloc, w.dulag, w.hx, w.hr, w.hp, w.hz, w.hw, w.tmp, w.V, w.Z, w.yl, w.vv, w.ec, w.rc, w.xc, w.wp};
+  double* all[] = {w.u, w.p, w.plag, w.pext, w.ulag, w.exlag, w.bf, w.rloc, w.bloc, w.dulag, w.hx, w.hr, w.hp, w.hz, w.hw, w.tmp, w.V, w.Z, w.yl, w.vv, w.ec, w.rc, w.xc, w.wp, w.pd, w.ped};
   for (size_t i = 0; i < sizeof(all) / sizeof(all[0]); ++i) free(all[i]);
   return local.unconverged ? 1 : 0;
 }

@@ -106,3 +106,90 @@ def test_shard_arguments_are_checked(hip6, case6):
         assert e.value.code == -1 and "no row for vertex" in str(e.value)
     finally:
         lp.close()
+
+
+def test_non_finite_input_is_reported_by_the_map_and_does_not_poison_the_context(case6):
+    """A NaN in the input vector: the MAP returns NSK_ENAN (BENCH_r04: it surfaced one call later, in nsk_orth), on one lane and
+    on the lane of a batch that got it; the context resets its solver state, so the next map of a clean vector equals the map
+    of a fresh context bit for bit (lag arrays and the projection space carry nothing over)."""
+    from nekstab_amd import seed
+    from nekstab_amd.capi import NekStabHip, NskError
+    kw = dict(tol_helm=1e-11, tol_pres=1e-4, tol_relative=1, max_helm_iter=100, max_pres_iter=48, nproj=8)
+    qx, qy = seed.add_noise(case6)
+    zp = np.zeros((case6.nel, 4, 4))
+
+    def fresh():
+        h = NekStabHip(case6, case6.meta["vert"], case6.meta["nvert"], **kw)
+        h.set_nsteps(8)
+        return h
+    h0 = fresh()
+    a, f = h0.alloc(2)
+    h0.upload(a, qx, qy, zp)
+    h0.matvec(f, a, 0)
+    ref = h0.download(f)
+    h0.close()
+    h = fresh()
+    a, b, f, g = h.alloc(4)
+    h.upload(a, qx, qy, zp)
+    bad = qx.copy(); bad[5, 2, 3] = np.nan
+    h.upload(b, bad, qy, zp)
+    with pytest.raises(NskError) as e:
+        h.matvec(f, b, 0)
+    assert e.value.code == -3 and "non-finite" in str(e.value)
+    h.matvec(f, a, 0)
+    got = h.download(f)
+    assert all(np.array_equal(x, y) for x, y in zip(got[:2], ref[:2]))
+    with pytest.raises(NskError) as e:                      # lane 1 gets the bad vector
+        h.matvec_batch([f, g], [a, b], 0)
+    assert e.value.code == -3 and "lane 1" in str(e.value)
+    h.matvec_batch([f, g], [a, a], 0)                       # both lanes clean again
+    for v in (f, g):
+        got = h.download(v)
+        assert all(np.allclose(x, y, rtol=0, atol=1e-9 * np.abs(y).max()) for x, y in zip(got[:2], ref[:2]))
+    h.close()
+
+
+def test_kernel_timing_hook_leaves_no_trace_in_the_next_map():
+    """nsk_bench_kernel runs the step's kernels hundreds of times on the live solver state (bench.py's roofline and --extras);
+    the sequence of BENCH_r04 -- every timing back to back, then maps on lane 0 and on a new lane -- produced NaN.  Now the hook
+    marks the state dirty and the next map starts from a reset state: finite, equal to a fresh context's map, band Arnoldi
+    (nsk_matvec_batch) with bench.py's old second seed included."""
+    import os
+    from nekstab_amd import krylov, mesh, seed
+    from nekstab_amd.settings import production_context
+    from tests.conftest import GOLDEN
+    case = mesh.load_case_npz(os.path.join(GOLDEN, "cylinder_case.npz"), 8)
+    qx, qy = seed.add_noise(case)
+    zp = np.zeros((case.nel, 6, 6))
+    h0 = production_context(case)
+    a, f = h0.alloc(2)
+    h0.upload(a, qx, qy, zp)
+    h0.scal(a, 1.0 / h0.norm(a))
+    h0.matvec(f, a, 0)
+    ref = h0.download(f)
+    h0.close()
+    h = production_context(case)
+    Q = h.alloc(31)
+    h.upload(Q[0], qx, qy, zp)
+    h.scal(Q[0], 1.0 / h.norm(Q[0]))
+    H = np.zeros((31, 30))
+    krylov.arnoldi_factorization(h, Q, H, 1, 30, 0, stats={})
+    for kn in ("helm", "convect", "rhs", "pres_rhs", "proj_apply", "gmres_update", "schwarz", "divgs2", "pres_update", "vel_update_proj", "proj_update", "update_coarse3"):
+        assert h.bench_kernel(kn, 100)["avg_us"] > 0
+    f = h.alloc(1)[0]
+    h.matvec(f, Q[0], 0)
+    got = h.download(f)
+    assert all(np.array_equal(x, y) for x, y in zip(got[:2], ref[:2]))          # reset state = fresh context
+    for kn in ("helm", "rhs", "pres_update", "vel_update_proj", "proj_update", "update_coarse3"):
+        h.bench_kernel(kn, 100)
+    for bw in (2, 3):
+        sd = h.alloc(bw)
+        h.copy(sd[0], Q[0])
+        for j in range(1, bw):
+            h.upload(sd[j], qy * np.cos(0.2 * j * case.x), qx * np.cos(0.3 * j * case.y), zp)
+        rb = krylov.band_arnoldi(h, sd, 24)
+        assert np.isfinite(rb.H).all() and np.isfinite(rb.vals).all()
+        h.free(rb.Q); h.free(sd)
+        for kn in ("pres_update", "proj_update"):
+            h.bench_kernel(kn, 100)
+    h.close()

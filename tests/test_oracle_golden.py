@@ -135,3 +135,30 @@ def test_cpu_port_matches_oracle(case6, oracle6, modes):
     cp.set_threads(4)
     f4 = cp.matvec(q, nsteps=2)
     assert max(np.abs(a - b).max() for a, b in zip(f1[:2], f4[:2])) < 1e-12
+
+
+def test_cpu_port_projection_space_same_map_fewer_iterations(case6, oracle6, modes):
+    """The pressure projection space of the C port (what bench.py's cpu_baseline runs since round 5, as the HIP path does):
+    the same map as without it to the pressure tolerance, with fewer GMRES iterations per step; kept from map to map."""
+    from oracle.cpu_port import CpuPort
+    o = oracle6
+    u = modes["dRe_u"].astype(np.float64)
+    q = (u[0], u[1], o.J12 @ modes["dRe_p"].astype(np.float64) @ o.J12.T)
+    kw = dict(tol_helm=1e-12, tol_pres=3e-2, tol_relative=1, min_pres=2)          # bench.py's pressure settings
+    base = CpuPort(o, case6.meta["vert"], case6.meta["nvert"], **kw)
+    f0 = base.matvec(q, nsteps=20)
+    it0 = base.stats["pres_iters"]
+    cp = CpuPort(o, case6.meta["vert"], case6.meta["nvert"], nproj=8, **kw)
+    f1 = cp.matvec(q, nsteps=20)
+    it1 = cp.stats["pres_iters"]
+    num = sum(np.sum(o.bm1 * (a - b) ** 2) for a, b in zip(f1[:2], f0[:2]))
+    den = sum(np.sum(o.bm1 * b ** 2) for b in f0[:2])
+    print("relative difference of the maps %.2e, pressure iterations %d -> %d" % (np.sqrt(num / den), it0, it1))
+    assert np.sqrt(num / den) < 1e-5, np.sqrt(num / den)
+    assert cp.stats["unconverged"] == 0 and it1 < 0.8 * it0, (it0, it1)
+    cp.matvec(q, nsteps=20)                           # the space of the last map is still there (another iteration history)
+    assert cp.stats["pres_iters"] != it1 and cp.stats["pres_iters"] < 0.8 * it0
+    cp.proj_reset()
+    f3 = cp.matvec(q, nsteps=20)
+    assert cp.stats["pres_iters"] == it1
+    assert max(np.abs(a - b).max() for a, b in zip(f3[:2], f1[:2])) < 1e-12
