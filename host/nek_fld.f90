@@ -151,31 +151,44 @@ contains
     integer :: u, e, nn, wd, nx, ny, nz, nel, nelg, ios
     integer(c_int), allocatable :: emap(:)
     real(c_double), allocatable :: xy(:)
+    real(c_float), allocatable :: xy4(:)
     ok = .false.
     nn = g%lx1 * g%lx1
     open(newunit=u, file=trim(path), access='stream', form='unformatted', status='old', iostat=ios)
     if (ios /= 0) return
     read(u) hdr
     read(hdr, *, iostat=ios) tag, wd, nx, ny, nz, nel, nelg
-    if (ios /= 0 .or. wd /= 8 .or. nx /= g%lx1 .or. nel /= g%nel .or. index(hdr, 'XUP') == 0) then
+    ! wdsize 8: this host's own checkpoints; wdsize 4: what the reference's outpost writes (KRY files of a run checkpointed by
+    ! nekStab itself, param(63) = 0): read as real(4) and promoted
+    if (ios /= 0 .or. (wd /= 8 .and. wd /= 4) .or. nx /= g%lx1 .or. nel /= g%nel .or. index(hdr, 'XUP') == 0) then
       close(u); return
     endif
     read(u) endian
-    allocate(emap(nel), xy(2 * nn))
+    allocate(emap(nel), xy(2 * nn), xy4(2 * nn))
     read(u) emap
     do e = 1, nel
-      read(u) xy
+      call rd(2 * nn)
     enddo
     do e = 1, nel
-      read(u) xy
+      call rd(2 * nn)
       vx((emap(e) - 1) * nn + 1:emap(e) * nn) = xy(1:nn); vy((emap(e) - 1) * nn + 1:emap(e) * nn) = xy(nn + 1:2 * nn)
     enddo
     do e = 1, nel
-      read(u) xy(1:nn)
+      call rd(nn)
       p1((emap(e) - 1) * nn + 1:emap(e) * nn) = xy(1:nn)
     enddo
     close(u)
     ok = .true.
+  contains
+    subroutine rd(n)                                   ! n values of the file's word size into xy(1:n)
+      integer, intent(in) :: n
+      if (wd == 8) then
+        read(u) xy(1:n)
+      else
+        read(u) xy4(1:n)
+        xy(1:n) = real(xy4(1:n), c_double)
+      endif
+    end subroutine
   end subroutine
 
   ! device state <-> field file (pressure through map21 / map12, as outpost / load_fld do)

@@ -389,6 +389,13 @@ module nekstab_hip
       integer(c_int), value :: nq
       real(c_double), dimension(*) :: h
     end function
+    integer(c_int) function nsk_get_step_iters(ctx, n, helm, pres, nsteps) bind(c, name='nsk_get_step_iters')
+      import
+      type(c_ptr), value :: ctx
+      integer(c_int), value :: n
+      integer(c_int), dimension(*) :: helm, pres
+      integer(c_int) :: nsteps
+    end function
     integer(c_int) function nsk_bench_kernel(ctx, name, reps, avg_us) bind(c, name='nsk_bench_kernel')
       import
       type(c_ptr), value :: ctx

@@ -278,6 +278,10 @@ int nsk_group_test(nsk_ctx** shards, int n, int which, const double* const* in, 
 int nsk_local_dots(nsk_ctx* ctx, nsk_vec f, const nsk_vec* Q, int nq, double* out);
 int nsk_project_out(nsk_ctx* ctx, nsk_vec f, const nsk_vec* Q, int nq, const double* h);
 
+/* diagnostics: CG (slower component) and GMRES iteration counts of every time step of the last map of this context (what the
+ * per-step launch budgets follow); *nsteps = steps recorded (0 before the first map and on shard contexts) */
+int nsk_get_step_iters(nsk_ctx* ctx, int n, int* helm, int* pres, int* nsteps);
+
 /* measurement hook for bench.py: average duration (us) of `reps` back-to-back launches of a hot
  * kernel ("helm"), HIP events on the library's stream, full work in every launch */
 int nsk_bench_kernel(nsk_ctx* ctx, const char* name, int reps, double* avg_us);

@@ -104,6 +104,7 @@ SYMBOLS = {
     "nsk_local_dots": (C.c_int, [_vp, _vp, _vpp, C.c_int, _dp]),
     "nsk_project_out": (C.c_int, [_vp, _vp, _vpp, C.c_int, _dp]),
     "nsk_bench_kernel": (C.c_int, [_vp, C.c_char_p, C.c_int, _dp]),
+    "nsk_get_step_iters": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "nsk_get_stats": (C.c_int, [_vp, C.POINTER(NskStats)]),
     "nsk_test_axhelm": (C.c_int, [_vp, _dp, C.c_double, C.c_double, _dp]),
     "nsk_test_dssum": (C.c_int, [_vp, _dp, _dp]),
@@ -373,6 +374,14 @@ class NekStabHip:
         us = C.c_double()
         self._chk(self.lib.nsk_bench_kernel(self.ctx, name.encode(), reps, C.byref(us)))
         return {"kernel": name, "avg_us": us.value, "reps": reps}
+
+    def step_iters(self):
+        """(helm, pres): iteration counts of every time step of this context's last map"""
+        n = C.c_int(0)
+        self._chk(self.lib.nsk_get_step_iters(self.ctx, 0, None, None, C.byref(n)))
+        hh = np.zeros(max(n.value, 1), dtype=np.int32); pp = np.zeros(max(n.value, 1), dtype=np.int32)
+        self._chk(self.lib.nsk_get_step_iters(self.ctx, n.value, hh.ctypes.data_as(C.POINTER(C.c_int)), pp.ctypes.data_as(C.POINTER(C.c_int)), C.byref(n)))
+        return hh[:n.value], pp[:n.value]
 
     def stats(self):
         s = NskStats()

@@ -138,6 +138,10 @@ struct nsk_ctx {
   hipStream_t stream = nullptr;
   std::vector<void*> allocs;
   std::map<void*, size_t> alloc_bytes;  // size of every device allocation of this context (reset_solver_state)
+  // per-time-step iteration record of the last map (Dev::step_iters, copied behind every map): [2 * nsteps] ints
+  static constexpr int STEP_CAP = 8192;
+  int* h_step_iters = nullptr;          // pinned
+  int step_rec_n = 0;                   // time steps of the map the record belongs to
   bool state_dirty = false;             // the mutable solver state is not what a map left (nsk_bench_kernel ran on it): the next map starts from a reset state
   // krylov scratch
   double* kpart = nullptr; double* kout = nullptr; double** kptr = nullptr; int kblk = 0;
@@ -1315,12 +1319,32 @@ static int reset_solver_state(nsk_ctx* c) {
   return 0;
 }
 
+// per-step iteration record: device arrays + pinned host copy, made at the first map of a context (before any graph is captured:
+// the kernels take the pointers by value inside Dev)
+static int ensure_step_record(nsk_ctx* c) {
+  if (c->d.step_iters) return 0;
+  int rc;
+  int *ctr = nullptr, *rec = nullptr;
+  if ((rc = dalloc(c, &ctr, 4)) || (rc = dalloc(c, &rec, (size_t)2 * nsk_ctx::STEP_CAP))) return rc;
+  HIPCHK(hipHostMalloc((void**)&c->h_step_iters, (size_t)2 * nsk_ctx::STEP_CAP * sizeof(int)));
+  std::memset(c->h_step_iters, 0, (size_t)2 * nsk_ctx::STEP_CAP * sizeof(int));
+  c->d.stepctr = ctr; c->d.step_iters = rec; c->d.step_cap = nsk_ctx::STEP_CAP;
+  for (auto& a : c->graphs) for (auto& g : a) g.nh = -1;
+  return 0;
+}
+
 static int map_launch(nsk_ctx* c, int adjoint, double* f, const double* src) {
   if (c->state_dirty) { int rc0 = reset_solver_state(c); if (rc0) return rc0; }
+  { int rc0 = ensure_step_record(c); if (rc0) return rc0; }
+  const int nrec = std::min(c->nsteps, nsk_ctx::STEP_CAP);
   HIPCHK(hipMemsetAsync(c->d.stats, 0, sizeof(Stats), c->stream));
+  HIPCHK(hipMemsetAsync(c->d.stepctr, 0, sizeof(int), c->stream));
+  HIPCHK(hipMemsetAsync(c->d.step_iters, 0, (size_t)2 * nrec * sizeof(int), c->stream));
   int rc = run_map(c, adjoint, f, src);
   if (rc) return rc;
   HIPCHK(hipMemcpyAsync(c->hstat_pin, c->d.stats, sizeof(Stats), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(c->h_step_iters, c->d.step_iters, (size_t)2 * nrec * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  c->step_rec_n = nrec;
   return 0;
 }
 static int map_finish(nsk_ctx* c) {
@@ -1348,12 +1372,14 @@ static int map_finish(nsk_ctx* c) {
     (void)reset_solver_state(c);        // ... and the next map of this context starts clean
     return fail(NSK_ENAN, "non-finite state inside the map: " + std::to_string((long long)h.nonfinite) + " time steps with a NaN / Inf pressure right-hand side (input vector not finite?)");
   }
+  const bool hcm = hostcheck_on(c);     // host-checked eager steps iterate to the caps whatever the budgets say
   if (h.unconverged == 0) {
-    if (c->nsteps > 2) budgets_update(c, h);
+    if (c->nsteps > 2 && !hcm) budgets_update(c, h);
     return 0;
   }
   bool capped = true;
   for (int k = 0; k < NCLS; ++k) capped = capped && c->cur_helm[k] >= c->max_helm && c->cur_pres[k] >= c->max_pres;
+  if (hcm) capped = true;               // ... so an unconverged solve there IS capped: redoing the map with doubled budgets the mode ignores would repeat it (as group_run_map)
   if (capped) {
     c->hstats.unconverged += h.unconverged;
     return fail(NSK_ENOCONV, "inner solve hit its iteration cap (" + std::to_string(h.unconverged) + " solves)");
@@ -1875,6 +1901,7 @@ int nsk_finalize(nsk_ctx* c) {
   for (void* p : c->allocs) (void)hipFree(p);
   if (c->hpin) (void)hipHostFree(c->hpin);
   if (c->hstat_pin) (void)hipHostFree(c->hstat_pin);
+  if (c->h_step_iters) (void)hipHostFree(c->h_step_iters);
   if (c->hs_send) (void)hipHostFree(c->hs_send);
   if (c->hs_recv) (void)hipHostFree(c->hs_recv);
   if (c->comm_stream) { (void)hipStreamSynchronize(c->comm_stream); for (auto& e : c->orth_ev) if (e) (void)hipEventDestroy(e); (void)hipStreamDestroy(c->comm_stream); }
@@ -2479,6 +2506,7 @@ int nsk_clone(nsk_ctx* P, nsk_ctx** out) {
   Dev& d = c->d;
   d = P->d;                                               // every immutable pointer: geometry, bases, gather tables, preconditioner
   d.dbg = nullptr;
+  d.stepctr = nullptr; d.step_iters = nullptr;            // (the lane's own per-step record is made at its first map)
   const long long npr = c->npr;
   int rc;
   // the mutable set of build(): time-stepper state, CG / GMRES work arrays, projection space, partial sums, counters
@@ -2540,6 +2568,17 @@ int nsk_matvec_batch(nsk_ctx** lanes, int b, int mode, nsk_vec* f, nsk_vec* q) {
   run_lane(0);
   for (auto& t : th) t.join();
   for (int k = 0; k < b; ++k) if (rcs[k]) return fail(rcs[k], "lane " + std::to_string(k) + ": " + errs[k]);
+  return 0;
+}
+
+// iteration counts of every time step of the LAST map of this context: helm[s] CG iterations (the slower component), pres[s]
+// GMRES iterations of step s + 1; returns the number of steps recorded through *nsteps (0: no map yet, or a sharded context)
+int nsk_get_step_iters(nsk_ctx* c, int n, int* helm, int* pres, int* nsteps) {
+  if (!c || n < 0 || (n > 0 && (!helm || !pres)) || !nsteps) return fail(NSK_EINVAL, "bad argument");
+  HIPCHK(hipStreamSynchronize(c->stream));
+  const int m = c->h_step_iters ? c->step_rec_n : 0;
+  *nsteps = m;
+  for (int s = 0; s < std::min(n, m); ++s) { helm[s] = c->h_step_iters[2 * s]; pres[s] = c->h_step_iters[2 * s + 1]; }
   return 0;
 }
 

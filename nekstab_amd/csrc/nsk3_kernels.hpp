@@ -569,6 +569,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_rhs(Dev d, StepCoef sc) {
   double* su = reg; double* st = reg + NN;
   const int tid = threadIdx.x;
   if (d.bf_stride && sc.adjoint != 2 && blockIdx.x == 0 && tid == 0) *d.bstep += 1;     // next step reads the next orbit slot (as the 2-D k_rhs)
+  if (d.stepctr && blockIdx.x == 0 && tid == 0) *d.stepctr += 1;                          // per-step iteration record (rec_step_iters)
   const long long e = blockIdx.x;
   const bool act = tid < NN;
   const int k = tid / (N * N), j = (tid / N) % N, i = tid % N;
@@ -693,7 +694,7 @@ __global__ __launch_bounds__(Cfg<N>::NT, 4) void k_helm(Dev d, StepCoef sc, int 
         if (done[c] && !was) {
           if (c == 0) atomicAdd((unsigned long long*)&d.stats->helm_iters, (unsigned long long)(it - 1));
           atomicMax((unsigned long long*)&d.stats->max_helm, (unsigned long long)(it - 1));
-          atomicMax((unsigned long long*)&d.stats->max_helm_k[sc.cls], (unsigned long long)(it - 1));
+          atomicMax((unsigned long long*)&d.stats->max_helm_k[sc.cls], (unsigned long long)(it - 1)); rec_step_iters(d, 0, it - 1);
         }
       }
     }
@@ -817,7 +818,7 @@ __global__ __launch_bounds__(Cfg<N>::NT, 4) void k_helm_fa(Dev d, StepCoef sc, i
         if (done[c] && !was) {
           if (c == 0) atomicAdd((unsigned long long*)&d.stats->helm_iters, (unsigned long long)(it - 1));
           atomicMax((unsigned long long*)&d.stats->max_helm, (unsigned long long)(it - 1));
-          atomicMax((unsigned long long*)&d.stats->max_helm_k[sc.cls], (unsigned long long)(it - 1));
+          atomicMax((unsigned long long*)&d.stats->max_helm_k[sc.cls], (unsigned long long)(it - 1)); rec_step_iters(d, 0, it - 1);
         }
       }
     }
@@ -1000,7 +1001,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_pres_rhs(Dev d, StepCoef sc, int
         if (!was) {
           if (c == 0) atomicAdd((unsigned long long*)&d.stats->helm_iters, (unsigned long long)check_helm);
           atomicMax((unsigned long long*)&d.stats->max_helm, (unsigned long long)check_helm);
-          atomicMax((unsigned long long*)&d.stats->max_helm_k[sc.cls], (unsigned long long)check_helm);
+          atomicMax((unsigned long long*)&d.stats->max_helm_k[sc.cls], (unsigned long long)check_helm); rec_step_iters(d, 0, check_helm);
         }
       }
       d.stats->last_helm_res = worst;
@@ -1203,7 +1204,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_gmres_update(Dev d, int j, doubl
       if ((res <= tol && (j + 1) >= min_iter) || !(hn > 0.0) || (d.pres_cap > 0 && (j + 1) >= d.pres_cap)) {
         atomicAdd((unsigned long long*)&d.stats->pres_iters, (unsigned long long)(G->nit_prev + j + 1));
         atomicMax((unsigned long long*)&d.stats->max_pres, (unsigned long long)(G->nit_prev + j + 1));
-        atomicMax((unsigned long long*)&d.stats->max_pres_k[ord], (unsigned long long)(G->nit_prev + j + 1));
+        atomicMax((unsigned long long*)&d.stats->max_pres_k[ord], (unsigned long long)(G->nit_prev + j + 1)); rec_step_iters(d, 1, G->nit_prev + j + 1);
         d.stats->last_pres_res = res;
         if (!(res <= tol) && hn > 0.0) {           // ended by the cap, not by its tolerance: counted, never silent
           d.stats->capped_solves += 1;
@@ -1446,11 +1447,15 @@ __global__ __launch_bounds__(64) void k_gmres_col(Dev d, int j, double scale, in
   const double res = fabs(sj * gj) * scale;
   G->resid = res;
   const double tol = d.tol_relative ? fmax(d.tol_pres * G->gnorm0 * scale, d.tol_pres_floor) : d.tol_pres;
-  if ((res <= tol && (j + 1) >= min_iter) || !(hn > 0.0)) {
+  if ((res <= tol && (j + 1) >= min_iter) || !(hn > 0.0) || (d.pres_cap > 0 && (j + 1) >= d.pres_cap)) {
     atomicAdd((unsigned long long*)&d.stats->pres_iters, (unsigned long long)(G->nit_prev + j + 1));
     atomicMax((unsigned long long*)&d.stats->max_pres, (unsigned long long)(G->nit_prev + j + 1));
-    atomicMax((unsigned long long*)&d.stats->max_pres_k[ord], (unsigned long long)(G->nit_prev + j + 1));
+    atomicMax((unsigned long long*)&d.stats->max_pres_k[ord], (unsigned long long)(G->nit_prev + j + 1)); rec_step_iters(d, 1, G->nit_prev + j + 1);
     d.stats->last_pres_res = res;
+    if (!(res <= tol) && hn > 0.0) {             // ended by the cap, not by its tolerance: counted, never silent (as k_gmres_update)
+      d.stats->capped_solves += 1;
+      if (res / tol > d.stats->worst_cap_ratio) d.stats->worst_cap_ratio = res / tol;
+    }
     G->done = 1;
   }
 }

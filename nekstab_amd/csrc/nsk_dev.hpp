@@ -151,6 +151,17 @@ struct Dev {
   double *gtot2, *ptot;
   double *htot;                  // [2 parities][8]  Helmholtz sums over all ranks
   double *gtot;                  // [MAXMR + 2]      GMRES sums over all ranks
+  // per-TIME-STEP iteration record of the running map: stepctr = time steps started (k_rhs), step_iters[2 s] / [2 s + 1] =
+  // CG iterations / GMRES iterations of step s (0-based): what the per-step launch budgets follow (nsk.hip: step_budgets)
+  int *stepctr, *step_iters;
+  int step_cap;
 };
+
+// iteration count of the current time step's velocity (which = 0) or pressure (1) solve into the per-step record
+__device__ inline void rec_step_iters(const Dev& d, int which, int count) {
+  if (!d.step_iters) return;
+  const int s = *d.stepctr - 1;
+  if (s >= 0 && s < d.step_cap) atomicMax(&d.step_iters[2 * s + which], count);
+}
 
 }  // namespace nsk

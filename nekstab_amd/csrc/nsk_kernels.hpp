@@ -544,6 +544,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_rhs(Dev d, StepCoef sc) {
   BasisRegs<N> br;
   br.issue(d, tid, true, true);
   if (d.bf_stride && sc.adjoint != 2 && blockIdx.x == 0 && tid == 0) *d.bstep += 1;     // next step reads the next orbit slot
+  if (d.stepctr && blockIdx.x == 0 && tid == 0) *d.stepctr += 1;                          // per-step iteration record (rec_step_iters)
   if (d.nproj_max > 0 && blockIdx.x == 0 && tid == 0) {
     GmresScal* G = d.gsc;
     if (G->st_pending) {
@@ -739,7 +740,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_helm(Dev d, StepCoef sc, int it,
         if (done[c] && !was) {
           if (c == 0) atomicAdd((unsigned long long*)&d.stats->helm_iters, (unsigned long long)(it - 1));
           atomicMax((unsigned long long*)&d.stats->max_helm, (unsigned long long)(it - 1));
-          atomicMax((unsigned long long*)&d.stats->max_helm_k[sc.cls], (unsigned long long)(it - 1));
+          atomicMax((unsigned long long*)&d.stats->max_helm_k[sc.cls], (unsigned long long)(it - 1)); rec_step_iters(d, 0, it - 1);
         }
       }
     }
@@ -849,7 +850,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_pres_rhs(Dev d, StepCoef sc, int
         const double rr = was ? d.hscal[helm_par * 8 + c * 4 + 3] : res;
         worst = fmax(worst, rr);
         if (!was && !(res <= tol)) bad = 1;
-        if (!was) { if (c == 0) atomicAdd((unsigned long long*)&d.stats->helm_iters, (unsigned long long)check_helm); atomicMax((unsigned long long*)&d.stats->max_helm, (unsigned long long)check_helm); atomicMax((unsigned long long*)&d.stats->max_helm_k[sc.cls], (unsigned long long)check_helm); }
+        if (!was) { if (c == 0) atomicAdd((unsigned long long*)&d.stats->helm_iters, (unsigned long long)check_helm); atomicMax((unsigned long long*)&d.stats->max_helm, (unsigned long long)check_helm); atomicMax((unsigned long long*)&d.stats->max_helm_k[sc.cls], (unsigned long long)check_helm); rec_step_iters(d, 0, check_helm); }
       }
       d.stats->last_helm_res = worst;
       if (bad) atomicAdd((unsigned long long*)&d.stats->unconverged, 1ull);
@@ -1092,7 +1093,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_gmres_update(Dev d, int j, doubl
       if ((res <= tol && (j + 1) >= min_iter) || !(hn > 0.0) || (d.pres_cap > 0 && (j + 1) >= d.pres_cap)) {
         atomicAdd((unsigned long long*)&d.stats->pres_iters, (unsigned long long)(G->nit_prev + j + 1));
         atomicMax((unsigned long long*)&d.stats->max_pres, (unsigned long long)(G->nit_prev + j + 1));
-        atomicMax((unsigned long long*)&d.stats->max_pres_k[ord], (unsigned long long)(G->nit_prev + j + 1));
+        atomicMax((unsigned long long*)&d.stats->max_pres_k[ord], (unsigned long long)(G->nit_prev + j + 1)); rec_step_iters(d, 1, G->nit_prev + j + 1);
         d.stats->last_pres_res = res;
         if (!(res <= tol) && hn > 0.0) {           // ended by the cap, not by its tolerance: counted, never silent
           d.stats->capped_solves += 1;
@@ -1406,7 +1407,7 @@ __global__ __launch_bounds__(256) void k_update_coarse(Dev d, int j, double scal
       if (conv) {
         atomicAdd((unsigned long long*)&d.stats->pres_iters, (unsigned long long)(G->nit_prev + jj + 1));
         atomicMax((unsigned long long*)&d.stats->max_pres, (unsigned long long)(G->nit_prev + jj + 1));
-        atomicMax((unsigned long long*)&d.stats->max_pres_k[ord], (unsigned long long)(G->nit_prev + jj + 1));
+        atomicMax((unsigned long long*)&d.stats->max_pres_k[ord], (unsigned long long)(G->nit_prev + jj + 1)); rec_step_iters(d, 1, G->nit_prev + jj + 1);
         d.stats->last_pres_res = res;
         if (!(res <= tol) && hn > 0.0) {
           d.stats->capped_solves += 1;

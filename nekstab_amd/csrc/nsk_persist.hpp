@@ -146,6 +146,7 @@ __global__ __launch_bounds__(Cfg<N>::NT, 2) void k_helm_fused(Dev d, StepCoef sc
 
   // ================= K2 (k_rhs) =================
   if (d.bf_stride && sc.adjoint != 2 && blockIdx.x == 0 && tid == 0) *d.bstep += 1;
+  if (d.stepctr && blockIdx.x == 0 && tid == 0) *d.stepctr += 1;
   if (d.nproj_max > 0 && blockIdx.x == 0 && tid == 0) {
     GmresScal* G = d.gsc;
     if (G->st_pending) {
@@ -315,7 +316,7 @@ __global__ __launch_bounds__(Cfg<N>::NT, 2) void k_helm_fused(Dev d, StepCoef sc
     if (ok) {
       atomicAdd((unsigned long long*)&d.stats->helm_iters, (unsigned long long)used);
       atomicMax((unsigned long long*)&d.stats->max_helm, (unsigned long long)used);
-      atomicMax((unsigned long long*)&d.stats->max_helm_k[sc.cls], (unsigned long long)used);
+      atomicMax((unsigned long long*)&d.stats->max_helm_k[sc.cls], (unsigned long long)used); rec_step_iters(d, 0, used);
       d.stats->last_helm_res = fmax(resrec[0], resrec[1]);
       if (unconv) atomicAdd((unsigned long long*)&d.stats->unconverged, 1ull);
     }

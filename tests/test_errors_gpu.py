@@ -145,7 +145,7 @@ def test_non_finite_input_is_reported_by_the_map_and_does_not_poison_the_context
     h.matvec_batch([f, g], [a, a], 0)                       # both lanes clean again
     for v in (f, g):
         got = h.download(v)
-        assert all(np.allclose(x, y, rtol=0, atol=1e-9 * np.abs(y).max()) for x, y in zip(got[:2], ref[:2]))
+        assert all(np.allclose(x, y, rtol=0, atol=1e-6 * np.abs(y).max()) for x, y in zip(got[:2], ref[:2]))      # (lane 1 has its own, cold, projection space: solver tolerance)
     h.close()
 
 
