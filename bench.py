@@ -653,7 +653,10 @@ def main():
             tsteps = max(st["total_steps"], 1)
             out.update({"helm_iters_per_step": st["total_helm_iters"] / tsteps, "pres_iters_per_step": st["total_pres_iters"] / tsteps,
                         "map_retries": st["retries"], "graph_recaptures": st["recaptures"], "graph_recapture_s": st["recapture_seconds"],
-                        "capped_solves": st["total_capped_solves"], "worst_cap_ratio": st["total_worst_cap_ratio"]})
+                        "capped_solves": st["total_capped_solves"], "worst_cap_ratio": st["total_worst_cap_ratio"],
+                        "launch_budgets": {"per_time_step": {"maps": st["step_budget_maps"], "helm_launches_per_step": st["step_budget_helm_mean"], "pres_iterations_per_step": st["step_budget_pres_mean"]},
+                                           "last_step_class": {"helm": st["budget_helm"], "pres": st["budget_pres"]},
+                                           "note": "launches budgeted per time step (a launch beyond a solve's own count returns on a device flag); per-time-step budgets follow the per-step iteration record of the last 8 maps (nsk.hip: step_budgets_update)"}})
             # ---- SURVEY 8(d) accounting: algorithmic bytes per matvec from the logged iteration counts
             geom = dict(nel=case.nel, lx1=case.lx1, ndim=2, nvert=int(case.meta["nvert"]), coarse_lda=((int(case.meta["nvert"]) + 255) // 256) * 256,
                         patch_stride=(((case.lx1 - 2 + 4) ** 2 + 3) // 4) * 4, nproj=a.nproj)

@@ -31,6 +31,8 @@ module nekstab_hip
     real(c_double) :: recapture_seconds
     integer(c_long_long) :: total_pres_jsum
     real(c_double) :: coarse_bytes_per_solve
+    integer(c_long_long) :: step_budget_maps
+    real(c_double) :: step_budget_helm_mean, step_budget_pres_mean
   end type
 
   interface

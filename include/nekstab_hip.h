@@ -196,6 +196,10 @@ typedef struct {
   double recapture_seconds;                 /* host time spent (re)capturing and instantiating the step graphs since nsk_init */
   long long total_pres_jsum;                /* since nsk_init: sum over all GMRES columns of their basis index j (Gram-Schmidt bytes) */
   double coarse_bytes_per_solve;            /* operator bytes ONE coarse solve reads (dense / block-circulant inverse, or degree x sparse rows) */
+  /* per-time-step launch budgets (option "step_budgets"): maps run on them since init and the launches they budgeted per
+   * time step on average (velocity: k_helm launches; pressure: GMRES iterations), 0 while none ran */
+  long long step_budget_maps;
+  double step_budget_helm_mean, step_budget_pres_mean;
 } nsk_stats;
 int nsk_get_stats(nsk_ctx* ctx, nsk_stats* s);
 

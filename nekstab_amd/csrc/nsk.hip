@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <array>
 #include <map>
 #include <utility>
 #include <string>
@@ -103,6 +104,27 @@ struct nsk_ctx {
   // `graph_steps` consecutive steps: fewer graph launches and graph-to-graph hand-overs per map (option "graph_steps", 1 = off)
   struct StepGraph { hipGraphExec_t exec = nullptr; int nh = -1, np = -1; } graphs[3][NCLS + 1];
   int graph_steps = 1;                  // (measured on config 2: 11.79 / 11.80 / 11.84 matvecs/s at 1 / 8 / 16 steps per graph: within noise, off)
+  // ---- launch budgets PER TIME STEP (round 5; option "step_budgets", default on for graph-replayed single-rank contexts).
+  // The iteration counts of a map decay along its time steps (config 2: 28 CG iterations at step 1, 9 at step 40, 7 at step
+  // 183) and the pressure counts wander between 2 and 10 with the restarts of the projection space: one budget per step CLASS
+  // must cover the largest count of its class (the class of steps >= 17 holds 167 steps), and every budgeted launch beyond a
+  // solve's own count still costs its dispatch (2-4 us; 39 % of the kernel time of a config-2 map in round 4).  With the
+  // per-step record of the last SBW maps (Dev::step_iters) the budget of step s follows the largest count seen at steps
+  // s-2..s+2 in those maps + head-room: measured on 56 maps of config 2 (scripts/step_iters_dump.py, profiles/r05_step_budgets.txt)
+  // 14.4 + 9.9 launches per step instead of 20.5 + 13.7, no overflow.  One captured graph per (step class, budget pair), kept
+  // in `gcache` (a few dozen pairs occur); a map that overflows is redone with the class budgets.
+  static constexpr int SBW = 8, SBN = 2;
+  int step_budgets = 1;
+  struct StepBudgets {                   // one history per kind of map (0 direct, 1 adjoint): their solves differ
+    std::vector<int> hist_h[SBW], hist_p[SBW];
+    int n = 0;                           // maps in the history (ring slot = n % SBW)
+    std::vector<int> bh, bp;             // budgets of the next map of this kind (empty: class budgets)
+  } sb[2];
+  int last_map_kind = 0;
+  bool sb_force_class = false;           // the redo of an overflowed map runs on the (doubled) class budgets
+  long long sb_maps = 0, sb_steps = 0, sb_launch_h = 0, sb_launch_p = 0;     // maps / time steps run on per-step budgets and their budgeted launches (diagnostics)
+  bool last_map_per_step = false;        // the map just run took the per-step budgets
+  std::map<std::array<int, 4>, hipGraphExec_t> gcache;         // (adjoint, class, nh, np) -> captured step
   std::vector<nsk_ctx*> graph_members;  // sharded step graphs (held by the first rank of a process): the ranks they were captured for
   int merged_iters = 24;                // ... for the first merged_iters iterations of a solve (see pres_solve_launch; 12 until round 4: 24 covers the tightened solves of time steps 1-3 too, +2 % on config 2 at identical iteration counts)
   int merged_update = 1;                // GMRES column bookkeeping inside the coarse-solve kernel (k_update_coarse)
@@ -190,6 +212,15 @@ struct nsk_ctx {
   int orbit_steps = 0;
 };
 
+// every captured step is stale (Dev, coefficients, kernel choices are baked in): class graphs re-captured on next use, the
+// per-step budget cache emptied, the per-step iteration history forgotten (the solves of a new operator behave differently)
+static void invalidate_graphs(nsk_ctx* c) {
+  for (auto& a : c->graphs) for (auto& g : a) g.nh = -1;
+  for (auto& kv : c->gcache) if (kv.second) (void)hipGraphExecDestroy(kv.second);
+  c->gcache.clear();
+  for (auto& b : c->sb) { b.n = 0; b.bh.clear(); b.bp.clear(); }
+}
+
 template <class T>
 static int dalloc(nsk_ctx* c, T** p, size_t n) {
   void* q = nullptr;
@@ -210,6 +241,8 @@ static int dupload(nsk_ctx* c, const T** p, const std::vector<T>& h) {
   *p = q;
   return 0;
 }
+
+static bool lda_ok_for_ecv(const nsk_ctx* c) { return c->ndim == 2 && c->coarse_lda > 0 && c->coarse_lda <= 3072 && !c->local; }      // where k_update_coarse runs
 
 static StepCoef make_coef(const nsk_ctx* c, int istep, int adjoint) {
   static const double BD[3][4] = {{1.0, 1.0, 0.0, 0.0}, {1.5, 2.0, -0.5, 0.0}, {11.0 / 6.0, 3.0, -1.5, 1.0 / 3.0}};
@@ -729,6 +762,13 @@ static int build(nsk_ctx* c, const nsk_case& cs) {
       for (int k = 0; k < n; ++k) vtab[(size_t)v * CVT + k] = v_ent[v_off[v] + k];
     }
     if ((rc = dupload(c, &d.vtab, vtab))) return rc;
+    // vertex-major slots of the element-corner restrictions (Dev::ecv): the inverse of vtab
+    if (CVT == 8 && lda_ok_for_ecv(c)) {
+      std::vector<int> ecslot((size_t)nel * 4, 0);
+      for (int v = 0; v < nvert; ++v)
+        for (int k = 0; k < v_off[v + 1] - v_off[v]; ++k) ecslot[v_ent[v_off[v] + k]] = v * 8 + k;
+      if ((rc = dupload(c, &d.ecslot, ecslot)) || (rc = dalloc(c, &d.ecv, (size_t)8 * d.coarse_lda))) return rc;
+    }
   }
   c->h_evert = evert;
   if ((rc = dupload(c, &d.v_off, v_off)) || (rc = dupload(c, &d.v_ent, v_ent)) || (rc = dupload(c, &d.evert, evert)) ||
@@ -811,6 +851,7 @@ static int build(nsk_ctx* c, const nsk_case& cs) {
   if (const char* g = std::getenv("NSK_GRAPH_STEPS")) c->graph_steps = std::max(1, std::min(std::atoi(g), 64));
   if (const char* g = std::getenv("NSK_MERGED_ITERS")) c->merged_iters = std::max(0, std::min(std::atoi(g), MAXMR));
   if (const char* g = std::getenv("NSK_DEBUG")) c->debug = std::atoi(g);
+  if (const char* g = std::getenv("NSK_STEP_BUDGETS")) c->step_budgets = std::atoi(g);
   HIPCHK(hipStreamSynchronize(c->stream));
   return 0;
 }
@@ -1020,7 +1061,7 @@ static int pres_solve_launch(nsk_ctx* c, double h2, int ord, int np, double tol_
     // Only the first `merged_iters` (24) iterations of a solve: x_c(v_j) by linearity is a recurrence, its rounding error grows by
     // ~|h_jj / h_{j+1,j}| per iteration (harmless in a preconditioner for a dozen iterations, a stalled solve after forty:
     // measured on the 1e-8 solves of test_newton_gpu); later iterations take the classic four kernels.
-    const bool merged = c->merged_update && c->ndim == 2 && d.coarse_lda <= 3072 && !d.use_tot && d.nranks <= 1 && d.rch && !hc;
+    const bool merged = c->merged_update && c->ndim == 2 && d.coarse_lda <= 3072 && !d.use_tot && d.nranks <= 1 && d.rch && d.ecv && !hc;
     const int nm = merged ? std::min(np, std::min(c->merged_iters, c->gmres_cycle)) : 0;
     if (hc && c->hc_pres[ord] <= 1) {                     // the projection space may have solved this right-hand side alone
       bool done = false;
@@ -1114,11 +1155,11 @@ static int fused_possible(nsk_ctx* c) {
   return need <= std::min(per, 5);      // 5: what ~110 SGPRs admit (floor(800 / 128) = 6) minus one
 }
 
-static int step(nsk_ctx* c, int istep, int adjoint) {
+static int step(nsk_ctx* c, int istep, int adjoint, int nh_over = -1, int np_over = -1) {
   Dev& d = c->d;
   const StepCoef sc = make_coef(c, istep, adjoint);
   const bool hc = hostcheck_on(c) && !stream_capturing(c->stream);
-  int nh = hc ? c->max_helm : c->cur_helm[sc.cls];
+  int nh = hc ? c->max_helm : (nh_over > 0 ? nh_over : c->cur_helm[sc.cls]);
   DISPATCH_N(c->key, {
     constexpr int NT = Cfg<N>::NT;
     if (c->key == 108 && adjoint != 2 && c->mfma_convect)
@@ -1146,7 +1187,7 @@ static int step(nsk_ctx* c, int istep, int adjoint) {
   });
   // The first steps of a map project out whatever divergence the input vector has (a noise seed is far from
   // solenoidal): an error there survives to the end of the map, so those solves are converged further.
-  int rc = pres_solve_launch(c, sc.h2, sc.cls, hc ? c->max_pres : c->cur_pres[sc.cls], istep <= 3 ? c->early_pres_mul : 1.0, adjoint != 2, hc);
+  int rc = pres_solve_launch(c, sc.h2, sc.cls, hc ? c->max_pres : (np_over > 0 ? np_over : c->cur_pres[sc.cls]), istep <= 3 ? c->early_pres_mul : 1.0, adjoint != 2, hc);
   if (rc) return rc;
   const bool flat = flat_proj_on(c);
   Dev df = d; df.flat_proj = flat ? 1 : 0;
@@ -1209,14 +1250,57 @@ static int ensure_graph_multi(nsk_ctx* c, int adjoint) {
   return 0;
 }
 
+// the captured step of class `cls` with the launch budgets (nh, np): per-step budgets (nsk_ctx::gcache)
+static int graph_for(nsk_ctx* c, int adjoint, int cls, int nh, int np, hipGraphExec_t* out) {
+  const std::array<int, 4> key{adjoint, cls, nh, np};
+  auto it = c->gcache.find(key);
+  if (it != c->gcache.end()) { *out = it->second; return 0; }
+  if (c->gcache.size() >= 1024) {                          // (never seen: a few dozen budget pairs occur) start again
+    for (auto& kv : c->gcache) if (kv.second) (void)hipGraphExecDestroy(kv.second);
+    c->gcache.clear();
+  }
+  const auto t_cap0 = std::chrono::steady_clock::now();
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+  int rc = step(c, CLS_ISTEP[cls], adjoint, nh, np);
+  hipError_t e = hipStreamEndCapture(c->stream, &graph);
+  if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+  if (e != hipSuccess) return fail(NSK_EHIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+  HIPCHK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+  HIPCHK(hipGraphDestroy(graph));
+  c->recaptures++;
+  c->recapture_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_cap0).count();
+  c->gcache[key] = exec;
+  *out = exec;
+  return 0;
+}
+static bool step_budgets_ready(const nsk_ctx* c, int kind) {
+  if (kind < 0 || kind > 1) return false;
+  const nsk_ctx::StepBudgets& b = c->sb[kind];
+  return c->step_budgets && !c->sb_force_class && !c->fused && !c->budget_freeze && c->d.step_iters && (int)b.bh.size() == c->nsteps && (int)b.bp.size() == c->nsteps;
+}
+
 static int run_map(nsk_ctx* c, int adjoint, double* f, const double* q) {
   Dev& d = c->d;
   // one- and two-step maps (newton.py: time derivative of the orbit) run eagerly: capturing six step-class graphs for them
   // costs more than the steps, and their iteration counts say nothing about the budgets of the real maps
   const bool use_graph = c->use_graph && c->nsteps > 2 && !hostcheck_on(c);
-  if (use_graph)
+  const bool per_step = use_graph && step_budgets_ready(c, adjoint);
+  c->last_map_per_step = per_step; c->last_map_kind = adjoint;
+  std::vector<hipGraphExec_t> plan;
+  if (per_step) {                                           // every graph of the plan exists before the first launch (captures end the stream's queue)
+    plan.resize(c->nsteps);
+    for (int istep = 1; istep <= c->nsteps; ++istep) {
+      const nsk_ctx::StepBudgets& b = c->sb[adjoint];
+      int rc = graph_for(c, adjoint, step_class(istep), b.bh[istep - 1], b.bp[istep - 1], &plan[istep - 1]);
+      if (rc) return rc;
+      c->sb_launch_h += b.bh[istep - 1]; c->sb_launch_p += b.bp[istep - 1];
+    }
+    c->sb_maps++; c->sb_steps += c->nsteps;
+  } else if (use_graph)
     for (int k = 0; k < NCLS; ++k) { int rc = ensure_graph(c, k, adjoint); if (rc) return rc; }
-  const int gsteps = (use_graph && c->graph_steps > 1 && c->nsteps >= CLS_ISTEP[NCLS - 1] + 2 * c->graph_steps) ? c->graph_steps : 1;
+  const int gsteps = (use_graph && !per_step && c->graph_steps > 1 && c->nsteps >= CLS_ISTEP[NCLS - 1] + 2 * c->graph_steps) ? c->graph_steps : 1;
   if (gsteps > 1) { int rc = ensure_graph_multi(c, adjoint); if (rc) return rc; }
   for (int cc = 0; cc < c->ndim; ++cc)
     HIPCHK(hipMemcpyAsync(d.u + cc * d.cs, q + cc * d.nloc, d.nloc * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
@@ -1226,7 +1310,9 @@ static int run_map(nsk_ctx* c, int adjoint, double* f, const double* q) {
     HIPCHK(hipMemsetAsync(d.bstep, 0, sizeof(int), c->stream));
   }
   for (int istep = 1; istep <= c->nsteps; ++istep) {
-    if (use_graph) {
+    if (per_step) {
+      HIPCHK(hipGraphLaunch(plan[istep - 1], c->stream));
+    } else if (use_graph) {
       if (gsteps > 1 && istep >= CLS_ISTEP[NCLS - 1] && istep + gsteps - 1 <= c->nsteps) {
         HIPCHK(hipGraphLaunch(c->graphs[adjoint][NCLS].exec, c->stream));
         istep += gsteps - 1;
@@ -1292,6 +1378,35 @@ static void budgets_update(nsk_ctx* c, const Stats& h) {
   }
 }
 
+// Per-step budgets of the NEXT map from the per-step iteration counts of the last SBW maps (see nsk_ctx::step_budgets).
+// Helmholtz: launches = largest count at steps s-SBN..s+SBN + 3 (a solve that took I iterations needs I + 1 launches: 2 spare);
+// pressure: + 2.  Steps 1-6 and the first maps of a run vary most (the class budgets' rule): wider margins there.
+static void step_budgets_update(nsk_ctx* c) {
+  const int ns = c->step_rec_n, kind = c->last_map_kind;
+  if (kind < 0 || kind > 1) return;
+  nsk_ctx::StepBudgets& b = c->sb[kind];
+  if (!c->step_budgets || !c->h_step_iters || ns != c->nsteps || ns < 3) { b.bh.clear(); b.bp.clear(); return; }
+  if (b.n > 0 && (int)b.hist_h[0].size() != ns) b.n = 0;                     // (nsteps changed under us: start again)
+  const int slot = b.n % nsk_ctx::SBW;
+  b.hist_h[slot].resize(ns); b.hist_p[slot].resize(ns);
+  for (int s = 0; s < ns; ++s) { b.hist_h[slot][s] = c->h_step_iters[2 * s]; b.hist_p[slot][s] = c->h_step_iters[2 * s + 1]; }
+  b.n++;
+  const int nv = std::min(b.n, nsk_ctx::SBW);
+  b.bh.assign(ns, 0); b.bp.assign(ns, 0);
+  static const int head_h = std::getenv("NSK_SB_HEAD_H") ? std::atoi(std::getenv("NSK_SB_HEAD_H")) : 3;
+  static const int head_p = std::getenv("NSK_SB_HEAD_P") ? std::atoi(std::getenv("NSK_SB_HEAD_P")) : 2;
+  for (int s = 0; s < ns; ++s) {
+    int mh = 0, mp = 0;
+    for (int i = 0; i < nv; ++i)
+      for (int t = std::max(0, s - nsk_ctx::SBN); t <= std::min(ns - 1, s + nsk_ctx::SBN); ++t) { mh = std::max(mh, b.hist_h[i][t]); mp = std::max(mp, b.hist_p[i][t]); }
+    int xh = 0, xp = 0;
+    if (s < 6) { xh = std::max(4, mh / 2); xp = std::max(4, mp); }                    // time steps 1-6: counts vary most (noise left by the input vector)
+    if (nv < 4) { xh += std::max(2, mh / 4); xp += std::max(3, mp / 2); }            // first maps of a run: noise seed, empty projection space
+    b.bh[s] = std::min(c->max_helm, mh + head_h + xh);
+    b.bp[s] = std::min(c->max_pres, std::max(c->min_pres, mp) + head_p + xp);
+  }
+}
+
 // run one map with the adaptive launch budgets: every inner solve early-exits on its
 // own convergence flag; a solve that runs out of launched iterations is counted on the
 // device and the whole map is redone with larger budgets.
@@ -1307,7 +1422,7 @@ static void budgets_update(nsk_ctx* c, const Stats& h) {
 static int reset_solver_state(nsk_ctx* c) {
   Dev& d = c->d;
   void* mut[] = {d.u, d.p, d.plag, d.pext, d.ulag, d.exlag, d.bf, d.rloc, d.bloc, d.dulag, d.hx, d.hr, d.hp, d.hs, d.hwl, d.hpart, d.hscal,
-                 d.V, d.Z, d.yl, d.ec, d.xc, d.gpart, d.xacc, d.dpw, d.hz, d.hy, d.rch, d.gsc, d.PX, d.PEX, d.PD, d.PED, d.ppart, d.stats,
+                 d.V, d.Z, d.yl, d.ec, d.ecv, d.xc, d.gpart, d.xacc, d.dpw, d.hz, d.hy, d.rch, d.gsc, d.PX, d.PEX, d.PD, d.PED, d.ppart, d.stats,
                  d.gpart2, d.gtot2, d.ptot, d.htot, d.gtot, c->rc_big, c->cw_d0, c->cw_d1, c->cw_r, c->circ_rh, c->circ_xh, c->rc_part, c->sync};
   for (void* p : mut) {
     if (!p) continue;
@@ -1329,7 +1444,7 @@ static int ensure_step_record(nsk_ctx* c) {
   HIPCHK(hipHostMalloc((void**)&c->h_step_iters, (size_t)2 * nsk_ctx::STEP_CAP * sizeof(int)));
   std::memset(c->h_step_iters, 0, (size_t)2 * nsk_ctx::STEP_CAP * sizeof(int));
   c->d.stepctr = ctr; c->d.step_iters = rec; c->d.step_cap = nsk_ctx::STEP_CAP;
-  for (auto& a : c->graphs) for (auto& g : a) g.nh = -1;
+  invalidate_graphs(c);
   return 0;
 }
 
@@ -1374,8 +1489,14 @@ static int map_finish(nsk_ctx* c) {
   }
   const bool hcm = hostcheck_on(c);     // host-checked eager steps iterate to the caps whatever the budgets say
   if (h.unconverged == 0) {
-    if (c->nsteps > 2 && !hcm) budgets_update(c, h);
+    if (c->nsteps > 2 && !hcm) { budgets_update(c, h); step_budgets_update(c); }
+    c->sb_force_class = false;
     return 0;
+  }
+  if (c->last_map_per_step) {           // a per-step budget overflowed: the redo runs on the class budgets as they stand (they cover the class maxima of the last maps)
+    c->sb_force_class = true;
+    c->retries++;
+    return 1;
   }
   bool capped = true;
   for (int k = 0; k < NCLS; ++k) capped = capped && c->cur_helm[k] >= c->max_helm && c->cur_pres[k] >= c->max_pres;
@@ -1558,7 +1679,7 @@ static int group_set_baseflow(std::vector<nsk_ctx*>& G, const double* const* q) 
           dinv[(size_t)k * c->nloc + (size_t)le * NN + i] = P->h_mask[lg] / (d.nu * P->h_dAs[lg] + bd0[k] / c->dt * P->h_bs[lg]);
         }
     HIPCHK(hipMemcpy((double*)d.dinv, dinv.data(), dinv.size() * sizeof(double), hipMemcpyHostToDevice));
-    for (auto& a : c->graphs) for (auto& g : a) g.nh = -1;
+    invalidate_graphs(c);
     for (int k = 0; k < NCLS; ++k) { c->cur_helm[k] = c->max_helm; c->cur_pres[k] = c->max_pres; }
     c->bh_n = 0;
   }
@@ -1655,7 +1776,7 @@ int nsk_group_set_orbit(nsk_ctx** shards, int n, nsk_vec* q0, double spng_str, n
       d.bf_stride = (long long)c->nel * c->NDD;
     }
     c->orbit_steps = c->nsteps;
-    for (auto& a : c->graphs) for (auto& g : a) g.nh = -1;
+    invalidate_graphs(c);
   }
   return 0;
 }
@@ -1761,6 +1882,7 @@ int nsk_init(const nsk_case* cs, nsk_ctx** out) {
     return fail(NSK_EHIP, "no HIP device: libnekstab_hip has no CPU fallback");
   nsk_ctx* c = new nsk_ctx();
   int rc = (cs->ndim == 3) ? build3(c, *cs) : build(c, *cs);
+  if (!rc) rc = ensure_step_record(c);       // (here, not at the first map: an allocation memsets on the null stream, which would end another lane's stream capture)
   if (rc) { std::string keep = g_err; nsk_finalize(c); g_err = keep; return rc; }
   *out = c;
   return 0;
@@ -1898,6 +2020,7 @@ int nsk_finalize(nsk_ctx* c) {
   if (!c) return 0;
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (auto& a : c->graphs) for (auto& g : a) if (g.exec) (void)hipGraphExecDestroy(g.exec);
+  for (auto& kv : c->gcache) if (kv.second) (void)hipGraphExecDestroy(kv.second);
   for (void* p : c->allocs) (void)hipFree(p);
   if (c->hpin) (void)hipHostFree(c->hpin);
   if (c->hstat_pin) (void)hipHostFree(c->hstat_pin);
@@ -1931,7 +2054,7 @@ int nsk_set_nsteps(nsk_ctx* c, int nsteps) {
 int nsk_set_tolerances(nsk_ctx* c, double th, double tp, int relative) {
   if (!c) return fail(NSK_EINVAL, "null ctx");
   c->d.tol_helm = th; c->d.tol_pres = tp; c->d.tol_relative = relative;
-  for (auto& a : c->graphs) for (auto& g : a) g.nh = -1;   // Dev is captured by value: re-capture
+  invalidate_graphs(c);   // Dev is captured by value: re-capture
   for (int k = 0; k < NCLS; ++k) { c->cur_helm[k] = c->max_helm; c->cur_pres[k] = c->max_pres; }
   c->bh_n = 0;
   return 0;
@@ -1955,8 +2078,8 @@ int nsk_set_option(nsk_ctx* c, const char* name, double value) {
     int rc = dalloc(c, &c->scratch, (size_t)c->nstate);       // vectors allocated before this call keep the old length: set it first
     if (rc) return rc;
   }
-  else if (n == "merged_iters") { c->merged_iters = std::max(0, std::min((int)value, MAXMR)); for (auto& a : c->graphs) for (auto& g : a) g.nh = -1; }
-  else if (n == "merged_update") { c->merged_update = (int)value; for (auto& a : c->graphs) for (auto& g : a) g.nh = -1; }
+  else if (n == "merged_iters") { c->merged_iters = std::max(0, std::min((int)value, MAXMR)); invalidate_graphs(c); }
+  else if (n == "merged_update") { c->merged_update = (int)value; invalidate_graphs(c); }
   else if (n == "min_pres_iter") c->min_pres = (int)value;
   else if (n == "pres_cap") {
     if (value > 0 && c->ndim != 2) return fail(NSK_EINVAL, "pres_cap is validated on quadrilateral linearised maps only (DESIGN.md section 1)");
@@ -1966,12 +2089,12 @@ int nsk_set_option(nsk_ctx* c, const char* name, double value) {
   else if (n == "gs2_from") c->gs2_from = std::max(0, (int)value);
   else if (n == "gs_lag") c->gs_lag = (int)value;
   else if (n == "flat_proj") c->flat_proj = (int)value;
-  else if (n == "divgs_c3") { c->divgs_c3 = (int)value; for (auto& a : c->graphs) for (auto& g : a) g.nh = -1; }
-  else if (n == "eapply_pipe") { c->eapply_pipe = (int)value; for (auto& a : c->graphs) for (auto& g : a) g.nh = -1; }
+  else if (n == "divgs_c3") { c->divgs_c3 = (int)value; invalidate_graphs(c); }
+  else if (n == "eapply_pipe") { c->eapply_pipe = (int)value; invalidate_graphs(c); }
   else if (n == "helm_fdm") {           // 0: back to Jacobi (the factors stay); 1: only if the set-up built them (NSK_HELM_FDM=1 or an anisotropic mesh)
     if (value != 0.0 && !c->d.hfS) return fail(NSK_EINVAL, "helm_fdm: the fast-diagonalisation factors were not built at set-up (NSK_HELM_FDM=1)");
     c->d.helm_fdm = value != 0.0 ? 1 : 0;
-    for (auto& a : c->graphs) for (auto& g : a) g.nh = -1;
+    invalidate_graphs(c);
   }
   else if (n == "graph_steps") { c->graph_steps = std::max(1, std::min((int)value, 64)); for (auto& a : c->graphs) a[NCLS].nh = -1; }
   else if (n == "dbg_max_order") c->dbg_max_order = (int)value;
@@ -1998,8 +2121,9 @@ int nsk_set_option(nsk_ctx* c, const char* name, double value) {
   else if (n == "budget_add_helm") { for (int k = 0; k < NCLS; ++k) c->cur_helm[k] = std::min(c->max_helm, std::max(1, c->cur_helm[k] + (int)value)); }
   else if (n == "budget_add_pres") { for (int k = 0; k < NCLS; ++k) c->cur_pres[k] = std::min(c->max_pres, std::max(1, c->cur_pres[k] + (int)value)); }
   else if (n == "budget_freeze") c->budget_freeze = (int)value;
+  else if (n == "step_budgets") c->step_budgets = (int)value;
   else return fail(NSK_EINVAL, "unknown option " + n);
-  for (auto& a : c->graphs) for (auto& g : a) g.nh = -1;
+  invalidate_graphs(c);
   return 0;
 }
 
@@ -2100,6 +2224,9 @@ int nsk_get_stats(nsk_ctx* c, nsk_stats* s) {
   s->total_helm_iters = c->tot_helm_iters; s->total_pres_iters = c->tot_pres_iters; s->total_steps = c->tot_steps;
   s->recapture_seconds = c->recapture_s;
   s->total_pres_jsum = c->tot_pres_jsum; s->coarse_bytes_per_solve = c->coarse_bytes;
+  s->step_budget_maps = c->sb_maps;
+  s->step_budget_helm_mean = c->sb_maps ? (double)c->sb_launch_h / ((double)c->sb_steps) : 0.0;
+  s->step_budget_pres_mean = c->sb_maps ? (double)c->sb_launch_p / ((double)c->sb_steps) : 0.0;
   return 0;
 }
 
@@ -2167,7 +2294,7 @@ int nsk_set_baseflow(nsk_ctx* c, nsk_vec qv) {
   for (int k = 0; k < 3; ++k)
     for (long long l = 0; l < c->nloc; ++l) dinv[(size_t)k * c->nloc + l] = c->h_mask[l] / (d.nu * c->h_dAs[l] + bd0[k] / c->dt * c->h_bs[l]);
   HIPCHK(hipMemcpy((double*)d.dinv, dinv.data(), dinv.size() * sizeof(double), hipMemcpyHostToDevice));
-  for (auto& a : c->graphs) for (auto& g : a) g.nh = -1;           // coefficients are baked into the captured graphs
+  invalidate_graphs(c);           // coefficients are baked into the captured graphs
   return 0;
 }
 
@@ -2194,7 +2321,7 @@ int nsk_set_orbit(nsk_ctx* c, nsk_vec q0v, double spng_str, nsk_vec end) {
     for (int cc = 0; cc < 3; ++cc) HIPCHK(hipMemcpyAsync(vr + cc * d.cs, q0 + cc * d.nloc, d.nloc * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     d.spng_vr = vr; d.nl_spng_str = spng_str;
     if (!d.bstep && (rc = dalloc(c, &d.bstep, 4))) return rc;
-    for (auto& a : c->graphs) for (auto& g : a) g.nh = -1;
+    invalidate_graphs(c);
     for (int k = 0; k < NCLS; ++k) { c->cur_helm[k] = c->max_helm; c->cur_pres[k] = c->max_pres; }
     c->bh_n = 0;
     HIPCHK(hipMemsetAsync(d.stats, 0, sizeof(Stats), c->stream));
@@ -2219,7 +2346,7 @@ int nsk_set_orbit(nsk_ctx* c, nsk_vec q0v, double spng_str, nsk_vec end) {
     c->steady[0] = d.bfc;
     d.bfc = c->orbit[0]; d.cUr = c->orbit[0];
     d.bf_stride = 12 * nfine; c->orbit_steps = c->nsteps;
-    for (auto& a : c->graphs) for (auto& g : a) g.nh = -1;
+    invalidate_graphs(c);
     return 0;
   }
   if (d.bf_stride) {                                            // back to the steady arrays first
@@ -2239,7 +2366,7 @@ int nsk_set_orbit(nsk_ctx* c, nsk_vec q0v, double spng_str, nsk_vec end) {
   HIPCHK(hipMemcpyAsync(vr + d.cs, q0 + d.nloc, d.nloc * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
   d.spng_vr = vr; d.nl_spng_str = spng_str;
   if (!d.bstep && (rc = dalloc(c, &d.bstep, 4))) return rc;
-  for (auto& a : c->graphs) for (auto& g : a) g.nh = -1;
+  invalidate_graphs(c);
   for (int k = 0; k < NCLS; ++k) { c->cur_helm[k] = c->max_helm; c->cur_pres[k] = c->max_pres; }
   c->bh_n = 0;
   HIPCHK(hipMemsetAsync(d.stats, 0, sizeof(Stats), c->stream));
@@ -2267,7 +2394,7 @@ int nsk_set_orbit(nsk_ctx* c, nsk_vec q0v, double spng_str, nsk_vec end) {
   c->steady[0] = d.cUr; c->steady[1] = d.cUs; c->steady[2] = d.GUx; c->steady[3] = d.GUy; c->steady[4] = d.GVx; c->steady[5] = d.GVy;
   d.cUr = c->orbit[0]; d.cUs = c->orbit[1]; d.GUx = c->orbit[2]; d.GUy = c->orbit[3]; d.GVx = c->orbit[4]; d.GVy = c->orbit[5];
   d.bf_stride = nfine; c->orbit_steps = c->nsteps;
-  for (auto& a : c->graphs) for (auto& g : a) g.nh = -1;
+  invalidate_graphs(c);
   return 0;
 }
 
@@ -2526,6 +2653,7 @@ int nsk_clone(nsk_ctx* P, nsk_ctx** out) {
         (rc = dalloc(c, &d.PD, npr)) || (rc = dalloc(c, &d.PED, npr)) || (rc = dalloc(c, &d.ppart, (size_t)(MAXPROJ + 2) * c->nblk))) return bail(rc);
   if (P->rc_big && (rc = dalloc(c, &c->rc_big, c->coarse_lda))) return bail(rc);
   if (P->d.rch && (rc = dalloc(c, &d.rch, (size_t)MAXMR * c->coarse_lda))) return bail(rc);
+  if (P->d.ecv && (rc = dalloc(c, &d.ecv, (size_t)8 * c->coarse_lda))) return bail(rc);
   if (d.use_tot && ((rc = dalloc(c, &d.htot, 32)) || (rc = dalloc(c, &d.gtot, MAXMR + 8)) || (rc = dalloc(c, &d.gtot2, MAXMR + 8)) || (rc = dalloc(c, &d.ptot, MAXPROJ + 2)))) return bail(rc);
   if ((rc = dalloc(c, &c->sync, SYNC_WORDS))) return bail(rc);
   c->kblk = 256;
@@ -2533,6 +2661,7 @@ int nsk_clone(nsk_ctx* P, nsk_ctx** out) {
   if (hipHostMalloc((void**)&c->hpin, 4096 * sizeof(double)) != hipSuccess || hipHostMalloc((void**)&c->hstat_pin, sizeof(Stats)) != hipSuccess)
     return bail(fail(NSK_ENOMEM, "hipHostMalloc"));
   c->bm1s_host = P->bm1s_host;
+  if ((rc = ensure_step_record(c))) return bail(rc);
   HIPCHK(hipStreamSynchronize(c->stream));
   *out = c;
   return 0;
@@ -2680,6 +2809,7 @@ int nsk_bench_kernel(nsk_ctx* c, const char* name, int reps, double* avg_us) {
     // kernels of the pressure solve, back to back on the state the last map left (run one first).  Tolerance 0 and a cleared
     // `done` flag: every launch does full work.  `pres_chain`: whole GMRES iterations j = 0..7 (coarse, Schwarz, E, update).
     if (c->ndim != 2 || d.coarse_lda > 3072) return fail(NSK_EINVAL, "pressure-kernel timing: quadrilateral contexts with the dense in-LDS coarse solve");
+    if ((n.rfind("update_coarse", 0) == 0 || n == "pres_chain_merged") && !d.ecv) return fail(NSK_EINVAL, "merged coarse-solve kernel not available in this context");
     d.tol_pres = 0.0; d.tol_relative = 0; d.pres_cap = 0;
     const StepCoef sc = make_coef(c, 17, 0);
     const double scale = 1.0 / (sc.h2 * std::sqrt(d.vol));

@@ -119,6 +119,13 @@ struct Dev {
   const int* hfT;                // [nel] 1: this element takes its fast-diagonalisation block, 0: it is isotropic enough for the Jacobi diagonal
   double *hz, *hy;
   double *rch;                   // [MAXMR][coarse_lda] coarse solutions x_c(v_i) of the GMRES basis vectors (k_update_coarse)
+  // element-corner restrictions in VERTEX-major slots (quadrilateral merged coarse solve): ecv[8 v + k] = the value of the k-th
+  // element corner at vertex v (the order of vtab; unused slots stay zero), ecslot[4 e + c] = the slot of corner c of element e.
+  // The restriction R w of vertex v is then 64 contiguous bytes at an address known from v alone: k_update_coarse, which every
+  // workgroup runs over ALL vertices, reads it with coalesced 16-byte loads in its first round trip instead of two dependent
+  // rounds of scattered 8-byte gathers through vtab (round 5: 14.9 -> see DESIGN.md section 5.1)
+  double *ecv;
+  const int *ecslot;
   GmresScal* gsc;
   // projection onto previous pressure solutions (E-orthonormal)
   double *PX, *PEX, *PD, *PED, *ppart;

@@ -1121,6 +1121,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_gmres_update(Dev d, int j, doubl
 #pragma unroll 6
     for (int k = 0; k < MM; ++k) s += shat[nd * MM + k] * sv[el * MM + k];
     d.ec[e * 4 + nd] = s;
+    if (d.ecv) d.ecv[d.ecslot[e * 4 + nd]] = s;
   }
 }
 
@@ -1298,12 +1299,13 @@ __global__ __launch_bounds__(256) void k_update_coarse(Dev d, int j, double scal
   const int jj = j - 1;                       // the column this launch closes (j > 0)
   // Loads return in issue order: the short dependent chains go first (vertex tables -> corner values; partials of the first
   // row per wavefront), the 24 independent matrix loads last -- they are needed at the product only.
-  int4 va[MAXIT], vb[MAXIT];
+  // corner restrictions of this thread's vertices, vertex-major slots (Dev::ecv): 64 contiguous bytes per vertex
+  double2 cv[MAXIT][4];
 #pragma unroll
   for (int i = 0; i < MAXIT; ++i) {
     const int v = tid + i * 256;
-    if (i < nit && v < nv) { va[i] = reinterpret_cast<const int4*>(d.vtab)[2 * v]; vb[i] = reinterpret_cast<const int4*>(d.vtab)[2 * v + 1]; }
-    else { va[i] = make_int4(-1, -1, -1, -1); vb[i] = va[i]; }
+    const double2* E = reinterpret_cast<const double2*>(d.ecv) + (size_t)(i < nit && v < nv ? v : 0) * 4;
+    if (i < nit) { cv[i][0] = E[0]; cv[i][1] = E[1]; cv[i][2] = E[2]; cv[i][3] = E[3]; }
   }
   double gj = 0.0;
   double pr[8], pr2[8];                       // partials of rows `w` and `w + 4` (the first two this wavefront sums): d.nblk <= 512 here
@@ -1335,16 +1337,9 @@ __global__ __launch_bounds__(256) void k_update_coarse(Dev d, int j, double scal
       if (i < nit) am[r][i] = A[i * 64];
   }
 #pragma unroll
-  for (int i = 0; i < MAXIT; ++i) {           // R w (raw): gather of the element-corner restrictions
+  for (int i = 0; i < MAXIT; ++i) {           // R w (raw): the corner restrictions of a vertex in the order of vtab (unused slots are zero)
     const int v = tid + i * 256;
-    if (i < nit) {
-      const int4 a = va[i], b = vb[i];
-      const double e0 = (a.x >= 0) ? d.ec[a.x] : 0.0;
-      const double e1 = (a.y >= 0) ? d.ec[a.y] : 0.0, e2 = (a.z >= 0) ? d.ec[a.z] : 0.0, e3 = (a.w >= 0) ? d.ec[a.w] : 0.0;
-      const double e4 = (b.x >= 0) ? d.ec[b.x] : 0.0, e5 = (b.y >= 0) ? d.ec[b.y] : 0.0, e6 = (b.z >= 0) ? d.ec[b.z] : 0.0;
-      const double e7 = (b.w >= 0) ? d.ec[b.w] : 0.0;
-      srcv[v] = ((((((e0 + e1) + e2) + e3) + e4) + e5) + e6) + e7;
-    }
+    if (i < nit) srcv[v] = (v < nv) ? ((((((cv[i][0].x + cv[i][0].y) + cv[i][1].x) + cv[i][1].y) + cv[i][2].x) + cv[i][2].y) + cv[i][3].x) + cv[i][3].y : 0.0;
   }
   if (j > 0) {
     if (d.nblk <= 512) {                      // first row per wavefront from the registers, the rest as sum_partials_multi
@@ -1624,6 +1619,8 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_divgs(Dev d, const double* __res
   int4 tab = make_int4(0, -1, -1, -1);
   double bi = 0;
   if (act) { tab = d.gs_tab[l]; bi = d.binv[l]; }
+  int ecs = 0;
+  if (check_done == 2 && d.ecv && act && nd < 4) ecs = d.ecslot[e * 4 + nd];      // (with the first loads: the store at the end waits for nothing)
   double j12a = 0, d12a = 0;
   if (tid < NM) { j12a = d.J12[tid]; d12a = d.D12[tid]; }
   GsVals g0, g1;
@@ -1650,6 +1647,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_divgs(Dev d, const double* __res
 #pragma unroll 6
       for (int k = 0; k < MM; ++k) s += shat[nd * MM + k] * swr[el * MM + k];
       d.ec[e * 4 + nd] = s;
+      if (d.ecv) d.ecv[ecs] = s;
     }
   }
   if (j >= 0) {
