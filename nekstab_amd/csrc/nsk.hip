@@ -140,6 +140,10 @@ struct nsk_ctx {
   // "shard_hostcheck" the host reads the device's convergence flags (identical on every rank: they come from all-reduced
   // sums) and stops issuing iterations: -1 = yes with a communicator / host transport, 0 = never, 1 = always.
   int shard_hostcheck = -1;
+  // RCCL ranks: the all-reduce of an iteration's dot products travels in the SAME ncclGroupStart / ncclGroupEnd as that iteration's
+  // halo send / recv pairs (one group per CG iteration instead of two, three per GMRES iteration instead of four): option
+  // "rccl_fuse" (NSK_RCCL_FUSE=0 restores the separate calls; bench.py's eager retry attempt does)
+  int rccl_fuse = 1;
   // The same on a full-mesh context (option "hostcheck"): eager steps, no launch budgets, no redone maps.  -1 = yes for large
   // hexahedral meshes (>= 8192 elements: a launch that only finds its solve converged costs 25-140 us there and a map redone
   // with larger budgets tens of seconds) and for quadrilateral meshes of more than 4096 workgroups (config 3), 0 = never, 1 = always.
@@ -2068,6 +2072,7 @@ int nsk_set_option(nsk_ctx* c, const char* name, double value) {
   else if (n == "shard_hostcheck") c->shard_hostcheck = (int)value;
   else if (n == "hostcheck") c->hostcheck = (int)value;
   else if (n == "halo_overlap") c->halo_overlap = value != 0.0;
+  else if (n == "rccl_fuse") c->rccl_fuse = (int)value;
   else if (n == "orth_overlap") c->orth_overlap = (int)value;
   else if (n == "nscal") {
     // krylov_vector%theta (core/krylov_subspace.f:13): carried by every vector operation and by the inner product; the time
