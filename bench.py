@@ -655,8 +655,9 @@ def main():
                         "map_retries": st["retries"], "graph_recaptures": st["recaptures"], "graph_recapture_s": st["recapture_seconds"],
                         "capped_solves": st["total_capped_solves"], "worst_cap_ratio": st["total_worst_cap_ratio"],
                         "launch_budgets": {"per_time_step": {"maps": st["step_budget_maps"], "helm_launches_per_step": st["step_budget_helm_mean"], "pres_iterations_per_step": st["step_budget_pres_mean"]},
+                                           "persistent_tail_maps": st["tail_maps"],
                                            "last_step_class": {"helm": st["budget_helm"], "pres": st["budget_pres"]},
-                                           "note": "launches budgeted per time step (a launch beyond a solve's own count returns on a device flag); per-time-step budgets follow the per-step iteration record of the last 8 maps (nsk.hip: step_budgets_update)"}})
+                                           "note": "launches per time step in the captured graphs; with persistent tails (persistent_tail_maps > 0) these are the HEADS (median count of the step over the last 8 maps) and one persistent launch per solve runs whatever is left (nsk_persist.hpp); otherwise budgets (largest count + head-room), a launch beyond a solve's own count returning on a device flag"}})
             # ---- SURVEY 8(d) accounting: algorithmic bytes per matvec from the logged iteration counts
             geom = dict(nel=case.nel, lx1=case.lx1, ndim=2, nvert=int(case.meta["nvert"]), coarse_lda=((int(case.meta["nvert"]) + 255) // 256) * 256,
                         patch_stride=(((case.lx1 - 2 + 4) ** 2 + 3) // 4) * 4, nproj=a.nproj)

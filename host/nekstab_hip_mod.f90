@@ -33,6 +33,7 @@ module nekstab_hip
     real(c_double) :: coarse_bytes_per_solve
     integer(c_long_long) :: step_budget_maps
     real(c_double) :: step_budget_helm_mean, step_budget_pres_mean
+    integer(c_long_long) :: tail_maps
   end type
 
   interface

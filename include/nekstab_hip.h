@@ -200,6 +200,7 @@ typedef struct {
    * time step on average (velocity: k_helm launches; pressure: GMRES iterations), 0 while none ran */
   long long step_budget_maps;
   double step_budget_helm_mean, step_budget_pres_mean;
+  long long tail_maps;                      /* maps whose solves ended in the persistent tail kernels (option "tail"): the per-step numbers above are then HEADS */
 } nsk_stats;
 int nsk_get_stats(nsk_ctx* ctx, nsk_stats* s);
 

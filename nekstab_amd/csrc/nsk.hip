@@ -122,6 +122,14 @@ struct nsk_ctx {
   } sb[2];
   int last_map_kind = 0;
   bool sb_force_class = false;           // the redo of an overflowed map runs on the (doubled) class budgets
+  // ---- persistent tails (nsk_persist.hpp: k_helm_tail, k_pres_tail; option "tail"): -1 = where every workgroup of the grid is
+  // resident at once (quadrilateral single-rank contexts of at most ~3 workgroups per CU: configs 1, 2), 0 = never.  With tails
+  // the per-step budgets become HEADS: the median count of the step over the last maps (launches that almost always do work);
+  // the tail runs whatever is left, to the solver's caps, in one launch.
+  int tail = -1;
+  int tail_ok = -1;                      // residency verdict (-1: not asked yet)
+  int tail_off_h = 0, tail_off_p = 0;    // heads = median + these (options "tail_off_h" / "tail_off_p": tests push work into the tails with negative values)
+  long long tail_maps = 0;
   long long sb_maps = 0, sb_steps = 0, sb_launch_h = 0, sb_launch_p = 0;     // maps / time steps run on per-step budgets and their budgeted launches (diagnostics)
   bool last_map_per_step = false;        // the map just run took the per-step budgets
   std::map<std::array<int, 4>, hipGraphExec_t> gcache;         // (adjoint, class, nh, np) -> captured step
@@ -844,7 +852,7 @@ static int build(nsk_ctx* c, const nsk_case& cs) {
   }
   for (int k = 0; k < NCLS; ++k) { c->cur_helm[k] = c->max_helm; c->cur_pres[k] = c->max_pres; }
   c->bh_n = 0;
-  if ((rc = dalloc(c, &c->sync, SYNC_WORDS))) return rc;
+  if ((rc = dalloc(c, &c->sync, 2 * SYNC_WORDS))) return rc;      // two sets: the tails alternate (nsk_persist.hpp)
   // persistent velocity solve: available where the grid is resident, OFF by default -- measured on config 2 it is not faster
   // than the launch-per-iteration form (13.6 vs 13.5 us per CG iteration: DESIGN.md section 5); option "fused" / NSK_FUSED=1
   c->fused = 0;
@@ -856,6 +864,9 @@ static int build(nsk_ctx* c, const nsk_case& cs) {
   if (const char* g = std::getenv("NSK_MERGED_ITERS")) c->merged_iters = std::max(0, std::min(std::atoi(g), MAXMR));
   if (const char* g = std::getenv("NSK_DEBUG")) c->debug = std::atoi(g);
   if (const char* g = std::getenv("NSK_STEP_BUDGETS")) c->step_budgets = std::atoi(g);
+  if (const char* g = std::getenv("NSK_TAIL")) c->tail = std::atoi(g);
+  if (const char* g = std::getenv("NSK_TAIL_OFF_H")) c->tail_off_h = std::atoi(g);
+  if (const char* g = std::getenv("NSK_TAIL_OFF_P")) c->tail_off_p = std::atoi(g);
   HIPCHK(hipStreamSynchronize(c->stream));
   return 0;
 }
@@ -1044,7 +1055,8 @@ static void launch_proj_dots3(nsk_ctx* c, const Dev& d) {
   }
 }
 
-static int pres_solve_launch(nsk_ctx* c, double h2, int ord, int np, double tol_mul = 1.0, bool allow_cap = false, bool hc = false) {
+template <int N> static void launch_pres_tail(nsk_ctx* c, const Dev& d, int j0, int j1, double scale, int min_iter, int ord);
+static int pres_solve_launch(nsk_ctx* c, double h2, int ord, int np, double tol_mul = 1.0, bool allow_cap = false, bool hc = false, bool tail = false) {
   Dev d = c->d;                                            // by value: the early steps of a map run with a tighter tolerance
   d.tol_pres = early_tol(d, tol_mul);
   // time steps >= 4: optionally a bounded solve (min_pres_iter .. pres_cap iterations): nothing is launched beyond the cap
@@ -1066,6 +1078,11 @@ static int pres_solve_launch(nsk_ctx* c, double h2, int ord, int np, double tol_
     // ~|h_jj / h_{j+1,j}| per iteration (harmless in a preconditioner for a dozen iterations, a stalled solve after forty:
     // measured on the 1e-8 solves of test_newton_gpu); later iterations take the classic four kernels.
     const bool merged = c->merged_update && c->ndim == 2 && d.coarse_lda <= 3072 && !d.use_tot && d.nranks <= 1 && d.rch && d.ecv && !hc;
+    // with a persistent tail `np` is the HEAD (merged iterations launched one by one); the tail covers the rest of the merged
+    // range in one launch, and iterations beyond it (classic form) keep the class budget
+    const bool tl = tail && merged && d.pres_cap == 0;
+    const int nhead = tl ? std::max(0, std::min(np, std::min(c->merged_iters, c->gmres_cycle) - 1)) : 0;
+    if (tl) np = std::max(c->cur_pres[ord], std::min(c->max_pres, std::min(c->merged_iters, c->gmres_cycle)));
     const int nm = merged ? std::min(np, std::min(c->merged_iters, c->gmres_cycle)) : 0;
     if (hc && c->hc_pres[ord] <= 1) {                     // the projection space may have solved this right-hand side alone
       bool done = false;
@@ -1073,11 +1090,12 @@ static int pres_solve_launch(nsk_ctx* c, double h2, int ord, int np, double tol_
       if (rc2) return rc2;
       if (done) { c->hc_pres[ord] = 0; np = 0; }
     }
-    for (int j = 0; j < nm; ++j) {
+    for (int j = 0; j < (tl ? nhead : nm); ++j) {
       launch_update_coarse(c, d, j, scale, c->min_pres, ord);
       hipLaunchKernelGGL(k_schwarz<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, (const double*)(d.V + (size_t)j * d.ps), d.Z + (size_t)j * d.npr, 1, 1);
       hipLaunchKernelGGL(k_divgs<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, (const double*)d.yl, d.V + (size_t)(j + 1) * d.ps, j, 2);
     }
+    if (tl && nhead < nm) launch_pres_tail<N>(c, d, nhead, nm, scale, c->min_pres, ord);
     // closes the last merged column (normalises v_nm and writes its corner restriction: what the classic iteration nm reads)
     if (nm > 0) hipLaunchKernelGGL(k_gmres_update<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, nm - 1, scale, c->min_pres, ord);
     for (int jt = nm; jt < np; ++jt) {
@@ -1159,7 +1177,60 @@ static int fused_possible(nsk_ctx* c) {
   return need <= std::min(per, 5);      // 5: what ~110 SGPRs admit (floor(800 / 128) = 6) minus one
 }
 
-static int step(nsk_ctx* c, int istep, int adjoint, int nh_over = -1, int np_over = -1) {
+// persistent tails: both kernels resident with one workgroup per CU of margin (the occupancy query can be one high)
+template <int N>
+static int tails_resident(nsk_ctx* c, int ncu) {
+  const size_t sh = (size_t)c->d.coarse_lda * sizeof(double);
+  const int nit = c->d.coarse_lda / 256;
+  int ph = 0, pp = 0;
+  hipError_t e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&ph, nsk::k2::k_helm_tail<N>, nsk::k2::Cfg<N>::NT, 0), e2 = hipErrorUnknown;
+  if (nit <= 3) e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&pp, (nsk::k2::k_pres_tail<N, 3>), nsk::k2::Cfg<N>::NT, sh);
+  else if (nit <= 6) e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&pp, (nsk::k2::k_pres_tail<N, 6>), nsk::k2::Cfg<N>::NT, sh);
+  else if (nit <= 9) e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&pp, (nsk::k2::k_pres_tail<N, 9>), nsk::k2::Cfg<N>::NT, sh);
+  else e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&pp, (nsk::k2::k_pres_tail<N, 12>), nsk::k2::Cfg<N>::NT, sh);
+  if (e1 != hipSuccess || e2 != hipSuccess) return 0;
+  const int need = (c->nblk + ncu - 1) / ncu;
+  if (c->debug) fprintf(stderr, "persistent tails: %d workgroups per CU needed, occupancy %d (velocity) / %d (pressure)\n", need, ph, pp);
+  return need + 1 <= std::min(std::min(ph, pp), 6);
+}
+static bool tails_on(nsk_ctx* c) {
+  if (c->tail == 0 || c->fused || c->ndim != 2 || c->parent || c->clone_of || c->d.use_tot || c->d.nranks > 1 || !c->d.ecv || !c->d.rch || !c->merged_update) return false;
+  if (hostcheck_on(c) || !c->use_graph) return false;
+  if (c->tail_ok < 0) {
+    int ncu = 0, dev = 0;
+    c->tail_ok = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && ncu > 0) {
+      switch (c->N) {
+        case 6: c->tail_ok = tails_resident<6>(c, ncu); break;
+        case 8: c->tail_ok = tails_resident<8>(c, ncu); break;
+        case 10: c->tail_ok = tails_resident<10>(c, ncu); break;
+        case 12: c->tail_ok = tails_resident<12>(c, ncu); break;
+        default: break;
+      }
+    }
+  }
+  return c->tail_ok > 0;
+}
+template <int N>
+static void launch_helm_tail(nsk_ctx* c, const Dev& d, const StepCoef& sc, int it0, int it_end) {
+  if (c->ndim != 2) return;
+  hipLaunchKernelGGL(nsk::k2::k_helm_tail<N>, dim3(c->nblk), dim3(nsk::k2::Cfg<N>::NT), 0, c->stream, d, sc, it0, it_end, (const double*)d.rloc, c->sync, c->sync + SYNC_WORDS);
+}
+template <int N>
+static void launch_pres_tail(nsk_ctx* c, const Dev& d, int j0, int j1, double scale, int min_iter, int ord) {
+  if (c->ndim != 2) return;
+  const unsigned cgrid = (d.nvert + 4 * UC_ROWS - 1) / (4 * UC_ROWS);
+  const size_t sh = d.coarse_lda * sizeof(double);
+  const int nit = d.coarse_lda / 256;
+  unsigned* sy = c->sync + SYNC_WORDS;          // (set 1; zeroes set 0 for the next velocity tail)
+  const dim3 grid(c->nblk), blk(nsk::k2::Cfg<N>::NT);
+  if (nit <= 3) hipLaunchKernelGGL((nsk::k2::k_pres_tail<N, 3>), grid, blk, sh, c->stream, d, j0, j1, scale, min_iter, ord, cgrid, sy, c->sync);
+  else if (nit <= 6) hipLaunchKernelGGL((nsk::k2::k_pres_tail<N, 6>), grid, blk, sh, c->stream, d, j0, j1, scale, min_iter, ord, cgrid, sy, c->sync);
+  else if (nit <= 9) hipLaunchKernelGGL((nsk::k2::k_pres_tail<N, 9>), grid, blk, sh, c->stream, d, j0, j1, scale, min_iter, ord, cgrid, sy, c->sync);
+  else hipLaunchKernelGGL((nsk::k2::k_pres_tail<N, 12>), grid, blk, sh, c->stream, d, j0, j1, scale, min_iter, ord, cgrid, sy, c->sync);
+}
+
+static int step(nsk_ctx* c, int istep, int adjoint, int nh_over = -1, int np_over = -1, bool tail = false) {
   Dev& d = c->d;
   const StepCoef sc = make_coef(c, istep, adjoint);
   const bool hc = hostcheck_on(c) && !stream_capturing(c->stream);
@@ -1176,6 +1247,7 @@ static int step(nsk_ctx* c, int istep, int adjoint, int nh_over = -1, int np_ove
       launch_fused<N>(c, sc);
     } else {
       hipLaunchKernelGGL(k_rhs<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, sc);
+      if (tail) nh = std::max(1, std::min(nh, c->max_helm - 1));      // HEAD launches; the persistent tail runs launches nh .. max_helm-1
       for (int it = 0; it < nh; ++it) {
         launch_helm_iter<N>(c, d, sc, it, (const double*)d.rloc);
         tot_rows(c, d.hpart + (size_t)(it & 1) * c->hrows * c->nblk, c->hrows, d.htot + (it & 1) * c->hstride);
@@ -1186,12 +1258,13 @@ static int step(nsk_ctx* c, int istep, int adjoint, int nh_over = -1, int np_ove
           if (done) { c->hc_helm[sc.cls] = std::max(1, it - 1); nh = it + 1; break; }
         }
       }
+      if (tail) { launch_helm_tail<N>(c, d, sc, nh, c->max_helm); nh = c->max_helm; }
       hipLaunchKernelGGL(k_pres_rhs<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, sc, (nh - 1) & 1, nh - 1);
     }
   });
   // The first steps of a map project out whatever divergence the input vector has (a noise seed is far from
   // solenoidal): an error there survives to the end of the map, so those solves are converged further.
-  int rc = pres_solve_launch(c, sc.h2, sc.cls, hc ? c->max_pres : (np_over > 0 ? np_over : c->cur_pres[sc.cls]), istep <= 3 ? c->early_pres_mul : 1.0, adjoint != 2, hc);
+  int rc = pres_solve_launch(c, sc.h2, sc.cls, hc ? c->max_pres : (np_over > 0 ? np_over : c->cur_pres[sc.cls]), istep <= 3 ? c->early_pres_mul : 1.0, adjoint != 2, hc, tail);
   if (rc) return rc;
   const bool flat = flat_proj_on(c);
   Dev df = d; df.flat_proj = flat ? 1 : 0;
@@ -1256,7 +1329,8 @@ static int ensure_graph_multi(nsk_ctx* c, int adjoint) {
 
 // the captured step of class `cls` with the launch budgets (nh, np): per-step budgets (nsk_ctx::gcache)
 static int graph_for(nsk_ctx* c, int adjoint, int cls, int nh, int np, hipGraphExec_t* out) {
-  const std::array<int, 4> key{adjoint, cls, nh, np};
+  const bool tail = tails_on(c);
+  const std::array<int, 4> key{adjoint, cls + (tail ? 16 : 0), nh, np};
   auto it = c->gcache.find(key);
   if (it != c->gcache.end()) { *out = it->second; return 0; }
   if (c->gcache.size() >= 1024) {                          // (never seen: a few dozen budget pairs occur) start again
@@ -1267,7 +1341,7 @@ static int graph_for(nsk_ctx* c, int adjoint, int cls, int nh, int np, hipGraphE
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
   HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-  int rc = step(c, CLS_ISTEP[cls], adjoint, nh, np);
+  int rc = step(c, CLS_ISTEP[cls], adjoint, nh, np, tail);
   hipError_t e = hipStreamEndCapture(c->stream, &graph);
   if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
   if (e != hipSuccess) return fail(NSK_EHIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
@@ -1302,6 +1376,7 @@ static int run_map(nsk_ctx* c, int adjoint, double* f, const double* q) {
       c->sb_launch_h += b.bh[istep - 1]; c->sb_launch_p += b.bp[istep - 1];
     }
     c->sb_maps++; c->sb_steps += c->nsteps;
+    if (tails_on(c)) c->tail_maps++;
   } else if (use_graph)
     for (int k = 0; k < NCLS; ++k) { int rc = ensure_graph(c, k, adjoint); if (rc) return rc; }
   const int gsteps = (use_graph && !per_step && c->graph_steps > 1 && c->nsteps >= CLS_ISTEP[NCLS - 1] + 2 * c->graph_steps) ? c->graph_steps : 1;
@@ -1399,6 +1474,21 @@ static void step_budgets_update(nsk_ctx* c) {
   b.bh.assign(ns, 0); b.bp.assign(ns, 0);
   static const int head_h = std::getenv("NSK_SB_HEAD_H") ? std::atoi(std::getenv("NSK_SB_HEAD_H")) : 3;
   static const int head_p = std::getenv("NSK_SB_HEAD_P") ? std::atoi(std::getenv("NSK_SB_HEAD_P")) : 2;
+  if (tails_on(c)) {
+    // HEADS for the persistent tails: the MEDIAN count of this step over the window (offline on 56 maps of config 2: the cheapest
+    // predictor, 0.44 launches that find nothing to do and 0.56 tail iterations per pressure solve; profiles/r05_step_budgets.txt).
+    // Velocity: a solve of I iterations is found finished by launch I (0-based), i.e. I + 1 launches.
+    const int off_h = c->tail_off_h, off_p = c->tail_off_p;
+    int vh[nsk_ctx::SBW], vp[nsk_ctx::SBW];
+    for (int s = 0; s < ns; ++s) {
+      for (int i = 0; i < nv; ++i) { vh[i] = b.hist_h[i][s]; vp[i] = b.hist_p[i][s]; }
+      std::sort(vh, vh + nv); std::sort(vp, vp + nv);
+      const int mh = vh[nv / 2], mp = vp[nv / 2];
+      b.bh[s] = std::max(1, std::min(c->max_helm - 1, mh + 1 + off_h));
+      b.bp[s] = std::max(0, std::min(c->max_pres, mp + off_p));
+    }
+    return;
+  }
   for (int s = 0; s < ns; ++s) {
     int mh = 0, mp = 0;
     for (int i = 0; i < nv; ++i)
@@ -2127,6 +2217,9 @@ int nsk_set_option(nsk_ctx* c, const char* name, double value) {
   else if (n == "budget_add_pres") { for (int k = 0; k < NCLS; ++k) c->cur_pres[k] = std::min(c->max_pres, std::max(1, c->cur_pres[k] + (int)value)); }
   else if (n == "budget_freeze") c->budget_freeze = (int)value;
   else if (n == "step_budgets") c->step_budgets = (int)value;
+  else if (n == "tail") c->tail = (int)value;
+  else if (n == "tail_off_h") c->tail_off_h = (int)value;
+  else if (n == "tail_off_p") c->tail_off_p = (int)value;
   else return fail(NSK_EINVAL, "unknown option " + n);
   invalidate_graphs(c);
   return 0;
@@ -2230,6 +2323,7 @@ int nsk_get_stats(nsk_ctx* c, nsk_stats* s) {
   s->recapture_seconds = c->recapture_s;
   s->total_pres_jsum = c->tot_pres_jsum; s->coarse_bytes_per_solve = c->coarse_bytes;
   s->step_budget_maps = c->sb_maps;
+  s->tail_maps = c->tail_maps;
   s->step_budget_helm_mean = c->sb_maps ? (double)c->sb_launch_h / ((double)c->sb_steps) : 0.0;
   s->step_budget_pres_mean = c->sb_maps ? (double)c->sb_launch_p / ((double)c->sb_steps) : 0.0;
   return 0;
@@ -2633,6 +2727,10 @@ int nsk_clone(nsk_ctx* P, nsk_ctx** out) {
   c->dbg_max_order = P->dbg_max_order; c->dbg_ab2 = P->dbg_ab2; c->dbg_pext = P->dbg_pext;
   c->PS = P->PS; c->coarse_lda = P->coarse_lda; c->cfl_target = P->cfl_target; c->xyz = P->xyz;
   c->clone_of = P;
+  // two persistent grids launched at once can each get a share of the CUs' slots and wait for the rest for ever: contexts with
+  // lanes run their maps on launch budgets only
+  if (P->tail != 0) { P->tail = 0; invalidate_graphs(P); }
+  c->tail = 0;
   for (int k = 0; k < NCLS; ++k) { c->cur_helm[k] = c->max_helm; c->cur_pres[k] = c->max_pres; }
   if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return fail(NSK_EHIP, "hipStreamCreate"); }
   Dev& d = c->d;
@@ -2660,7 +2758,7 @@ int nsk_clone(nsk_ctx* P, nsk_ctx** out) {
   if (P->d.rch && (rc = dalloc(c, &d.rch, (size_t)MAXMR * c->coarse_lda))) return bail(rc);
   if (P->d.ecv && (rc = dalloc(c, &d.ecv, (size_t)8 * c->coarse_lda))) return bail(rc);
   if (d.use_tot && ((rc = dalloc(c, &d.htot, 32)) || (rc = dalloc(c, &d.gtot, MAXMR + 8)) || (rc = dalloc(c, &d.gtot2, MAXMR + 8)) || (rc = dalloc(c, &d.ptot, MAXPROJ + 2)))) return bail(rc);
-  if ((rc = dalloc(c, &c->sync, SYNC_WORDS))) return bail(rc);
+  if ((rc = dalloc(c, &c->sync, 2 * SYNC_WORDS))) return bail(rc);
   c->kblk = 256;
   if ((rc = dalloc(c, &c->kpart, (size_t)c->kblk * 1024)) || (rc = dalloc(c, &c->kout, 1024)) || (rc = dalloc(c, &c->kptr, 1024))) return bail(rc);
   if (hipHostMalloc((void**)&c->hpin, 4096 * sizeof(double)) != hipSuccess || hipHostMalloc((void**)&c->hstat_pin, sizeof(Stats)) != hipSuccess)

@@ -7,6 +7,7 @@
 // gather-scatter launch.  All reductions are two-level with a fixed order.
 #pragma once
 #include "nsk_dev.hpp"
+#include "nsk_crtrig.hpp"
 
 namespace nsk {
 
@@ -629,10 +630,10 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_rhs(Dev d, StepCoef sc) {
 //   hscal[par][c*4 + {0:gamma,1:alpha,2:done,3:res}]
 // ---------------------------------------------------------------------------
 template <int N>
-__global__ __launch_bounds__(Cfg<N>::NT) void k_helm(Dev d, StepCoef sc, int it, const double* rhs) {
+__device__ __forceinline__ void helm_body(const Dev& d, const StepCoef& sc, int it, const double* rhs, const unsigned bx_, const unsigned gx_) {
   // (shards with halo / interior overlap launch the boundary workgroups first, the rest with an offset; XCD-contiguous runs of
   //  element blocks: the neighbours' edge values are L2 hits where the grid is larger than the caches, config 3)
-  const int bid = d.boff + (int)xcd_element(blockIdx.x, gridDim.x);
+  const int bid = d.boff + (int)xcd_element(bx_, gx_);
   using C = Cfg<N>;
   constexpr int NN = C::NN, EPB = C::EPB, NT = C::NT;
   __shared__ double sD[NN], sDt[NN];
@@ -795,6 +796,11 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_helm(Dev d, StepCoef sc, int it,
   if (tid < 8) d.hpart[((size_t)par * 8 + tid) * d.nblk + bid] = v[tid];
   NSK_STAMP(7);
 }
+template <int N>
+__global__ __launch_bounds__(Cfg<N>::NT) void k_helm(Dev d, StepCoef sc, int it, const double* rhs) {
+  helm_body<N>(d, sc, it, rhs, blockIdx.x, gridDim.x);
+}
+
 
 // ---------------------------------------------------------------------------
 // K4: u* = u + du ;  g = -D u*  -> V[0] (unnormalised), |g|^2 partials
@@ -1286,7 +1292,7 @@ __global__ __launch_bounds__(256) void k_coarse(Dev d) {
 // 2 rows / 263 workgroups beat 3 rows / 175 workgroups by 5 % of a matvec).
 constexpr int UC_ROWS = 2;
 template <int MAXIT>
-__global__ __launch_bounds__(256) void k_update_coarse(Dev d, int j, double scale, int min_iter, int ord) {
+__device__ __forceinline__ void update_coarse_body(const Dev& d, int j, double scale, int min_iter, int ord, const unsigned bx_, const unsigned gx_) {
   extern __shared__ double srcv[];            // lda
   __shared__ double sh[MAXMR + 2], scs[MAXMR], ssn[MAXMR], scol[MAXMR + 2], sbc[2];
   const int tid = threadIdx.x;
@@ -1294,7 +1300,7 @@ __global__ __launch_bounds__(256) void k_update_coarse(Dev d, int j, double scal
   if (G->done) return;                        // (first: a launch that finds its solve done must stay cheap)
   const int nv = d.nvert, lda = d.coarse_lda;
   const int lane = tid & 63, w = tid >> 6;
-  const int row0 = (blockIdx.x * 4 + w) * UC_ROWS;
+  const int row0 = (bx_ * 4 + w) * UC_ROWS;
   const int nit = lda / 256;
   const int jj = j - 1;                       // the column this launch closes (j > 0)
   // Loads return in issue order: the short dependent chains go first (vertex tables -> corner values; partials of the first
@@ -1319,7 +1325,7 @@ __global__ __launch_bounds__(256) void k_update_coarse(Dev d, int j, double scal
 #pragma unroll
   for (int r = 0; r < UC_ROWS; ++r) rh[r] = (lane < j && row0 + r < nv) ? d.rch[(size_t)lane * lda + row0 + r] : 0.0;
   // this thread's entry of v_j and of the basis vectors it is orthogonalised against (the first 8; more in the loop below)
-  const long long q0 = (long long)blockIdx.x * 256 + tid;
+  const long long q0 = (long long)bx_ * 256 + tid;
   double vq = 0.0, vk[8];
   if (j > 0 && q0 < d.npr) vq = d.V[(size_t)j * d.ps + q0];
 #pragma unroll
@@ -1391,7 +1397,7 @@ __global__ __launch_bounds__(256) void k_update_coarse(Dev d, int j, double scal
     const bool conv = (res <= tol && (jj + 1) >= min_iter) || !(hn > 0.0) || (d.pres_cap > 0 && (jj + 1) >= d.pres_cap);
     sbc[0] = (hn > 0.0) ? 1.0 / hn : 0.0;
     sbc[1] = conv ? 1.0 : 0.0;
-    if (blockIdx.x == 0) {
+    if (bx_ == 0) {
       G->cs[jj] = cj; G->sn[jj] = sj;
       for (int q = 0; q <= jj; ++q) G->R[jj * MAXMR + q] = col[q];
       G->g[jj] = cj * gj;
@@ -1437,7 +1443,7 @@ __global__ __launch_bounds__(256) void k_update_coarse(Dev d, int j, double scal
       for (int k = 8; k < j; ++k) x -= sh[k] * d.V[(size_t)k * d.ps + q0];
       d.V[(size_t)j * d.ps + q0] = x * hinv;
     }
-    for (long long q = q0 + (long long)gridDim.x * 256; q < d.npr; q += (long long)gridDim.x * 256) {
+    for (long long q = q0 + (long long)gx_ * 256; q < d.npr; q += (long long)gx_ * 256) {
       double x = d.V[(size_t)j * d.ps + q];
 #pragma unroll 4
       for (int k = 0; k < j; ++k) x -= sh[k] * d.V[(size_t)k * d.ps + q];
@@ -1456,6 +1462,11 @@ __global__ __launch_bounds__(256) void k_update_coarse(Dev d, int j, double scal
       if (row0 + r < nv) { d.xc[row0 + r] = sr[r]; d.rch[(size_t)j * lda + row0 + r] = sr[r]; }
   }
 }
+template <int MAXIT>
+__global__ __launch_bounds__(256) void k_update_coarse(Dev d, int j, double scale, int min_iter, int ord) {
+  update_coarse_body<MAXIT>(d, j, scale, min_iter, ord, blockIdx.x, gridDim.x);
+}
+
 
 // large coarse spaces (nvert > 3072, e.g. the 2x2-refined mesh): streaming variant, the vertex
 // restriction r_c is built once per launch in global memory by a separate tiny kernel.
@@ -1496,9 +1507,7 @@ namespace k2 {
 // z_j = RAS(v_j) + R^T x_c ;  yl = D^T z_j  (unassembled velocity-space)
 // patch tables have a fixed stride PS per element: idx[e*PS + k] (-1 padded), inverse [e][k][MM] fp32
 template <int N>
-__global__ __launch_bounds__(Cfg<N>::NT) void k_schwarz(Dev d, const double* __restrict__ vin,
-                                                        double* __restrict__ zout, int use_coarse,
-                                                        int check_done) {
+__device__ __forceinline__ void schwarz_body(const Dev& d, const double* __restrict__ vin, double* __restrict__ zout, int use_coarse, int check_done, const unsigned bx_, const unsigned gx_) {
   using C = Cfg<N>;
   constexpr int NN = C::NN, M = C::M, MM = C::MM, EPB = C::EPB, NT = C::NT, NM = N * M;
   constexpr int MAXP = (M + 8) * (M + 8);
@@ -1506,7 +1515,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_schwarz(Dev d, const double* __r
   __shared__ double sP[4 * EPB * MM], sB[4 * EPB * NM];
   __shared__ double sr[EPB * MAXP];
   const int tid = threadIdx.x, el = tid / NN, nd = tid % NN;
-  const int bid = d.boff + (int)xcd_element(blockIdx.x, gridDim.x);
+  const int bid = d.boff + (int)xcd_element(bx_, gx_);
   const long long e = (long long)bid * EPB + el;
   const bool act = (el < EPB) && (e < d.nel);
   if (check_done && d.gsc->done) return;
@@ -1567,6 +1576,13 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_schwarz(Dev d, const double* __r
     d.yl[d.cs + l] = gy;
   }
 }
+template <int N>
+__global__ __launch_bounds__(Cfg<N>::NT) void k_schwarz(Dev d, const double* __restrict__ vin,
+                                                        double* __restrict__ zout, int use_coarse,
+                                                        int check_done) {
+  schwarz_body<N>(d, vin, zout, use_coarse, check_done, blockIdx.x, gridDim.x);
+}
+
 
 // yl = D^T p for an arbitrary pressure vector (setup probes, tests, projection)
 template <int N>
@@ -1601,15 +1617,14 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_gradt(Dev d, const double* __res
 // w = D ( B^-1 mask dssum(yl) ) ; optional dots (w, V_i), i <= j, and (w,w)
 // check_done: 0 = always run, 1 = leave when the solve is done, 2 = the same and write the corner restriction of w to d.ec
 template <int N>
-__global__ __launch_bounds__(Cfg<N>::NT) void k_divgs(Dev d, const double* __restrict__ yl,
-                                                      double* __restrict__ wout, int j, int check_done) {
+__device__ __forceinline__ void divgs_body(const Dev& d, const double* __restrict__ yl, double* __restrict__ wout, int j, int check_done, const unsigned bx_, const unsigned gx_) {
   using C = Cfg<N>;
   constexpr int NN = C::NN, M = C::M, MM = C::MM, EPB = C::EPB, NT = C::NT, NM = N * M;
   __shared__ double sJ12[NM], sD12[NM];
   __shared__ double su[2 * EPB * NN], sA[4 * EPB * NM];
   __shared__ double sdot[(MAXMR + 2) * 4];
   const int tid = threadIdx.x, el = tid / NN, nd = tid % NN;
-  const int bid = d.boff + (int)xcd_element(blockIdx.x, gridDim.x);
+  const int bid = d.boff + (int)xcd_element(bx_, gx_);
   const long long e = (long long)bid * EPB + el;
   const bool act = (el < EPB) && (e < d.nel);
   NSK_STAMP(0);
@@ -1670,6 +1685,12 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_divgs(Dev d, const double* __res
     NSK_STAMP(4);
   }
 }
+template <int N>
+__global__ __launch_bounds__(Cfg<N>::NT) void k_divgs(Dev d, const double* __restrict__ yl,
+                                                      double* __restrict__ wout, int j, int check_done) {
+  divgs_body<N>(d, yl, wout, j, check_done, blockIdx.x, gridDim.x);
+}
+
 
 // after GMRES: dp = h2 * sum_i y_i Z_i (+ projected part) ; p = p* + dp ; yl = D^T dp
 template <int N>
@@ -2001,6 +2022,8 @@ __global__ void k_scale_rsqrt(double* __restrict__ y, const double* __restrict__
 // (nekstab_amd/seed.py) one by one and fused multiply-adds are off: both then differ by the rounding of sin/cos only.
 __global__ void k_seed_rand(const double* __restrict__ xyz, long long nloc, int ndim, int N, double* __restrict__ out) {
 #pragma clang fp contract(off)
+  // mth_rand (core/utils.f:457-469) in the reference's operation order, every operation rounded once, with the correctly rounded
+  // sin / cos of nsk_crtrig.hpp: bit for bit the host mirror nekstab_amd/seed.py (tests/test_kernels_gpu.py)
   const long long l = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (l >= nloc) return;
   const int per = (ndim == 3) ? N * N * N : N * N;
@@ -2009,22 +2032,23 @@ __global__ void k_seed_rand(const double* __restrict__ xyz, long long nloc, int 
   const double ix = (double)(nd % N + 1), iy = (double)((nd / N) % N + 1), iz = (double)(nd / (N * N) + 1);
   const double x = xyz[l], y = xyz[nloc + l], z = (ndim == 3) ? xyz[2 * nloc + l] : 0.0;
   const double FC[3][3] = {{3.0e4, -1.5e3, 0.5e5}, {2.3e4, 2.3e3, -2.0e5}, {2.0e4, 1.0e3, 1.0e5}};
+  const double siny = crtrig::sin_cr(y);
   for (int c = 0; c < ndim; ++c) {
-    const double t0 = x * sin(y);
+    const double t0 = x * siny;
     const double t1 = FC[c][0] * (ieg + t0);
     const double t2 = (FC[c][1] * ix) * iy;
     const double t3 = FC[c][2] * ix;
     double r = (t1 + t2) + t3;
     if (ndim == 3) {
-      const double u0 = z * sin(r);
+      const double u0 = z * crtrig::sin_cr(r);
       const double u1 = FC[c][0] * (ieg + u0);
       const double u2 = (FC[c][1] * iz) * ix;
       const double u3 = FC[c][2] * iz;
       r = (u1 + u2) + u3;
     }
-    r = 1.0e3 * sin(r);
-    r = 1.0e3 * sin(r);
-    out[(size_t)c * nloc + l] = cos(r);
+    r = 1.0e3 * crtrig::sin_cr(r);
+    r = 1.0e3 * crtrig::sin_cr(r);
+    out[(size_t)c * nloc + l] = crtrig::cos_cr(r);
   }
 }
 // face averaging of add_noise: pass 0: t = (dssum(q) / mult) / mult ; pass 1: q = mask * dssum(t)   (opdssum, opcolv(vmult), dsavg, bcdirvc)

@@ -373,4 +373,84 @@ __global__ __launch_bounds__(Cfg<N>::NT, 2) void k_helm_fused(Dev d, StepCoef sc
 }
 
 }  // namespace k2
+
+// ---------------------------------------------------------------------------
+// Persistent TAILS of the two inner solves (round 5).  A step's captured graph cannot know how many iterations a solve will
+// take, so rounds 1-4 budgeted launches: every launch beyond a solve's own count still costs its dispatch and one cold flag
+// load (4.4 us in the graph-mode trace of config 2; 19-39 % of the kernel time of a map).  Now the graph holds a HEAD of
+// launches -- the median count of this time step over the last maps: almost all of them do work -- and ONE persistent launch
+// that runs the rest of the solve, however long, as a loop over the SAME kernel bodies with a grid barrier where a kernel
+// boundary was: bit-identical arithmetic, no launch for an iteration that is not needed, no budget that can overflow (the loop
+// runs to the solver's caps: no redone maps).  A tail iteration costs more than a launched one (a grid barrier with agent-scope
+// release / acquire is ~9 us against a ~4.4 us launch floor), so the head takes what is predictable; measured on config 2 the
+// tail runs 0.6 iterations per solve on average.  Requirements as k_helm_fused: every workgroup of the grid resident at once
+// (checked on the host with a margin), bounded spins, time-outs reported through Stats::sync_timeouts.
+// Barrier words: two sets; a tail uses one and zeroes the other for the next persistent launch (velocity tail: set 0, pressure
+// tail: set 1: they alternate within every step), so no memset node is spent on them.
+// ---------------------------------------------------------------------------
+__device__ inline void zero_sync(unsigned* w, int tid, int nt) {
+  if (blockIdx.x == 0) for (int k = tid; k < SYNC_WORDS; k += nt) w[k] = 0u;
+}
+
+namespace k2 {
+
+// CG iterations it0 .. it_end-1 of the velocity solve (launch indices as k_helm's `it`); leaves the state exactly as the launches
+// it0 .. it_end-1 would: k_pres_rhs follows with helm_par = (it_end-1) & 1, check_helm = it_end-1.
+template <int N>
+__global__ __launch_bounds__(Cfg<N>::NT, 2) void k_helm_tail(Dev d, StepCoef sc, int it0, int it_end, const double* rhs, unsigned* sync, unsigned* sync_other) {
+  __shared__ int s_fail;
+  const int tid = threadIdx.x;
+  if (tid == 0) s_fail = 0;
+  zero_sync(sync_other, tid, Cfg<N>::NT);
+  __syncthreads();
+  unsigned epoch = 1;
+  bool ok = true, fin = false;
+  int it = it0;
+  for (; it < it_end; ++it) {
+    if (it > 1) {                                // both components finished in an earlier launch (flags written by launch it-1)
+      const double f0 = __hip_atomic_load(d.hscal + ((it - 1) & 1) * 8 + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const double f1 = __hip_atomic_load(d.hscal + ((it - 1) & 1) * 8 + 6, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (f0 != 0.0 && f1 != 0.0) { fin = true; break; }
+    }
+    helm_body<N>(d, sc, it, rhs, blockIdx.x, gridDim.x);
+    ok = grid_barrier(sync, epoch++, (int)gridDim.x, &s_fail);
+    if (!ok) break;
+  }
+  if (!ok) { if (tid == 0) atomicAdd((unsigned long long*)&d.stats->sync_timeouts, 1ull); return; }
+  if (!fin && it > 1) {                          // the last launch of the loop may have been the one that found the solve finished
+    const double f0 = __hip_atomic_load(d.hscal + ((it - 1) & 1) * 8 + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double f1 = __hip_atomic_load(d.hscal + ((it - 1) & 1) * 8 + 6, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    fin = f0 != 0.0 && f1 != 0.0;
+  }
+  // finished at launch it-1: what the remaining launches would have done is to hand the flags (and the recorded residuals) on to
+  // the other parity; k_pres_rhs reads the parity of launch it_end-1
+  if (fin && blockIdx.x == 0 && tid < 8) d.hscal[(it & 1) * 8 + tid] = d.hscal[((it - 1) & 1) * 8 + tid];
+}
+
+// merged pressure GMRES iterations j0 .. j1-1 (k_update_coarse, k_schwarz, k_divgs of each); the closing k_gmres_update(j1-1)
+// launch follows as behind the launched form
+template <int N, int MAXIT>
+__global__ __launch_bounds__(Cfg<N>::NT, 2) void k_pres_tail(Dev d, int j0, int j1, double scale, int min_iter, int ord, unsigned cgrid, unsigned* sync, unsigned* sync_other) {
+  __shared__ int s_fail;
+  const int tid = threadIdx.x;
+  if (tid == 0) s_fail = 0;
+  zero_sync(sync_other, tid, Cfg<N>::NT);
+  __syncthreads();
+  unsigned epoch = 1;
+  bool ok = true;
+  for (int j = j0; j < j1 && ok; ++j) {
+    if (__hip_atomic_load(&d.gsc->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+    if (blockIdx.x < cgrid) update_coarse_body<MAXIT>(d, j, scale, min_iter, ord, blockIdx.x, cgrid);
+    ok = grid_barrier(sync, epoch++, (int)gridDim.x, &s_fail);
+    if (!ok || __hip_atomic_load(&d.gsc->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;      // column j-1 closed the solve
+    schwarz_body<N>(d, (const double*)(d.V + (size_t)j * d.ps), d.Z + (size_t)j * d.npr, 1, 1, blockIdx.x, gridDim.x);
+    ok = grid_barrier(sync, epoch++, (int)gridDim.x, &s_fail);
+    if (!ok) break;
+    divgs_body<N>(d, (const double*)d.yl, d.V + (size_t)(j + 1) * d.ps, j, 2, blockIdx.x, gridDim.x);
+    ok = grid_barrier(sync, epoch++, (int)gridDim.x, &s_fail);
+  }
+  if (!ok && tid == 0) atomicAdd((unsigned long long*)&d.stats->sync_timeouts, 1ull);
+}
+
+}  // namespace k2
 }  // namespace nsk

@@ -114,7 +114,7 @@ def test_non_finite_input_is_reported_by_the_map_and_does_not_poison_the_context
     of a fresh context bit for bit (lag arrays and the projection space carry nothing over)."""
     from nekstab_amd import seed
     from nekstab_amd.capi import NekStabHip, NskError
-    kw = dict(tol_helm=1e-11, tol_pres=1e-4, tol_relative=1, max_helm_iter=100, max_pres_iter=48, nproj=8)
+    kw = dict(tol_helm=1e-12, tol_pres=1e-6, tol_relative=1, max_helm_iter=120, max_pres_iter=192, nproj=8)
     qx, qy = seed.add_noise(case6)
     zp = np.zeros((case6.nel, 4, 4))
 
@@ -145,7 +145,9 @@ def test_non_finite_input_is_reported_by_the_map_and_does_not_poison_the_context
     h.matvec_batch([f, g], [a, a], 0)                       # both lanes clean again
     for v in (f, g):
         got = h.download(v)
-        assert all(np.allclose(x, y, rtol=0, atol=1e-6 * np.abs(y).max()) for x, y in zip(got[:2], ref[:2]))      # (lane 1 has its own, cold, projection space: solver tolerance)
+        err = max(np.abs(x - y).max() / np.abs(y).max() for x, y in zip(got[:2], ref[:2]))
+        print("batch after the failed one: lane result vs fresh context, max relative difference %.2e" % err)
+        assert err < 1e-6                                   # (lane 1 has its own, cold, projection space: solver tolerance)
     h.close()
 
 

@@ -75,3 +75,43 @@ def test_fused_full_map_vs_oracle_lx1_8():
         print("fused", fused, "rel L2 vs oracle %.2e" % np.sqrt(num / den))
         assert np.sqrt(num / den) < 1e-9
     h.close()
+
+
+def test_persistent_tails_are_bit_identical_to_launch_budgets():
+    """Round 5: heads + persistent tails (k_helm_tail, k_pres_tail: the same kernel bodies in a loop with grid barriers) against the
+    launch-budget form on config 2's mesh: identical Hessenberg matrix and vectors, bit for bit, also with the heads pushed far
+    below the iteration counts so that the tails do most of the iterations; no barrier time-out, no redone map."""
+    import os
+    from nekstab_amd import krylov, mesh, seed
+    from nekstab_amd.settings import production_context
+    from tests.conftest import GOLDEN
+    case = mesh.load_case_npz(os.path.join(GOLDEN, "cylinder_case.npz"), 8)
+    qx, qy = seed.add_noise(case)
+    zp = np.zeros((case.nel, 6, 6))
+    K = 14
+
+    def run(tail, off_h=0, off_p=0):
+        h = production_context(case)
+        h.set_option("tail", tail)
+        h.set_option("tail_off_h", off_h)
+        h.set_option("tail_off_p", off_p)
+        Q = h.alloc(K + 1)
+        h.upload(Q[0], qx, qy, zp)
+        h.scal(Q[0], 1.0 / h.norm(Q[0]))
+        H = np.zeros((K + 1, K))
+        krylov.arnoldi_factorization(h, Q, H, 1, K, 0, stats={})
+        last = h.download(Q[K])
+        st = h.stats()
+        hh, pp = h.step_iters()
+        h.close()
+        return H, last, st, hh.copy(), pp.copy()
+    H0, v0, s0, h0, p0 = run(0)
+    assert s0["tail_maps"] == 0
+    for off in ((0, 0), (-6, -3)):
+        H1, v1, s1, h1, p1 = run(-1, *off)
+        print("tail maps", s1["tail_maps"], "heads per step %.2f / %.2f" % (s1["step_budget_helm_mean"], s1["step_budget_pres_mean"]), "retries", s1["retries"],
+              "iterations per step %.3f / %.3f" % (s1["total_helm_iters"] / s1["total_steps"], s1["total_pres_iters"] / s1["total_steps"]))
+        assert s1["tail_maps"] >= K - 2 and s1["retries"] == 0
+        assert np.array_equal(h0, h1) and np.array_equal(p0, p1)           # the same iteration counts, step by step
+        assert np.array_equal(H0, H1)
+        assert all(np.array_equal(a, b) for a, b in zip(v0, v1))
