@@ -444,6 +444,8 @@ def main():
                 sh.set_option("halo_overlap", 1)
         else:
             sh.set_option("shard_graph", 0)                # eager until the first exchanges have run (RCCL sets its peer connections up lazily: not inside a capture)
+            if int(os.environ.get("NSK_BENCH_ATTEMPT", "0")) > 0:
+                sh.set_option("rccl_fuse", 0)              # the retry attempt: the all-reduces as calls of their own (the grouped form has not run on hardware before this node)
         return sh
 
     def barrier():

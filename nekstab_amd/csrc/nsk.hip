@@ -1191,7 +1191,9 @@ static int tails_resident(nsk_ctx* c, int ncu) {
   if (e1 != hipSuccess || e2 != hipSuccess) return 0;
   const int need = (c->nblk + ncu - 1) / ncu;
   if (c->debug) fprintf(stderr, "persistent tails: %d workgroups per CU needed, occupancy %d (velocity) / %d (pressure)\n", need, ph, pp);
-  return need + 1 <= std::min(std::min(ph, pp), 6);
+  // (the occupancy query is one workgroup per CU high only where it is bound by scalar registers, 7-8 per CU: MI355X_MICROARCH.md,
+  //  residency; grids of up to 5 per CU take it as it is, as fused_possible does)
+  return need <= std::min(std::min(ph, pp), 5);
 }
 static bool tails_on(nsk_ctx* c) {
   if (c->tail == 0 || c->fused || c->ndim != 2 || c->parent || c->clone_of || c->d.use_tot || c->d.nranks > 1 || !c->d.ecv || !c->d.rch || !c->merged_update) return false;
@@ -1219,15 +1221,16 @@ static void launch_helm_tail(nsk_ctx* c, const Dev& d, const StepCoef& sc, int i
 template <int N>
 static void launch_pres_tail(nsk_ctx* c, const Dev& d, int j0, int j1, double scale, int min_iter, int ord) {
   if (c->ndim != 2) return;
+  launch_update_coarse(c, d, j0, scale, min_iter, ord);      // closes column j0-1 as a launch: a solve of exactly j0 iterations ends here (k_pres_tail: skip_a)
   const unsigned cgrid = (d.nvert + 4 * UC_ROWS - 1) / (4 * UC_ROWS);
   const size_t sh = d.coarse_lda * sizeof(double);
   const int nit = d.coarse_lda / 256;
   unsigned* sy = c->sync + SYNC_WORDS;          // (set 1; zeroes set 0 for the next velocity tail)
   const dim3 grid(c->nblk), blk(nsk::k2::Cfg<N>::NT);
-  if (nit <= 3) hipLaunchKernelGGL((nsk::k2::k_pres_tail<N, 3>), grid, blk, sh, c->stream, d, j0, j1, scale, min_iter, ord, cgrid, sy, c->sync);
-  else if (nit <= 6) hipLaunchKernelGGL((nsk::k2::k_pres_tail<N, 6>), grid, blk, sh, c->stream, d, j0, j1, scale, min_iter, ord, cgrid, sy, c->sync);
-  else if (nit <= 9) hipLaunchKernelGGL((nsk::k2::k_pres_tail<N, 9>), grid, blk, sh, c->stream, d, j0, j1, scale, min_iter, ord, cgrid, sy, c->sync);
-  else hipLaunchKernelGGL((nsk::k2::k_pres_tail<N, 12>), grid, blk, sh, c->stream, d, j0, j1, scale, min_iter, ord, cgrid, sy, c->sync);
+  if (nit <= 3) hipLaunchKernelGGL((nsk::k2::k_pres_tail<N, 3>), grid, blk, sh, c->stream, d, j0, j1, scale, min_iter, ord, cgrid, 1, sy, c->sync);
+  else if (nit <= 6) hipLaunchKernelGGL((nsk::k2::k_pres_tail<N, 6>), grid, blk, sh, c->stream, d, j0, j1, scale, min_iter, ord, cgrid, 1, sy, c->sync);
+  else if (nit <= 9) hipLaunchKernelGGL((nsk::k2::k_pres_tail<N, 9>), grid, blk, sh, c->stream, d, j0, j1, scale, min_iter, ord, cgrid, 1, sy, c->sync);
+  else hipLaunchKernelGGL((nsk::k2::k_pres_tail<N, 12>), grid, blk, sh, c->stream, d, j0, j1, scale, min_iter, ord, cgrid, 1, sy, c->sync);
 }
 
 static int step(nsk_ctx* c, int istep, int adjoint, int nh_over = -1, int np_over = -1, bool tail = false) {

@@ -1291,7 +1291,10 @@ __global__ __launch_bounds__(256) void k_coarse(Dev d) {
 // MAXIT >= coarse_lda / 256 (3, 6, 9 or 12) sizes every per-thread table; UC_ROWS rows per wavefront (measured on config 2:
 // 2 rows / 263 workgroups beat 3 rows / 175 workgroups by 5 % of a matvec).
 constexpr int UC_ROWS = 2;
-template <int MAXIT>
+// LEAN (the persistent pressure tail, which must stay below 256 registers to be resident at two workgroups per CU): the corner
+// restrictions and the matrix rows are loaded in chunks of three 256-column blocks where they are used instead of all at the
+// top; the same operations in the same order, so both forms return the same bits.
+template <int MAXIT, bool LEAN = false>
 __device__ __forceinline__ void update_coarse_body(const Dev& d, int j, double scale, int min_iter, int ord, const unsigned bx_, const unsigned gx_) {
   extern __shared__ double srcv[];            // lda
   __shared__ double sh[MAXMR + 2], scs[MAXMR], ssn[MAXMR], scol[MAXMR + 2], sbc[2];
@@ -1306,12 +1309,15 @@ __device__ __forceinline__ void update_coarse_body(const Dev& d, int j, double s
   // Loads return in issue order: the short dependent chains go first (vertex tables -> corner values; partials of the first
   // row per wavefront), the 24 independent matrix loads last -- they are needed at the product only.
   // corner restrictions of this thread's vertices, vertex-major slots (Dev::ecv): 64 contiguous bytes per vertex
-  double2 cv[MAXIT][4];
+  constexpr int CVN = LEAN ? 1 : MAXIT;
+  double2 cv[CVN][4];
+  if constexpr (!LEAN) {
 #pragma unroll
-  for (int i = 0; i < MAXIT; ++i) {
-    const int v = tid + i * 256;
-    const double2* E = reinterpret_cast<const double2*>(d.ecv) + (size_t)(i < nit && v < nv ? v : 0) * 4;
-    if (i < nit) { cv[i][0] = E[0]; cv[i][1] = E[1]; cv[i][2] = E[2]; cv[i][3] = E[3]; }
+    for (int i = 0; i < MAXIT; ++i) {
+      const int v = tid + i * 256;
+      const double2* E = reinterpret_cast<const double2*>(d.ecv) + (size_t)(i < nit && v < nv ? v : 0) * 4;
+      if (i < nit) { cv[i][0] = E[0]; cv[i][1] = E[1]; cv[i][2] = E[2]; cv[i][3] = E[3]; }
+    }
   }
   double gj = 0.0;
   double pr[8], pr2[8];                       // partials of rows `w` and `w + 4` (the first two this wavefront sums): d.nblk <= 512 here
@@ -1334,18 +1340,31 @@ __device__ __forceinline__ void update_coarse_body(const Dev& d, int j, double s
     if (tid < jj) { scs[tid] = G->cs[tid]; ssn[tid] = G->sn[tid]; }
     gj = G->gpre[jj];
   }
-  float4 am[UC_ROWS][MAXIT];
+  constexpr int AMN = LEAN ? 1 : MAXIT;
+  float4 am[UC_ROWS][AMN];
+  if constexpr (!LEAN) {
 #pragma unroll
-  for (int r = 0; r < UC_ROWS; ++r) {
-    const float4* A = reinterpret_cast<const float4*>(d.Acif + (size_t)(row0 + r < nv ? row0 + r : 0) * lda) + lane;
+    for (int r = 0; r < UC_ROWS; ++r) {
+      const float4* A = reinterpret_cast<const float4*>(d.Acif + (size_t)(row0 + r < nv ? row0 + r : 0) * lda) + lane;
 #pragma unroll
-    for (int i = 0; i < MAXIT; ++i)
-      if (i < nit) am[r][i] = A[i * 64];
-  }
+      for (int i = 0; i < MAXIT; ++i)
+        if (i < nit) am[r][i] = A[i * 64];
+    }
 #pragma unroll
-  for (int i = 0; i < MAXIT; ++i) {           // R w (raw): the corner restrictions of a vertex in the order of vtab (unused slots are zero)
-    const int v = tid + i * 256;
-    if (i < nit) srcv[v] = (v < nv) ? ((((((cv[i][0].x + cv[i][0].y) + cv[i][1].x) + cv[i][1].y) + cv[i][2].x) + cv[i][2].y) + cv[i][3].x) + cv[i][3].y : 0.0;
+    for (int i = 0; i < MAXIT; ++i) {         // R w (raw): the corner restrictions of a vertex in the order of vtab (unused slots are zero)
+      const int v = tid + i * 256;
+      if (i < nit) srcv[v] = (v < nv) ? ((((((cv[i][0].x + cv[i][0].y) + cv[i][1].x) + cv[i][1].y) + cv[i][2].x) + cv[i][2].y) + cv[i][3].x) + cv[i][3].y : 0.0;
+    }
+  } else {
+#pragma unroll 3
+    for (int i = 0; i < MAXIT; ++i) {
+      const int v = tid + i * 256;
+      if (i < nit) {
+        const double2* E = reinterpret_cast<const double2*>(d.ecv) + (size_t)(v < nv ? v : 0) * 4;
+        const double2 c0 = E[0], c1 = E[1], c2 = E[2], c3 = E[3];
+        srcv[v] = (v < nv) ? ((((((c0.x + c0.y) + c1.x) + c1.y) + c2.x) + c2.y) + c3.x) + c3.y : 0.0;
+      }
+    }
   }
   if (j > 0) {
     if (d.nblk <= 512) {                      // first row per wavefront from the registers, the rest as sum_partials_multi
@@ -1421,14 +1440,28 @@ __device__ __forceinline__ void update_coarse_body(const Dev& d, int j, double s
   double sr[UC_ROWS];
 #pragma unroll
   for (int r = 0; r < UC_ROWS; ++r) sr[r] = 0.0;
+  if constexpr (!LEAN) {
 #pragma unroll
-  for (int i = 0; i < MAXIT; ++i)
-    if (i < nit) {
-      const double* x = srcv + i * 256 + lane * 4;
+    for (int i = 0; i < MAXIT; ++i)
+      if (i < nit) {
+        const double* x = srcv + i * 256 + lane * 4;
 #pragma unroll
-      for (int r = 0; r < UC_ROWS; ++r)
-        sr[r] += (double)am[r][i].x * x[0] + (double)am[r][i].y * x[1] + (double)am[r][i].z * x[2] + (double)am[r][i].w * x[3];
-    }
+        for (int r = 0; r < UC_ROWS; ++r)
+          sr[r] += (double)am[r][i].x * x[0] + (double)am[r][i].y * x[1] + (double)am[r][i].z * x[2] + (double)am[r][i].w * x[3];
+      }
+  } else {
+    const float4* A0 = reinterpret_cast<const float4*>(d.Acif + (size_t)(row0 < nv ? row0 : 0) * lda) + lane;
+    const float4* A1 = reinterpret_cast<const float4*>(d.Acif + (size_t)(row0 + 1 < nv ? row0 + 1 : 0) * lda) + lane;
+    static_assert(UC_ROWS == 2, "lean form: two rows per wavefront");
+#pragma unroll 3
+    for (int i = 0; i < MAXIT; ++i)
+      if (i < nit) {
+        const float4 a0 = A0[i * 64], a1 = A1[i * 64];
+        const double* x = srcv + i * 256 + lane * 4;
+        sr[0] += (double)a0.x * x[0] + (double)a0.y * x[1] + (double)a0.z * x[2] + (double)a0.w * x[3];
+        sr[1] += (double)a1.x * x[0] + (double)a1.y * x[1] + (double)a1.z * x[2] + (double)a1.w * x[3];
+      }
+  }
 #pragma unroll
   for (int r = 0; r < UC_ROWS; ++r) sr[r] = wave_sum63(sr[r]);
   double hinv = 1.0;

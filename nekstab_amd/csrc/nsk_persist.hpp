@@ -428,9 +428,10 @@ __global__ __launch_bounds__(Cfg<N>::NT, 2) void k_helm_tail(Dev d, StepCoef sc,
 }
 
 // merged pressure GMRES iterations j0 .. j1-1 (k_update_coarse, k_schwarz, k_divgs of each); the closing k_gmres_update(j1-1)
-// launch follows as behind the launched form
+// launch follows as behind the launched form.  skip_a: k_update_coarse(j0) has been LAUNCHED in front of this kernel (it closes
+// column j0-1: a solve of exactly j0 iterations -- the predicted count -- then ends there and this launch finds nothing to do).
 template <int N, int MAXIT>
-__global__ __launch_bounds__(Cfg<N>::NT, 2) void k_pres_tail(Dev d, int j0, int j1, double scale, int min_iter, int ord, unsigned cgrid, unsigned* sync, unsigned* sync_other) {
+__global__ __launch_bounds__(Cfg<N>::NT, 2) void k_pres_tail(Dev d, int j0, int j1, double scale, int min_iter, int ord, unsigned cgrid, int skip_a, unsigned* sync, unsigned* sync_other) {
   __shared__ int s_fail;
   const int tid = threadIdx.x;
   if (tid == 0) s_fail = 0;
@@ -440,9 +441,11 @@ __global__ __launch_bounds__(Cfg<N>::NT, 2) void k_pres_tail(Dev d, int j0, int 
   bool ok = true;
   for (int j = j0; j < j1 && ok; ++j) {
     if (__hip_atomic_load(&d.gsc->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-    if (blockIdx.x < cgrid) update_coarse_body<MAXIT>(d, j, scale, min_iter, ord, blockIdx.x, cgrid);
-    ok = grid_barrier(sync, epoch++, (int)gridDim.x, &s_fail);
-    if (!ok || __hip_atomic_load(&d.gsc->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;      // column j-1 closed the solve
+    if (!(skip_a && j == j0)) {
+      if (blockIdx.x < cgrid) update_coarse_body<MAXIT, true>(d, j, scale, min_iter, ord, blockIdx.x, cgrid);
+      ok = grid_barrier(sync, epoch++, (int)gridDim.x, &s_fail);
+      if (!ok || __hip_atomic_load(&d.gsc->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;      // column j-1 closed the solve
+    }
     schwarz_body<N>(d, (const double*)(d.V + (size_t)j * d.ps), d.Z + (size_t)j * d.npr, 1, 1, blockIdx.x, gridDim.x);
     ok = grid_barrier(sync, epoch++, (int)gridDim.x, &s_fail);
     if (!ok) break;

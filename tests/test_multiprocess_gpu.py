@@ -89,3 +89,19 @@ def test_bench_eight_ranks_gloo_dry_run():
     sm = r["shard_mode"]
     assert sm["picked"] in ("graph", "hostcheck", "hostcheck_overlap") and all(sm[k] > 0 for k in ("graph", "hostcheck", "hostcheck_overlap"))
     assert r["single_gpu_same_config"]["matvecs_per_s"] > 0 and r["roofline"]["peak"] == 8000.0
+
+
+def test_rccl_two_gpus():
+    """RCCL between two GPUs: two processes, one GPU each, the sharded map with the all-reduce inside the
+    halo group and with separate calls, and nsk_orth across the ranks -- equal to the single-rank result.  Skipped on one-GPU boxes
+    (every development box so far); the first node with two GPUs runs it before bench.py --gpus 2 does."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (%d visible)" % torch.cuda.device_count())
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29671", os.path.join(ROOT, "tests", "mp_rccl_worker.py")], capture_output=True, text=True, timeout=900, env=env)
+    line = [l for l in out.stdout.splitlines() if l.startswith("MPRCCL")]
+    print(line, out.stderr[-1500:] if out.returncode else "")
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert line
