@@ -125,8 +125,12 @@ struct nsk_ctx {
   // ---- persistent tails (nsk_persist.hpp: k_helm_tail, k_pres_tail; option "tail"): -1 = where every workgroup of the grid is
   // resident at once (quadrilateral single-rank contexts of at most ~3 workgroups per CU: configs 1, 2), 0 = never.  With tails
   // the per-step budgets become HEADS: the median count of the step over the last maps (launches that almost always do work);
-  // the tail runs whatever is left, to the solver's caps, in one launch.
-  int tail = -1;
+  // the tail runs whatever is left, to the solver's caps, in one launch: no budget can overflow, no map is redone.
+  // OFF by default: measured on config 2 (scripts/ab_tail.sh, ab_tail_driver.sh) 13.11 against 13.09 matvecs/s, 13.0-13.2 both
+  // ways on the driver's command -- bit-identical results, the same speed.  The kernel trace had promised more (a launch that
+  // finds its solve finished shows as 4.4 us there); in an un-profiled graph replay such a launch costs ~1.5 us, and a tail
+  // iteration ~2x a launched one (three grid barriers with agent-scope release / acquire, two workgroups per CU).
+  int tail = 0;
   int tail_ok = -1;                      // residency verdict (-1: not asked yet)
   int tail_off_h = 0, tail_off_p = 0;    // heads = median + these (options "tail_off_h" / "tail_off_p": tests push work into the tails with negative values)
   long long tail_maps = 0;
@@ -1579,7 +1583,19 @@ static int map_finish(nsk_ctx* c) {
     for (int k = 0; k < NCLS; ++k) fprintf(stderr, " %llu/%d", (unsigned long long)h.max_pres_k[k], c->cur_pres[k]);
     fprintf(stderr, "\n");
   }
-  if (h.sync_timeouts) return fail(NSK_EHIP, "grid barrier of the persistent velocity solve timed out (workgroups not co-resident?): set option fused = 0");
+  if (h.sync_timeouts) {
+    if (!c->fused && c->tail != 0 && c->last_map_per_step) {
+      // a grid barrier of a persistent tail gave up (its workgroups were not all resident: another process on the device, fewer
+      // CUs than the occupancy query promised): this context goes back to launch budgets for good and the map is redone
+      fprintf(stderr, "libnekstab_hip: a grid barrier of the persistent tails timed out (%lld): tails off for this context, map redone on launch budgets\n", (long long)h.sync_timeouts);
+      c->tail = 0;
+      invalidate_graphs(c);
+      (void)reset_solver_state(c);
+      c->retries++;
+      return 1;
+    }
+    return fail(NSK_EHIP, "grid barrier of the persistent velocity solve timed out (workgroups not co-resident?): set option fused = 0");
+  }
   if (h.nonfinite) {                    // the MAP says so (the reference's only guard is the NaN check of the next inner product, core/krylov_subspace.f:52-55)
     (void)reset_solver_state(c);        // ... and the next map of this context starts clean
     return fail(NSK_ENAN, "non-finite state inside the map: " + std::to_string((long long)h.nonfinite) + " time steps with a NaN / Inf pressure right-hand side (input vector not finite?)");
