@@ -113,7 +113,12 @@ int nsk_set_tolerances(nsk_ctx* ctx, double tol_helm, double tol_pres, int relat
  * per captured graph of the last step class, default 1),
  * "budget_freeze" / "budget_add_helm" / "budget_add_pres" (measurement switches of scripts/noop_cost.py),
  * "dbg_max_order" / "dbg_ab2" / "dbg_pext" (time-scheme sensitivity switches of scripts/wake_bisect.py; defaults = SURVEY App. A),
- * "dbg" (developer ablation mask) */
+ * "dbg" (developer ablation mask),
+ * "step_budgets" (1, default: launch budgets per TIME STEP from the per-step iteration record of the last maps instead of one
+ *   per step class; graph-replayed single-rank contexts), "tail" (persistent tail kernels of the two inner solves behind a head
+ *   of launches: -1 = where the grid is resident, 0 = never (default: measured the same speed), with "tail_off_h" / "tail_off_p"
+ *   = offsets of the heads from the median count), "rccl_fuse" (1, default: on RCCL ranks the all-reduce of an iteration rides
+ *   in the group of that iteration's halo messages) */
 int nsk_set_option(nsk_ctx* ctx, const char* name, double value);
 
 /* allocate(Q(k_dim+1)) (core/eigensolvers.f:170) */

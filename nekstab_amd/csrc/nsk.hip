@@ -122,15 +122,19 @@ struct nsk_ctx {
   } sb[2];
   int last_map_kind = 0;
   bool sb_force_class = false;           // the redo of an overflowed map runs on the (doubled) class budgets
-  // ---- persistent tails (nsk_persist.hpp: k_helm_tail, k_pres_tail; option "tail"): -1 = where every workgroup of the grid is
-  // resident at once (quadrilateral single-rank contexts of at most ~3 workgroups per CU: configs 1, 2), 0 = never.  With tails
-  // the per-step budgets become HEADS: the median count of the step over the last maps (launches that almost always do work);
-  // the tail runs whatever is left, to the solver's caps, in one launch: no budget can overflow, no map is redone.
-  // OFF by default: measured on config 2 (scripts/ab_tail.sh, ab_tail_driver.sh) 13.11 against 13.09 matvecs/s, 13.0-13.2 both
-  // ways on the driver's command -- bit-identical results, the same speed.  The kernel trace had promised more (a launch that
-  // finds its solve finished shows as 4.4 us there); in an un-profiled graph replay such a launch costs ~1.5 us, and a tail
-  // iteration ~2x a launched one (three grid barriers with agent-scope release / acquire, two workgroups per CU).
-  int tail = 0;
+  // ---- persistent tails (nsk_persist.hpp: k_helm_tail, k_pres_tail; option "tail").  Behind the launches of a solve ONE persistent
+  // launch runs whatever iterations are left, to the solver's caps: no budget can overflow, no map is redone.
+  //   0: never.   1: HEADS = the median count of the step over the last maps, the tail does the rest (0.25 + 0.52 tail iterations per
+  //   step on config 2).   2: SAFETY NET: the per-time-step budgets (largest count + head-room) and the tail behind them: it runs only
+  //   when a solve outruns its budget, which lets the head-room shrink from 3 / 2 to 1 / 0.   -1 (default): 2 where every
+  //   workgroup of the grid is resident at once (quadrilateral single-rank contexts of at most ~3 workgroups per CU: configs 1, 2),
+  //   else 0.
+  // Measured on config 2, 118 timed Arnoldi steps (scripts/ab_safety.sh, ab_safety2.sh; run-to-run +-0.1): budgets alone 13.18
+  // matvecs/s with 3 redone maps; mode 2 at head-room 3/2: 13.18, 2/1: 13.26-13.47, 1/0: 13.51, no redone map; mode 1: 13.29.
+  // All modes return the same bits (tests/test_persistent_gpu.py).  (The kernel trace had promised more: a launch that finds its
+  // solve finished shows as 4.4 us there; in an un-profiled graph replay it costs ~1.5 us, and a tail iteration ~2x a launched one:
+  // three grid barriers with agent-scope release / acquire, two workgroups per CU.)
+  int tail = -1;
   int tail_ok = -1;                      // residency verdict (-1: not asked yet)
   int tail_off_h = 0, tail_off_p = 0;    // heads = median + these (options "tail_off_h" / "tail_off_p": tests push work into the tails with negative values)
   long long tail_maps = 0;
@@ -1479,9 +1483,13 @@ static void step_budgets_update(nsk_ctx* c) {
   b.n++;
   const int nv = std::min(b.n, nsk_ctx::SBW);
   b.bh.assign(ns, 0); b.bp.assign(ns, 0);
-  static const int head_h = std::getenv("NSK_SB_HEAD_H") ? std::atoi(std::getenv("NSK_SB_HEAD_H")) : 3;
-  static const int head_p = std::getenv("NSK_SB_HEAD_P") ? std::atoi(std::getenv("NSK_SB_HEAD_P")) : 2;
-  if (tails_on(c)) {
+  // (tail = 2: the budgets below + a persistent tail behind them as a SAFETY NET: a solve that outruns its budget continues
+  //  in the tail instead of costing a redone map)
+  const bool net = tails_on(c);
+  static const int env_h = std::getenv("NSK_SB_HEAD_H") ? std::atoi(std::getenv("NSK_SB_HEAD_H")) : -1;
+  static const int env_p = std::getenv("NSK_SB_HEAD_P") ? std::atoi(std::getenv("NSK_SB_HEAD_P")) : -1;
+  const int head_h = env_h >= 0 ? env_h : (net ? 1 : 3), head_p = env_p >= 0 ? env_p : (net ? 0 : 2);
+  if (tails_on(c) && c->tail == 1) {
     // HEADS for the persistent tails: the MEDIAN count of this step over the window (offline on 56 maps of config 2: the cheapest
     // predictor, 0.44 launches that find nothing to do and 0.56 tail iterations per pressure solve; profiles/r05_step_budgets.txt).
     // Velocity: a solve of I iterations is found finished by launch I (0-based), i.e. I + 1 launches.
@@ -1502,7 +1510,7 @@ static void step_budgets_update(nsk_ctx* c) {
       for (int t = std::max(0, s - nsk_ctx::SBN); t <= std::min(ns - 1, s + nsk_ctx::SBN); ++t) { mh = std::max(mh, b.hist_h[i][t]); mp = std::max(mp, b.hist_p[i][t]); }
     int xh = 0, xp = 0;
     if (s < 6) { xh = std::max(4, mh / 2); xp = std::max(4, mp); }                    // time steps 1-6: counts vary most (noise left by the input vector)
-    if (nv < 4) { xh += std::max(2, mh / 4); xp += std::max(3, mp / 2); }            // first maps of a run: noise seed, empty projection space
+    if (nv < 4 && !net) { xh += std::max(2, mh / 4); xp += std::max(3, mp / 2); }    // first maps of a run: noise seed, empty projection space (with the safety-net tail an early overflow costs a tail iteration, not a map)
     b.bh[s] = std::min(c->max_helm, mh + head_h + xh);
     b.bp[s] = std::min(c->max_pres, std::max(c->min_pres, mp) + head_p + xp);
   }
