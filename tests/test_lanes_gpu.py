@@ -76,6 +76,6 @@ def test_band_arnoldi_on_two_lanes_reproduces_the_adjoint_table(spectre):
         r2 = krylov.band_arnoldi(h, [s0, s1], 40, mode=1)
         rate2 = 40 / (time.perf_counter() - t0)
         print("adjoint maps per second incl. orthogonalisation (k = 40): one at a time %.2f, in pairs on two lanes %.2f: x%.2f" % (rate1, rate2, rate2 / rate1))
-        assert rate2 > 1.2 * rate1
+        assert rate2 > 1.05 * rate1                      # (x1.5-1.6 in round 3, x1.16 since the per-time-step launch budgets of round 5 made the single map faster)
     finally:
         h.close()
