@@ -659,7 +659,7 @@ def main():
                         "launch_budgets": {"per_time_step": {"maps": st["step_budget_maps"], "helm_launches_per_step": st["step_budget_helm_mean"], "pres_iterations_per_step": st["step_budget_pres_mean"]},
                                            "persistent_tail_maps": st["tail_maps"],
                                            "last_step_class": {"helm": st["budget_helm"], "pres": st["budget_pres"]},
-                                           "note": "launches per time step in the captured graphs; with persistent tails (persistent_tail_maps > 0) these are the HEADS (median count of the step over the last 8 maps) and one persistent launch per solve runs whatever is left (nsk_persist.hpp); otherwise budgets (largest count + head-room), a launch beyond a solve's own count returning on a device flag"}})
+                                           "note": "launches per time step in the captured graphs: budgets = largest count of the step and its neighbours over the last 8 maps + head-room, a launch beyond a solve's own count returning on a device flag; persistent_tail_maps > 0: one persistent launch per solve behind them runs whatever a solve still needs, so no budget overflows and no map is redone (default where the grid is resident: safety net, head-room 1 / 0; option tail = 1: the numbers are HEADS = median counts and the tail does the rest; nsk_persist.hpp)"}})
             # ---- SURVEY 8(d) accounting: algorithmic bytes per matvec from the logged iteration counts
             geom = dict(nel=case.nel, lx1=case.lx1, ndim=2, nvert=int(case.meta["nvert"]), coarse_lda=((int(case.meta["nvert"]) + 255) // 256) * 256,
                         patch_stride=(((case.lx1 - 2 + 4) ** 2 + 3) // 4) * 4, nproj=a.nproj)

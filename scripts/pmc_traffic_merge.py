@@ -18,6 +18,6 @@ if os.path.exists(p):
             out["k_helm<12>"] = {"bytes_per_launch": (2.0 * v["fetch_kb_p90"] + v["write_kb_p90"]) * 1024.0, "fetch_kb_p90": v["fetch_kb_p90"], "write_kb_p90": v["write_kb_p90"]}
 stamp = os.path.join(ROOT, "nekstab_amd", "lib", "libnekstab_hip.so.srchash")
 json.dump({"srchash": open(stamp).read().strip() if os.path.exists(stamp) else None, "kernels": out,
-           "source": "scripts/profile_r04.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, kernel trace only); config 2: p90 over the launches of the bench command; config 4: p50 over launches of scripts/kernels3d_bench.py at a known basis index; config 3: k_helm<12>"},
+           "source": "scripts/profile_r04.sh / profile_r05.sh + profile_r05_b.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, kernel trace only); config 2: p90 over the launches of the bench command; config 4: p50 over launches of scripts/kernels3d_bench.py at a known basis index; config 3: k_helm<12>"},
           open(os.path.join(d, tag + "_pmc_traffic.json"), "w"), indent=1)
 print(sorted(out))
