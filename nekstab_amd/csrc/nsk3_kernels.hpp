@@ -47,6 +47,16 @@ __device__ inline double gs_wide_sum(const double* __restrict__ f, const Dev& d,
   return s;
 }
 
+// gs_csr as a plain loop, one entry per trip: for the paths a regular mesh never takes (its eight-wide form costs the kernel
+// around it twenty registers)
+__device__ inline double gs_csr_rolled(const double* __restrict__ f, const Dev& d, long long l) {
+  const int o0 = d.gs_off[l], o1 = d.gs_off[l + 1];
+  double s = 0.0;
+#pragma unroll 1
+  for (int k = o0; k < o1; ++k) s += f[d.gs_idx[k]];
+  return s;
+}
+
 // Element corners are the nodes of valence 5..8 of a regular hexahedral mesh.  Their lists live in a table addressed by
 // (element, corner) -- known from the thread index -- so the index loads go out with the kernel's first loads instead of
 // behind gs_tab -> gs_off -> gs_idx (measured at config 4's size, k_divgs: the loading phase of a workgroup took 10.4 us = five
@@ -655,14 +665,94 @@ __device__ inline double uniform_f64(double v) {
   u.i[1] = __builtin_amdgcn_readfirstlane(u.i[1]);
   return u.d;
 }
+// The eight-member lists of the element corners, one ENTRY per thread: thread p = (field, corner, member) loads its index with the
+// kernel's first loads and its value with the gather; the corner thread adds the eight values from LDS in list order (the sum of
+// gs_csr; a missing member is -0.0, the identity of the addition; NaN in member 0 = more than eight members: the CSR lists).
+__device__ inline double corner_list_sum(const double* v, const double* __restrict__ f, const Dev& d, long long l) {
+  if (v[0] != v[0]) return gs_csr_rolled(f, d, l);
+  double s = 0.0;
+#pragma unroll
+  for (int m = 0; m < 8; ++m) s += v[m];
+  return s;
+}
+// it = 0 of k_helm: r = mask dssum(rhs), (b, b), x = p = s = 0, z = r / diag, A z.  Once per solve: one component after the other.
+template <int N>
+__device__ inline void helm_first(const Dev& d, const StepCoef& sc, const double* __restrict__ rhs, double* sD, double* sDt,
+                                  double* sz, double* st, double* sred, double* scv) {
+  using C = Cfg<N>;
+  constexpr int NN = C::NN, NT = C::NT;
+  static_assert(NT >= 128 && N * N <= NT, "corner entries and the basis: one per thread");
+  const int tid = threadIdx.x;
+  const long long e = d.boff + xcd_element(blockIdx.x, gridDim.x);
+  const bool act = tid < NN;
+  const int k = tid / (N * N), j = (tid / N) % N, i = tid % N;
+  const long long l = e * NN + tid, nl = d.cs;
+  const double dv = (tid < N * N) ? d.D[tid] : 0.0;
+  const int cm = (d.gs_corner && tid < 128) ? d.gs_corner[(size_t)e * 64 + (tid & 63)] : -1;      // tid = field * 64 + corner * 8 + member
+  int4 tab = make_int4(0, -1, -1, -1);
+  double bm = 0, g[6] = {0, 0, 0, 0, 0, 0}, mk = 0, mi = 0, di = 0;
+  if (act) {
+    tab = d.gs_tab[l];
+    bm = d.bm1[l]; mk = d.mask[l]; mi = d.minv[l];
+    g[0] = d.g1[l]; g[1] = d.g2[l]; g[2] = d.g3[l]; g[3] = d.g4[l]; g[4] = d.g5[l]; g[5] = d.g6[l];
+    di = d.dinv[(size_t)(sc.k - 1) * d.nloc + l];
+  }
+  if (tid < N * N) { sD[tid] = dv; sDt[(tid % N) * N + tid / N] = dv; }
+  const int cid = act ? corner_id<N>(k, j, i) : -1;
+  const bool wide = act && tab.x < 0, from_list = wide && cid >= 0 && d.gs_corner;
+#pragma unroll 1
+  for (int c = 0; c < 3; ++c) {
+    const long long lc = c * nl + l;
+    const double* f0 = rhs + c * nl;
+    const double* f1 = d.bloc + c * nl;
+    if (tid < 128) scv[tid] = (cm == -2) ? __builtin_nan("") : ((cm >= 0) ? ((tid < 64) ? f0[cm] : f1[cm]) : -0.0);
+    GsVals gv, gb;
+    if (act && !wide) { gv = gs_load_o(f0, tab, (unsigned)l); gb = gs_load_o(f1, tab, (unsigned)l); }
+    lds_barrier();
+    double r = 0.0, z = 0.0, bb = 0.0;
+    if (act) {
+      if (!wide) { r = mk * (((gv.a + gv.b) + gv.c) + gv.d); bb = mk * (((gb.a + gb.b) + gb.c) + gb.d); }
+      else if (from_list) { r = mk * corner_list_sum(scv + cid * 8, f0, d, l); bb = mk * corner_list_sum(scv + 64 + cid * 8, f1, d, l); }
+      else { r = mk * gs_csr_rolled(f0, d, l); bb = mk * gs_csr_rolled(f1, d, l); }
+      d.hx[lc] = 0.0; d.hp[lc] = 0.0; d.hs[lc] = 0.0; d.hr[lc] = r;
+      z = di * r;
+      sz[tid] = z;
+    }
+    lds_barrier();
+    double au[1];
+    axhelm3<N, 1>(sD, sDt, sz, st, act, k, j, i, g, au);
+    double v[4] = {0, 0, 0, 0};
+    if (act) {
+      const double wl = d.nu * au[0] + sc.h2 * bm * z;
+      d.hwl[(size_t)c * nl + l] = wl;                                     // parity 0
+      v[0] = r * z * mi; v[1] = z * wl; v[2] = r * r * mi; v[3] = bb * bb * mi;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const double x = wave_sum63(v[q]);
+      if ((tid & 63) == 63) sred[q * 16 + (tid >> 6)] = x;
+    }
+    lds_barrier();
+    if (tid < 4) {
+      double s = 0.0;
+      for (int w = 0; w < NT / 64; ++w) s += sred[tid * 16 + w];
+      d.hpart[((size_t)(tid < 3 ? c * 3 + tid : 9 + c)) * d.nblk + e] = s;
+    }
+  }
+}
+// it >= 1: every load of the three components is issued before the first is used -- two round trips to memory per workgroup (the
+// arrays addressable from the thread index, then the neighbours' values) where the component loop of rounds 2-4 had five -- and the
+// three components' A z then run one after the other on one set of LDS tiles.
 template <int N>
 __global__ __launch_bounds__(Cfg<N>::NT, 4) void k_helm(Dev d, StepCoef sc, int it, const double* rhs) {
   using C = Cfg<N>;
   constexpr int NN = C::NN, NT = C::NT;
+  static_assert(NT >= 192, "corner entries: one per thread");
   __shared__ double sD[N * N], sDt[N * N];
-  __shared__ double sz[NN], st[3 * NN];
-  __shared__ double sred[4 * 16];
-  __shared__ int sW[NT * 8];
+  __shared__ double sz[3 * NN], st[3 * NN];
+  __shared__ double sred[12 * 16];
+  __shared__ double scv[192];
+  if (it == 0) { helm_first<N>(d, sc, rhs, sD, sDt, sz, st, sred, scv); return; }
   const int tid = threadIdx.x;
   const long long e = d.boff + xcd_element(blockIdx.x, gridDim.x);      // (boff: shards launch their boundary elements first, the interior behind)
   const bool act = tid < NN;
@@ -671,7 +761,7 @@ __global__ __launch_bounds__(Cfg<N>::NT, 4) void k_helm(Dev d, StepCoef sc, int 
   const int par = it & 1, ppar = par ^ 1;
   double alpha[3] = {0, 0, 0}, beta[3] = {0, 0, 0};
   bool done[3] = {false, false, false};
-  if (it > 0) {
+  {
     const double* ps = d.htot + ppar * 16;
     const double* o = d.hscal + ppar * 16;
 #pragma unroll
@@ -699,70 +789,92 @@ __global__ __launch_bounds__(Cfg<N>::NT, 4) void k_helm(Dev d, StepCoef sc, int 
       }
     }
     if (done[0] && done[1] && done[2]) return;
-    // wave-uniform CG scalars go to scalar registers (126 VGPRs, no spills => two workgroups per CU)
+    // wave-uniform CG scalars go to scalar registers
 #pragma unroll
     for (int c = 0; c < 3; ++c) { alpha[c] = uniform_f64(alpha[c]); beta[c] = uniform_f64(beta[c]); done[c] = __builtin_amdgcn_readfirstlane((int)done[c]) != 0; }
   }
-  for (int q = tid; q < N * N; q += NT) { const double v = d.D[q]; sD[q] = v; sDt[(q % N) * N + q / N] = v; }
+  // ---- round trip 1: everything addressable from the thread index
+  const double dv = (tid < N * N) ? d.D[tid] : 0.0;
+  const int cm = (d.gs_corner && tid < 192) ? d.gs_corner[(size_t)e * 64 + (tid & 63)] : -1;      // tid = component * 64 + corner * 8 + member
   int4 tab = make_int4(0, -1, -1, -1);
   double bm = 0, g[6] = {0, 0, 0, 0, 0, 0}, mk = 0, mi = 0, di = 0;
+  double ro[3] = {0, 0, 0}, po[3] = {0, 0, 0}, so[3] = {0, 0, 0}, xo[3] = {0, 0, 0};
   if (act) {
     tab = d.gs_tab[l];
-    bm = d.bm1[l]; mk = d.mask[l]; mi = d.minv[l];
+    mk = d.mask[l]; di = d.dinv[(size_t)(sc.k - 1) * d.nloc + l];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const long long lc = c * nl + l;
+      ro[c] = d.hr[lc];
+      if (!done[c]) { po[c] = d.hp[lc]; so[c] = d.hs[lc]; xo[c] = d.hx[lc]; }
+    }
+    bm = d.bm1[l]; mi = d.minv[l];
     g[0] = d.g1[l]; g[1] = d.g2[l]; g[2] = d.g3[l]; g[3] = d.g4[l]; g[4] = d.g5[l]; g[5] = d.g6[l];
-    di = d.dinv[(size_t)(sc.k - 1) * d.nloc + l];
-    const int cid = corner_id<N>(k, j, i);
-    gs_wide_stage(d, tab, l, sW + tid * 8, (cid >= 0 && d.gs_corner) ? reinterpret_cast<const int4*>(d.gs_corner + ((size_t)e * 8 + cid) * 8) : nullptr);
   }
+  // ---- round trip 2: the neighbours' values of A z of the previous iteration
+  const double* wl0 = d.hwl + (size_t)ppar * 3 * nl;
+  const bool wide = act && tab.x < 0;
+  {
+    const int cc = tid >> 6;
+    const bool cdone = (cc == 0) ? done[0] : ((cc == 1) ? done[1] : done[2]);
+    if (tid < 192) scv[tid] = (cm == -2) ? __builtin_nan("") : ((cm >= 0 && !cdone) ? wl0[(size_t)cc * nl + cm] : -0.0);
+  }
+  GsVals gv[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+    if (act && !wide && !done[c]) gv[c] = gs_load_o(wl0 + (size_t)c * nl, tab, (unsigned)l);
+  if (tid < N * N) { sD[tid] = dv; sDt[(tid % N) * N + tid / N] = dv; }
+  const int cid = act ? corner_id<N>(k, j, i) : -1;
+  const bool from_list = wide && cid >= 0 && d.gs_corner;
+  lds_barrier();
+  double rz[3] = {0, 0, 0}, rr[3] = {0, 0, 0};
+  if (act) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const long long lc = c * nl + l;
+      double r = ro[c];
+      if (!done[c]) {
+        const double* wl = wl0 + (size_t)c * nl;
+        const double sum = !wide ? (((gv[c].a + gv[c].b) + gv[c].c) + gv[c].d)
+                                 : (from_list ? corner_list_sum(scv + c * 64 + cid * 8, wl, d, l) : gs_csr_rolled(wl, d, l));
+        const double w = mk * sum;
+        const double pn = di * ro[c] + beta[c] * po[c];
+        const double sn = w + beta[c] * so[c];
+        d.hp[lc] = pn; d.hs[lc] = sn;
+        d.hx[lc] = xo[c] + alpha[c] * pn;
+        r = ro[c] - alpha[c] * sn;
+        d.hr[lc] = r;
+      }
+      const double z = di * r;
+      sz[c * NN + tid] = z;
+      rz[c] = r * z * mi; rr[c] = r * r * mi;
+    }
+  }
+  lds_barrier();
 #pragma unroll 1
   for (int c = 0; c < 3; ++c) {
-    const long long lc = c * nl + l;
-    double r = 0.0, z = 0.0, bb = 0.0;
-    if (act) {
-      if (it == 0) {
-        const GsVals gv = gs_load(rhs + c * nl, tab, l), gb = gs_load(d.bloc + c * nl, tab, l);
-        r = mk * (tab.x < 0 ? gs_wide_sum(rhs + c * nl, d, l, sW + tid * 8) : gs_sum(gv, rhs + c * nl, d, tab, l));
-        bb = mk * (tab.x < 0 ? gs_wide_sum(d.bloc + c * nl, d, l, sW + tid * 8) : gs_sum(gb, d.bloc + c * nl, d, tab, l));
-        d.hx[lc] = 0.0; d.hp[lc] = 0.0; d.hs[lc] = 0.0; d.hr[lc] = r;
-      } else if (!done[c]) {
-        const double* wl = d.hwl + ((size_t)ppar * 3 + c) * nl;
-        const GsVals gv = gs_load(wl, tab, l);
-        const double rold = d.hr[lc], pold = d.hp[lc], sold = d.hs[lc], xold = d.hx[lc];
-        const double w = mk * (tab.x < 0 ? gs_wide_sum(wl, d, l, sW + tid * 8) : gs_sum(gv, wl, d, tab, l));
-        const double pn = di * rold + beta[c] * pold;
-        const double sn = w + beta[c] * sold;
-        d.hp[lc] = pn; d.hs[lc] = sn;
-        d.hx[lc] = xold + alpha[c] * pn;
-        r = rold - alpha[c] * sn;
-        d.hr[lc] = r;
-      } else {
-        r = d.hr[lc];
-      }
-      z = di * r;
-      sz[tid] = z;
-    }
-    lds_barrier();
     double au[1];
-    axhelm3<N, 1>(sD, sDt, sz, st, act, k, j, i, g, au);
-    double v[4] = {0, 0, 0, 0};
+    axhelm3<N, 1>(sD, sDt, sz + c * NN, st, act, k, j, i, g, au);
+    double v[3] = {0, 0, 0};
     if (act) {
+      const double z = sz[c * NN + tid];
       const double wl = d.nu * au[0] + sc.h2 * bm * z;
       d.hwl[((size_t)par * 3 + c) * nl + l] = wl;
-      v[0] = r * z * mi; v[1] = z * wl; v[2] = r * r * mi; v[3] = bb * bb * mi;
+      v[0] = (c == 0) ? rz[0] : ((c == 1) ? rz[1] : rz[2]); v[1] = z * wl; v[2] = (c == 0) ? rr[0] : ((c == 1) ? rr[1] : rr[2]);
     }
-    // workgroup sums: wave sums to LDS, rows added (fixed order) by the four threads that store them;
-    // sred is rewritten only after the next component's barriers
+    // workgroup sums: wave sums to LDS, rows added (fixed order) by the threads that store them
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < 3; ++q) {
       const double x = wave_sum63(v[q]);
-      if ((tid & 63) == 63) sred[q * 16 + (tid >> 6)] = x;
+      if ((tid & 63) == 63) sred[(c * 3 + q) * 16 + (tid >> 6)] = x;
     }
-    lds_barrier();
-    if (tid < 4) {
-      double s = 0.0;
+    lds_barrier();                                           // (st is rewritten by the next component)
+  }
+  if (tid < 12) {
+    double s = 0.0;
+    if (tid < 9)
       for (int w = 0; w < NT / 64; ++w) s += sred[tid * 16 + w];
-      d.hpart[((size_t)par * 12 + (tid < 3 ? c * 3 + tid : 9 + c)) * d.nblk + e] = s;
-    }
+    d.hpart[((size_t)par * 12 + tid) * d.nblk + e] = s;      // (rows 9..11, (b, b), are it = 0's)
   }
 }
 
@@ -1878,13 +1990,22 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_gradt(Dev d, const double* __res
 }
 
 // w = D ( B^-1 mask dssum(yl) ) ; optional dots (w, V_i), i <= j, and (w,w)
+// Two round trips to memory per workgroup: (1) everything addressable from the thread index -- gather table, 1/B, the nine metric
+// terms of the pressure node, the basis, and the element corners' lists, one list ENTRY per thread (3 components x 8 corners x 8
+// members = 192 threads); (2) the neighbours' values, one per corner-list entry.  The corner threads then add their eight values
+// from LDS in list order (the left-to-right sum of gs_csr; a missing member is -0.0, the identity of the addition).
+// (Until round 5 the basis was a round trip of its own ahead of the table, the metric terms went out after the gather and a
+//  corner thread walked its three components' lists one after the other: five round trips, 9 of a workgroup's 14 us.)
 template <int N>
 __global__ __launch_bounds__(Cfg<N>::NT) void k_divgs(Dev d, const double* __restrict__ yl,
                                                       double* __restrict__ wout, int j, int check_done) {
   using C = Cfg<N>;
   constexpr int NN = C::NN, M = C::M, MM = C::MM, NT = C::NT, NM = N * M, NNM = C::NNM, NMM = C::NMM;
+  constexpr int CW = 192, NCS = (CW + NT - 1) / NT;
+  static_assert(NM <= NT, "basis: one entry per thread");
   __shared__ double sJ12[NM], sD12[NM];
   __shared__ double su[3 * NN], sA[2 * NNM], sB[3 * NMM];
+  __shared__ double scv[CW];
   __shared__ double sdot[(MAXMR + 2) * 16];
   const int tid = threadIdx.x;
   const long long e = d.boff + xcd_element(blockIdx.x, gridDim.x);      // XCD-contiguous runs of elements: the neighbours' face lines hit the L2 that streams them
@@ -1892,22 +2013,65 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_divgs(Dev d, const double* __res
   if (check_done && d.gsc->done) return;
   NSK_STAMP(0);
   const long long l = e * NN + tid;
-  load_basis3<N>(d, nullptr, nullptr, sJ12, sD12, tid, NT);
-  if (act) {
-    CornerList CL;
-    corner_issue(d, e, corner_id<N>(tid / (N * N), (tid / N) % N, tid % N), CL);
-    const int4 tab = d.gs_tab[l];
-    const double bi = d.binv[l];
-    GsVals g0 = gs_load(yl, tab, l), g1 = gs_load(yl + d.cs, tab, l), g2 = gs_load(yl + 2 * d.cs, tab, l);
-    su[tid] = bi * gs_sum3(g0, yl, d, tab, l, CL);
-    su[NN + tid] = bi * gs_sum3(g1, yl + d.cs, d, tab, l, CL);
-    su[2 * NN + tid] = bi * gs_sum3(g2, yl + 2 * d.cs, d, tab, l, CL);
-  }
   const bool pact = tid < MM;
   const long long q = e * MM + tid;
+  // ---- round trip 1
+  int cm[NCS];
+#pragma unroll
+  for (int s = 0; s < NCS; ++s) {
+    const int p = tid + s * NT;
+    cm[s] = (d.gs_corner && p < CW) ? d.gs_corner[(size_t)e * 64 + (p & 63)] : -1;
+  }
+  int4 tab = make_int4(0, -1, -1, -1);
+  double bi = 0.0;
+  if (act) { tab = d.gs_tab[l]; bi = d.binv[l]; }
   double w2[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   if (pact) load_w2(d, q, w2);
+  // ---- round trip 2
+  double cv[NCS];
+#pragma unroll
+  for (int s = 0; s < NCS; ++s) {
+    const int p = tid + s * NT;
+    cv[s] = (cm[s] >= 0) ? yl[(size_t)(p >> 6) * d.cs + cm[s]] : -0.0;
+  }
+  const int cid = act ? corner_id<N>(tid / (N * N), (tid / N) % N, tid % N) : -1;
+  const bool wide = act && tab.x < 0;
+  const bool from_list = wide && cid >= 0 && d.gs_corner;
+  GsVals g0, g1, g2;
+  if (act && !wide) { g0 = gs_load_o(yl, tab, (unsigned)l); g1 = gs_load_o(yl + d.cs, tab, (unsigned)l); g2 = gs_load_o(yl + 2 * d.cs, tab, (unsigned)l); }
+  double bJ = 0.0, bD = 0.0;
+  if (tid < NM) { bJ = d.J12[tid]; bD = d.D12[tid]; }
+  if (act) {
+    if (!wide) {
+      su[tid] = bi * (((g0.a + g0.b) + g0.c) + g0.d);
+      su[NN + tid] = bi * (((g1.a + g1.b) + g1.c) + g1.d);
+      su[2 * NN + tid] = bi * (((g2.a + g2.b) + g2.c) + g2.d);
+    } else if (!from_list) {                                  // more than four co-located nodes away from the corners: the CSR lists
+#pragma unroll 1
+      for (int c = 0; c < 3; ++c) su[c * NN + tid] = bi * gs_csr_rolled(yl + (size_t)c * d.cs, d, l);
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < NCS; ++s) {
+    const int p = tid + s * NT;
+    if (p < CW) scv[p] = (cm[s] == -2) ? __builtin_nan("") : cv[s];
+  }
+  if (tid < NM) { sJ12[tid] = bJ; sD12[tid] = bD; }
   NSK_STAMP(1);
+  lds_barrier();
+  if (from_list) {
+#pragma unroll 1
+    for (int c = 0; c < 3; ++c) {
+      const double* v = scv + c * 64 + cid * 8;
+      double sum = 0.0;
+      if (v[0] != v[0]) sum = gs_csr_rolled(yl + (size_t)c * d.cs, d, l);       // more than eight members (or a NaN in the data: same result)
+      else {
+#pragma unroll
+        for (int m = 0; m < 8; ++m) sum += v[m];
+      }
+      su[c * NN + tid] = bi * sum;
+    }
+  }
   lds_barrier();
   NSK_STAMP(2);
   const double w = opdiv3<N>(sJ12, sD12, su, sA, sB, tid, NT, w2);
