@@ -34,6 +34,7 @@ module nekstab_hip
     integer(c_long_long) :: step_budget_maps
     real(c_double) :: step_budget_helm_mean, step_budget_pres_mean
     integer(c_long_long) :: tail_maps
+    integer(c_long_long) :: zero_arrays
   end type
 
   interface

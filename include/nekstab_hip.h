@@ -118,7 +118,11 @@ int nsk_set_tolerances(nsk_ctx* ctx, double tol_helm, double tol_pres, int relat
  *   per step class; graph-replayed single-rank contexts), "tail" (persistent tail kernels of the two inner solves behind a head
  *   of launches: -1 = where the grid is resident, 0 = never (default: measured the same speed), with "tail_off_h" / "tail_off_p"
  *   = offsets of the heads from the median count), "rccl_fuse" (1, default: on RCCL ranks the all-reduce of an iteration rides
- *   in the group of that iteration's halo messages) */
+ *   in the group of that iteration's halo messages),
+ * "zero_metrics" (hexahedra; 1, default: arrays of the mapping and of the base-flow constants that are zero on every node -- the
+ *   cross terms Nek5000 skips on its undeformed elements, hmholtz.f axhelm / ifdfrm -- are not loaded; 0: every array is loaded,
+ *   same bits.  The set-up sets derivatives of the mapping that are rounding noise on every node to zero; NSK_ZERO_METRICS=0 in
+ *   the environment of nsk_init keeps the noise, as rounds 1-4 did) */
 int nsk_set_option(nsk_ctx* ctx, const char* name, double value);
 
 /* allocate(Q(k_dim+1)) (core/eigensolvers.f:170) */
@@ -206,6 +210,9 @@ typedef struct {
   long long step_budget_maps;
   double step_budget_helm_mean, step_budget_pres_mean;
   long long tail_maps;                      /* maps whose solves ended in the persistent tail kernels (option "tail"): the per-step numbers above are then HEADS */
+  long long zero_arrays;                    /* hexahedra: bit mask of the arrays that are zero on every node and therefore not loaded: bits 0-8 the
+                                               nine metric terms, 9-11 the G factors g4 g5 g6 (set-up), 12-23 the twelve base-flow constants of the
+                                               convection kernel (nsk_set_baseflow); 0 on quadrilaterals, on deformed meshes, with option zero_metrics = 0 */
 } nsk_stats;
 int nsk_get_stats(nsk_ctx* ctx, nsk_stats* s);
 

@@ -46,7 +46,7 @@ class NskStats(C.Structure):
                 ("total_helm_iters", C.c_longlong), ("total_pres_iters", C.c_longlong), ("total_steps", C.c_longlong),
                 ("recapture_seconds", C.c_double), ("total_pres_jsum", C.c_longlong), ("coarse_bytes_per_solve", C.c_double),
                 ("step_budget_maps", C.c_longlong), ("step_budget_helm_mean", C.c_double), ("step_budget_pres_mean", C.c_double),
-                ("tail_maps", C.c_longlong)]
+                ("tail_maps", C.c_longlong), ("zero_arrays", C.c_longlong)]
 
 
 # every symbol include/nekstab_hip.h declares: (restype, argtypes)

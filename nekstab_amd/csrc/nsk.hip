@@ -86,6 +86,8 @@ struct nsk_ctx {
   int budget_freeze = 0;
   int helm_fdm = -1;                    // hexahedra: element-block fast-diagonalisation preconditioner of the velocity solves (NSK_HELM_FDM=1 builds it; measured slower than Jacobi-CG, off)
   int eapply_pipe = 4;                  // hexahedra, the Schwarz + D^T kernel: 0 = one workgroup per element, 1 = resident workgroups with the next element's loads in flight (k_schwarz_p), 2 = one wavefront per element (k_schwarz_w), 3 = 2 + k_divgs_w, 4 = one wavefront per element, sixteen per CU (k_schwarz_w16; default, lx1 <= 8)
+  int zero_metrics = 1;                 // hexahedra: arrays of the mapping / base-flow constants that are zero on every node are cleaned at set-up and not loaded by the kernels (Dev::zmask, Dev::bfmask); NSK_ZERO_METRICS=0: set-up as rounds 1-4 (rounding noise kept); option zero_metrics = 0: cleaned arrays, every one loaded
+  unsigned zmask_built = 0, bfmask_built = 0;
   int divgs_c3 = 0;                     // hexahedra: k_divgs with the three components' pass chains side by side (k_divgs_c3: 5 barriers instead of 12; measured 6 % SLOWER at config 4's size, 718 against 678 us: the gather, not the passes, is what a workgroup waits for; kept as an option)
   int eapply_grid[2] = {0, 0};          // their grid sizes (workgroups that fit the device at once; 0 = not yet asked)
   int flat_proj = -1;                   // hexahedra: once-per-step sums over the GMRES / projection bases as streaming kernels (k_pres_comb, k_proj_dots); -1 = yes on single-rank contexts
@@ -879,6 +881,7 @@ static int build(nsk_ctx* c, const nsk_case& cs) {
   return 0;
 }
 
+static int scan_bfmask(nsk_ctx* c);
 #include "nsk3_setup.inc"
 
 // ---------------------------------------------------------------------------
@@ -1760,6 +1763,7 @@ static int group_set_baseflow(std::vector<nsk_ctx*>& G, const double* const* q) 
     nsk_ctx* c = G[r]; nsk_ctx* P = c->parent; Dev& d = c->d;
     if (!P) return fail(NSK_EINVAL, "needs shard contexts");
     const int nd = c->ndim, NN = c->NN;
+    d.bfmask = 0;                                          // (the new constants are not scanned for zero arrays on shards)
     DISPATCH_N(c->key, {                                   // (hexahedra: Dev::cUr aliases the 12-constant array bfc)
       hipLaunchKernelGGL(k_baseflow<N>, dim3(c->nel), dim3(Cfg<N>::NTD), 0, c->stream, d, q[r], (double*)d.cUr, (double*)d.cUs,
                          (double*)d.GUx, (double*)d.GUy, (double*)d.GVx, (double*)d.GVy);
@@ -1889,7 +1893,7 @@ int nsk_group_set_orbit(nsk_ctx** shards, int n, nsk_vec* q0, double spng_str, n
     Dev& d = c->d;
     if (nd == 3) {
       c->steady[0] = d.bfc;
-      d.bfc = c->orbit[0]; d.cUr = c->orbit[0];
+      d.bfc = c->orbit[0]; d.cUr = c->orbit[0]; d.bfmask = 0;
       d.bf_stride = 12 * d.nfine;
     } else {
       c->steady[0] = d.cUr; c->steady[1] = d.cUs; c->steady[2] = d.GUx; c->steady[3] = d.GUy; c->steady[4] = d.GVx; c->steady[5] = d.GVy;
@@ -2212,6 +2216,10 @@ int nsk_set_option(nsk_ctx* c, const char* name, double value) {
   else if (n == "gs_lag") c->gs_lag = (int)value;
   else if (n == "flat_proj") c->flat_proj = (int)value;
   else if (n == "divgs_c3") { c->divgs_c3 = (int)value; invalidate_graphs(c); }
+  else if (n == "zero_metrics") {       // 0: every array is loaded (the cleaned ones included: same bits); 1: back to the masks of the set-up
+    c->d.zmask = value != 0.0 ? c->zmask_built : 0u; c->d.bfmask = (value != 0.0 && !c->d.bf_stride) ? c->bfmask_built : 0u;
+    invalidate_graphs(c);
+  }
   else if (n == "eapply_pipe") { c->eapply_pipe = (int)value; invalidate_graphs(c); }
   else if (n == "helm_fdm") {           // 0: back to Jacobi (the factors stay); 1: only if the set-up built them (NSK_HELM_FDM=1 or an anisotropic mesh)
     if (value != 0.0 && !c->d.hfS) return fail(NSK_EINVAL, "helm_fdm: the fast-diagonalisation factors were not built at set-up (NSK_HELM_FDM=1)");
@@ -2351,6 +2359,7 @@ int nsk_get_stats(nsk_ctx* c, nsk_stats* s) {
   s->total_pres_jsum = c->tot_pres_jsum; s->coarse_bytes_per_solve = c->coarse_bytes;
   s->step_budget_maps = c->sb_maps;
   s->tail_maps = c->tail_maps;
+  s->zero_arrays = (long long)c->d.zmask | ((long long)c->d.bfmask << 12);
   s->step_budget_helm_mean = c->sb_maps ? (double)c->sb_launch_h / ((double)c->sb_steps) : 0.0;
   s->step_budget_pres_mean = c->sb_maps ? (double)c->sb_launch_p / ((double)c->sb_steps) : 0.0;
   return 0;
@@ -2382,6 +2391,49 @@ int nsk_matvec(nsk_ctx* c, int mode, nsk_vec fv, nsk_vec qv) {
     default: return fail(NSK_EINVAL, "unknown mode");
   }
   return rc;
+}
+
+// Which of the twelve base-flow constants of the hexahedral convection kernel vanish on every dealiasing node (a two-dimensional
+// base flow on a spanwise-extruded mesh: the third convecting component and five of the nine gradient terms): Dev::bfmask.
+// "Vanish": largest magnitude below 1e-10 of the largest of its group (convecting field / gradient) -- d U / d z of a z-invariant
+// field comes out of the derivative matrix as rounding noise, as the mapping's cross derivatives do (nsk3_setup.inc) -- and such an
+// array is then SET to zero, so that loading it or not gives the same bits.  Steady sets only; a stored orbit loads everything.
+__global__ void k_absmax_scan(const double* __restrict__ a, size_t n, unsigned long long* out) {
+  const int q = blockIdx.y;
+  const double* p = a + (size_t)q * n;
+  double m = 0.0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    double v = fabs(p[i]);
+    if (!(v == v)) v = INFINITY;
+    m = fmax(m, v);
+  }
+  for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0 && m > 0.0) atomicMax(out + q, (unsigned long long)__double_as_longlong(m));     // (non-negative doubles order as integers)
+}
+static int scan_bfmask(nsk_ctx* c) {
+  Dev& d = c->d;
+  d.bfmask = 0; c->bfmask_built = 0;
+  if (c->ndim != 3 || !c->zero_metrics || !d.zmask || d.bf_stride || !d.bfc) return 0;
+  unsigned long long* dm = nullptr;
+  unsigned long long hm[12];
+  HIPCHK(hipMalloc(&dm, sizeof(hm)));
+  HIPCHK(hipMemsetAsync(dm, 0, sizeof(hm), c->stream));
+  hipLaunchKernelGGL(k_absmax_scan, dim3(1024, 12), dim3(256), 0, c->stream, d.bfc, (size_t)d.nfine, dm);
+  HIPCHK(hipMemcpyAsync(hm, dm, sizeof(hm), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipFree(dm));
+  double mx[12], gmax[2] = {0.0, 0.0};
+  for (int q = 0; q < 12; ++q) { std::memcpy(&mx[q], &hm[q], sizeof(double)); gmax[q >= 3] = std::max(gmax[q >= 3], mx[q]); }
+  unsigned mask = 0;
+  for (int q = 0; q < 12; ++q)
+    if (mx[q] <= 1e-10 * gmax[q >= 3]) {
+      mask |= 1u << q;
+      if (mx[q] != 0.0) HIPCHK(hipMemsetAsync((double*)d.bfc + (size_t)q * d.nfine, 0, (size_t)d.nfine * sizeof(double), c->stream));
+    }
+  HIPCHK(hipStreamSynchronize(c->stream));
+  c->bfmask_built = mask;
+  d.bfmask = mask;
+  return 0;
 }
 
 // New linearisation point (core/newton_krylov.f:371-372 + prepare_linearized_solver): base-flow
@@ -2420,6 +2472,7 @@ int nsk_set_baseflow(nsk_ctx* c, nsk_vec qv) {
   for (int k = 0; k < 3; ++k)
     for (long long l = 0; l < c->nloc; ++l) dinv[(size_t)k * c->nloc + l] = c->h_mask[l] / (d.nu * c->h_dAs[l] + bd0[k] / c->dt * c->h_bs[l]);
   HIPCHK(hipMemcpy((double*)d.dinv, dinv.data(), dinv.size() * sizeof(double), hipMemcpyHostToDevice));
+  { const int rc = scan_bfmask(c); if (rc) return rc; }
   invalidate_graphs(c);           // coefficients are baked into the captured graphs
   return 0;
 }
@@ -2470,7 +2523,7 @@ int nsk_set_orbit(nsk_ctx* c, nsk_vec q0v, double spng_str, nsk_vec end) {
     HIPCHK(hipStreamSynchronize(c->stream));
     if (h.unconverged > 0) return fail(NSK_ENOCONV, "inner solve hit its iteration cap while integrating the base-flow orbit");
     c->steady[0] = d.bfc;
-    d.bfc = c->orbit[0]; d.cUr = c->orbit[0];
+    d.bfc = c->orbit[0]; d.cUr = c->orbit[0]; d.bfmask = 0;
     d.bf_stride = 12 * nfine; c->orbit_steps = c->nsteps;
     invalidate_graphs(c);
     return 0;

@@ -267,9 +267,22 @@ __device__ inline void load_basis3(const Dev& d, double* sD, double* sDt, double
     for (int k = tid; k < M * N; k += nt) { sJ12[k] = d.J12[k]; sD12[k] = d.D12[k]; }
 }
 
+// Metric and G arrays that are zero on every node (Dev::zmask: a spanwise-extruded or a box mesh) are not loaded: 4 of the 9
+// metric terms and 2 of the 6 G factors at config 4, 6 and 3 at config 5.  The branch is on a kernel argument: wave-uniform.
 __device__ inline void load_w2(const Dev& d, long long q, double (&w2)[9]) {
 #pragma unroll
-  for (int a = 0; a < 9; ++a) w2[a] = d.w2m[(size_t)a * d.npr + q];
+  for (int a = 0; a < 9; ++a) w2[a] = ((d.zmask >> a) & 1u) ? 0.0 : d.w2m[(size_t)a * d.npr + q];
+}
+__device__ inline void load_g6(const Dev& d, long long l, double (&g)[6]) {
+  g[0] = d.g1[l]; g[1] = d.g2[l]; g[2] = d.g3[l];
+  g[3] = (d.zmask & (1u << 9)) ? 0.0 : d.g4[l];
+  g[4] = (d.zmask & (1u << 10)) ? 0.0 : d.g5[l];
+  g[5] = (d.zmask & (1u << 11)) ? 0.0 : d.g6[l];
+}
+// constant q of the twelve base-flow constants on the dealiasing mesh (Dev::bfmask: a two-dimensional base flow on an extruded mesh
+// leaves 6 of the 12 zero)
+__device__ inline double ld_bfc(const Dev& d, const double* __restrict__ bfc, int q, size_t nf, size_t node) {
+  return ((d.bfmask >> q) & 1u) ? 0.0 : bfc[(size_t)q * nf + node];
 }
 
 // interpolation GLL -> dealiasing mesh of one component: in (global, [NN]) -> sf [NDD]; scratch t1 [N*N*ND], t2 [N*ND*ND]
@@ -393,7 +406,8 @@ __device__ inline void convect_lds(const Dev& d, const double* __restrict__ uin,
         double v = 0.0;
 #pragma unroll
         for (int a2 = 0; a2 < 3; ++a2)               // convecting field c_a = w_d J (u . grad xi_a)
-          v += (d.mtd[(a2 * 3 + 0) * nf + q] * u0 + d.mtd[(a2 * 3 + 1) * nf + q] * u1 + d.mtd[(a2 * 3 + 2) * nf + q] * u2) * g[a2];
+          v += ((((d.zmask >> (a2 * 3 + 0)) & 1u) ? 0.0 : d.mtd[(a2 * 3 + 0) * nf + q]) * u0 + (((d.zmask >> (a2 * 3 + 1)) & 1u) ? 0.0 : d.mtd[(a2 * 3 + 1) * nf + q]) * u1 +
+                (((d.zmask >> (a2 * 3 + 2)) & 1u) ? 0.0 : d.mtd[(a2 * 3 + 2) * nf + q]) * u2) * g[a2];
         sf[p] = v;
       }
       lds_barrier();
@@ -416,12 +430,12 @@ __device__ inline void convect_lds(const Dev& d, const double* __restrict__ uin,
       fine_grad<N>(sDd, sf, a, b, cc, g);
       const double uf = sf[p];
       const size_t q = (size_t)e * NDD + p;
-      const double conv = bfc[0 * nf + q] * g[0] + bfc[1 * nf + q] * g[1] + bfc[2 * nf + q] * g[2];   // (U.grad) u'_c
+      const double conv = ld_bfc(d, bfc, 0, nf, q) * g[0] + ld_bfc(d, bfc, 1, nf, q) * g[1] + ld_bfc(d, bfc, 2, nf, q) * g[2];   // (U.grad) u'_c
       so[c * NDD + p] += adjoint ? -conv : conv;
 #pragma unroll
       for (int x = 0; x < 3; ++x) {
         // direct:  + u'_c dU_x/dx_c   (u'.grad) U ;   adjoint:  + u'_c dU_c/dx_x   (grad U)^T u'
-        const double G = adjoint ? bfc[(3 + 3 * c + x) * nf + q] : bfc[(3 + 3 * x + c) * nf + q];
+        const double G = ld_bfc(d, bfc, adjoint ? 3 + 3 * c + x : 3 + 3 * x + c, nf, q);
         so[x * NDD + p] += uf * G;
       }
     }
@@ -466,7 +480,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_convect(Dev d, const double* __r
           const size_t q = (size_t)e * NDD + p;
           const double uf = sf[p];
 #pragma unroll
-          for (int a2 = 0; a2 < 3; ++a2) ca[r][a2] += d.mtd[(a2 * 3 + c) * nf + q] * uf;
+          for (int a2 = 0; a2 < 3; ++a2) ca[r][a2] += (((d.zmask >> (a2 * 3 + c)) & 1u) ? 0.0 : d.mtd[(a2 * 3 + c) * nf + q]) * uf;
         }
       }
       lds_barrier();
@@ -488,13 +502,13 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_convect(Dev d, const double* __r
           const double v = ca[r][0] * g[0] + ca[r][1] * g[1] + ca[r][2] * g[2];
           if (c == 0) o[r][0] = v; else if (c == 1) o[r][1] = v; else o[r][2] = v;
         } else {
-          const double conv = bfc[0 * nf + q] * g[0] + bfc[1 * nf + q] * g[1] + bfc[2 * nf + q] * g[2];   // (U.grad) u'_c
+          const double conv = ld_bfc(d, bfc, 0, nf, q) * g[0] + ld_bfc(d, bfc, 1, nf, q) * g[1] + ld_bfc(d, bfc, 2, nf, q) * g[2];   // (U.grad) u'_c
           const double sg = adjoint ? -conv : conv;
           if (c == 0) o[r][0] += sg; else if (c == 1) o[r][1] += sg; else o[r][2] += sg;
 #pragma unroll
           for (int x = 0; x < 3; ++x) {
             // direct:  + u'_c dU_x/dx_c   (u'.grad) U ;   adjoint:  + u'_c dU_c/dx_x   (grad U)^T u'
-            const double G = adjoint ? bfc[(3 + 3 * c + x) * nf + q] : bfc[(3 + 3 * x + c) * nf + q];
+            const double G = ld_bfc(d, bfc, adjoint ? 3 + 3 * c + x : 3 + 3 * x + c, nf, q);
             o[r][x] += uf * G;
           }
         }
@@ -604,7 +618,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_rhs(Dev d, StepCoef sc) {
   double u[3] = {0, 0, 0}, bfv[3] = {0, 0, 0}, bm = 0, g[6] = {0, 0, 0, 0, 0, 0};
   if (act) {
     bm = d.bm1[l];
-    g[0] = d.g1[l]; g[1] = d.g2[l]; g[2] = d.g3[l]; g[3] = d.g4[l]; g[4] = d.g5[l]; g[5] = d.g6[l];
+    load_g6(d, l, g);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const long long lc = c * nl + l;
@@ -676,6 +690,12 @@ __device__ inline double corner_list_sum(const double* v, const double* __restri
   return s;
 }
 // it = 0 of k_helm: r = mask dssum(rhs), (b, b), x = p = s = 0, z = r / diag, A z.  Once per solve: one component after the other.
+// Wave-uniform scalars that another kernel left in global memory, fetched with ONE load per wavefront (lane q loads word q) and
+// spread with v_readlane: the compiler turns `x = p[3]; y = q[1]; ...` on pointers it cannot prove invariant into vector loads with a
+// full wait behind each -- nine dependent trips to L2 in k_helm's preamble, 3.6 us of a workgroup's 15.8 (stamps, config 4's size).
+__device__ inline double lane_f64(double v, int lane) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
 template <int N>
 __device__ inline void helm_first(const Dev& d, const StepCoef& sc, const double* __restrict__ rhs, double* sD, double* sDt,
                                   double* sz, double* st, double* sred, double* scv) {
@@ -694,7 +714,7 @@ __device__ inline void helm_first(const Dev& d, const StepCoef& sc, const double
   if (act) {
     tab = d.gs_tab[l];
     bm = d.bm1[l]; mk = d.mask[l]; mi = d.minv[l];
-    g[0] = d.g1[l]; g[1] = d.g2[l]; g[2] = d.g3[l]; g[3] = d.g4[l]; g[4] = d.g5[l]; g[5] = d.g6[l];
+    load_g6(d, l, g);
     di = d.dinv[(size_t)(sc.k - 1) * d.nloc + l];
   }
   if (tid < N * N) { sD[tid] = dv; sDt[(tid % N) * N + tid / N] = dv; }
@@ -740,45 +760,57 @@ __device__ inline void helm_first(const Dev& d, const StepCoef& sc, const double
     }
   }
 }
+#ifndef NSK_HELM3_WAVES
+#define NSK_HELM3_WAVES 4
+#endif
 // it >= 1: every load of the three components is issued before the first is used -- two round trips to memory per workgroup (the
 // arrays addressable from the thread index, then the neighbours' values) where the component loop of rounds 2-4 had five -- and the
-// three components' A z then run one after the other on one set of LDS tiles.
+// three components' A z then run one after the other on one set of LDS tiles, on the matrix cores (axhelm3_mfma).
 template <int N>
-__global__ __launch_bounds__(Cfg<N>::NT, 4) void k_helm(Dev d, StepCoef sc, int it, const double* rhs) {
+__global__ __launch_bounds__(Cfg<N>::NT, NSK_HELM3_WAVES) void k_helm(Dev d, StepCoef sc, int it, const double* rhs) {
   using C = Cfg<N>;
   constexpr int NN = C::NN, NT = C::NT;
   static_assert(NT >= 192, "corner entries: one per thread");
-  __shared__ double sD[N * N], sDt[N * N];
-  __shared__ double sz[3 * NN], st[3 * NN];
+  using L = SlimLay<N>;
+  constexpr int EXT = L::EXT;
+  static_assert(2 * N * N + 3 * NN <= 5 * EXT, "it = 0 borrows the tiles");
+  __shared__ double tiles[8 * EXT];
+  double* sz = tiles; double* sW = tiles + 3 * EXT; double* sO = tiles + 6 * EXT;
   __shared__ double sred[12 * 16];
   __shared__ double scv[192];
-  if (it == 0) { helm_first<N>(d, sc, rhs, sD, sDt, sz, st, sred, scv); return; }
+  if (it == 0) { helm_first<N>(d, sc, rhs, sW, sW + N * N, sz, sW + 2 * N * N, sred, scv); return; }
   const int tid = threadIdx.x;
   const long long e = d.boff + xcd_element(blockIdx.x, gridDim.x);      // (boff: shards launch their boundary elements first, the interior behind)
   const bool act = tid < NN;
   const int k = tid / (N * N), j = (tid / N) % N, i = tid % N;
   const long long l = e * NN + tid, nl = d.cs;
+  NSK_STAMP(0);
   const int par = it & 1, ppar = par ^ 1;
   double alpha[3] = {0, 0, 0}, beta[3] = {0, 0, 0};
   bool done[3] = {false, false, false};
   {
-    const double* ps = d.htot + ppar * 16;
-    const double* o = d.hscal + ppar * 16;
+    // lanes 0..11: htot[ppar][0..11]; 12..27: hscal[ppar][0..15]; 28..30: hscal[32..34]
+    const int ln = tid & 63;
+    double hv = 0.0;
+    if (ln < 12) hv = d.htot[ppar * 16 + ln];
+    else if (ln < 28) hv = d.hscal[ppar * 16 + ln - 12];
+    else if (ln < 31) hv = d.hscal[32 + ln - 28];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      const double gg = ps[c * 3 + 0], del = ps[c * 3 + 1], rr = ps[c * 3 + 2];
+      const double gg = lane_f64(hv, c * 3 + 0), del = lane_f64(hv, c * 3 + 1), rr = lane_f64(hv, c * 3 + 2);
+      const double o0 = lane_f64(hv, 12 + c * 4 + 0), o1 = lane_f64(hv, 12 + c * 4 + 1), o2 = lane_f64(hv, 12 + c * 4 + 2), o3 = lane_f64(hv, 12 + c * 4 + 3);
       const double res = sqrt(rr / d.vol);
-      const double ref = (it == 1) ? sqrt(ps[9 + c] / d.vol) : d.hscal[32 + c];
+      const double ref = (it == 1) ? sqrt(lane_f64(hv, 9 + c) / d.vol) : lane_f64(hv, 28 + c);
       const double tol = d.tol_relative ? d.tol_helm * ref : d.tol_helm;
-      const bool was = (it > 1 && o[c * 4 + 2] != 0.0);
+      const bool was = (it > 1 && o2 != 0.0);
       done[c] = was || (res <= tol) || !(gg > 0.0);
       if (!done[c]) {
         if (it == 1) { beta[c] = 0.0; alpha[c] = gg / del; }
-        else { beta[c] = gg / o[c * 4 + 0]; alpha[c] = gg / (del - beta[c] * gg / o[c * 4 + 1]); }
+        else { beta[c] = gg / o0; alpha[c] = gg / (del - beta[c] * gg / o1); }
       }
       if (blockIdx.x == 0 && d.boff == 0 && tid == 0) {
         double* cur = d.hscal + par * 16 + c * 4;
-        const double keep = was ? o[c * 4 + 3] : res;
+        const double keep = was ? o3 : res;
         cur[0] = gg; cur[1] = alpha[c]; cur[2] = done[c] ? 1.0 : 0.0; cur[3] = keep;
         if (it == 1) d.hscal[32 + c] = ref;
         if (done[c] && !was) {
@@ -793,14 +825,16 @@ __global__ __launch_bounds__(Cfg<N>::NT, 4) void k_helm(Dev d, StepCoef sc, int 
 #pragma unroll
     for (int c = 0; c < 3; ++c) { alpha[c] = uniform_f64(alpha[c]); beta[c] = uniform_f64(beta[c]); done[c] = __builtin_amdgcn_readfirstlane((int)done[c]) != 0; }
   }
-  // ---- round trip 1: everything addressable from the thread index
-  const double dv = (tid < N * N) ? d.D[tid] : 0.0;
+  NSK_STAMP(1);
+  // ---- round trip 1: everything addressable from the thread index (gather table and corner entries first: the second trip hangs on them)
   const int cm = (d.gs_corner && tid < 192) ? d.gs_corner[(size_t)e * 64 + (tid & 63)] : -1;      // tid = component * 64 + corner * 8 + member
   int4 tab = make_int4(0, -1, -1, -1);
+  if (act) tab = d.gs_tab[l];
+  const AxFrag<N> F = ax_frags<N>(d.D, tid & 63);
+  const int tn = k * L::PS + j * L::RS + i;
   double bm = 0, g[6] = {0, 0, 0, 0, 0, 0}, mk = 0, mi = 0, di = 0;
   double ro[3] = {0, 0, 0}, po[3] = {0, 0, 0}, so[3] = {0, 0, 0}, xo[3] = {0, 0, 0};
   if (act) {
-    tab = d.gs_tab[l];
     mk = d.mask[l]; di = d.dinv[(size_t)(sc.k - 1) * d.nloc + l];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -809,24 +843,26 @@ __global__ __launch_bounds__(Cfg<N>::NT, 4) void k_helm(Dev d, StepCoef sc, int 
       if (!done[c]) { po[c] = d.hp[lc]; so[c] = d.hs[lc]; xo[c] = d.hx[lc]; }
     }
     bm = d.bm1[l]; mi = d.minv[l];
-    g[0] = d.g1[l]; g[1] = d.g2[l]; g[2] = d.g3[l]; g[3] = d.g4[l]; g[4] = d.g5[l]; g[5] = d.g6[l];
+    load_g6(d, l, g);
   }
-  // ---- round trip 2: the neighbours' values of A z of the previous iteration
   const double* wl0 = d.hwl + (size_t)ppar * 3 * nl;
   const bool wide = act && tab.x < 0;
+  double cv = -0.0;
   {
     const int cc = tid >> 6;
     const bool cdone = (cc == 0) ? done[0] : ((cc == 1) ? done[1] : done[2]);
-    if (tid < 192) scv[tid] = (cm == -2) ? __builtin_nan("") : ((cm >= 0 && !cdone) ? wl0[(size_t)cc * nl + cm] : -0.0);
+    if (tid < 192 && cm >= 0 && !cdone) cv = wl0[(size_t)cc * nl + cm];
   }
   GsVals gv[3];
 #pragma unroll
   for (int c = 0; c < 3; ++c)
     if (act && !wide && !done[c]) gv[c] = gs_load_o(wl0 + (size_t)c * nl, tab, (unsigned)l);
-  if (tid < N * N) { sD[tid] = dv; sDt[(tid % N) * N + tid / N] = dv; }
+  if (tid < 192) scv[tid] = (cm == -2) ? __builtin_nan("") : cv;            // (after the gather is out: the store waits for its value)
   const int cid = act ? corner_id<N>(k, j, i) : -1;
   const bool from_list = wide && cid >= 0 && d.gs_corner;
+  NSK_STAMP(2);
   lds_barrier();
+  NSK_STAMP(3);
   double rz[3] = {0, 0, 0}, rr[3] = {0, 0, 0};
   if (act) {
 #pragma unroll
@@ -846,19 +882,20 @@ __global__ __launch_bounds__(Cfg<N>::NT, 4) void k_helm(Dev d, StepCoef sc, int 
         d.hr[lc] = r;
       }
       const double z = di * r;
-      sz[c * NN + tid] = z;
+      sz[c * EXT + tn] = z;
       rz[c] = r * z * mi; rr[c] = r * r * mi;
     }
   }
+  NSK_STAMP(4);
   lds_barrier();
+  NSK_STAMP(5);
 #pragma unroll 1
   for (int c = 0; c < 3; ++c) {
-    double au[1];
-    axhelm3<N, 1>(sD, sDt, sz + c * NN, st, act, k, j, i, g, au);
+    double z;
+    const double au = axhelm3_mfma<N>(F, sz + c * EXT, sW, sO, g, act, tn, tid >> 6, NT / 64, tid & 63, z);
     double v[3] = {0, 0, 0};
     if (act) {
-      const double z = sz[c * NN + tid];
-      const double wl = d.nu * au[0] + sc.h2 * bm * z;
+      const double wl = d.nu * au + sc.h2 * bm * z;
       d.hwl[((size_t)par * 3 + c) * nl + l] = wl;
       v[0] = (c == 0) ? rz[0] : ((c == 1) ? rz[1] : rz[2]); v[1] = z * wl; v[2] = (c == 0) ? rr[0] : ((c == 1) ? rr[1] : rr[2]);
     }
@@ -868,8 +905,9 @@ __global__ __launch_bounds__(Cfg<N>::NT, 4) void k_helm(Dev d, StepCoef sc, int 
       const double x = wave_sum63(v[q]);
       if ((tid & 63) == 63) sred[(c * 3 + q) * 16 + (tid >> 6)] = x;
     }
-    lds_barrier();                                           // (st is rewritten by the next component)
+    lds_barrier();                                           // (the tiles are rewritten by the next component)
   }
+  NSK_STAMP(6);
   if (tid < 12) {
     double s = 0.0;
     if (tid < 9)
@@ -1044,7 +1082,7 @@ __global__ __launch_bounds__(Cfg<N>::NT, 4) void k_helm_fb(Dev d, StepCoef sc, i
   if (act) {
     tab = d.gs_tab[l];
     bm = d.bm1[l]; mk = d.mask[l]; mi = d.minv[l];
-    g[0] = d.g1[l]; g[1] = d.g2[l]; g[2] = d.g3[l]; g[3] = d.g4[l]; g[4] = d.g5[l]; g[5] = d.g6[l];
+    load_g6(d, l, g);
     const int cid = corner_id<N>(k, j, i);
     gs_wide_stage(d, tab, l, sW + tid * 8, (cid >= 0 && d.gs_corner) ? reinterpret_cast<const int4*>(d.gs_corner + ((size_t)e * 8 + cid) * 8) : nullptr);
   }
@@ -1729,7 +1767,7 @@ __device__ __forceinline__ void schwarz_p_body(const Dev& d, const double* __res
     double w2[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (pactl) {
 #pragma unroll
-      for (int m = 0; m < 9; ++m) w2[m] = ld_boff(d.w2m + (size_t)m * d.npr + e * MM, tl * 8u);      // parked in sP after the forward passes
+      for (int m = 0; m < 9; ++m) w2[m] = ((d.zmask >> m) & 1u) ? 0.0 : ld_boff(d.w2m + (size_t)m * d.npr + e * MM, tl * 8u);      // parked in sP after the forward passes
     }
     double zc = 0.0;
     if (use_coarse) {                                  // R^T x_c: the eight vertex values sit in lanes 0..7 of every wave
@@ -1852,7 +1890,7 @@ __global__ __launch_bounds__(64) void k_schwarz_w(Dev d, const double* __restric
 #pragma unroll
   for (int m = 0; m < 9; ++m)
 #pragma unroll
-    for (int r = 0; r < RM; ++r) { const int idx = r * 64 + lane; w2[m][r] = (idx < MM) ? d.w2m[(size_t)m * d.npr + e * MM + idx] : 0.0; }
+    for (int r = 0; r < RM; ++r) { const int idx = r * 64 + lane; w2[m][r] = (idx < MM && !((d.zmask >> m) & 1u)) ? d.w2m[(size_t)m * d.npr + e * MM + idx] : 0.0; }
   const double xl = use_coarse ? d.xc[d.evert[e * 8 + (lane & 7)]] : 0.0;
   load_basis3<N>(d, nullptr, nullptr, sJ12, sD12, lane, 64);
   if (lane < 2 * M) sH[lane] = d.hat[8 * MM + lane];
@@ -1963,7 +2001,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
     }
   }
   wave_sync();
-  opgradt3_wave_ld<N, L, RM>(sJ12, sD12, z, d.w2m + e * MM, d.npr, buf, lane, d.yl + e * NN, d.cs);
+  opgradt3_wave_ld<N, L, RM>(sJ12, sD12, z, d.w2m + e * MM, d.npr, d.zmask, buf, lane, d.yl + e * NN, d.cs);
 }
 
 // yl = D^T p for an arbitrary pressure vector
@@ -2464,7 +2502,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_axhelm_test(Dev d, const double*
   double z = 0, g[6] = {0, 0, 0, 0, 0, 0};
   if (act) {
     z = u[l]; sz[tid] = z;
-    g[0] = d.g1[l]; g[1] = d.g2[l]; g[2] = d.g3[l]; g[3] = d.g4[l]; g[4] = d.g5[l]; g[5] = d.g6[l];
+    load_g6(d, l, g);
   }
   lds_barrier();
   double au[1];

@@ -87,12 +87,12 @@ __global__ __launch_bounds__(512) void k_convect_mfma8(Dev d, const double* __re
       if (p < NDD) {
         const double g0 = gr[p], g1 = gs[p], g2 = gt[p], uf = sf[p];
         const size_t q = (size_t)e * NDD + p;
-        const double conv = bfc[0 * nf + q] * g0 + bfc[1 * nf + q] * g1 + bfc[2 * nf + q] * g2;   // (U.grad) u'_c
+        const double conv = ld_bfc(d, bfc, 0, nf, q) * g0 + ld_bfc(d, bfc, 1, nf, q) * g1 + ld_bfc(d, bfc, 2, nf, q) * g2;   // (U.grad) u'_c
         const double sg = adjoint ? -conv : conv;
         if (c == 0) o[r][0] += sg; else if (c == 1) o[r][1] += sg; else o[r][2] += sg;
 #pragma unroll
         for (int x = 0; x < 3; ++x) {
-          const double G = adjoint ? bfc[(3 + 3 * c + x) * nf + q] : bfc[(3 + 3 * x + c) * nf + q];
+          const double G = ld_bfc(d, bfc, adjoint ? 3 + 3 * c + x : 3 + 3 * x + c, nf, q);
           o[r][x] += uf * G;
         }
       }

@@ -503,11 +503,58 @@ __device__ inline void fd_solve_inplace_wave(const double* sS, const double* sL,
   fd_pass_inplace<N, CS, false>(sS + N * N, X, lane, same);
   fd_pass_inplace<N, CR, false>(sS, X, lane, same);
 }
+// ---- D^T G D of one component on the matrix cores, one workgroup per element (k_helm, k_rhs) ----------------------------------------
+// Six passes of the 1-D derivative operator (three directions forward, the metric products per node, three directions back) as
+// tile jobs of sixteen columns spread over the workgroup's wavefronts; the operator's fragments (D and D^T, 2 x RB x KQ doubles a
+// lane) come straight from global memory with the kernel's first loads.  Tiles in the (PS, RS, 1) strides of SlimLay.
+// LDS traffic per component: 84 KB against the 393 KB of the per-node sums of axhelm3 (lx1 = 8), which kept the LDS of a CU busy
+// for 41 % of k_helm<8>'s time.
+template <int N> struct AxFrag { Frag4<(N + 3) / 4, (N + 3) / 4> d, dt; };
+template <int N>
+__device__ inline AxFrag<N> ax_frags(const double* __restrict__ D, int lane) {        // D[a][b] row-major, as Dev::D
+  constexpr int KQ = (N + 3) / 4, RB = (N + 3) / 4;
+  AxFrag<N> f;
+  f.d = make_frag4<KQ, RB>(lane, [&](int m, int k) { return (m < N && k < N) ? D[m * N + k] : 0.0; });
+  f.dt = make_frag4<KQ, RB>(lane, [&](int m, int k) { return (m < N && k < N) ? D[k * N + m] : 0.0; });
+  return f;
+}
+// Z: the component's tile (overwritten), W: three tiles, O12: two tiles.  Returns (A z)(node tn) and z itself in zout.
+// Ends without a barrier: the caller's next barrier separates the reads of Z / O12 from the next component's writes.
+template <int N>
+__device__ inline double axhelm3_mfma(const AxFrag<N>& F, double* Z, double* W, double* O12, const double (&g)[6], bool act, int tn,
+                                      int wave, int nwaves, int lane, double& zout) {
+  using S = SlimLay<N>;
+  typedef Col2<N, S::PS, S::RS, 1> CR;           // columns (k, j): contract i
+  typedef Col2<N, S::PS, 1, S::RS> CS;           // columns (k, i): contract j
+  typedef Col2<N, S::RS, 1, S::PS> CT;           // columns (j, i): contract k
+  constexpr int KQ = (N + 3) / 4, RB = (N + 3) / 4, NCOL = N * N, NT16 = (NCOL + 15) / 16, EXT = S::EXT;
+  // job (direction d, tile t) goes to wavefront (d NT16 + t) mod nwaves
+  const int w1 = (wave + nwaves - NT16 % nwaves) % nwaves, w2 = (wave + nwaves - (2 * NT16) % nwaves) % nwaves;
+  mo_pass4<N, KQ, RB, NCOL, CR, StLin<CR, 1, N>, false>(F.d, Z, F.d, Z, W, wave, nwaves, lane);
+  mo_pass4<N, KQ, RB, NCOL, CS, StLin<CS, S::RS, N>, false>(F.d, Z, F.d, Z, W + EXT, w1, nwaves, lane);
+  mo_pass4<N, KQ, RB, NCOL, CT, StLin<CT, S::PS, N>, false>(F.d, Z, F.d, Z, W + 2 * EXT, w2, nwaves, lane);
+  lds_barrier();
+  zout = 0.0;
+  if (act) {
+    const double ur = W[tn], us = W[EXT + tn], ut = W[2 * EXT + tn];
+    zout = Z[tn];
+    W[tn] = g[0] * ur + g[3] * us + g[4] * ut;
+    W[EXT + tn] = g[3] * ur + g[1] * us + g[5] * ut;
+    W[2 * EXT + tn] = g[4] * ur + g[5] * us + g[2] * ut;
+  }
+  lds_barrier();
+  mo_pass4<N, KQ, RB, NCOL, CR, StLin<CR, 1, N>, false>(F.dt, W, F.dt, W, Z, wave, nwaves, lane);
+  mo_pass4<N, KQ, RB, NCOL, CS, StLin<CS, S::RS, N>, false>(F.dt, W + EXT, F.dt, W + EXT, O12, w1, nwaves, lane);
+  mo_pass4<N, KQ, RB, NCOL, CT, StLin<CT, S::PS, N>, false>(F.dt, W + 2 * EXT, F.dt, W + 2 * EXT, O12 + EXT, w2, nwaves, lane);
+  lds_barrier();
+  return act ? ((Z[tn] + O12[tn]) + O12[EXT + tn]) : 0.0;
+}
+
 // opgradt3_wave with the metrics of a component loaded when its turn comes (the next component's are in flight under the current
 // one's passes): 24 registers of metrics instead of 72.  wm = the element's first metric, npr = stride between the nine.
 template <int N, class L, int RM>
 __device__ inline void opgradt3_wave_ld(const double* sJ12, const double* sD12, const double (&z)[RM], const double* __restrict__ wm,
-                                        long long npr, double* buf, int lane, double* __restrict__ y, long long cs) {
+                                        long long npr, unsigned zmask, double* buf, int lane, double* __restrict__ y, long long cs) {
   using G = GtWave<N, L>;
   constexpr int M = N - 2, MM = M * M * M, KQ = (M + 3) / 4;
   constexpr int RB = (N + 3) / 4;
@@ -527,7 +574,7 @@ __device__ inline void opgradt3_wave_ld(const double* sJ12, const double* sD12, 
 #pragma unroll
       for (int r = 0; r < RM; ++r) {
         const int idx = r * 64 + lane;
-        wn[a][r] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(wm + (size_t)(a * 3 + c) * npr) + (unsigned)(idx < MM ? idx : 0) * 8u);
+        wn[a][r] = ((zmask >> (a * 3 + c)) & 1u) ? 0.0 : *reinterpret_cast<const double*>(reinterpret_cast<const char*>(wm + (size_t)(a * 3 + c) * npr) + (unsigned)(idx < MM ? idx : 0) * 8u);      // (zmask: Dev::zmask)
       }
   };
   load_w(0);

@@ -150,6 +150,9 @@ struct Dev {
   int ndim;
   long long nfine;
   const double *g3, *g5, *g6, *w2m, *bfc, *mtd, *fdS, *fdL;
+  // Arrays that are zero on every node are not loaded (nsk3_setup.inc: structural zeros of the mapping; nsk_set_baseflow: of the
+  // base flow).  zmask bit q < 9: metric term q of w2m / mtd; bit 9 + m: g4, g5, g6.  bfmask bit q < 12: constant q of bfc.
+  unsigned zmask, bfmask;
   double fd_eps;
   double* gpart2;                // partial sums of the second Gram-Schmidt pass (3-D GMRES)
   // hexahedral meshes have one workgroup per element (10^3-10^5 of them): every set of per-workgroup partials is

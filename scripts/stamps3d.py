@@ -1,7 +1,7 @@
 """In-kernel phase stamps (s_memrealtime, 100 MHz) of the hexahedral pressure kernels at config 4's size.
 Needs the -DNSK_STAMPS build:  hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -shared -DNSK_STAMPS -o nekstab_amd/lib/libnekstab_hip_stamps.so nekstab_amd/csrc/nsk.hip
 
-    NSK_STAMP_KERNEL=schwarz|schwarz_p|schwarz_w|divgs [NSK_STAMP_J=5] python scripts/stamps3d.py [nz=30]"""
+    NSK_STAMP_KERNEL=schwarz|schwarz_p|schwarz_w|divgs|helm [NSK_STAMP_J=5] python scripts/stamps3d.py [nz=30]"""
 import ctypes as C, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -27,11 +27,12 @@ which = os.environ.get("NSK_STAMP_KERNEL", "divgs")
 names = {"divgs": ["loads + dssum gather -> LDS tile", "barrier", "opdiv3 (MFMA passes)", "dots + partials"],
          "schwarz_w": ["loads -> LDS", "forward passes", "backward passes", "restrict + coarse term", "D^T (3 components) + stores"],
          "schwarz_p": ["barrier, coarse term, metric loads issued", "forward passes", "metrics -> LDS (wait)", "prefetch issue + backward passes", "restrict + products", "opgradt3", "next tile -> LDS (wait)", "stores"],
+         "helm": ["CG scalars (htot, hscal)", "loads issued; corner values of wavefront 0 arrived", "barrier", "updates of three components + stores issued", "barrier", "A z of three components (matrix cores) + stores + wave sums"],
          "schwarz": ["loads: factors, metrics, patch gather", "barrier", "fast diagonalisation, 6 passes", "restrict + opgradt3 (MFMA passes)", "stores"]}[which]
 ns = len(names) + 1
 out = np.zeros(16 * nb, dtype=np.uint64)
 fn = h.lib.nsk_debug_stamps; fn.restype = C.c_int; fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
-rc = fn(h.ctx, out.ctypes.data, nb); assert rc == 0
+rc = fn(h.ctx, out.ctypes.data, -nb if which == "helm" else nb); assert rc == 0
 t = out.reshape(nb, 16)[:, :ns].astype(np.int64)
 ok = t[:, 0] > 0
 t = t[ok]

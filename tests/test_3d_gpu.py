@@ -234,6 +234,50 @@ def test_ifbf2d_forces_the_third_base_flow_component_to_zero():
         ha.close(); hb.close(); hc.close()
 
 
+def test_arrays_that_are_zero_on_every_node_are_not_loaded_same_bits(monkeypatch):
+    """Spanwise-extruded mesh, two-dimensional base flow (BASELINE config 4's shape): four of the nine metric terms, g5 and g6 and
+    six of the twelve base-flow constants of the convection kernel vanish on every node.  The set-up finds them (stats:
+    zero_arrays), the kernels skip their loads; with option zero_metrics = 0 every array is loaded again: bit-identical maps,
+    direct and adjoint.  A context set up with NSK_ZERO_METRICS=0 (the rounding noise of the derivatives kept, as rounds 1-4)
+    agrees to rounding."""
+    import os
+    from nekstab_amd import mesh
+    here = os.path.dirname(os.path.abspath(__file__))
+    c2 = mesh.load_case_npz(os.path.join(here, "golden", "cylinder_case.npz"), 8)
+    c3 = mesh3d.extrude_case(c2, 2, 1.0, periodic=True)
+    kw = dict(tol_helm=1e-11, tol_pres=1e-8, tol_relative=1, max_helm_iter=150, max_pres_iter=144)
+    x, y, z = c3.x, c3.y, c3.z
+    q = [np.sin(x + np.pi * z) * c3.mask, np.cos(y) * np.cos(np.pi * z) * c3.mask, np.sin(x - y) * c3.mask, np.zeros(1)]
+    ha = _hip(c3, **kw)
+    monkeypatch.setenv("NSK_ZERO_METRICS", "0")
+    hb = _hip(c3, **kw)
+    monkeypatch.delenv("NSK_ZERO_METRICS")
+    try:
+        za, zb = ha.stats()["zero_arrays"], hb.stats()["zero_arrays"]
+        metrics = {2, 5, 6, 7}; gfac = {10, 11}; bfc = {12 + 2, 12 + 5, 12 + 8, 12 + 9, 12 + 10, 12 + 11}
+        assert {b for b in range(24) if za >> b & 1} == metrics | gfac | bfc, sorted(b for b in range(24) if za >> b & 1)
+        assert zb == 0
+        q[3] = np.zeros(ha.npres)
+        out = {}
+        for name, h, opt in (("masked", ha, 1), ("loaded", ha, 0), ("noise", hb, None)):
+            if opt is not None:
+                h.set_option("zero_metrics", opt)
+                assert (h.stats()["zero_arrays"] != 0) == bool(opt)
+            v0, v1 = h.alloc(2)
+            h.upload3(v0, *q); h.set_nsteps(3)
+            for adj in (0, 1):
+                h.matvec(v1, v0, adj)
+                out[name, adj] = h.download3(v1)
+        for adj in (0, 1):
+            for k in range(4):
+                assert np.array_equal(out["masked", adj][k], out["loaded", adj][k])
+                sc = max(np.abs(out["noise", adj][k]).max(), 1e-30)
+                assert np.abs(out["masked", adj][k] - out["noise", adj][k]).max() < 1e-6 * sc
+        assert ha.stats()["unconverged"] == 0
+    finally:
+        ha.close(); hb.close()
+
+
 def test_host_checked_convergence_full_mesh_context():
     """Option hostcheck (default on hexahedral meshes of >= 8192 elements, where a launch that only finds its solve converged
     costs 25-140 us and a map redone with larger launch budgets tens of seconds): eager steps, the host reads the device's
