@@ -12,26 +12,36 @@ the *compulsory* traffic of the launch-per-kernel formulation, so a kernel that 
 from __future__ import annotations
 
 
+def _zero_counts(zero_arrays, ndim):
+    """(metric terms, G factors, base-flow constants) that are zero on every node and not loaded (nsk_stats.zero_arrays; hexahedra)."""
+    if ndim != 3 or not zero_arrays:
+        return 0, 0, 0
+    z = int(zero_arrays)
+    return bin(z & 0x1ff).count("1"), bin((z >> 9) & 0x7).count("1"), bin((z >> 12) & 0xfff).count("1")
+
+
 def per_step_bytes(*, nel, lx1, ndim=2, nvert=0, coarse_lda=0, patch_stride=0, nproj=0, helm_iters=0.0, pres_iters=0.0,
-                   pres_jsum=None, coarse_bytes=None, gs_lag=1):
+                   pres_jsum=None, coarse_bytes=None, gs_lag=1, zero_arrays=0):
     """Algorithmic bytes of ONE time step, by kernel family.  ``helm_iters`` / ``pres_iters``: mean iterations per step
     (all velocity components advance together in one CG iteration).  Hexahedra (``ndim = 3``): ``pres_jsum`` = mean per step of
     the sum over the GMRES columns of their basis index j (nsk_stats.total_pres_jsum / total_steps; the Gram-Schmidt bytes
     are proportional to it), ``coarse_bytes`` = nsk_stats.coarse_bytes_per_solve, ``gs_lag``: the lagged Gram-Schmidt
-    sequence (two basis reads per column) or the classic one (four)."""
+    sequence (two basis reads per column) or the classic one (four).  ``zero_arrays``: nsk_stats.zero_arrays -- arrays that vanish on
+    every node are not inputs of the kernels (Nek5000 skips them on its undeformed elements the same way) and are not counted."""
+    zm, zg, zb = _zero_counts(zero_arrays, ndim)
     d = ndim
     N, M, ND = lx1, lx1 - 2, 3 * lx1 // 2
     P, P2, Pd = nel * N ** d, nel * M ** d, nel * ND ** d
     f = 8.0
-    nmet2 = d * d                       # Gauss-mesh metrics per pressure point
+    nmet2 = d * d - zm                  # Gauss-mesh metrics per pressure point
     out = {}
     # K1 convection + sponge: u' (d), spng, bm1, bf out (d) on P; base-flow constants on the dealiasing mesh: 2-D 6, 3-D 12
-    out["K1 convect"] = f * (P * (2 * d + 2) + Pd * (6 if d == 2 else 12))
+    out["K1 convect"] = f * (P * (2 * d + 2) + Pd * (6 if d == 2 else 12 - zb))
     # K2 rhs: u (d), dulag (3d), bf (d), exlag rw (2d + 2d), ulag rw (2d + 2d), bm1, G factors (3 | 6); p, plag rw, pext, metrics on P2; rloc, bloc out (2d)
-    ng = 3 if d == 2 else 6
+    ng = 3 if d == 2 else 6 - zg
     out["K2 rhs"] = f * (P * (d + 3 * d + d + 4 * d + 4 * d + 1 + ng + 2 * d) + P2 * (4 + nmet2))
     # K3+K4+K5 one CG iteration of one component: SURVEY 8(d) table: 148 B/pt (2-D), 172 B/pt (3-D)
-    out["K3 helm iteration (x n_helm x d)"] = (148.0 if d == 2 else 172.0) * P * d * helm_iters
+    out["K3 helm iteration (x n_helm x d)"] = (148.0 if d == 2 else 172.0 - f * zg) * P * d * helm_iters
     # K4' pressure rhs: hx (d), dulag rw (3d + 3d), u rw (2d); metrics, V0 out, PX reads on P2
     out["K4 pres_rhs"] = f * (P * (d + 6 * d + 2 * d) + P2 * (nmet2 + 1 + nproj))
     # per GMRES iteration (mean basis index j ~ (n-1)/2 unless the sum of the basis indices was logged)
@@ -72,13 +82,14 @@ def per_step_bytes(*, nel, lx1, ndim=2, nvert=0, coarse_lda=0, patch_stride=0, n
     return out
 
 
-def helm_launch_bytes(*, nel, lx1, ndim):
+def helm_launch_bytes(*, nel, lx1, ndim, zero_arrays=0):
     """One Helmholtz CG launch (ALL components): (SURVEY 8(d) per-component rule, distinct arrays counted once).  The rule
     counts the arrays the components share -- geometric factors, mass, mask, multiplicity, the 16-B gather table -- once per
     component; the launch reads them once."""
     P = nel * lx1 ** ndim
-    rule = (148.0 if ndim == 2 else 172.0) * P * ndim
-    ng = 3 if ndim == 2 else 6
+    zg = _zero_counts(zero_arrays, ndim)[1]
+    rule = (148.0 if ndim == 2 else 172.0 - 8.0 * zg) * P * ndim
+    ng = 3 if ndim == 2 else 6 - zg
     per_comp = 8.0 * (4 * 2 + 2 + 1)                    # x, r, p, s read + write; A z of the last iteration in, of this one out; Jacobi diagonal
     shared = 8.0 * (ng + 3) + 16.0                      # G factors, mass, mask, 1 / multiplicity; gather table
     return rule, P * (per_comp * ndim + shared)

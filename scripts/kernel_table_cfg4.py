@@ -18,12 +18,16 @@ for l in open(txt):
     m = re.match(r"^E = (\d+), P = ([\d.]+) M, P2 = ([\d.]+) M", l)
     if m:
         nel = int(m.group(1))
+    m = re.match(r"^zero_arrays = 0x([0-9a-f]+)", l)
+    if m:
+        za = int(m.group(1), 16)
 N, M = 8, 6
+za = globals().get("za", 0)        # arrays that vanish on every node: not loaded, not counted (nekstab_amd/roofline.py)
 P, P2 = nel * N ** 3, nel * M ** 3
 nvert = 53670
-one = roofline.per_step_bytes(nel=nel, lx1=N, ndim=3, nvert=nvert, nproj=0, helm_iters=0.0, pres_iters=1.0, pres_jsum=0.0, coarse_bytes=0.0)
-rule, distinct = roofline.helm_launch_bytes(nel=nel, lx1=N, ndim=3)
-stepb = roofline.per_step_bytes(nel=nel, lx1=N, ndim=3, nvert=nvert, nproj=32, helm_iters=0.0, pres_iters=0.0, pres_jsum=0.0, coarse_bytes=0.0)
+one = roofline.per_step_bytes(nel=nel, lx1=N, ndim=3, nvert=nvert, nproj=0, helm_iters=0.0, pres_iters=1.0, pres_jsum=0.0, coarse_bytes=0.0, zero_arrays=za)
+rule, distinct = roofline.helm_launch_bytes(nel=nel, lx1=N, ndim=3, zero_arrays=za)
+stepb = roofline.per_step_bytes(nel=nel, lx1=N, ndim=3, nvert=nvert, nproj=32, helm_iters=0.0, pres_iters=0.0, pres_jsum=0.0, coarse_bytes=0.0, zero_arrays=za)
 alg = {"helm": (distinct, "k3::k_helm<8>", "all arrays of the three components once (SURVEY rule, 172 B/pt and component: %.2f GB)" % (rule / 1e9)),
        "divgs": (one["K7 divgs (x n_pres)"], "k3::k_divgs<8>", "E apply without dots"),
        "schwarz": (one["K6 schwarz (x n_pres)"] - nel * 8 * 12.0, "k3::k_schwarz_w16<8>", "fast-diagonalisation Schwarz + D^T, one wavefront per element, sixteen per CU"),

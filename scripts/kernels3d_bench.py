@@ -22,6 +22,9 @@ h.set_nsteps(3)
 h.matvec(f, q, 1)
 P, P2 = h.nvel, h.npres
 print("E = %d, P = %.2f M, P2 = %.2f M" % (c3.nel, 1e-6 * P, 1e-6 * P2))
+if os.environ.get("ZERO_METRICS") is not None:
+    h.set_option("zero_metrics", int(os.environ["ZERO_METRICS"]))
+print("zero_arrays = 0x%x" % h.stats().get("zero_arrays", 0))
 for n in names:
     try:
         r = h.bench_kernel(n, int(os.environ.get("REPS", "20")))
