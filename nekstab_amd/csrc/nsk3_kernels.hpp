@@ -771,6 +771,7 @@ __global__ __launch_bounds__(Cfg<N>::NT, NSK_HELM3_WAVES) void k_helm(Dev d, Ste
   using C = Cfg<N>;
   constexpr int NN = C::NN, NT = C::NT;
   static_assert(NT >= 192, "corner entries: one per thread");
+  constexpr bool HEAD_FIRST = NT >= 1024;
   using L = SlimLay<N>;
   constexpr int EXT = L::EXT;
   static_assert(2 * N * N + 3 * NN <= 5 * EXT, "it = 0 borrows the tiles");
@@ -788,6 +789,9 @@ __global__ __launch_bounds__(Cfg<N>::NT, NSK_HELM3_WAVES) void k_helm(Dev d, Ste
   const int par = it & 1, ppar = par ^ 1;
   double alpha[3] = {0, 0, 0}, beta[3] = {0, 0, 0};
   bool done[3] = {false, false, false};
+  int cm = -1;
+  int4 tab = make_int4(0, -1, -1, -1);
+  AxFrag<N> F;
   {
     // lanes 0..11: htot[ppar][0..11]; 12..27: hscal[ppar][0..15]; 28..30: hscal[32..34]
     const int ln = tid & 63;
@@ -795,6 +799,14 @@ __global__ __launch_bounds__(Cfg<N>::NT, NSK_HELM3_WAVES) void k_helm(Dev d, Ste
     if (ln < 12) hv = d.htot[ppar * 16 + ln];
     else if (ln < 28) hv = d.hscal[ppar * 16 + ln - 12];
     else if (ln < 31) hv = d.hscal[32 + ln - 28];
+    // lx1 = 10 (one workgroup per CU: nothing hides a trip): the head of the gather chain rides behind the scalars in the same trip.
+    // A launch that finds its solve finished has then fetched 16 B per node for nothing (245 us at config 4's size, where the two
+    // workgroups per CU hide the trip anyway: 1703 us with the head here, 1719 below): not at lx1 <= 8.
+    if constexpr (HEAD_FIRST) {
+      cm = (d.gs_corner && tid < 192) ? d.gs_corner[(size_t)e * 64 + (tid & 63)] : -1;      // tid = component * 64 + corner * 8 + member
+      if (act) tab = d.gs_tab[l];
+      F = ax_frags<N>(d.D, tid & 63);
+    }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const double gg = lane_f64(hv, c * 3 + 0), del = lane_f64(hv, c * 3 + 1), rr = lane_f64(hv, c * 3 + 2);
@@ -826,11 +838,12 @@ __global__ __launch_bounds__(Cfg<N>::NT, NSK_HELM3_WAVES) void k_helm(Dev d, Ste
     for (int c = 0; c < 3; ++c) { alpha[c] = uniform_f64(alpha[c]); beta[c] = uniform_f64(beta[c]); done[c] = __builtin_amdgcn_readfirstlane((int)done[c]) != 0; }
   }
   NSK_STAMP(1);
-  // ---- round trip 1: everything addressable from the thread index (gather table and corner entries first: the second trip hangs on them)
-  const int cm = (d.gs_corner && tid < 192) ? d.gs_corner[(size_t)e * 64 + (tid & 63)] : -1;      // tid = component * 64 + corner * 8 + member
-  int4 tab = make_int4(0, -1, -1, -1);
-  if (act) tab = d.gs_tab[l];
-  const AxFrag<N> F = ax_frags<N>(d.D, tid & 63);
+  // ---- everything (else) addressable from the thread index
+  if constexpr (!HEAD_FIRST) {
+    cm = (d.gs_corner && tid < 192) ? d.gs_corner[(size_t)e * 64 + (tid & 63)] : -1;
+    if (act) tab = d.gs_tab[l];
+    F = ax_frags<N>(d.D, tid & 63);
+  }
   const int tn = k * L::PS + j * L::RS + i;
   double bm = 0, g[6] = {0, 0, 0, 0, 0, 0}, mk = 0, mi = 0, di = 0;
   double ro[3] = {0, 0, 0}, po[3] = {0, 0, 0}, so[3] = {0, 0, 0}, xo[3] = {0, 0, 0};
@@ -2128,15 +2141,18 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_divgs(Dev d, const double* __res
   }
 }
 
-// k_divgs with the three components' pass chains side by side (opdiv3_mfma_c3): 5 workgroup barriers after the gather instead of 12
+// k_divgs with the three components' pass chains side by side (opdiv3_mfma_c3): 5 workgroup barriers after the gather instead of 12.
+// Same two round trips as k_divgs (the metrics go out first, in the accumulator order of the wavefront's last-pass tiles).
 template <int N>
 __global__ __launch_bounds__(Cfg<N>::NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_divgs_c3(Dev d, const double* __restrict__ yl,
                                                          double* __restrict__ wout, int j, int check_done) {
   using C = Cfg<N>;
   using W = DvWave<N>;
   constexpr int NN = C::NN, M = C::M, MM = C::MM, NT = C::NT, NM = N * M;
+  static_assert(NT >= 192 && NM <= NT, "corner entries and the basis: one per thread");
   __shared__ double sJ12[NM], sD12[NM];
   __shared__ double buf[3 * W::BUF];
+  __shared__ double scv[192];
   static_assert((MAXMR + 2) * 16 <= 3 * W::BUF, "the dot partials reuse the buffer");
   double* sdot = buf;
   const int tid = threadIdx.x;
@@ -2144,22 +2160,43 @@ __global__ __launch_bounds__(Cfg<N>::NT) __attribute__((amdgpu_waves_per_eu(8, 8
   const bool act = tid < NN;
   if (check_done && d.gsc->done) return;
   const long long l = e * NN + tid;
-  load_basis3<N>(d, nullptr, nullptr, sJ12, sD12, tid, NT);
+  // ---- round trip 1
+  const int cm = (d.gs_corner && tid < 192) ? d.gs_corner[(size_t)e * 64 + (tid & 63)] : -1;
+  int4 tab = make_int4(0, -1, -1, -1);
+  double bi = 0.0;
+  if (act) { tab = d.gs_tab[l]; bi = d.binv[l]; }
+  Dv3Met<N> mt;
+  dv3_metrics<N>(d, e, tid, NT, mt);
+  // ---- round trip 2
+  const double cv = (cm >= 0) ? yl[(size_t)(tid >> 6) * d.cs + cm] : -0.0;
+  const int cid = act ? corner_id<N>(tid / (N * N), (tid / N) % N, tid % N) : -1;
+  const bool wide = act && tab.x < 0;
+  const bool from_list = wide && cid >= 0 && d.gs_corner;
+  GsVals g0, g1, g2;
+  if (act && !wide) { g0 = gs_load_o(yl, tab, (unsigned)l); g1 = gs_load_o(yl + d.cs, tab, (unsigned)l); g2 = gs_load_o(yl + 2 * d.cs, tab, (unsigned)l); }
+  double bJ = 0.0, bD = 0.0;
+  if (tid < NM) { bJ = d.J12[tid]; bD = d.D12[tid]; }
   if (act) {
-    CornerList CL;
-    corner_issue(d, e, corner_id<N>(tid / (N * N), (tid / N) % N, tid % N), CL);
-    const int4 tab = *reinterpret_cast<const int4*>(reinterpret_cast<const char*>(d.gs_tab + e * NN) + (unsigned)tid * 16u);
-    const double bi = ld_boff(d.binv + e * NN, (unsigned)tid * 8u);
-    const unsigned lu = (unsigned)l;
-    GsVals g0 = gs_load_o(yl, tab, lu), g1 = gs_load_o(yl + d.cs, tab, lu), g2 = gs_load_o(yl + 2 * d.cs, tab, lu);
-    buf[W::oU + tid] = bi * gs_sum3(g0, yl, d, tab, l, CL);
-    buf[W::BUF + W::oU + tid] = bi * gs_sum3(g1, yl + d.cs, d, tab, l, CL);
-    buf[2 * W::BUF + W::oU + tid] = bi * gs_sum3(g2, yl + 2 * d.cs, d, tab, l, CL);
+    if (!wide) {
+      buf[W::oU + tid] = bi * (((g0.a + g0.b) + g0.c) + g0.d);
+      buf[W::BUF + W::oU + tid] = bi * (((g1.a + g1.b) + g1.c) + g1.d);
+      buf[2 * W::BUF + W::oU + tid] = bi * (((g2.a + g2.b) + g2.c) + g2.d);
+    } else if (!from_list) {
+#pragma unroll 1
+      for (int c = 0; c < 3; ++c) buf[c * W::BUF + W::oU + tid] = bi * gs_csr_rolled(yl + (size_t)c * d.cs, d, l);
+    }
+  }
+  if (tid < 192) scv[tid] = (cm == -2) ? __builtin_nan("") : cv;
+  if (tid < NM) { sJ12[tid] = bJ; sD12[tid] = bD; }
+  lds_barrier();
+  if (from_list) {
+#pragma unroll 1
+    for (int c = 0; c < 3; ++c) buf[c * W::BUF + W::oU + tid] = bi * corner_list_sum(scv + c * 64 + cid * 8, yl + (size_t)c * d.cs, d, l);
   }
   const bool pact = tid < MM;
   const long long q = e * MM + tid;
   lds_barrier();
-  const double w = opdiv3_mfma_c3<N>(d, e, sJ12, sD12, buf, tid, NT);
+  const double w = opdiv3_mfma_c3<N>(mt, sJ12, sD12, buf, tid, NT);
   if (pact) wout[q] = w;
   if (j >= 0) {
     const int lane = tid & 63, wv = tid >> 6;

@@ -616,8 +616,33 @@ __device__ inline void opgradt3_wave_ld(const double* sJ12, const double* sD12, 
 // combined with the metrics there (read in accumulator order by the wave that owns the tile); the three components' partial sums
 // meet in LDS.  buf: 3 regions of DvWave<N>::BUF doubles, component c gathered at region c + oU.  Returns the value of Gauss node tid.
 template <int N> constexpr int nt_min_sub() { return ((((N * N * N + 63) / 64)) / 3) < 1 ? 1 : (((N * N * N + 63) / 64)) / 3; }   // fewest waves a component gets
+// The metrics of a wavefront's tiles of the last pass, in accumulator order: addressable from (wavefront, lane) alone, so the
+// kernel issues them with its first loads (dv3_metrics) and hands them to opdiv3_mfma_c3.
+template <int N> struct Dv3Met {
+  static constexpr int TPW = (DvWave<N>::NT3 + (nt_min_sub<N>()) - 1) / nt_min_sub<N>();
+  double wa[TPW][DvWave<N>::RQ], wb[TPW][DvWave<N>::RQ], wc[TPW][DvWave<N>::RQ];
+};
 template <int N>
-__device__ inline double opdiv3_mfma_c3(const Dev& d, long long e, const double* sJ12, const double* sD12, double* buf, int tid, int nt) {
+__device__ inline void dv3_metrics(const Dev& d, long long e, int tid, int nt, Dv3Met<N>& mt) {
+  using W = DvWave<N>;
+  constexpr int M = N - 2, MM = M * M * M;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = nt >> 6, m16 = lane & 15, kq = lane >> 4;
+  const int comp = wave % 3, sub = wave / 3, nsub = (nw - comp + 2) / 3;
+  const bool za = (d.zmask >> (0 * 3 + comp)) & 1u, zb = (d.zmask >> (1 * 3 + comp)) & 1u, zc = (d.zmask >> (2 * 3 + comp)) & 1u;   // (Dev::zmask: zero on every node)
+#pragma unroll
+  for (int u = 0; u < Dv3Met<N>::TPW; ++u)
+#pragma unroll
+    for (int r = 0; r < W::RQ; ++r) {
+      const int t = sub + u * nsub, n = t * 16 + m16, cc = kq + 4 * r;
+      const bool ok = t < W::NT3 && n < M * M && cc < M;
+      const size_t q = (size_t)e * MM + (ok ? cc * M * M + n : 0);
+      mt.wa[u][r] = za ? 0.0 : d.w2m[(size_t)(0 * 3 + comp) * d.npr + q];
+      mt.wb[u][r] = zb ? 0.0 : d.w2m[(size_t)(1 * 3 + comp) * d.npr + q];
+      mt.wc[u][r] = zc ? 0.0 : d.w2m[(size_t)(2 * 3 + comp) * d.npr + q];
+    }
+}
+template <int N>
+__device__ inline double opdiv3_mfma_c3(const Dv3Met<N>& mt, const double* sJ12, const double* sD12, double* buf, int tid, int nt) {
   using W = DvWave<N>;
   constexpr int M = N - 2, MM = M * M * M, KQ = (N + 3) / 4, oPart = W::B;      // partial sums: [B, B + M^3) of the region (free after the s-axis)
   static_assert(W::B + MM <= 2 * W::A, "partial sums inside the dead sA tiles");
@@ -637,20 +662,7 @@ __device__ inline double opdiv3_mfma_c3(const Dev& d, long long e, const double*
   typedef ColPlane<M, N * M, M> CS_in;
   typedef ColPlane<M, M * M, M> CS_out;
   typedef ColLinear<M * M> CT;
-  // metrics of this wave's tiles of the last pass, in accumulator order; issued now, consumed after the three passes
-  constexpr int TPW = (W::NT3 + (nt_min_sub<N>()) - 1) / nt_min_sub<N>();
-  double wa[TPW][W::RQ], wb[TPW][W::RQ], wc[TPW][W::RQ];
-#pragma unroll
-  for (int u = 0; u < TPW; ++u)
-#pragma unroll
-    for (int r = 0; r < W::RQ; ++r) {
-      const int t = sub + u * nsub, n = t * 16 + m16, cc = kq + 4 * r;
-      const bool ok = t < W::NT3 && n < M * M && cc < M;
-      const size_t q = (size_t)e * MM + (ok ? cc * M * M + n : 0);
-      wa[u][r] = d.w2m[(size_t)(0 * 3 + comp) * d.npr + q];
-      wb[u][r] = d.w2m[(size_t)(1 * 3 + comp) * d.npr + q];
-      wc[u][r] = d.w2m[(size_t)(2 * 3 + comp) * d.npr + q];
-    }
+  constexpr int TPW = Dv3Met<N>::TPW;
   mo_pass<N, KQ, N * N, CR_in, StSplit<CR_out, 1, M, W::oA1 - W::oA0>, false>(aDJ, rb + W::oU, aDJ, rb, rb + W::oA0, sub, nsub, lane);
   lds_barrier();
   mo_pass<N, KQ, N * M, CS_in, StLin<CS_out, M, M>, false>(aJ, rb + W::oA0, aJ, rb, rb + W::oB0, sub, nsub, lane);
@@ -670,7 +682,7 @@ __device__ inline double opdiv3_mfma_c3(const Dev& d, long long e, const double*
 #pragma unroll
       for (int r = 0; r < W::RQ; ++r) {
         const int n = t * 16 + m16, cc = kq + 4 * r;
-        if (n < M * M && cc < M) rb[oPart + cc * M * M + n] = wa[u][r] * ur[r] + wb[u][r] * us[r] + wc[u][r] * ut[r];
+        if (n < M * M && cc < M) rb[oPart + cc * M * M + n] = mt.wa[u][r] * ur[r] + mt.wb[u][r] * us[r] + mt.wc[u][r] * ut[r];
       }
     }
   }

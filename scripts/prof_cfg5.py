@@ -29,3 +29,9 @@ for rep in range(int(os.environ.get('REPS', '2'))):
     t0 = time.time(); h.matvec(f, q, 0); h.norm(f); dt = time.time() - t0
     st = h.stats()
     print("%.1f ms per step (%.1f Helmholtz + %.1f pressure iterations per step)" % (1e3 * dt / nst, st["helm_iters"] / nst, st["pres_iters"] / nst), flush=True)
+for kn in os.environ.get("KERNELS", "").split():          # HIP-event timings of single kernels on the state the last map left
+    try:
+        print("%-16s %9.1f us" % (kn, h.bench_kernel(kn, 10)["avg_us"]), flush=True)
+    except Exception as exc:                               # noqa: BLE001
+        print("%-16s %s" % (kn, exc))
+print("zero_arrays = 0x%x" % h.stats().get("zero_arrays", 0))
