@@ -738,7 +738,7 @@ def main():
                     ktab[kn]["traffic"] = tr
                 out["kernels"] = ktab
                 traffic, tnote = pmc_traffic("k3::helm")
-                out["roofline"] = {"bound": "hbm", "kernel": "k3::k_helm<%d> (one CG iteration of the three components; the largest share of the kernel time: profiles/r04_cfg4_kernel_table.md)" % case.lx1,
+                out["roofline"] = {"bound": "hbm", "kernel": "k3::k_helm<%d> (one CG iteration of the three components; the largest share of the kernel time: profiles/r05_cfg4_kernel_table.md, r05_cfg4_trace_summary.txt)" % case.lx1,
                                    "achieved": ktab["helm"]["GBps"], "peak": 8000.0, "unit": "GB/s", "frac": ktab["helm"]["frac"], "traffic": traffic, "traffic_source": tnote,
                                    "avg_launch_us": ktab["helm"]["avg_us"], "algorithmic_bytes_per_launch": rule,
                                    "frac_shared_arrays_once": ktab["helm"]["frac_shared_arrays_once"],

@@ -1968,28 +1968,39 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
   const int lane = threadIdx.x;
   if (check_done && d.gsc->done) return;
   const long long e = d.boff + xcd_element(blockIdx.x, gridDim.x);
+  // Three trips to memory, not twelve (round 5: the instruction stream had a full wait behind the vertex list, behind the basis, behind
+  // the prolongation weights and behind EVERY ONE of the eight patch values -- `cond ? scale * load : 0` compiles to a load and
+  // its wait inside the branch -- : half of a wavefront's 31 us).  (1) everything addressable from the lane, the heads of the two
+  // dependent chains first; (2) the vertex values and the patch values, unconditionally (index 0 where the patch has no node);
+  // (3) nothing: the metrics of D^T go out per component under the passes.
+  static_assert(NM <= 64 && 2 * M <= 64, "basis and prolongation weights: one entry per lane");
+  const int ev = d.evert[e * 8 + (lane & 7)];            // (unconditional: a branch on use_coarse would hold the load and its wait)
   int id[RN];
 #pragma unroll
-  for (int r = 0; r < RN; ++r) { const int idx = r * 64 + lane; id[r] = (idx < NN) ? d.p_idx[e * NN + idx] : -1; }
+  for (int r = 0; r < RN; ++r) { const int idx = r * 64 + lane; id[r] = d.p_idx[e * NN + (idx < NN ? idx : 0)]; }
+  const int pend = d.gs_lag ? d.gsc->pending : 0;
+  const double phinv = d.gs_lag ? d.gsc->phinv : 1.0;
   double sv[RS];
 #pragma unroll
   for (int r = 0; r < RS; ++r) {
     const int idx = r * 64 + lane;
     sv[r] = (idx < NS) ? d.fdS[(size_t)e * NS + idx] : ((idx < NSL) ? d.fdL[(size_t)e * 3 * N + (idx - NS)] : 0.0);
   }
-  const double xl = use_coarse ? d.xc[d.evert[e * 8 + (lane & 7)]] : 0.0;
-  load_basis3<N>(d, nullptr, nullptr, sJ12, sD12, lane, 64);
-  if (lane < 2 * M) sH[lane] = d.hat[8 * MM + lane];
-  const double vsc = (d.gs_lag && d.gsc->pending) ? d.gsc->phinv : 1.0;
+  const double bJ = (lane < NM) ? d.J12[lane] : 0.0, bD = (lane < NM) ? d.D12[lane] : 0.0;
+  const double hh = (lane < 2 * M) ? d.hat[8 * MM + lane] : 0.0;
+  const double xl = d.xc[ev];
   double pv[RN];
 #pragma unroll
-  for (int r = 0; r < RN; ++r) pv[r] = (id[r] >= 0) ? vsc * vin[id[r]] : 0.0;
+  for (int r = 0; r < RN; ++r) pv[r] = vin[id[r] >= 0 ? id[r] : 0];
+  const double vsc = pend ? phinv : 1.0;
 #pragma unroll
   for (int r = 0; r < RS; ++r) { const int idx = r * 64 + lane; if (idx < NSL) sSL[idx] = sv[r]; }
+  if (lane < NM) { sJ12[lane] = bJ; sD12[lane] = bD; }
+  if (lane < 2 * M) sH[lane] = hh;
 #pragma unroll
   for (int r = 0; r < RN; ++r) {
     const int idx = r * 64 + lane;
-    if (idx < NN) sa[(idx / (N * N)) * S::PS + ((idx / N) % N) * S::RS + (idx % N)] = pv[r];
+    if (idx < NN) sa[(idx / (N * N)) * S::PS + ((idx / N) % N) * S::RS + (idx % N)] = (id[r] >= 0) ? vsc * pv[r] : 0.0;
   }
   wave_sync();
   fd_solve_inplace_wave<N>(sSL, sSL + NS, sa, d.fd_eps, lane);
