@@ -775,10 +775,8 @@ __global__ __launch_bounds__(Cfg<N>::NT, NSK_HELM3_WAVES) void k_helm(Dev d, Ste
   using L = SlimLay<N>;
   constexpr int EXT = L::EXT;
   static_assert(2 * N * N + 3 * NN <= 5 * EXT, "it = 0 borrows the tiles");
-  constexpr bool BY_COMPONENT = NT < 1024;
-  constexpr int NZ = BY_COMPONENT ? 1 : 3;
-  __shared__ double tiles[(NZ + 5) * EXT];
-  double* sz = tiles; double* sW = tiles + NZ * EXT; double* sO = tiles + (NZ + 3) * EXT;
+  __shared__ double tiles[8 * EXT];
+  double* sz = tiles; double* sW = tiles + 3 * EXT; double* sO = tiles + 6 * EXT;
   __shared__ double sred[12 * 16];
   __shared__ double scv[192];
   if (it == 0) { helm_first<N>(d, sc, rhs, sW, sW + N * N, sz, sW + 2 * N * N, sred, scv); return; }
@@ -878,96 +876,49 @@ __global__ __launch_bounds__(Cfg<N>::NT, NSK_HELM3_WAVES) void k_helm(Dev d, Ste
   NSK_STAMP(2);
   lds_barrier();
   NSK_STAMP(3);
-  // lx1 <= 8 (two workgroups per CU), component by component: update (its four stores leave), A z on the matrix cores (no memory
-  // traffic: the stores drain under it), A z's store and the wave sums: 1703-1719 -> 1634 us at config 4's size.  lx1 = 10 (one
-  // workgroup per CU): the three updates first, then the three A z: 8.5 ms per launch against 9.1 interleaved (scripts/stamps_cfg5.py:
-  // 5.0 us of the workgroup's 24.6 go into issuing the 13 stores per node either way).
-  if constexpr (BY_COMPONENT) {
+  double rz[3] = {0, 0, 0}, rr[3] = {0, 0, 0};
+  if (act) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      double rzc = 0.0, rrc = 0.0;
-      if (act) {
-        const long long lc = c * nl + l;
-        double r = ro[c];
-        if (!done[c]) {
-          const double* wl = wl0 + (size_t)c * nl;
-          const double sum = !wide ? (((gv[c].a + gv[c].b) + gv[c].c) + gv[c].d)
-                                           : (from_list ? corner_list_sum(scv + c * 64 + cid * 8, wl, d, l) : gs_csr_rolled(wl, d, l));
-          const double w = mk * sum;
-          const double pn = di * ro[c] + beta[c] * po[c];
-          const double sn = w + beta[c] * so[c];
-          d.hp[lc] = pn; d.hs[lc] = sn;
-          d.hx[lc] = xo[c] + alpha[c] * pn;
-          r = ro[c] - alpha[c] * sn;
-          d.hr[lc] = r;
-        }
-        const double z = di * r;
-        sz[tn] = z;
-        rzc = r * z * mi; rrc = r * r * mi;
+      const long long lc = c * nl + l;
+      double r = ro[c];
+      if (!done[c]) {
+        const double* wl = wl0 + (size_t)c * nl;
+        const double sum = !wide ? (((gv[c].a + gv[c].b) + gv[c].c) + gv[c].d)
+                                 : (from_list ? corner_list_sum(scv + c * 64 + cid * 8, wl, d, l) : gs_csr_rolled(wl, d, l));
+        const double w = mk * sum;
+        const double pn = di * ro[c] + beta[c] * po[c];
+        const double sn = w + beta[c] * so[c];
+        d.hp[lc] = pn; d.hs[lc] = sn;
+        d.hx[lc] = xo[c] + alpha[c] * pn;
+        r = ro[c] - alpha[c] * sn;
+        d.hr[lc] = r;
       }
-      if (c == 0) NSK_STAMP(4);
-      lds_barrier();
-      if (c == 0) NSK_STAMP(5);
-      double z;
-      const double au = axhelm3_mfma<N>(F, sz, sW, sO, g, act, tn, tid >> 6, NT / 64, tid & 63, z);
-      double v[3] = {0, 0, 0};
-      if (act) {
-        const double wl = d.nu * au + sc.h2 * bm * z;
-        d.hwl[((size_t)par * 3 + c) * nl + l] = wl;
-        v[0] = rzc; v[1] = z * wl; v[2] = rrc;
-      }
-      // workgroup sums: wave sums to LDS, rows added (fixed order) by the threads that store them
-#pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        const double x = wave_sum63(v[q]);
-        if ((tid & 63) == 63) sred[(c * 3 + q) * 16 + (tid >> 6)] = x;
-      }
-      lds_barrier();                                         // (the tiles are rewritten by the next component)
+      const double z = di * r;
+      sz[c * EXT + tn] = z;
+      rz[c] = r * z * mi; rr[c] = r * r * mi;
     }
-  } else {
-    double rz[3] = {0, 0, 0}, rr[3] = {0, 0, 0};
-    if (act) {
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const long long lc = c * nl + l;
-        double r = ro[c];
-        if (!done[c]) {
-          const double* wl = wl0 + (size_t)c * nl;
-          const double sum = !wide ? (((gv[c].a + gv[c].b) + gv[c].c) + gv[c].d)
-                                           : (from_list ? corner_list_sum(scv + c * 64 + cid * 8, wl, d, l) : gs_csr_rolled(wl, d, l));
-          const double w = mk * sum;
-          const double pn = di * ro[c] + beta[c] * po[c];
-          const double sn = w + beta[c] * so[c];
-          d.hp[lc] = pn; d.hs[lc] = sn;
-          d.hx[lc] = xo[c] + alpha[c] * pn;
-          r = ro[c] - alpha[c] * sn;
-          d.hr[lc] = r;
-        }
-        const double z = di * r;
-        sz[c * EXT + tn] = z;
-        rz[c] = r * z * mi; rr[c] = r * r * mi;
-      }
-    }
-    NSK_STAMP(4);
-    lds_barrier();
-    NSK_STAMP(5);
+  }
+  NSK_STAMP(4);
+  lds_barrier();
+  NSK_STAMP(5);
 #pragma unroll 1
-    for (int c = 0; c < 3; ++c) {
-      double z;
-      const double au = axhelm3_mfma<N>(F, sz + c * EXT, sW, sO, g, act, tn, tid >> 6, NT / 64, tid & 63, z);
-      double v[3] = {0, 0, 0};
-      if (act) {
-        const double wl = d.nu * au + sc.h2 * bm * z;
-        d.hwl[((size_t)par * 3 + c) * nl + l] = wl;
-        v[0] = (c == 0) ? rz[0] : ((c == 1) ? rz[1] : rz[2]); v[1] = z * wl; v[2] = (c == 0) ? rr[0] : ((c == 1) ? rr[1] : rr[2]);
-      }
-#pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        const double x = wave_sum63(v[q]);
-        if ((tid & 63) == 63) sred[(c * 3 + q) * 16 + (tid >> 6)] = x;
-      }
-      lds_barrier();                                         // (the tiles are rewritten by the next component)
+  for (int c = 0; c < 3; ++c) {
+    double z;
+    const double au = axhelm3_mfma<N>(F, sz + c * EXT, sW, sO, g, act, tn, tid >> 6, NT / 64, tid & 63, z);
+    double v[3] = {0, 0, 0};
+    if (act) {
+      const double wl = d.nu * au + sc.h2 * bm * z;
+      d.hwl[((size_t)par * 3 + c) * nl + l] = wl;
+      v[0] = (c == 0) ? rz[0] : ((c == 1) ? rz[1] : rz[2]); v[1] = z * wl; v[2] = (c == 0) ? rr[0] : ((c == 1) ? rr[1] : rr[2]);
     }
+    // workgroup sums: wave sums to LDS, rows added (fixed order) by the threads that store them
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const double x = wave_sum63(v[q]);
+      if ((tid & 63) == 63) sred[(c * 3 + q) * 16 + (tid >> 6)] = x;
+    }
+    lds_barrier();                                           // (the tiles are rewritten by the next component)
   }
   NSK_STAMP(6);
   if (tid < 12) {
