@@ -278,6 +278,37 @@ def test_arrays_that_are_zero_on_every_node_are_not_loaded_same_bits(monkeypatch
         ha.close(); hb.close()
 
 
+def test_a_three_dimensional_base_flow_on_an_extruded_mesh_takes_the_base_flow_bits_back():
+    """nsk_set_baseflow re-scans the twelve base-flow constants: with a spanwise-varying base flow on the extruded mesh only the
+    mapping's zeros stay in `zero_arrays`, and the map equals the one with every array loaded, bit for bit."""
+    import os
+    from nekstab_amd import mesh
+    here = os.path.dirname(os.path.abspath(__file__))
+    c2 = mesh.load_case_npz(os.path.join(here, "golden", "cylinder_case.npz"), 6)
+    c3 = mesh3d.extrude_case(c2, 2, 1.0, periodic=True)
+    kw = dict(tol_helm=1e-11, tol_pres=1e-8, tol_relative=1, max_helm_iter=150, max_pres_iter=144)
+    h = _hip(c3, **kw)
+    try:
+        assert (h.stats()["zero_arrays"] >> 12) != 0                       # two-dimensional base flow: six constants vanish
+        x, y, z = c3.x, c3.y, c3.z
+        b0, v0, v1 = h.alloc(3)
+        h.upload3(b0, c3.ub[0] * (1.0 + 0.05 * np.cos(2 * np.pi * z)), c3.ub[1] + 0.05 * np.sin(2 * np.pi * z) * c3.mask, 0.1 * np.cos(2 * np.pi * z) * np.sin(x) * c3.mask, np.zeros(h.npres))
+        h.set_baseflow(b0)
+        za = h.stats()["zero_arrays"]
+        assert (za >> 12) == 0 and {b for b in range(12) if za >> b & 1} == {2, 5, 6, 7, 10, 11}
+        q = [np.sin(x + np.pi * z) * c3.mask, np.cos(y) * np.cos(np.pi * z) * c3.mask, np.sin(x - y) * c3.mask, np.zeros(h.npres)]
+        h.upload3(v0, *q); h.set_nsteps(3)
+        h.matvec(v1, v0, 0); a = h.download3(v1)
+        h.set_option("zero_metrics", 0)
+        assert h.stats()["zero_arrays"] == 0
+        h.matvec(v1, v0, 0); b = h.download3(v1)
+        for k in range(4):
+            assert np.array_equal(a[k], b[k])
+        assert h.stats()["unconverged"] == 0
+    finally:
+        h.close()
+
+
 def test_host_checked_convergence_full_mesh_context():
     """Option hostcheck (default on hexahedral meshes of >= 8192 elements, where a launch that only finds its solve converged
     costs 25-140 us and a map redone with larger launch budgets tens of seconds): eager steps, the host reads the device's

@@ -162,3 +162,21 @@ def test_cpu_port_projection_space_same_map_fewer_iterations(case6, oracle6, mod
     f3 = cp.matvec(q, nsteps=20)
     assert cp.stats["pres_iters"] == it1
     assert max(np.abs(a - b).max() for a, b in zip(f3[:2], f1[:2])) < 1e-12
+
+
+def test_roofline_does_not_count_arrays_that_vanish():
+    """nekstab_amd/roofline.py: metric terms, G factors and base-flow constants flagged in nsk_stats.zero_arrays are not inputs of
+    the kernels (hexahedra only): the per-step bytes shrink by exactly those arrays."""
+    from nekstab_amd import roofline
+    geom = dict(nel=1000, lx1=8, ndim=3, nvert=1331, nproj=8, helm_iters=4.0, pres_iters=10.0, pres_jsum=45.0, coarse_bytes=1e6)
+    full = roofline.per_step_bytes(**geom)
+    za = sum(1 << b for b in (2, 5, 6, 7)) | (1 << 10) | (1 << 11) | sum(1 << (12 + b) for b in (2, 5, 8, 9, 10, 11))
+    cut = roofline.per_step_bytes(zero_arrays=za, **geom)
+    P, P2, Pd = 1000 * 512, 1000 * 216, 1000 * 1728
+    assert full["K1 convect"] - cut["K1 convect"] == 8.0 * Pd * 6
+    assert full["K3 helm iteration (x n_helm x d)"] - cut["K3 helm iteration (x n_helm x d)"] == 8.0 * 2 * P * 3 * 4.0
+    assert full["K7 divgs (x n_pres)"] - cut["K7 divgs (x n_pres)"] == 8.0 * P2 * 4 * 10.0
+    assert roofline.per_step_bytes(zero_arrays=za, **dict(geom, ndim=2, lx1=8)) == roofline.per_step_bytes(**dict(geom, ndim=2, lx1=8))
+    rule, distinct = roofline.helm_launch_bytes(nel=1000, lx1=8, ndim=3, zero_arrays=za)
+    rule0, distinct0 = roofline.helm_launch_bytes(nel=1000, lx1=8, ndim=3)
+    assert rule0 - rule == 8.0 * 2 * P * 3 and distinct0 - distinct == 8.0 * 2 * P
