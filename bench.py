@@ -675,6 +675,7 @@ def main():
                 out["zero_arrays"] = {"mask": geom["zero_arrays"], "note": "hexahedra: arrays that vanish on every node (bits 0-8 metric terms, 9-11 G factors 4-6, 12-23 base-flow constants of the convection kernel) are neither loaded nor counted in the algorithmic bytes; Nek5000 skips the same terms on its undeformed elements (hmholtz.f axhelm, ifdfrm)"}
             bpm, per = roofline.matvec_bytes(st, full.nsteps, **geom)
             st["_per"] = per
+            out["geometry"] = geom
             jmean = a.warmup + (steps + 1) / 2.0
             bpm_k = roofline.krylov_bytes(full.nstate, jmean)
             e2e = (bpm + bpm_k) / (elapsed / steps) / 1e9

@@ -146,6 +146,7 @@ struct nsk_ctx {
   std::vector<nsk_ctx*> graph_members;  // sharded step graphs (held by the first rank of a process): the ranks they were captured for
   int merged_iters = 24;                // ... for the first merged_iters iterations of a solve (see pres_solve_launch; 12 until round 4: 24 covers the tightened solves of time steps 1-3 too, +2 % on config 2 at identical iteration counts)
   int merged_update = 1;                // GMRES column bookkeeping inside the coarse-solve kernel (k_update_coarse)
+  int fuse2 = 1;                        // round 6: the merged iteration in TWO launches (k_schwarz_uc, k_divgs_t; option "fuse2", NSK_FUSE2); 0 = the three launches of rounds 3-5
   double* kacc = nullptr;               // nsk_orth: coefficients accumulated over the two passes + the squared norm (device)
   bool released = false;                // nsk_shard_release_parent: only the arrays shards share are left on the device
   static constexpr int ORTH_CHUNKS = 4;
@@ -792,6 +793,51 @@ static int build(nsk_ctx* c, const nsk_case& cs) {
       if ((rc = dupload(c, &d.ecslot, ecslot)) || (rc = dalloc(c, &d.ecv, (size_t)8 * d.coarse_lda))) return rc;
     }
   }
+  // ---- round 6 (k_schwarz_uc / k_divgs_t): the image of the coarse prolongation under E, block sparse, from the probed E blocks:
+  //   Tc[a][s][r] = sum_{b in nb(a)} sum_{c: evert[b][c] = evl[a][s]} sum_k E[(a,r),(b,k)] hat[c][k]
+  if (lda_ok_for_ecv(c) && d.ecv) {
+    std::vector<std::vector<int>> vl(nel);
+    int nvl = 0;
+    for (int a = 0; a < nel; ++a) {
+      std::vector<int>& v = vl[a];
+      for (int b : nb[a]) for (int cc = 0; cc < 4; ++cc) v.push_back(evert[(size_t)b * 4 + cc]);
+      std::sort(v.begin(), v.end());
+      v.erase(std::unique(v.begin(), v.end()), v.end());
+      nvl = std::max(nvl, (int)v.size());
+    }
+    nvl = ((nvl + 3) / 4) * 4;
+    if (nvl <= 32 && nvl <= NN) {
+      std::vector<int> evl((size_t)nel * nvl, 0);
+      std::vector<double> Tc((size_t)nel * nvl * MM, 0.0);
+      const int nth = std::max(1, std::min<int>(16, (int)std::thread::hardware_concurrency()));
+      // deterministic (fixed summation order): one thread per TARGET element a, contributions in the order of nb[a] and corner index
+      auto rows_a = [&](int t0) {
+        for (int a = t0; a < nel; a += nth)
+          for (int b : nb[a]) {
+            size_t sb = 0;
+            while (sb < nb[b].size() && nb[b][sb] != a) ++sb;
+            if (sb == nb[b].size()) continue;                                      // (adjacency is symmetric: not reached)
+            const double* blk = &Eblk[blk_off[b] + sb * MM * MM];
+            for (int cc = 0; cc < 4; ++cc) {
+              const int v = evert[(size_t)b * 4 + cc];
+              const int slot = (int)(std::lower_bound(vl[a].begin(), vl[a].end(), v) - vl[a].begin());
+              double* dst = &Tc[((size_t)a * nvl + slot) * MM];
+              for (int r = 0; r < MM; ++r) { double t = 0; for (int k = 0; k < MM; ++k) t += blk[(size_t)k * MM + r] * hat[cc * MM + k]; dst[r] += t; }
+            }
+          }
+      };
+      {
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nth; ++t) pool.emplace_back(rows_a, t);
+        rows_a(0);
+        for (auto& th : pool) th.join();
+      }
+      for (int a = 0; a < nel; ++a) for (size_t k = 0; k < vl[a].size(); ++k) evl[(size_t)a * nvl + k] = vl[a][k];
+      d.nvl = nvl;
+      if ((rc = dupload(c, &d.evl, evl)) || (rc = dupload(c, &d.Tc, Tc)) || (rc = dalloc(c, &d.Wr, (size_t)d.ps))) return rc;
+    }
+  }
+  tick("coarse image under E (Tc)");
   c->h_evert = evert;
   if ((rc = dupload(c, &d.v_off, v_off)) || (rc = dupload(c, &d.v_ent, v_ent)) || (rc = dupload(c, &d.evert, evert)) ||
       (rc = dalloc(c, &d.xc, nvert))) return rc;
@@ -869,6 +915,7 @@ static int build(nsk_ctx* c, const nsk_case& cs) {
   if (const char* g = std::getenv("NSK_FUSED")) c->fused = std::atoi(g) && fused_possible(c);
   if (const char* g = std::getenv("NSK_USE_GRAPH")) c->use_graph = std::atoi(g);
   if (const char* g = std::getenv("NSK_MERGED_UPDATE")) c->merged_update = std::atoi(g);
+  if (const char* g = std::getenv("NSK_FUSE2")) c->fuse2 = std::atoi(g);
   if (const char* g = std::getenv("NSK_HOSTCHECK")) c->hostcheck = std::atoi(g);
   if (const char* g = std::getenv("NSK_GRAPH_STEPS")) c->graph_steps = std::max(1, std::min(std::atoi(g), 64));
   if (const char* g = std::getenv("NSK_MERGED_ITERS")) c->merged_iters = std::max(0, std::min(std::atoi(g), MAXMR));
@@ -906,6 +953,26 @@ static void launch_update_coarse(nsk_ctx* c, const Dev& d, int j, double scale, 
   else if (nit <= 6) hipLaunchKernelGGL(k_update_coarse<6>, dim3(cgrid), dim3(256), sh, c->stream, d, j, scale, min_iter, ord);
   else if (nit <= 9) hipLaunchKernelGGL(k_update_coarse<9>, dim3(cgrid), dim3(256), sh, c->stream, d, j, scale, min_iter, ord);
   else hipLaunchKernelGGL(k_update_coarse<12>, dim3(cgrid), dim3(256), sh, c->stream, d, j, scale, min_iter, ord);
+}
+
+// round 6, the merged iteration in two launches: A_j (Schwarz workgroups + coarse workgroups) and B_j
+static bool fuse2_on(const nsk_ctx* c) { return c->fuse2 && c->d.Tc && c->d.Wr && c->d.ecv && c->d.rch; }
+template <int N>
+static void launch_schwarz_uc(nsk_ctx* c, const Dev& d, int j, double scale, int min_iter, int ord) {
+  if (c->ndim != 2) return;
+  const unsigned cgrid = (d.nvert + 4 * UC_ROWS - 1) / (4 * UC_ROWS), nsw = (unsigned)c->nblk;
+  const size_t sh = d.coarse_lda * sizeof(double);
+  const int nit = d.coarse_lda / 256;
+  const dim3 grid(nsw + cgrid), blk(256);
+  if (nit <= 3) hipLaunchKernelGGL((nsk::k2::k_schwarz_uc<N, 3>), grid, blk, sh, c->stream, d, j, scale, min_iter, ord, nsw, cgrid);
+  else if (nit <= 6) hipLaunchKernelGGL((nsk::k2::k_schwarz_uc<N, 6>), grid, blk, sh, c->stream, d, j, scale, min_iter, ord, nsw, cgrid);
+  else if (nit <= 9) hipLaunchKernelGGL((nsk::k2::k_schwarz_uc<N, 9>), grid, blk, sh, c->stream, d, j, scale, min_iter, ord, nsw, cgrid);
+  else hipLaunchKernelGGL((nsk::k2::k_schwarz_uc<N, 12>), grid, blk, sh, c->stream, d, j, scale, min_iter, ord, nsw, cgrid);
+}
+template <int N>
+static void launch_divgs_t(nsk_ctx* c, const Dev& d, int j) {
+  if (c->ndim != 2) return;
+  hipLaunchKernelGGL(nsk::k2::k_divgs_t<N>, dim3(c->nblk), dim3(256), 0, c->stream, d, j);
 }
 
 static bool stream_capturing(hipStream_t s) {
@@ -1101,14 +1168,27 @@ static int pres_solve_launch(nsk_ctx* c, double h2, int ord, int np, double tol_
       if (rc2) return rc2;
       if (done) { c->hc_pres[ord] = 0; np = 0; }
     }
+    const bool f2 = merged && fuse2_on(c);
     for (int j = 0; j < (tl ? nhead : nm); ++j) {
+      if (f2) {                                            // two launches per iteration (round 6)
+        launch_schwarz_uc<N>(c, d, j, scale, c->min_pres, ord);
+        launch_divgs_t<N>(c, d, j);
+        continue;
+      }
       launch_update_coarse(c, d, j, scale, c->min_pres, ord);
       hipLaunchKernelGGL(k_schwarz<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, (const double*)(d.V + (size_t)j * d.ps), d.Z + (size_t)j * d.npr, 1, 1);
       hipLaunchKernelGGL(k_divgs<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, (const double*)d.yl, d.V + (size_t)(j + 1) * d.ps, j, 2);
     }
     if (tl && nhead < nm) launch_pres_tail<N>(c, d, nhead, nm, scale, c->min_pres, ord);
+    // a velocity tail ran in this step but no pressure tail will: the velocity tail's barrier words (set 0) are re-zeroed by
+    // the pressure tail only, so zero them here (a dirty set lets the next velocity tail's first barriers fall through)
+    if (tail && !(tl && nhead < nm) && c->sync) (void)hipMemsetAsync(c->sync, 0, SYNC_WORDS * sizeof(unsigned), c->stream);
     // closes the last merged column (normalises v_nm and writes its corner restriction: what the classic iteration nm reads)
-    if (nm > 0) hipLaunchKernelGGL(k_gmres_update<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, nm - 1, scale, c->min_pres, ord);
+    if (nm > 0) {
+      Dev dcl = d;
+      if (f2) dcl.wraw = d.Wr;                             // the raw w of B_{nm-1}
+      hipLaunchKernelGGL(k_gmres_update<N>, dim3(c->nblk), dim3(NT), 0, c->stream, dcl, nm - 1, scale, c->min_pres, ord);
+    }
     for (int jt = nm; jt < np; ++jt) {
       const int j = jt % c->gmres_cycle;                 // index inside the current GMRES cycle
       if (jt > 0 && j == 0) {                            // cycle full and not converged: restart on the residual
@@ -1200,6 +1280,20 @@ static int tails_resident(nsk_ctx* c, int ncu) {
   else if (nit <= 9) e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&pp, (nsk::k2::k_pres_tail<N, 9>), nsk::k2::Cfg<N>::NT, sh);
   else e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&pp, (nsk::k2::k_pres_tail<N, 12>), nsk::k2::Cfg<N>::NT, sh);
   if (e1 != hipSuccess || e2 != hipSuccess) return 0;
+  if (fuse2_on(c)) {                             // the two-launch form's tail (256 threads whatever lx1)
+    int p2 = 0;
+    hipError_t e3;
+    if (nit <= 3) e3 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&p2, (nsk::k2::k_pres_tail2<N, 3>), 256, sh);
+    else if (nit <= 6) e3 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&p2, (nsk::k2::k_pres_tail2<N, 6>), 256, sh);
+    else if (nit <= 9) e3 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&p2, (nsk::k2::k_pres_tail2<N, 9>), 256, sh);
+    else e3 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&p2, (nsk::k2::k_pres_tail2<N, 12>), 256, sh);
+    if (e3 != hipSuccess) return 0;
+    pp = p2;
+  } else {
+    // k_pres_tail runs update_coarse_body, written for 256-thread workgroups, on its first cgrid workgroups
+    const unsigned cgrid = (c->d.nvert + 4 * UC_ROWS - 1) / (4 * UC_ROWS);
+    if (nsk::k2::Cfg<N>::NT != 256 || cgrid > (unsigned)c->nblk) return 0;
+  }
   const int need = (c->nblk + ncu - 1) / ncu;
   if (c->debug) fprintf(stderr, "persistent tails: %d workgroups per CU needed, occupancy %d (velocity) / %d (pressure)\n", need, ph, pp);
   // (the occupancy query is one workgroup per CU high only where it is bound by scalar registers, 7-8 per CU: MI355X_MICROARCH.md,
@@ -1232,11 +1326,20 @@ static void launch_helm_tail(nsk_ctx* c, const Dev& d, const StepCoef& sc, int i
 template <int N>
 static void launch_pres_tail(nsk_ctx* c, const Dev& d, int j0, int j1, double scale, int min_iter, int ord) {
   if (c->ndim != 2) return;
-  launch_update_coarse(c, d, j0, scale, min_iter, ord);      // closes column j0-1 as a launch: a solve of exactly j0 iterations ends here (k_pres_tail: skip_a)
   const unsigned cgrid = (d.nvert + 4 * UC_ROWS - 1) / (4 * UC_ROWS);
   const size_t sh = d.coarse_lda * sizeof(double);
   const int nit = d.coarse_lda / 256;
   unsigned* sy = c->sync + SYNC_WORDS;          // (set 1; zeroes set 0 for the next velocity tail)
+  if (fuse2_on(c)) {
+    launch_schwarz_uc<N>(c, d, j0, scale, min_iter, ord);    // A_{j0} as a launch: closes column j0-1 (a solve of exactly j0 iterations ends here: skip_a)
+    const dim3 grid(c->nblk), blk(256);
+    if (nit <= 3) hipLaunchKernelGGL((nsk::k2::k_pres_tail2<N, 3>), grid, blk, sh, c->stream, d, j0, j1, scale, min_iter, ord, cgrid, 1, sy, c->sync);
+    else if (nit <= 6) hipLaunchKernelGGL((nsk::k2::k_pres_tail2<N, 6>), grid, blk, sh, c->stream, d, j0, j1, scale, min_iter, ord, cgrid, 1, sy, c->sync);
+    else if (nit <= 9) hipLaunchKernelGGL((nsk::k2::k_pres_tail2<N, 9>), grid, blk, sh, c->stream, d, j0, j1, scale, min_iter, ord, cgrid, 1, sy, c->sync);
+    else hipLaunchKernelGGL((nsk::k2::k_pres_tail2<N, 12>), grid, blk, sh, c->stream, d, j0, j1, scale, min_iter, ord, cgrid, 1, sy, c->sync);
+    return;
+  }
+  launch_update_coarse(c, d, j0, scale, min_iter, ord);      // closes column j0-1 as a launch: a solve of exactly j0 iterations ends here (k_pres_tail: skip_a)
   const dim3 grid(c->nblk), blk(nsk::k2::Cfg<N>::NT);
   if (nit <= 3) hipLaunchKernelGGL((nsk::k2::k_pres_tail<N, 3>), grid, blk, sh, c->stream, d, j0, j1, scale, min_iter, ord, cgrid, 1, sy, c->sync);
   else if (nit <= 6) hipLaunchKernelGGL((nsk::k2::k_pres_tail<N, 6>), grid, blk, sh, c->stream, d, j0, j1, scale, min_iter, ord, cgrid, 1, sy, c->sync);
@@ -1347,10 +1450,7 @@ static int graph_for(nsk_ctx* c, int adjoint, int cls, int nh, int np, hipGraphE
   const std::array<int, 4> key{adjoint, cls + (tail ? 16 : 0), nh, np};
   auto it = c->gcache.find(key);
   if (it != c->gcache.end()) { *out = it->second; return 0; }
-  if (c->gcache.size() >= 1024) {                          // (never seen: a few dozen budget pairs occur) start again
-    for (auto& kv : c->gcache) if (kv.second) (void)hipGraphExecDestroy(kv.second);
-    c->gcache.clear();
-  }
+  // (the cache is bounded by run_map, BEFORE it builds a plan: evicting here would leave handles of the plan under construction dangling)
   const auto t_cap0 = std::chrono::steady_clock::now();
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
@@ -1382,6 +1482,13 @@ static int run_map(nsk_ctx* c, int adjoint, double* f, const double* q) {
   c->last_map_per_step = per_step; c->last_map_kind = adjoint;
   std::vector<hipGraphExec_t> plan;
   if (per_step) {                                           // every graph of the plan exists before the first launch (captures end the stream's queue)
+    // bound the cache of captured steps here, where no plan holds a handle of it (never seen: a few dozen budget pairs occur);
+    // a plan adds at most nsteps entries
+    if (c->gcache.size() + (size_t)c->nsteps > (size_t)std::max(4096, 2 * c->nsteps)) {
+      HIPCHK(hipStreamSynchronize(c->stream));              // (no replay of an evicted graph may still be queued)
+      for (auto& kv : c->gcache) if (kv.second) (void)hipGraphExecDestroy(kv.second);
+      c->gcache.clear();
+    }
     plan.resize(c->nsteps);
     for (int istep = 1; istep <= c->nsteps; ++istep) {
       const nsk_ctx::StepBudgets& b = c->sb[adjoint];
@@ -1534,7 +1641,7 @@ static void step_budgets_update(nsk_ctx* c) {
 static int reset_solver_state(nsk_ctx* c) {
   Dev& d = c->d;
   void* mut[] = {d.u, d.p, d.plag, d.pext, d.ulag, d.exlag, d.bf, d.rloc, d.bloc, d.dulag, d.hx, d.hr, d.hp, d.hs, d.hwl, d.hpart, d.hscal,
-                 d.V, d.Z, d.yl, d.ec, d.ecv, d.xc, d.gpart, d.xacc, d.dpw, d.hz, d.hy, d.rch, d.gsc, d.PX, d.PEX, d.PD, d.PED, d.ppart, d.stats,
+                 d.V, d.Z, d.yl, d.ec, d.ecv, d.Wr, d.xc, d.gpart, d.xacc, d.dpw, d.hz, d.hy, d.rch, d.gsc, d.PX, d.PEX, d.PD, d.PED, d.ppart, d.stats,
                  d.gpart2, d.gtot2, d.ptot, d.htot, d.gtot, c->rc_big, c->cw_d0, c->cw_d1, c->cw_r, c->circ_rh, c->circ_xh, c->rc_part, c->sync};
   for (void* p : mut) {
     if (!p) continue;
@@ -2206,6 +2313,7 @@ int nsk_set_option(nsk_ctx* c, const char* name, double value) {
   }
   else if (n == "merged_iters") { c->merged_iters = std::max(0, std::min((int)value, MAXMR)); invalidate_graphs(c); }
   else if (n == "merged_update") { c->merged_update = (int)value; invalidate_graphs(c); }
+  else if (n == "fuse2") { c->fuse2 = (int)value; c->tail_ok = -1; invalidate_graphs(c); }
   else if (n == "min_pres_iter") c->min_pres = (int)value;
   else if (n == "pres_cap") {
     if (value > 0 && c->ndim != 2) return fail(NSK_EINVAL, "pres_cap is validated on quadrilateral linearised maps only (DESIGN.md section 1)");
@@ -2837,6 +2945,7 @@ int nsk_clone(nsk_ctx* P, nsk_ctx** out) {
   if (P->rc_big && (rc = dalloc(c, &c->rc_big, c->coarse_lda))) return bail(rc);
   if (P->d.rch && (rc = dalloc(c, &d.rch, (size_t)MAXMR * c->coarse_lda))) return bail(rc);
   if (P->d.ecv && (rc = dalloc(c, &d.ecv, (size_t)8 * c->coarse_lda))) return bail(rc);
+  if (P->d.Wr && (rc = dalloc(c, &d.Wr, (size_t)d.ps))) return bail(rc);            // (Tc / evl are immutable: shared with the parent)
   if (d.use_tot && ((rc = dalloc(c, &d.htot, 32)) || (rc = dalloc(c, &d.gtot, MAXMR + 8)) || (rc = dalloc(c, &d.gtot2, MAXMR + 8)) || (rc = dalloc(c, &d.ptot, MAXPROJ + 2)))) return bail(rc);
   if ((rc = dalloc(c, &c->sync, 2 * SYNC_WORDS))) return bail(rc);
   c->kblk = 256;
@@ -2987,12 +3096,13 @@ int nsk_bench_kernel(nsk_ctx* c, const char* name, int reps, double* avg_us) {
       }
       HIPCHK(hipEventRecord(e1, c->stream));
     });
-  } else if (n == "coarse" || n == "schwarz" || n == "divgs" || n == "gmres_update" || n == "pres_chain" || n == "pres_chain3" || n == "pres_chain_merged" || n.rfind("update_coarse", 0) == 0 || n == "divgs2" ||
+  } else if (n == "coarse" || n == "schwarz" || n == "divgs" || n == "gmres_update" || n == "pres_chain" || n == "pres_chain3" || n == "pres_chain_merged" || n == "pres_chain_fused" || n.rfind("schwarz_uc", 0) == 0 || n == "divgs_t" || n.rfind("update_coarse", 0) == 0 || n == "divgs2" ||
              n == "proj_apply" || n == "proj_update" || n == "pres_update" || n == "vel_update_proj" || n == "pres_rhs" || n == "rhs") {
     // kernels of the pressure solve, back to back on the state the last map left (run one first).  Tolerance 0 and a cleared
     // `done` flag: every launch does full work.  `pres_chain`: whole GMRES iterations j = 0..7 (coarse, Schwarz, E, update).
     if (c->ndim != 2 || d.coarse_lda > 3072) return fail(NSK_EINVAL, "pressure-kernel timing: quadrilateral contexts with the dense in-LDS coarse solve");
     if ((n.rfind("update_coarse", 0) == 0 || n == "pres_chain_merged") && !d.ecv) return fail(NSK_EINVAL, "merged coarse-solve kernel not available in this context");
+    if ((n.rfind("schwarz_uc", 0) == 0 || n == "divgs_t" || n == "pres_chain_fused") && !(d.Tc && d.Wr && d.ecv && d.rch)) return fail(NSK_EINVAL, "two-launch GMRES iteration not available in this context");
     d.tol_pres = 0.0; d.tol_relative = 0; d.pres_cap = 0;
     const StepCoef sc = make_coef(c, 17, 0);
     const double scale = 1.0 / (sc.h2 * std::sqrt(d.vol));
@@ -3003,9 +3113,15 @@ int nsk_bench_kernel(nsk_ctx* c, const char* name, int reps, double* avg_us) {
       constexpr int NT = Cfg<N>::NT;
       for (int r = -3; r < reps; ++r) {
         if (r == 0) HIPCHK(hipEventRecord(e0, c->stream));
-        if (r <= 0 || n.rfind("update_coarse", 0) == 0 || n == "gmres_update") HIPCHK(clear_done());   // (a 4-byte memset node per launch, same for all)
+        if (r <= 0 || n.rfind("update_coarse", 0) == 0 || n.rfind("schwarz_uc", 0) == 0 || n == "gmres_update") HIPCHK(clear_done());   // (a 4-byte memset node per launch, same for all)
         if (n == "coarse") hipLaunchKernelGGL(k_coarse, dim3((d.nvert + 4 * CROWS_W - 1) / (4 * CROWS_W)), dim3(256), d.coarse_lda * sizeof(double), c->stream, d);
         else if (n.rfind("update_coarse", 0) == 0) launch_update_coarse(c, d, std::atoi(n.c_str() + 13), scale, 2, 5);
+        else if (n.rfind("schwarz_uc", 0) == 0) launch_schwarz_uc<N>(c, d, std::atoi(n.c_str() + 10), scale, 2, 5);
+        else if (n == "divgs_t") launch_divgs_t<N>(c, d, jj);
+        else if (n == "pres_chain_fused") {
+          HIPCHK(clear_done());
+          for (int j = 0; j < 8; ++j) { launch_schwarz_uc<N>(c, d, j, scale, 2, 5); launch_divgs_t<N>(c, d, j); }
+        }
         else if (n == "divgs2") hipLaunchKernelGGL(k_divgs<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, (const double*)d.yl, d.V + (size_t)(jj + 1) * d.ps, jj, 2);
         else if (n == "schwarz") hipLaunchKernelGGL(k_schwarz<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, (const double*)(d.V + (size_t)jj * d.ps), d.Z + (size_t)jj * d.npr, 1, 1);
         else if (n == "divgs") hipLaunchKernelGGL(k_divgs<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, (const double*)d.yl, d.V + (size_t)(jj + 1) * d.ps, jj, 1);
@@ -3035,7 +3151,7 @@ int nsk_bench_kernel(nsk_ctx* c, const char* name, int reps, double* avg_us) {
       }
       HIPCHK(hipEventRecord(e1, c->stream));
     });
-    if (n == "pres_chain" || n == "pres_chain3" || n == "pres_chain_merged") reps *= 8;                  // per GMRES iteration
+    if (n == "pres_chain" || n == "pres_chain3" || n == "pres_chain_merged" || n == "pres_chain_fused") reps *= 8;                  // per GMRES iteration
   } else {
     return fail(NSK_EINVAL, "unknown kernel " + n);
   }

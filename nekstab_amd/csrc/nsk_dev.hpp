@@ -126,6 +126,17 @@ struct Dev {
   // rounds of scattered 8-byte gathers through vtab (round 5: 14.9 -> see DESIGN.md section 5.1)
   double *ecv;
   const int *ecslot;
+  // Round 6, the merged GMRES iteration in two launches (k_schwarz_uc, k_divgs_t): the coarse part of the preconditioner enters
+  // the E-apply through its precomputed image  Tc = D B^-1 dssum D^T R^T  (block sparse: evl[e][nvl] = the vertices of element
+  // e and of its node-sharing neighbours, ascending, padded with vertex 0 / zero columns; Tc[e][nvl][MM]), so that the coarse
+  // solve can run NEXT TO the Schwarz solves instead of in front of them.  Wr: the raw w = E z_j of the last iteration (the
+  // Schwarz workgroups read it across element boundaries, so it cannot be normalised in place).  wraw (set per launch):
+  // k_gmres_update takes the raw w from here instead of V[j+1].
+  const int* evl;
+  const double* Tc;
+  int nvl;
+  double* Wr;
+  const double* wraw;
   GmresScal* gsc;
   // projection onto previous pressure solutions (E-orthonormal)
   double *PX, *PEX, *PD, *PED, *ppart;

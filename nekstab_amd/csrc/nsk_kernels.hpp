@@ -1032,7 +1032,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_gmres_update(Dev d, int j, doubl
 #pragma unroll
   for (int r = 0; r < (4 * MM + NT - 1) / NT; ++r) hatv[r] = (tid + r * NT < 4 * MM) ? d.hat[tid + r * NT] : 0.0;
   double wnew = 0.0;
-  if (act && nd < MM) wnew = d.V[(size_t)(j + 1) * d.ps + e * MM + nd];
+  if (act && nd < MM) wnew = d.wraw ? d.wraw[e * MM + nd] : d.V[(size_t)(j + 1) * d.ps + e * MM + nd];
   const int nv = (j < 0) ? 1 : j + 2;
   const bool two = d.gs2 && j >= 0;             // k_gmres_reorth ran for this column: V[j+1] already holds w - sum h_i v_i
   __shared__ double sc2[MAXMR + 2];
@@ -1291,10 +1291,59 @@ __global__ __launch_bounds__(256) void k_coarse(Dev d) {
 // MAXIT >= coarse_lda / 256 (3, 6, 9 or 12) sizes every per-thread table; UC_ROWS rows per wavefront (measured on config 2:
 // 2 rows / 263 workgroups beat 3 rows / 175 workgroups by 5 % of a matvec).
 constexpr int UC_ROWS = 2;
+// Closes GMRES column jj from the dot-product sums sh[0..jj+1] (one lane; the same arithmetic in every workgroup => the same
+// decision everywhere): Givens rotations, residual, convergence.  sbc = {1 / h_{jj+1,jj}, converged}; `record`: this workgroup
+// writes the solve's state (GmresScal, statistics).
+__device__ __forceinline__ void uc_rotate(const Dev& d, GmresScal* G, int jj, double gj, double scale, int min_iter, int ord, bool record,
+                                          const double* sh, const double* scs, const double* ssn, double* scol, double* sbc) {
+    double s2 = 0.0;
+    for (int q = 0; q <= jj; ++q) s2 += sh[q] * sh[q];
+    const double hn2 = sh[jj + 1] - s2;
+    const double hn = sqrt(hn2 > 0.0 ? hn2 : 0.0);
+    double* col = scol;
+    for (int q = 0; q <= jj; ++q) col[q] = sh[q];
+    col[jj + 1] = hn;
+    for (int q = 0; q < jj; ++q) {
+      const double t = scs[q] * col[q] + ssn[q] * col[q + 1];
+      col[q + 1] = -ssn[q] * col[q] + scs[q] * col[q + 1];
+      col[q] = t;
+    }
+    const double rho = sqrt(col[jj] * col[jj] + col[jj + 1] * col[jj + 1]);
+    const double cj = (rho > 0.0) ? col[jj] / rho : 1.0, sj = (rho > 0.0) ? col[jj + 1] / rho : 0.0;
+    col[jj] = rho;
+    const double res = fabs(sj * gj) * scale;
+    const double tol = d.tol_relative ? fmax(d.tol_pres * G->gnorm0 * scale, d.tol_pres_floor) : d.tol_pres;
+    const bool conv = (res <= tol && (jj + 1) >= min_iter) || !(hn > 0.0) || (d.pres_cap > 0 && (jj + 1) >= d.pres_cap);
+    sbc[0] = (hn > 0.0) ? 1.0 / hn : 0.0;
+    sbc[1] = conv ? 1.0 : 0.0;
+    if (record) {
+      G->cs[jj] = cj; G->sn[jj] = sj;
+      for (int q = 0; q <= jj; ++q) G->R[jj * MAXMR + q] = col[q];
+      G->g[jj] = cj * gj;
+      G->g[jj + 1] = -sj * gj; G->gpre[jj + 1] = -sj * gj;
+      G->nit = jj + 1;
+      G->resid = res;
+      d.stats->pres_jsum += jj;
+      if (conv) {
+        atomicAdd((unsigned long long*)&d.stats->pres_iters, (unsigned long long)(G->nit_prev + jj + 1));
+        atomicMax((unsigned long long*)&d.stats->max_pres, (unsigned long long)(G->nit_prev + jj + 1));
+        atomicMax((unsigned long long*)&d.stats->max_pres_k[ord], (unsigned long long)(G->nit_prev + jj + 1)); rec_step_iters(d, 1, G->nit_prev + jj + 1);
+        d.stats->last_pres_res = res;
+        if (!(res <= tol) && hn > 0.0) {
+          d.stats->capped_solves += 1;
+          if (res / tol > d.stats->worst_cap_ratio) d.stats->worst_cap_ratio = res / tol;
+        }
+        G->done = 1;
+      }
+    }
+}
+
 // LEAN (the persistent pressure tail, which must stay below 256 registers to be resident at two workgroups per CU): the corner
 // restrictions and the matrix rows are loaded in chunks of three 256-column blocks where they are used instead of all at the
 // top; the same operations in the same order, so both forms return the same bits.
-template <int MAXIT, bool LEAN = false>
+// NOV (round 6, k_schwarz_uc): the pointwise update of v_j is NOT done here (the Schwarz workgroups of the same launch form v_j
+// where they need it); everything else -- column, coarse solve by linearity, history -- as before.
+template <int MAXIT, bool LEAN = false, bool NOV = false>
 __device__ __forceinline__ void update_coarse_body(const Dev& d, int j, double scale, int min_iter, int ord, const unsigned bx_, const unsigned gx_) {
   extern __shared__ double srcv[];            // lda
   __shared__ double sh[MAXMR + 2], scs[MAXMR], ssn[MAXMR], scol[MAXMR + 2], sbc[2];
@@ -1333,9 +1382,11 @@ __device__ __forceinline__ void update_coarse_body(const Dev& d, int j, double s
   // this thread's entry of v_j and of the basis vectors it is orthogonalised against (the first 8; more in the loop below)
   const long long q0 = (long long)bx_ * 256 + tid;
   double vq = 0.0, vk[8];
-  if (j > 0 && q0 < d.npr) vq = d.V[(size_t)j * d.ps + q0];
+  if constexpr (!NOV) {
+    if (j > 0 && q0 < d.npr) vq = d.V[(size_t)j * d.ps + q0];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) vk[k] = (k < j && q0 < d.npr) ? d.V[(size_t)k * d.ps + q0] : 0.0;
+    for (int k = 0; k < 8; ++k) vk[k] = (k < j && q0 < d.npr) ? d.V[(size_t)k * d.ps + q0] : 0.0;
+  }
   if (j > 0) {
     if (tid < jj) { scs[tid] = G->cs[tid]; ssn[tid] = G->sn[tid]; }
     gj = G->gpre[jj];
@@ -1395,48 +1446,7 @@ __device__ __forceinline__ void update_coarse_body(const Dev& d, int j, double s
   } else {
     lds_barrier();
   }
-  if (j > 0 && tid == 0) {                    // one lane rotates the column while the others start on the matrix product
-    double s2 = 0.0;
-    for (int q = 0; q <= jj; ++q) s2 += sh[q] * sh[q];
-    const double hn2 = sh[jj + 1] - s2;
-    const double hn = sqrt(hn2 > 0.0 ? hn2 : 0.0);
-    double* col = scol;
-    for (int q = 0; q <= jj; ++q) col[q] = sh[q];
-    col[jj + 1] = hn;
-    for (int q = 0; q < jj; ++q) {
-      const double t = scs[q] * col[q] + ssn[q] * col[q + 1];
-      col[q + 1] = -ssn[q] * col[q] + scs[q] * col[q + 1];
-      col[q] = t;
-    }
-    const double rho = sqrt(col[jj] * col[jj] + col[jj + 1] * col[jj + 1]);
-    const double cj = (rho > 0.0) ? col[jj] / rho : 1.0, sj = (rho > 0.0) ? col[jj + 1] / rho : 0.0;
-    col[jj] = rho;
-    const double res = fabs(sj * gj) * scale;
-    const double tol = d.tol_relative ? fmax(d.tol_pres * G->gnorm0 * scale, d.tol_pres_floor) : d.tol_pres;
-    const bool conv = (res <= tol && (jj + 1) >= min_iter) || !(hn > 0.0) || (d.pres_cap > 0 && (jj + 1) >= d.pres_cap);
-    sbc[0] = (hn > 0.0) ? 1.0 / hn : 0.0;
-    sbc[1] = conv ? 1.0 : 0.0;
-    if (bx_ == 0) {
-      G->cs[jj] = cj; G->sn[jj] = sj;
-      for (int q = 0; q <= jj; ++q) G->R[jj * MAXMR + q] = col[q];
-      G->g[jj] = cj * gj;
-      G->g[jj + 1] = -sj * gj; G->gpre[jj + 1] = -sj * gj;
-      G->nit = jj + 1;
-      G->resid = res;
-      d.stats->pres_jsum += jj;
-      if (conv) {
-        atomicAdd((unsigned long long*)&d.stats->pres_iters, (unsigned long long)(G->nit_prev + jj + 1));
-        atomicMax((unsigned long long*)&d.stats->max_pres, (unsigned long long)(G->nit_prev + jj + 1));
-        atomicMax((unsigned long long*)&d.stats->max_pres_k[ord], (unsigned long long)(G->nit_prev + jj + 1)); rec_step_iters(d, 1, G->nit_prev + jj + 1);
-        d.stats->last_pres_res = res;
-        if (!(res <= tol) && hn > 0.0) {
-          d.stats->capped_solves += 1;
-          if (res / tol > d.stats->worst_cap_ratio) d.stats->worst_cap_ratio = res / tol;
-        }
-        G->done = 1;
-      }
-    }
-  }
+  if (j > 0 && tid == 0) uc_rotate(d, G, jj, gj, scale, min_iter, ord, bx_ == 0, sh, scs, ssn, scol, sbc);   // one lane rotates the column while the others start on the matrix product
   double sr[UC_ROWS];
 #pragma unroll
   for (int r = 0; r < UC_ROWS; ++r) sr[r] = 0.0;
@@ -1469,6 +1479,7 @@ __device__ __forceinline__ void update_coarse_body(const Dev& d, int j, double s
     lds_barrier();                            // column rotated
     hinv = sbc[0];
     if (sbc[1] != 0.0) return;                // converged: nothing of iteration j is needed
+    if constexpr (!NOV) {
     if (q0 < d.npr) {                         // first entry: operands already in registers
       double x = vq;
 #pragma unroll
@@ -1481,6 +1492,7 @@ __device__ __forceinline__ void update_coarse_body(const Dev& d, int j, double s
 #pragma unroll 4
       for (int k = 0; k < j; ++k) x -= sh[k] * d.V[(size_t)k * d.ps + q];
       d.V[(size_t)j * d.ps + q] = x * hinv;
+    }
     }
   }
 #pragma unroll
@@ -1724,6 +1736,268 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_divgs(Dev d, const double* __res
   divgs_body<N>(d, yl, wout, j, check_done, blockIdx.x, gridDim.x);
 }
 
+
+// ---------------------------------------------------------------------------
+// Round 6: the merged GMRES iteration in TWO launches instead of three (core/matvec.f:216-233 spends its time here).
+//   A_j = k_schwarz_uc (grid = nsw Schwarz workgroups + cgrid coarse workgroups, 256 threads each):
+//         every workgroup sums the dot-product partials of B_{j-1} and closes column j-1 (same arithmetic everywhere);
+//         Schwarz workgroups form  v_j = (w - sum_k h_k v_k) / h_{j,j-1}  ON THE FLY at their patch nodes from the raw w
+//         (Dev::Wr) and the basis, store their own nodes of it to V[j], apply the patch inverses and D^T:  yl = D^T RAS(v_j);
+//         coarse workgroups: x_c(v_j) by linearity as k_update_coarse (update_coarse_body<.., NOV>), next to them.
+//   B_j = k_divgs_t:  w = D B^-1 dssum(yl) + Tc x_c  (the coarse part of z_j through its precomputed image, Dev::Tc),
+//         Z_j += R^T x_c, dots against V_0..j, corner restrictions; raw w -> Dev::Wr.
+// The additive preconditioner is what allows it: Schwarz(v_j) and coarse(v_j) are independent given the column.  Same Krylov
+// method, same h and v_j bits as the three-launch form; w differs from it by rounding (the coarse part is summed separately).
+// ---------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ void uc_schwarz_role(const Dev& d, int j, double scale, int min_iter, int ord, const unsigned bx_, const unsigned gx_) {
+  using C = Cfg<N>;
+  constexpr int NN = C::NN, M = C::M, MM = C::MM, EPB = C::EPB, NM = N * M;
+  constexpr int MAXP = (M + 8) * (M + 8);
+  __shared__ double sJ12[NM], sD12[NM];
+  __shared__ double sP[4 * EPB * MM], sB[4 * EPB * NM];
+  __shared__ double sr[EPB * MAXP];
+  __shared__ double sh[MAXMR + 2], scs[MAXMR], ssn[MAXMR], scol[MAXMR + 2], sbc[2];
+  const int tid = threadIdx.x, el = tid / NN, nd = tid % NN;
+  const int bid = d.boff + (int)xcd_element(bx_, gx_);
+  const long long e = (long long)bid * EPB + el;
+  const bool act = (el < EPB) && (e < d.nel);
+  GmresScal* G = d.gsc;
+  const int PS = d.p_stride;
+  const int jj = j - 1;
+  int i0 = -1, i1 = -1;
+  if (act) {
+    if (nd < PS) i0 = d.p_idx[e * PS + nd];
+    if (nd + NN < PS) i1 = d.p_idx[e * PS + nd + NN];
+  }
+  PartialRows<2> pr;                          // rows w, w + 4 of the partials of B_{j-1} (d.nblk <= 512: the merged range)
+  pr.issue(d.gpart, d.nblk, (j > 0 && d.nblk <= 512) ? jj + 2 : 0, tid);
+  double gj = 0.0;
+  if (j > 0) {
+    if (tid < jj) { scs[tid] = G->cs[tid]; ssn[tid] = G->sn[tid]; }
+    gj = G->gpre[jj];
+  }
+  const bool pact = act && nd < MM;
+  const long long q = e * MM + nd;
+  double m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+  if (pact) { m0 = d.w2rx[q]; m1 = d.w2sx[q]; m2 = d.w2ry[q]; m3 = d.w2sy[q]; }
+  double j12a = 0, d12a = 0;
+  if (tid < NM) { j12a = d.J12[tid]; d12a = d.D12[tid]; }
+  // raw w (j = 0: V[0], normalised by k_gmres_update(-1)) and the basis at this thread's (up to) two patch nodes
+  const double* W = (j > 0) ? d.Wr : d.V;
+  double v0 = (i0 >= 0) ? W[i0] : 0.0, v1 = (i1 >= 0) ? W[i1] : 0.0;
+  double vk0[8], vk1[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    vk0[k] = (k < j && i0 >= 0) ? d.V[(size_t)k * d.ps + i0] : 0.0;
+    vk1[k] = (k < j && i1 >= 0) ? d.V[(size_t)k * d.ps + i1] : 0.0;
+  }
+  if (tid < NM) { sJ12[tid] = j12a; sD12[tid] = d12a; }
+  if (j > 0) {
+    if (d.nblk <= 512) pr.reduce(d.gpart, d.nblk, jj + 2, sh, tid);            // ends with an LDS barrier
+    else sum_partials_multi(d.gpart, d.nblk, jj + 2, sh, tid, 256);
+    if (tid == 0) uc_rotate(d, G, jj, gj, scale, min_iter, ord, false, sh, scs, ssn, scol, sbc);
+    lds_barrier();
+    const double hinv = sbc[0];
+    if (sbc[1] != 0.0) return;                // column j-1 closed the solve
+#pragma unroll
+    for (int k = 0; k < 8; ++k) if (k < j) { v0 -= sh[k] * vk0[k]; v1 -= sh[k] * vk1[k]; }
+    for (int k = 8; k < j; ++k) {
+      if (i0 >= 0) v0 -= sh[k] * d.V[(size_t)k * d.ps + i0];
+      if (i1 >= 0) v1 -= sh[k] * d.V[(size_t)k * d.ps + i1];
+    }
+    v0 *= hinv; v1 *= hinv;
+    if (pact) d.V[(size_t)j * d.ps + q] = v0;  // the first MM patch entries are the element's own nodes (p_idx[e][k] = e MM + k)
+  }
+  if (act) {
+    if (nd < PS) sr[el * MAXP + nd] = v0;
+    if (nd + NN < PS) sr[el * MAXP + nd + NN] = v1;
+  }
+  lds_barrier();
+  if (pact) {
+    const float4* A = reinterpret_cast<const float4*>(d.p_inv + (size_t)e * PS * MM) + nd;
+    const double* r = sr + el * MAXP;
+    double z0 = 0, z1 = 0, z2 = 0, z3 = 0;
+    const int nq = PS / 4;
+#pragma unroll 8
+    for (int k4 = 0; k4 < nq; ++k4) {
+      const float4 a = A[(size_t)k4 * MM];
+      z0 += (double)a.x * r[4 * k4 + 0];
+      z1 += (double)a.y * r[4 * k4 + 1];
+      z2 += (double)a.z * r[4 * k4 + 2];
+      z3 += (double)a.w * r[4 * k4 + 3];
+    }
+    const double z = (z0 + z1) + (z2 + z3);  // the Schwarz part of z_j; B_j adds R^T x_c
+    d.Z[(size_t)j * d.npr + q] = z;
+    sP[(0 * EPB + el) * MM + nd] = z * m0;
+    sP[(1 * EPB + el) * MM + nd] = z * m1;
+    sP[(2 * EPB + el) * MM + nd] = z * m2;
+    sP[(3 * EPB + el) * MM + nd] = z * m3;
+  }
+  lds_barrier();
+  double gx, gy;
+  opgradt_tiles<N, EPB>(sJ12, sD12, sP, sB, act, el, nd, gx, gy);
+  if (act) {
+    const long long l = e * NN + nd;
+    d.yl[l] = gx;
+    d.yl[d.cs + l] = gy;
+  }
+}
+// three workgroups per CU (12 wavefronts): nsw + cgrid = 762 workgroups on config 2 are resident at once on 256 CUs
+template <int N, int MAXIT>
+__global__ __launch_bounds__(256, 3) void k_schwarz_uc(Dev d, int j, double scale, int min_iter, int ord, unsigned nsw, unsigned cgrid) {
+  if (d.gsc->done) return;
+  if (blockIdx.x < nsw) uc_schwarz_role<N>(d, j, scale, min_iter, ord, blockIdx.x, nsw);
+  else update_coarse_body<MAXIT, true, true>(d, j, scale, min_iter, ord, blockIdx.x - nsw, cgrid);
+}
+
+// B_j: see above.  TPRE columns of Tc and VPRE basis vectors live in registers (loads issued with the first trip).
+template <int N, int TPRE = 20, int VPRE = 8>
+__device__ __forceinline__ void divgs_t_body(const Dev& d, int j, const unsigned bx_, const unsigned gx_) {
+  using C = Cfg<N>;
+  constexpr int NN = C::NN, M = C::M, MM = C::MM, EPB = C::EPB, NM = N * M;
+  constexpr int NVLMAX = 32;
+  __shared__ double sJ12[NM], sD12[NM];
+  __shared__ double su[2 * EPB * NN], sA[4 * EPB * NM];
+  __shared__ double sdot[(MAXMR + 2) * 4];
+  __shared__ double swr[EPB * MM], shat[4 * MM], sxc[EPB * NVLMAX];
+  const int tid = threadIdx.x, el = tid / NN, nd = tid % NN;
+  const int bid = d.boff + (int)xcd_element(bx_, gx_);
+  const long long e = (long long)bid * EPB + el;
+  const bool act = (el < EPB) && (e < d.nel);
+  if (d.gsc->done) return;
+  const long long l = e * NN + nd;
+  const bool pact = act && nd < MM;
+  const long long q = e * MM + nd;
+  const int nvl = d.nvl;
+  // ---- first trip: everything addressable from the thread index
+  int4 tab = make_int4(0, -1, -1, -1);
+  double bi = 0;
+  if (act) { tab = d.gs_tab[l]; bi = d.binv[l]; }
+  int ecs = 0;
+  if (act && nd < 4) ecs = d.ecslot[e * 4 + nd];
+  int iv = 0;
+  if (act && nd < nvl) iv = d.evl[e * nvl + nd];
+  int4 ev = make_int4(0, 0, 0, 0);
+  double mw0 = 0, mw1 = 0, mw2 = 0, mw3 = 0, zq = 0, h0 = 0, h1 = 0, h2 = 0, h3 = 0;
+  double tt[TPRE], vk[VPRE];
+  if (pact) {
+    ev = reinterpret_cast<const int4*>(d.evert)[e];
+    mw0 = d.w2rx[q]; mw1 = d.w2sx[q]; mw2 = d.w2ry[q]; mw3 = d.w2sy[q];
+    zq = d.Z[(size_t)j * d.npr + q];
+    h0 = d.hat[0 * MM + nd]; h1 = d.hat[1 * MM + nd]; h2 = d.hat[2 * MM + nd]; h3 = d.hat[3 * MM + nd];
+  }
+  {
+    const double* T = d.Tc + ((size_t)(act ? e : 0) * nvl) * MM + (nd < MM ? nd : 0);
+#pragma unroll
+    for (int s = 0; s < TPRE; ++s) tt[s] = (pact && s < nvl) ? T[(size_t)s * MM] : 0.0;
+  }
+#pragma unroll
+  for (int k = 0; k < VPRE; ++k) vk[k] = (pact && k <= j) ? d.V[(size_t)k * d.ps + q] : 0.0;
+  double j12a = 0, d12a = 0;
+  if (tid < NM) { j12a = d.J12[tid]; d12a = d.D12[tid]; }
+  double hatv[(4 * MM + 255) / 256];
+#pragma unroll
+  for (int r = 0; r < (4 * MM + 255) / 256; ++r) hatv[r] = (tid + r * 256 < 4 * MM) ? d.hat[tid + r * 256] : 0.0;
+  // ---- second trip: the neighbours' values of yl, the coarse solution at this element's vertices
+  GsVals g0, g1;
+  if (act) { g0 = gs_load(d.yl, tab, l); g1 = gs_load(d.yl + d.cs, tab, l); }
+  double xcv = 0.0, x0 = 0, x1 = 0, x2 = 0, x3 = 0;
+  if (act && nd < nvl) xcv = d.xc[iv];
+  if (pact) { x0 = d.xc[ev.x]; x1 = d.xc[ev.y]; x2 = d.xc[ev.z]; x3 = d.xc[ev.w]; }
+  if (tid < NM) { sJ12[tid] = j12a; sD12[tid] = d12a; }
+#pragma unroll
+  for (int r = 0; r < (4 * MM + 255) / 256; ++r) if (tid + r * 256 < 4 * MM) shat[tid + r * 256] = hatv[r];
+  if (act) {
+    su[(0 * EPB + el) * NN + nd] = bi * gs_sum(g0, d.yl, d, tab, l);
+    su[(1 * EPB + el) * NN + nd] = bi * gs_sum(g1, d.yl + d.cs, d, tab, l);
+    if (nd < nvl) sxc[el * NVLMAX + nd] = xcv;
+  }
+  lds_barrier();
+  // weak divergence (opdiv_tiles with the metrics already in registers)
+  if (act && nd < NM) {
+    const int jr = nd / M, a = nd % M;
+    const double* u = su + (0 * EPB + el) * NN + jr * N;
+    const double* v = su + (1 * EPB + el) * NN + jr * N;
+    double a1u = 0, a2u = 0, a1v = 0, a2v = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const double dd = sD12[a * N + i], jv = sJ12[a * N + i];
+      a1u += dd * u[i]; a2u += jv * u[i];
+      a1v += dd * v[i]; a2v += jv * v[i];
+    }
+    sA[(0 * EPB + el) * NM + nd] = a1u;
+    sA[(1 * EPB + el) * NM + nd] = a2u;
+    sA[(2 * EPB + el) * NM + nd] = a1v;
+    sA[(3 * EPB + el) * NM + nd] = a2v;
+  }
+  tile_barrier<N * N>();
+  double w = 0.0;
+  if (pact) {
+    const int b = nd / M, a = nd % M;
+    double ur = 0, us = 0, vr = 0, vs = 0;
+#pragma unroll
+    for (int jr = 0; jr < N; ++jr) {
+      const double jv = sJ12[b * N + jr], dd = sD12[b * N + jr];
+      ur += jv * sA[(0 * EPB + el) * NM + jr * M + a];
+      us += dd * sA[(1 * EPB + el) * NM + jr * M + a];
+      vr += jv * sA[(2 * EPB + el) * NM + jr * M + a];
+      vs += dd * sA[(3 * EPB + el) * NM + jr * M + a];
+    }
+    w = mw0 * ur + mw1 * us + mw2 * vr + mw3 * vs;
+    // + E R^T x_c through its precomputed image
+    const double* xl = sxc + el * NVLMAX;
+    double wc = 0.0;
+#pragma unroll
+    for (int s = 0; s < TPRE; ++s) if (s < nvl) wc += tt[s] * xl[s];
+    for (int s = TPRE; s < nvl; ++s) wc += d.Tc[((size_t)e * nvl + s) * MM + nd] * xl[s];
+    w += wc;
+    d.Wr[q] = w;
+    d.Z[(size_t)j * d.npr + q] = zq + (h0 * x0 + h1 * x1 + h2 * x2 + h3 * x3);
+    swr[el * MM + nd] = w;
+  }
+  lds_barrier();
+  if (act && nd < 4) {                 // element-corner restriction of the raw w (the coarse workgroups of A_{j+1} read it)
+    double s = 0.0;
+#pragma unroll 6
+    for (int k = 0; k < MM; ++k) s += shat[nd * MM + k] * swr[el * MM + k];
+    d.ec[e * 4 + nd] = s;
+    d.ecv[ecs] = s;
+  }
+  {
+    const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+    for (int k = 0; k < VPRE; ++k) {
+      if (k <= j) {
+        double x = pact ? w * vk[k] : 0.0;
+        x = wave_sum63(x);
+        if (lane == 63) sdot[k * 4 + wv] = x;
+      }
+    }
+#pragma unroll 4
+    for (int k = VPRE; k <= j; ++k) {
+      double x = pact ? w * d.V[(size_t)k * d.ps + q] : 0.0;
+      x = wave_sum63(x);
+      if (lane == 63) sdot[k * 4 + wv] = x;
+    }
+    {
+      double x = pact ? w * w : 0.0;
+      x = wave_sum63(x);
+      if (lane == 63) sdot[(j + 1) * 4 + wv] = x;
+    }
+    lds_barrier();
+    if (tid <= j + 1) {
+      double t = 0.0;
+#pragma unroll
+      for (int ww = 0; ww < 4; ++ww) t += sdot[tid * 4 + ww];
+      d.gpart[(size_t)tid * d.nblk + bid] = t;
+    }
+  }
+}
+template <int N>
+__global__ __launch_bounds__(256, 2) void k_divgs_t(Dev d, int j) {
+  divgs_t_body<N>(d, j, blockIdx.x, gridDim.x);
+}
 
 // after GMRES: dp = h2 * sum_i y_i Z_i (+ projected part) ; p = p* + dp ; yl = D^T dp
 template <int N>

@@ -455,5 +455,37 @@ __global__ __launch_bounds__(Cfg<N>::NT, 2) void k_pres_tail(Dev d, int j0, int 
   if (!ok && tid == 0) atomicAdd((unsigned long long*)&d.stats->sync_timeouts, 1ull);
 }
 
+// The same for the two-launch form of round 6 (k_schwarz_uc, k_divgs_t): iterations j0 .. j1-1 as
+//   [A_j: coarse role on workgroups < cgrid, then the Schwarz role on all]  barrier  [B_j]  barrier
+// two grid barriers per iteration instead of three.  skip_a: A_{j0} has been LAUNCHED in front of this kernel (it closes column
+// j0-1: a solve of exactly j0 iterations ends there).  256 threads per workgroup whatever lx1 (the coarse role is written for
+// four wavefronts); the coarse role loops over cgrid, so grids smaller than cgrid are covered too.
+template <int N, int MAXIT>
+__global__ __launch_bounds__(256, 2) void k_pres_tail2(Dev d, int j0, int j1, double scale, int min_iter, int ord, unsigned cgrid, int skip_a, unsigned* sync, unsigned* sync_other) {
+  __shared__ int s_fail;
+  const int tid = threadIdx.x;
+  if (tid == 0) s_fail = 0;
+  zero_sync(sync_other, tid, 256);
+  __syncthreads();
+  if (d.stats->sync_timeouts != 0) return;       // an earlier tail of this map timed out: the map is redone with launch budgets anyway
+  unsigned epoch = 1;
+  bool ok = true;
+  for (int j = j0; j < j1 && ok; ++j) {
+    if (__hip_atomic_load(&d.gsc->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+    if (!(skip_a && j == j0)) {
+      for (unsigned bx = blockIdx.x; bx < cgrid; bx += gridDim.x) {
+        update_coarse_body<MAXIT, true, true>(d, j, scale, min_iter, ord, bx, cgrid);
+        __syncthreads();                         // (its LDS is reused by the next pass / the Schwarz role)
+      }
+      uc_schwarz_role<N>(d, j, scale, min_iter, ord, blockIdx.x, gridDim.x);
+      ok = grid_barrier(sync, epoch++, (int)gridDim.x, &s_fail);
+      if (!ok || __hip_atomic_load(&d.gsc->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;      // column j-1 closed the solve
+    }
+    divgs_t_body<N, 4, 2>(d, j, blockIdx.x, gridDim.x);     // (register-lean: same sums in the same order)
+    ok = grid_barrier(sync, epoch++, (int)gridDim.x, &s_fail);
+  }
+  if (!ok && tid == 0) atomicAdd((unsigned long long*)&d.stats->sync_timeouts, 1ull);
+}
+
 }  // namespace k2
 }  // namespace nsk

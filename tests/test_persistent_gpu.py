@@ -77,8 +77,10 @@ def test_fused_full_map_vs_oracle_lx1_8():
     h.close()
 
 
-def test_persistent_tails_are_bit_identical_to_launch_budgets():
-    """Round 5: persistent tails (k_helm_tail, k_pres_tail: the same kernel bodies in a loop with grid barriers) against the
+@pytest.mark.parametrize("fuse2", [1, 0])
+def test_persistent_tails_are_bit_identical_to_launch_budgets(fuse2):
+    """(fuse2 = 1: the two-launch GMRES iteration of round 6 and its tail k_pres_tail2; 0: the three launches and k_pres_tail.)
+    Round 5: persistent tails (k_helm_tail, k_pres_tail: the same kernel bodies in a loop with grid barriers) against the
     launch-budget form on config 2's mesh: identical Hessenberg matrix and vectors, bit for bit -- heads = median counts, heads
     pushed far below the iteration counts so that the tails do most of the iterations, and the default (budgets with the tail as a
     safety net); no barrier time-out, no redone map."""
@@ -93,6 +95,7 @@ def test_persistent_tails_are_bit_identical_to_launch_budgets():
 
     def run(tail, off_h=0, off_p=0):
         h = production_context(case)
+        h.set_option("fuse2", fuse2)
         h.set_option("tail", tail)
         h.set_option("tail_off_h", off_h)
         h.set_option("tail_off_p", off_p)
@@ -108,7 +111,7 @@ def test_persistent_tails_are_bit_identical_to_launch_budgets():
         return H, last, st, hh.copy(), pp.copy()
     H0, v0, s0, h0, p0 = run(0)
     assert s0["tail_maps"] == 0
-    for mode, off in ((1, (0, 0)), (1, (-6, -3)), (2, (0, 0)), (-1, (0, 0))):       # median heads; heads far below the counts; safety net; the default
+    for mode, off in (((1, (0, 0)), (1, (-6, -3)), (2, (0, 0)), (-1, (0, 0))) if fuse2 else ((1, (-6, -3)), (-1, (0, 0)))):       # median heads; heads far below the counts; safety net; the default
         H1, v1, s1, h1, p1 = run(mode, *off)
         print("tail maps", s1["tail_maps"], "heads per step %.2f / %.2f" % (s1["step_budget_helm_mean"], s1["step_budget_pres_mean"]), "retries", s1["retries"],
               "iterations per step %.3f / %.3f" % (s1["total_helm_iters"] / s1["total_steps"], s1["total_pres_iters"] / s1["total_steps"]))
