@@ -61,6 +61,7 @@ def parse():
     ap.add_argument("--nproj", type=int, default=PRODUCTION["nproj"], help="pressure projection space (residualProj)")
     ap.add_argument("--fused", type=int, default=-1, help="persistent velocity solve: 1 / 0 / -1 = library default")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = all host cores)")
+    ap.add_argument("--ref-logfile", default=None, help="a logfile of a nekStab run of the same case (its 'Time per iteration' lines, core/krylov_decomposition.f:92-98, and Nek5000's step lines): the record gains `reference_logfile` with the reference's own matvecs/s")
     return ap.parse_args()
 
 
@@ -195,6 +196,50 @@ def cpu_baseline(case, threads, tol, nproj, gpu_value, q_sample=None):
                                          "note": "the algorithm rounds 1-4 reported as cpu_baseline (their C port had no projection space)"},
             "config1_k32_4threads": {"matvecs_per_s": c4["matvecs_per_s"], "threads": c4["threads"],
                                      "wall_time_k32_s_projected": c4["s_per_matvec"] * 32, "sample": c4["sample"]}}
+
+
+def parse_reference_logfile(path):
+    """A true reference number, when somebody has one: the per-iteration timing a nekStab run prints (the only route to it here:
+    Nek5000 is not vendored in the reference tree).  arnoldi_factorization writes, per Arnoldi step,
+        ' iteration current and total:  <mstep> / <mend>'                                   (core/krylov_decomposition.f:75)
+        ' Time per iteration/remaining:  0h  1min /  0h 14min'                              (core/krylov_decomposition.f:92-98)
+    -- whole minutes, ROUNDED UP (ceiling) -- and Nek5000 writes one line per time step in between,
+        'Step    100, t= 1.0000000E+00, DT= 1.0000000E-02, C=  0.494 2.2841E+00 2.1910E-02'     (elapsed seconds, seconds of the step)
+    When the step lines are there, an iteration's wall time is the sum of its steps' seconds (exact); otherwise the minute lines
+    give an upper bound of the time = a lower bound of matvecs/s.  Returns a dict for the record."""
+    import re
+    it_re = re.compile(r"iteration current and total:\s*(\d+)\s*/\s*(\d+)")
+    tm_re = re.compile(r"Time per iteration/remaining:\s*(\d+)h\s*(\d+)min")
+    st_re = re.compile(r"^\s*Step\s+(\d+),\s*t=\s*([-+0-9.eEdD]+),\s*DT=\s*([-+0-9.eEdD]+),\s*C=\s*([-+0-9.eEdD]+)\s+([-+0-9.eEdD]+)\s+([-+0-9.eEdD]+)")
+    iters, cur = [], None
+    with open(path, errors="replace") as fh:
+        for line in fh:
+            m = it_re.search(line)
+            if m:
+                cur = {"mstep": int(m.group(1)), "mend": int(m.group(2)), "step_s": 0.0, "steps": 0, "minutes": None}
+                iters.append(cur)
+                continue
+            if cur is None:
+                continue
+            m = st_re.match(line)
+            if m and cur["minutes"] is None:
+                cur["step_s"] += float(m.group(6).replace("D", "E").replace("d", "e")); cur["steps"] += 1
+                continue
+            m = tm_re.search(line)
+            if m:
+                cur["minutes"] = 60 * int(m.group(1)) + int(m.group(2))
+    done = [i for i in iters if i["minutes"] is not None]
+    if not done:
+        return {"path": path, "error": "no completed Arnoldi iteration ('Time per iteration/remaining:' line) found"}
+    out = {"path": path, "iterations": len(done), "k_dim": done[-1]["mend"], "time_steps_per_iteration": float(sum(i["steps"] for i in done)) / len(done)}
+    if all(i["steps"] > 0 for i in done):
+        t = sum(i["step_s"] for i in done) / len(done)
+        out.update({"s_per_iteration": t, "matvecs_per_s": 1.0 / t, "resolution": "exact: the seconds Nek5000 prints per time step, summed over the steps of an Arnoldi iteration"})
+    else:
+        t = 60.0 * sum(i["minutes"] for i in done) / len(done)
+        out.update({"s_per_iteration_upper_bound": t, "matvecs_per_s_lower_bound": (1.0 / t) if t > 0 else None,
+                    "resolution": "whole minutes rounded up ('Time per iteration' lines only: core/krylov_decomposition.f:92-98): an upper bound of the time"})
+    return out
 
 
 def fortran_host_leg(case, seed_state, a, steps, py_value):
@@ -596,12 +641,22 @@ def main():
     _printed = {"done": False}
 
     def emit():
-        """print THE one JSON line, once"""
+        """print THE one JSON line, once.  The watchdog thread may call this while the main thread is adding a field: serialise
+        first (retrying while the dictionary changes), and only a printed line counts as done."""
         with _plock:
             if _printed["done"] or rank != 0:
                 return
+            line = None
+            for _ in range(50):
+                try:
+                    line = json.dumps(dict(out))
+                    break
+                except RuntimeError:                           # dictionary changed size during iteration
+                    time.sleep(0.02)
+            if line is None:                                    # the record proper (scalars and the small dictionaries of the timed region)
+                line = json.dumps({k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data") if k in out})
+            print(line, flush=True)
             _printed["done"] = True
-            print(json.dumps(out), flush=True)
 
     def guarded(field, fn):
         """run an optional section; its failure is a field of the record, never the end of the run"""
@@ -614,6 +669,15 @@ def main():
             out[field] = {"error": repr(e)[:300]}
             print("[bench] section %s failed: %r" % (field, e), file=sys.stderr, flush=True)
         print("[bench] section %s: %.1f s" % (field, time.perf_counter() - t_sec), file=sys.stderr, flush=True)
+
+    if a.ref_logfile:
+        def sec_reflog():
+            r = parse_reference_logfile(a.ref_logfile)
+            ref = r.get("matvecs_per_s") or r.get("matvecs_per_s_lower_bound")
+            if ref:
+                r["gpu_over_reference"] = out["value"] / ref
+            out["reference_logfile"] = r
+        guarded("reference_logfile", sec_reflog)
 
     opt_wd = None
     if world == 1:

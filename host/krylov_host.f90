@@ -229,15 +229,16 @@ contains
     mstart = 1; schur_cnt = 0; matvecs = 0; converged = .false.
     if (present(restart_from) .and. present(geom) .and. present(outdir)) then
       if (restart_from > 0) then                                                 ! :284-325
-        if (restart_from > k_dim) then      ! (the reference's k_dim < mstart branch, :295-301, re-reads a sub-sampled HES file: not built here)
-          write(*,*) 'krylov_schur: restart_from = ', restart_from, ' exceeds k_dim = ', k_dim, ': restart with k_dim >= the checkpointed step'; stop 1
-        endif
         call load_checkpoint(ctx, geom, Q, H, restart_from, k_dim, outdir, okr)
         if (.not. okr) then
           write(*,*) 'krylov_schur: no usable checkpoint of step ', restart_from, ' in ', trim(outdir); stop 1
         endif
-        mstart = restart_from + 1
-        write(*,'(a,i0)') ' restarted from the checkpoint of Arnoldi step ', restart_from
+        mstart = min(restart_from, k_dim) + 1
+        if (restart_from > k_dim) then       ! the reference's k_dim < mstart branch (core/eigensolvers.f:295-301): sub-sampled Hessenberg matrix
+          write(*,'(a,i0,a,i0,a)') ' restarted from the checkpoint of Arnoldi step ', restart_from, ', sub-sampled to k_dim = ', k_dim, ' (leading block of H, first k_dim+1 vectors)'
+        else
+          write(*,'(a,i0)') ' restarted from the checkpoint of Arnoldi step ', restart_from
+        endif
       endif
     endif
     do while (.not. converged)                                                   ! :335-373

@@ -293,13 +293,15 @@ contains
     read(u, *, iostat=ios) hm
     close(u)
     if (ios /= 0) return
+    ! mstart > ksize ("subsampling", core/eigensolvers.f:295-301): the leading (ksize+1) x ksize block of the checkpointed
+    ! factorisation and its first ksize+1 vectors -- a leading part of an Arnoldi factorisation is an Arnoldi factorisation
     H = 0.0d0
-    do i = 1, mstart + 1
-      do j = 1, mstart
+    do i = 1, min(mstart, ksize) + 1
+      do j = 1, min(mstart, ksize)
         H(i, j) = hm((i - 1) * mstart + j)
       enddo
     enddo
-    do i = 1, mstart + 1
+    do i = 1, min(mstart, ksize) + 1
       call state_read(ctx, g, Q(i), trim(indir)//'/'//trim(kry_name(g, i)), ok)
       if (.not. ok) return
     enddo

