@@ -61,6 +61,7 @@ def parse():
     ap.add_argument("--nproj", type=int, default=PRODUCTION["nproj"], help="pressure projection space (residualProj)")
     ap.add_argument("--fused", type=int, default=-1, help="persistent velocity solve: 1 / 0 / -1 = library default")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = all host cores)")
+    ap.add_argument("--cpu-baseline-child", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--ref-logfile", default=None, help="a logfile of a nekStab run of the same case (its 'Time per iteration' lines, core/krylov_decomposition.f:92-98, and Nek5000's step lines): the record gains `reference_logfile` with the reference's own matvecs/s")
     return ap.parse_args()
 
@@ -118,7 +119,48 @@ def supervise(a):
     return rc or 1
 
 
-def cpu_baseline(case, threads, tol, nproj, gpu_value, q_sample=None):
+def cpu_baseline(case, threads, tol, nproj, gpu_value, q_sample=None, lx1=None):
+    """The CPU baseline in a CHILD process with the OpenMP environment a CPU run would use (libgomp reads it when it is loaded):
+    threads bound to cores, close to each other, spinning between the (many, short) parallel regions -- measured on the GPU box's
+    256-core host (profiles/r06_cpu_scaling_v0.txt: ms per time step at 8 / 16 / 32 / 64 threads): 32.6 / 30.6 / 30.0 / 44.8 with
+    the passive, unbound settings rounds 2-5 timed, 18.7 / 12.7 / 13.0 / 35.2 with OMP_WAIT_POLICY=active OMP_PROC_BIND=close
+    OMP_PLACES=cores.  The child never touches the GPU; the Krylov vector of the sample travels in a temporary .npz."""
+    import tempfile
+    import numpy as np
+    with tempfile.TemporaryDirectory() as td:
+        f = os.path.join(td, "q.npz")
+        if q_sample is not None:
+            np.savez(f, *[np.asarray(x, dtype=np.float64) for x in q_sample])
+        env = dict(os.environ, OMP_WAIT_POLICY="active", OMP_PROC_BIND="close", OMP_PLACES="cores", GOMP_SPINCOUNT="infinite")
+        env.pop("OMP_NUM_THREADS", None)
+        try:
+            visible = len(os.sched_getaffinity(0))
+        except AttributeError:
+            visible = os.cpu_count() or 1
+        spec = json.dumps({"visible": visible, "lx1": lx1 or case.lx1, "threads": threads, "tol": list(tol), "nproj": nproj, "gpu_value": gpu_value, "q": f if q_sample is not None else None})
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", spec], env=env, capture_output=True, text=True, timeout=900)
+        sys.stderr.write(r.stderr[-4000:])
+        line = [l for l in r.stdout.splitlines() if l.startswith("CPU_BASELINE ")]
+        if r.returncode != 0 or not line:
+            raise RuntimeError("CPU baseline child failed (rc %d): %s" % (r.returncode, (r.stderr or r.stdout)[-300:]))
+        out = json.loads(line[-1][len("CPU_BASELINE "):])
+        out["openmp_environment"] = {k: env[k] for k in ("OMP_WAIT_POLICY", "OMP_PROC_BIND", "OMP_PLACES")}
+        return out
+
+
+def _cpu_baseline_child(spec):
+    sp = json.loads(spec)
+    import numpy as np
+    case = build_case("cfg2", sp["lx1"] if sp["lx1"] != 8 else None)
+    q = None
+    if sp["q"]:
+        z = np.load(sp["q"])
+        q = tuple(z[k] for k in z.files)
+    out = _cpu_baseline_impl(case, sp["threads"], tuple(sp["tol"]), sp["nproj"], sp["gpu_value"], q, visible=sp.get("visible"))
+    print("CPU_BASELINE " + json.dumps(out), flush=True)
+
+
+def _cpu_baseline_impl(case, threads, tol, nproj, gpu_value, q_sample=None, visible=None):
     """The CPU port of the same step (oracle/cpu_step.c: C + OpenMP, the same PCG / GMRES + Schwarz + coarse algorithms,
     tolerances AND pressure projection space as the GPU path) timed on the host cores of the GPU box.  Thread count: the
     fastest of {8, 16, 32, 64} (capped at the visible cores) on a short calibration.  Bounded samples (about 25 s of CPU work
@@ -132,7 +174,6 @@ def cpu_baseline(case, threads, tol, nproj, gpu_value, q_sample=None):
     from oracle.cpu_port import CpuPort
     from oracle.linns import LinNS2D
     log = lambda *x: print("[bench cpu_baseline]", *x, file=sys.stderr, flush=True)
-    os.environ.setdefault("OMP_WAIT_POLICY", "passive")
     t0 = time.perf_counter()
     o = LinNS2D(x=case.x, y=case.y, gid=case.gid, nglob=case.nglob, mask=case.mask, ub=case.ub, spng=case.spng, re=case.re,
                 endtime=case.endtime, lxd=case.lxd, has_outflow=case.has_outflow, factorize_pressure=False)
@@ -147,14 +188,16 @@ def cpu_baseline(case, threads, tol, nproj, gpu_value, q_sample=None):
         qx, qy = seed.add_noise(case)
         q0 = (qx, qy, np.zeros((case.nel, case.lx1 - 2, case.lx1 - 2)))
         what_vec = "noise-seed vector"
-    try:
-        visible = len(os.sched_getaffinity(0))
-    except AttributeError:
-        visible = os.cpu_count() or 1
+    if visible is None:                                     # (with OMP_PROC_BIND libgomp pins the main thread: the parent counts the cores)
+        try:
+            visible = len(os.sched_getaffinity(0))
+        except AttributeError:
+            visible = os.cpu_count() or 1
     # candidates in ascending order, at most 64 threads: this problem has 128 k points per field, and with one thread per
     # visible core of a 256-core host a time step takes 67 s instead of 35 ms (measured in round 2)
     cands = [threads] if threads else sorted({min(visible, 8), min(visible, 16), min(visible, 32), min(visible, 64)})
     best = None
+    calib = {}
     for nt in cands:                                        # calibration: one time step, then three more unless it is already hopeless
         cp.set_threads(nt)
         cp.proj_reset()
@@ -164,6 +207,7 @@ def cpu_baseline(case, threads, tol, nproj, gpu_value, q_sample=None):
             continue
         t0 = time.perf_counter(); cp.matvec(q0, nsteps=4); t = (time.perf_counter() - t0) / 4
         log("calibration: %d threads %.1f ms per time step" % (nt, 1e3 * t))
+        calib[str(nt)] = 1e3 * t
         if best is None or t < best[1]:
             best = (nt, t)
 
@@ -184,7 +228,12 @@ def cpu_baseline(case, threads, tol, nproj, gpu_value, q_sample=None):
     b = sample(cp0, best[0], best[1], 6.0)
     n4 = min(4, visible)
     c4 = sample(cp, n4, best[1] * best[0] / n4, 6.0)
-    return {"value": a["matvecs_per_s"], "unit": "matvecs/s", "cores": a["threads"], "kind": "port",
+    return {"value": a["matvecs_per_s"], "unit": "matvecs/s", "cores": a["threads"], "cores_used": a["threads"], "cores_visible": visible, "kind": "port",
+            "thread_calibration_ms_per_time_step": calib,
+            "thread_scaling_note": "fastest thread count of the calibration; beyond ~32 threads the port slows down again: a time step of this case is ~250 OpenMP "
+                                   "parallel regions of 127 744 points (two Helmholtz components solved one after the other, modified Gram-Schmidt with two regions "
+                                   "per basis vector), i.e. ~40 us of work per region at 16 threads against a fork-join cost that grows with the team and crosses "
+                                   "the socket's CCX / NUMA boundaries: profiles/r06_cpu_scaling_v0.txt (same table with and without binding)",
             "sample": ("%s of the same case (lx1=%d, E=%d), " + what_vec + "; oracle/cpu_step.c (C + OpenMP: Jacobi-PCG, GMRES + restricted Schwarz + vertex coarse "
                        "solve, tolerances %g / %g and a %d-vector pressure projection space as the GPU run); the Krylov projection (0.2 %% of a GPU step) is not in the sample; "
                        "%d cores visible; set-up %.0f s excluded") % (a["sample"], case.lx1, case.nel, tol[0], tol[1], nproj, visible, setup),
@@ -370,6 +419,8 @@ def build_case(name, lx1_override=None):
 
 def main():
     a = parse()
+    if a.cpu_baseline_child:
+        return _cpu_baseline_child(a.cpu_baseline_child)
     if a.gpus > 1 and os.environ.get("NSK_BENCH_WORKER") != "1":
         raise SystemExit(supervise(a))
     rank = int(os.environ.get("RANK", "0"))
@@ -732,7 +783,7 @@ def main():
                                            "last_step_class": {"helm": st["budget_helm"], "pres": st["budget_pres"]},
                                            "note": "launches per time step in the captured graphs: budgets = largest count of the step and its neighbours over the last 8 maps + head-room, a launch beyond a solve's own count returning on a device flag; persistent_tail_maps > 0: one persistent launch per solve behind them runs whatever a solve still needs, so no budget overflows and no map is redone (default where the grid is resident: safety net, head-room 1 / 0; option tail = 1: the numbers are HEADS = median counts and the tail does the rest; nsk_persist.hpp)"}})
             # ---- SURVEY 8(d) accounting: algorithmic bytes per matvec from the logged iteration counts
-            geom = dict(nel=case.nel, lx1=case.lx1, ndim=2, nvert=int(case.meta["nvert"]), coarse_lda=((int(case.meta["nvert"]) + 255) // 256) * 256,
+            geom = dict(nel=case.nel, lx1=case.lx1, ndim=2, nvert=int(case.meta["nvert"]), coarse_lda=(lambda nv: ((nv + 767) // 768) * 768 if ((nv + 767) // 768) * 768 <= 3072 else ((nv + 255) // 256) * 256)(int(case.meta["nvert"])),
                         patch_stride=(((case.lx1 - 2 + 4) ** 2 + 3) // 4) * 4, nproj=a.nproj)
             if hexa:
                 geom = dict(nel=case.nel, lx1=case.lx1, ndim=3, nvert=int(case.meta["nvert"]), nproj=a.nproj, zero_arrays=int(full.stats().get("zero_arrays", 0)))

@@ -146,6 +146,8 @@ struct nsk_ctx {
   std::vector<nsk_ctx*> graph_members;  // sharded step graphs (held by the first rank of a process): the ranks they were captured for
   int merged_iters = 24;                // ... for the first merged_iters iterations of a solve (see pres_solve_launch; 12 until round 4: 24 covers the tightened solves of time steps 1-3 too, +2 % on config 2 at identical iteration counts)
   int merged_update = 1;                // GMRES column bookkeeping inside the coarse-solve kernel (k_update_coarse)
+  int tc32 = 0;                         // k_divgs_t: the fp32 copy of the coarse image (0 = never (default: it moves a map by 2e-8 for 0.6 us per iteration), 1 = always, -1 = where the solve's relative tolerance is >= 1e-5; option "tc32", NSK_TC32)
+  int fuse2_start = 1;                  // ... and the solve's start inside its first launch (k_proj_apply_e; no k_gmres_update(-1) launch); option "fuse2_start", NSK_FUSE2_START
   int fuse2 = 1;                        // round 6: the merged iteration in TWO launches (k_schwarz_uc, k_divgs_t; option "fuse2", NSK_FUSE2); 0 = the three launches of rounds 3-5
   double* kacc = nullptr;               // nsk_orth: coefficients accumulated over the two passes + the squared norm (device)
   bool released = false;                // nsk_shard_release_parent: only the arrays shards share are left on the device
@@ -759,7 +761,11 @@ static int build(nsk_ctx* c, const nsk_case& cs) {
             Ac[(size_t)evert[a * 4 + cc] * nvert + evert[b * 4 + c2]] += t;
           }
       }
-    const int lda = ((nvert + 255) / 256) * 256;
+    // leading dimension of the dense coarse inverse: a multiple of 768 (= three 256-column blocks) where the in-LDS coarse solve
+    // runs (lda <= 3072), so that the number of column blocks is one of the COMPILE-TIME sizes 3 / 6 / 9 / 12 of k_schwarz_uc's
+    // coarse role (run-time loop bounds cost that kernel 70 registers and its load batching: round 6); zero padded
+    int lda = ((nvert + 255) / 256) * 256;
+    if (((nvert + 767) / 768) * 768 <= 3072) lda = ((nvert + 767) / 768) * 768;
     d.coarse_lda = lda; c->coarse_lda = lda;
     if (lda > 3072 && (rc = dalloc(c, &c->rc_big, lda))) return rc;
     if (lda <= 3072 && (rc = dalloc(c, &d.rch, (size_t)MAXMR * lda))) return rc;     // restriction history (k_update_coarse)
@@ -805,8 +811,8 @@ static int build(nsk_ctx* c, const nsk_case& cs) {
       v.erase(std::unique(v.begin(), v.end()), v.end());
       nvl = std::max(nvl, (int)v.size());
     }
-    nvl = ((nvl + 3) / 4) * 4;
-    if (nvl <= 32 && nvl <= NN) {
+    if (nvl <= nsk::k2::UC_NVL && nsk::k2::UC_NVL <= NN) {          // (k_divgs_t holds exactly nsk::k2::UC_NVL = 20 columns in registers: vertices of valence > 5 take the three-launch form)
+      nvl = nsk::k2::UC_NVL;
       std::vector<int> evl((size_t)nel * nvl, 0);
       std::vector<double> Tc((size_t)nel * nvl * MM, 0.0);
       const int nth = std::max(1, std::min<int>(16, (int)std::thread::hardware_concurrency()));
@@ -834,7 +840,8 @@ static int build(nsk_ctx* c, const nsk_case& cs) {
       }
       for (int a = 0; a < nel; ++a) for (size_t k = 0; k < vl[a].size(); ++k) evl[(size_t)a * nvl + k] = vl[a][k];
       d.nvl = nvl;
-      if ((rc = dupload(c, &d.evl, evl)) || (rc = dupload(c, &d.Tc, Tc)) || (rc = dalloc(c, &d.Wr, (size_t)d.ps))) return rc;
+      std::vector<float> Tc32(Tc.begin(), Tc.end());
+      if ((rc = dupload(c, &d.evl, evl)) || (rc = dupload(c, &d.Tc, Tc)) || (rc = dupload(c, &d.Tc32, Tc32)) || (rc = dalloc(c, &d.Wr, (size_t)d.ps))) return rc;
     }
   }
   tick("coarse image under E (Tc)");
@@ -916,6 +923,8 @@ static int build(nsk_ctx* c, const nsk_case& cs) {
   if (const char* g = std::getenv("NSK_USE_GRAPH")) c->use_graph = std::atoi(g);
   if (const char* g = std::getenv("NSK_MERGED_UPDATE")) c->merged_update = std::atoi(g);
   if (const char* g = std::getenv("NSK_FUSE2")) c->fuse2 = std::atoi(g);
+  if (const char* g = std::getenv("NSK_TC32")) c->tc32 = std::atoi(g);
+  if (const char* g = std::getenv("NSK_FUSE2_START")) c->fuse2_start = std::atoi(g);
   if (const char* g = std::getenv("NSK_HOSTCHECK")) c->hostcheck = std::atoi(g);
   if (const char* g = std::getenv("NSK_GRAPH_STEPS")) c->graph_steps = std::max(1, std::min(std::atoi(g), 64));
   if (const char* g = std::getenv("NSK_MERGED_ITERS")) c->merged_iters = std::max(0, std::min(std::atoi(g), MAXMR));
@@ -956,7 +965,13 @@ static void launch_update_coarse(nsk_ctx* c, const Dev& d, int j, double scale, 
 }
 
 // round 6, the merged iteration in two launches: A_j (Schwarz workgroups + coarse workgroups) and B_j
-static bool fuse2_on(const nsk_ctx* c) { return c->fuse2 && c->d.Tc && c->d.Wr && c->d.ecv && c->d.rch; }
+// (needs: the coarse image Tc with nsk::k2::UC_NVL columns, coarse_lda a multiple of 768, two overlap layers of the Schwarz patches)
+static bool fuse2_on(const nsk_ctx* c) {
+  if (!(c->fuse2 && c->d.Tc && c->d.Wr && c->d.ecv && c->d.rch && c->ndim == 2)) return false;
+  if (c->d.nvl != nsk::k2::UC_NVL || c->d.coarse_lda % 768 != 0 || c->d.coarse_lda > 3072) return false;
+  const int M = c->N - 2;
+  return c->d.p_stride == (((M + 4) * (M + 4) + 3) / 4) * 4;
+}
 template <int N>
 static void launch_schwarz_uc(nsk_ctx* c, const Dev& d, int j, double scale, int min_iter, int ord) {
   if (c->ndim != 2) return;
@@ -964,15 +979,22 @@ static void launch_schwarz_uc(nsk_ctx* c, const Dev& d, int j, double scale, int
   const size_t sh = d.coarse_lda * sizeof(double);
   const int nit = d.coarse_lda / 256;
   const dim3 grid(nsw + cgrid), blk(256);
-  if (nit <= 3) hipLaunchKernelGGL((nsk::k2::k_schwarz_uc<N, 3>), grid, blk, sh, c->stream, d, j, scale, min_iter, ord, nsw, cgrid);
-  else if (nit <= 6) hipLaunchKernelGGL((nsk::k2::k_schwarz_uc<N, 6>), grid, blk, sh, c->stream, d, j, scale, min_iter, ord, nsw, cgrid);
-  else if (nit <= 9) hipLaunchKernelGGL((nsk::k2::k_schwarz_uc<N, 9>), grid, blk, sh, c->stream, d, j, scale, min_iter, ord, nsw, cgrid);
-  else hipLaunchKernelGGL((nsk::k2::k_schwarz_uc<N, 12>), grid, blk, sh, c->stream, d, j, scale, min_iter, ord, nsw, cgrid);
+  // (fuse2_on: nit is exactly 3, 6, 9 or 12)
+  if (nit == 3) hipLaunchKernelGGL((nsk::k2::k_schwarz_uc<N, 3>), grid, blk, sh, c->stream, d, j, scale, min_iter, ord, nsw, cgrid);
+  else if (nit == 6) hipLaunchKernelGGL((nsk::k2::k_schwarz_uc<N, 6>), grid, blk, sh, c->stream, d, j, scale, min_iter, ord, nsw, cgrid);
+  else if (nit == 9) hipLaunchKernelGGL((nsk::k2::k_schwarz_uc<N, 9>), grid, blk, sh, c->stream, d, j, scale, min_iter, ord, nsw, cgrid);
+  else if (nit == 12) hipLaunchKernelGGL((nsk::k2::k_schwarz_uc<N, 12>), grid, blk, sh, c->stream, d, j, scale, min_iter, ord, nsw, cgrid);
+}
+template <int N>
+static void launch_proj_apply_e(nsk_ctx* c, const Dev& d) {
+  if (c->ndim != 2) return;
+  hipLaunchKernelGGL(nsk::k2::k_proj_apply_e<N>, dim3(c->nblk), dim3(256), 0, c->stream, d);
 }
 template <int N>
 static void launch_divgs_t(nsk_ctx* c, const Dev& d, int j) {
   if (c->ndim != 2) return;
-  hipLaunchKernelGGL(nsk::k2::k_divgs_t<N>, dim3(c->nblk), dim3(256), 0, c->stream, d, j);
+  if (d.tc32) hipLaunchKernelGGL((nsk::k2::k_divgs_t<N, true>), dim3(c->nblk), dim3(256), 0, c->stream, d, j);
+  else hipLaunchKernelGGL((nsk::k2::k_divgs_t<N, false>), dim3(c->nblk), dim3(256), 0, c->stream, d, j);
 }
 
 static bool stream_capturing(hipStream_t s) {
@@ -1149,8 +1171,14 @@ static int pres_solve_launch(nsk_ctx* c, double h2, int ord, int np, double tol_
     tot_rows(c, d.gpart, d.has_outflow ? 1 : 2, d.gtot);
     if (d.nproj_max > 0 && !c->in_test) tot_rows(c, d.ppart, MAXPROJ + 1, d.ptot);
     if (!d.has_outflow && !c->in_test) { hipLaunchKernelGGL(k_ortho, dim3(c->nblk), dim3(256), 0, c->stream, d); tot_rows(c, d.gpart, 1, d.gtot); }
-    if (d.nproj_max > 0 && !c->in_test) { hipLaunchKernelGGL(k_proj_apply, dim3(c->nblk), dim3(256), 0, c->stream, d); tot_rows(c, d.gpart, 1, d.gtot); }
-    hipLaunchKernelGGL(k_gmres_update<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, -1, scale, c->min_pres, ord);
+    // round 6: with the two-launch iteration the solve starts INSIDE A_0 (element-aligned projection kernel -> raw g' in Wr
+    // + its corner restrictions; no k_gmres_update(-1) launch) where the projection kernel is the last producer of g'
+    const bool merged0 = c->merged_update && c->ndim == 2 && d.coarse_lda <= 3072 && !d.use_tot && d.nranks <= 1 && d.rch && d.ecv && !hc;
+    const bool f2start = merged0 && fuse2_on(c) && c->fuse2_start && d.nproj_max > 0 && d.nproj_max <= MAXPROJ && !c->in_test && np > 0 &&
+                         std::min(np, std::min(c->merged_iters, c->gmres_cycle)) > 0 && !(tail && std::min(np, std::min(c->merged_iters, c->gmres_cycle) - 1) <= 0);
+    if (f2start) launch_proj_apply_e<N>(c, d);
+    else if (d.nproj_max > 0 && !c->in_test) { hipLaunchKernelGGL(k_proj_apply, dim3(c->nblk), dim3(256), 0, c->stream, d); tot_rows(c, d.gpart, 1, d.gtot); }
+    if (!f2start) hipLaunchKernelGGL(k_gmres_update<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, -1, scale, c->min_pres, ord);
     // merged bookkeeping (k_update_coarse): quadrilateral single-rank contexts with the dense in-LDS coarse solve.
     // Only the first `merged_iters` (24) iterations of a solve: x_c(v_j) by linearity is a recurrence, its rounding error grows by
     // ~|h_jj / h_{j+1,j}| per iteration (harmless in a preconditioner for a dozen iterations, a stalled solve after forty:
@@ -1169,9 +1197,12 @@ static int pres_solve_launch(nsk_ctx* c, double h2, int ord, int np, double tol_
       if (done) { c->hc_pres[ord] = 0; np = 0; }
     }
     const bool f2 = merged && fuse2_on(c);
+    // the fp32 copy of the coarse image where the tolerance of THIS solve is loose (relative, >= 1e-5): option "tc32" = -1 (default) / 0 / 1
+    d.tc32 = (c->tc32 < 0) ? ((d.tol_relative && d.tol_pres >= 1e-5 && d.Tc32) ? 1 : 0) : ((c->tc32 && d.Tc32) ? 1 : 0);
     for (int j = 0; j < (tl ? nhead : nm); ++j) {
       if (f2) {                                            // two launches per iteration (round 6)
-        launch_schwarz_uc<N>(c, d, j, scale, c->min_pres, ord);
+        Dev d0 = d; d0.uc_start = (f2start && j == 0) ? 1 : 0;
+        launch_schwarz_uc<N>(c, d0, j, scale, c->min_pres, ord);
         launch_divgs_t<N>(c, d, j);
         continue;
       }
@@ -2314,6 +2345,8 @@ int nsk_set_option(nsk_ctx* c, const char* name, double value) {
   else if (n == "merged_iters") { c->merged_iters = std::max(0, std::min((int)value, MAXMR)); invalidate_graphs(c); }
   else if (n == "merged_update") { c->merged_update = (int)value; invalidate_graphs(c); }
   else if (n == "fuse2") { c->fuse2 = (int)value; c->tail_ok = -1; invalidate_graphs(c); }
+  else if (n == "tc32") { c->tc32 = (int)value; invalidate_graphs(c); }
+  else if (n == "fuse2_start") { c->fuse2_start = (int)value; invalidate_graphs(c); }
   else if (n == "min_pres_iter") c->min_pres = (int)value;
   else if (n == "pres_cap") {
     if (value > 0 && c->ndim != 2) return fail(NSK_EINVAL, "pres_cap is validated on quadrilateral linearised maps only (DESIGN.md section 1)");
@@ -2872,6 +2905,7 @@ int nsk_debug_stamps(nsk_ctx* c, unsigned long long* out, int nblk_max) {
   if (sk && (std::string(sk) == "schwarz_uc" || std::string(sk) == "divgs_t")) {
     if (!fuse2_on(c)) return fail(NSK_EINVAL, "two-launch GMRES iteration not available in this context");
     Dev dd = d; dd.tol_pres = 0.0; dd.tol_relative = 0; dd.pres_cap = 0;
+    dd.tc32 = (c->tc32 != 0 && d.Tc32) ? 1 : 0;
     const StepCoef sc = make_coef(c, 17, 0);
     const double scale = 1.0 / (sc.h2 * std::sqrt(d.vol));
     const int jd = std::getenv("NSK_STAMP_J") ? std::atoi(std::getenv("NSK_STAMP_J")) : 3;
@@ -3125,6 +3159,7 @@ int nsk_bench_kernel(nsk_ctx* c, const char* name, int reps, double* avg_us) {
     if ((n.rfind("update_coarse", 0) == 0 || n == "pres_chain_merged") && !d.ecv) return fail(NSK_EINVAL, "merged coarse-solve kernel not available in this context");
     if ((n.rfind("schwarz_uc", 0) == 0 || n == "divgs_t" || n == "pres_chain_fused") && !(d.Tc && d.Wr && d.ecv && d.rch)) return fail(NSK_EINVAL, "two-launch GMRES iteration not available in this context");
     d.tol_pres = 0.0; d.tol_relative = 0; d.pres_cap = 0;
+    d.tc32 = (c->tc32 != 0 && d.Tc32) ? 1 : 0;              // (as a production solve)
     const StepCoef sc = make_coef(c, 17, 0);
     const double scale = 1.0 / (sc.h2 * std::sqrt(d.vol));
     const int jj = 3;

@@ -134,9 +134,12 @@ struct Dev {
   // k_gmres_update takes the raw w from here instead of V[j+1].
   const int* evl;
   const double* Tc;
+  const float* Tc32;             // fp32 copy of Tc: taken by solves whose tolerance is far above 1e-7 (tc32, set per launch); E z_j = w_j then
+  int tc32;                      // holds to ~1e-8 of the coarse part instead of rounding -- invisible at a relative tolerance >= 1e-5
   int nvl;
   double* Wr;
   const double* wraw;
+  int uc_start;                  // set per launch (A_0 only): the solve starts inside k_schwarz_uc (g' raw in Wr, written by k_proj_apply_e)
   GmresScal* gsc;
   // projection onto previous pressure solutions (E-orthonormal)
   double *PX, *PEX, *PD, *PED, *ppart;

@@ -133,13 +133,27 @@ __device__ inline void sum_partials_multi(const double* part, int n, int nq, dou
 template <int R>
 struct PartialRows {
   double p[R][8];
+  // (unconditional loads from clamped addresses + a select: `cond ? load : 0` costs a branch per load)
   __device__ inline void issue(const double* part, int n, int nq_issue, int tid, int row0 = 0) {
     const int lane = tid & 63, w = tid >> 6;
+    if (nq_issue <= row0) {                     // (uniform) nothing to load
 #pragma unroll
-    for (int r = 0; r < R; ++r)
+      for (int r = 0; r < R; ++r)
 #pragma unroll
-      for (int k = 0; k < 8; ++k)
-        p[r][k] = (row0 + w + 4 * r < nq_issue && lane + 64 * k < n) ? part[(size_t)(row0 + w + 4 * r) * n + lane + 64 * k] : 0.0;
+        for (int k = 0; k < 8; ++k) p[r][k] = 0.0;
+      return;
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int row = row0 + w + 4 * r;
+      const double* prow = part + (size_t)(row < nq_issue ? row : row0) * n;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int col = lane + 64 * k;
+        const double v = prow[col < n ? col : 0];
+        p[r][k] = (row < nq_issue && col < n) ? v : 0.0;
+      }
+    }
   }
   // sums rows row0 .. row0 + 4 R - 1 (those below nq) from the registers; `tail`: the rows behind them by the loop, then a barrier
   __device__ inline void reduce(const double* part, int n, int nq, double* sh, int tid, int row0 = 0, bool tail = true) {
@@ -1316,6 +1330,7 @@ __device__ __forceinline__ void uc_rotate(const Dev& d, GmresScal* G, int jj, do
     const bool conv = (res <= tol && (jj + 1) >= min_iter) || !(hn > 0.0) || (d.pres_cap > 0 && (jj + 1) >= d.pres_cap);
     sbc[0] = (hn > 0.0) ? 1.0 / hn : 0.0;
     sbc[1] = conv ? 1.0 : 0.0;
+    sbc[2] = cj * gj; sbc[3] = -sj * gj;          // g_jj, g_{jj+1} after the rotation (k_pres_update's folded close)
     if (record) {
       G->cs[jj] = cj; G->sn[jj] = sj;
       for (int q = 0; q <= jj; ++q) G->R[jj * MAXMR + q] = col[q];
@@ -1338,15 +1353,37 @@ __device__ __forceinline__ void uc_rotate(const Dev& d, GmresScal* G, int jj, do
     }
 }
 
+// The START of a solve inside A_0 (Dev::uc_start, set per launch): what k_gmres_update(j = -1) does -- |g'| from the partials
+// the (element-aligned) projection kernel left in row 0, the solve's state, the convergence flag -- by one lane of every
+// workgroup from sh[0] = |g'|^2; sbc = {1 / |g'|, done}.  The raw g' is in Dev::Wr, its corner restrictions in Dev::ecv.
+__device__ __forceinline__ void uc_start_solve(const Dev& d, GmresScal* G, double scale, int min_iter, bool record, const double* sh, double* sbc) {
+  const double hn = sqrt(sh[0]);
+  const double gn0 = (d.nproj_max <= 0) ? hn : G->gnorm0;
+  const double tol0 = d.tol_relative ? fmax(d.tol_pres * gn0 * scale, d.tol_pres_floor) : d.tol_pres;
+  const int dn = (!(hn > 0.0) || (min_iter <= 0 && hn * scale <= tol0)) ? 1 : 0;
+  sbc[0] = (hn > 0.0) ? 1.0 / hn : 0.0;
+  sbc[1] = dn ? 1.0 : 0.0;
+  if (record) {
+    G->beta0 = hn; G->g[0] = hn; G->gpre[0] = hn; G->nit = 0; G->nit_prev = 0; G->resid = hn * scale;
+    if (d.nproj_max <= 0) G->gnorm0 = hn;
+    if (dn) d.stats->last_pres_res = hn * scale;
+    if (!(hn * 0.0 == 0.0)) d.stats->nonfinite += 1;      // |g| is NaN or Inf (map_finish returns NSK_ENAN)
+    G->done = dn;
+  }
+}
+
 // LEAN (the persistent pressure tail, which must stay below 256 registers to be resident at two workgroups per CU): the corner
 // restrictions and the matrix rows are loaded in chunks of three 256-column blocks where they are used instead of all at the
 // top; the same operations in the same order, so both forms return the same bits.
 // NOV (round 6, k_schwarz_uc): the pointwise update of v_j is NOT done here (the Schwarz workgroups of the same launch form v_j
 // where they need it); everything else -- column, coarse solve by linearity, history -- as before.
-template <int MAXIT, bool LEAN = false, bool NOV = false>
+// LEAN_AM (default = LEAN): the same choice for the matrix rows alone.  k_schwarz_uc takes <LEAN = true, NOV, LEAN_AM = false>: the
+// corner values in chunks (they are consumed first), ALL matrix loads in flight behind the first chunk (stamps, round 6: the
+// chunked product was 3.9 of the coarse role's 10.8 us).
+template <int MAXIT, bool LEAN = false, bool NOV = false, bool LEAN_AM = LEAN>
 __device__ __forceinline__ void update_coarse_body(const Dev& d, int j, double scale, int min_iter, int ord, const unsigned bx_, const unsigned gx_) {
   extern __shared__ double srcv[];            // lda
-  __shared__ double sh[MAXMR + 2], scs[MAXMR], ssn[MAXMR], scol[MAXMR + 2], sbc[2];
+  __shared__ double sh[MAXMR + 2], scs[MAXMR], ssn[MAXMR], scol[MAXMR + 2], sbc[4];
   const int tid = threadIdx.x;
   GmresScal* G = d.gsc;
   if (G->done) return;                        // (first: a launch that finds its solve done must stay cheap)
@@ -1392,9 +1429,9 @@ __device__ __forceinline__ void update_coarse_body(const Dev& d, int j, double s
     if (tid < jj) { scs[tid] = G->cs[tid]; ssn[tid] = G->sn[tid]; }
     gj = G->gpre[jj];
   }
-  constexpr int AMN = LEAN ? 1 : MAXIT;
+  constexpr int AMN = LEAN_AM ? 1 : MAXIT;
   float4 am[UC_ROWS][AMN];
-  if constexpr (!LEAN) {
+  if constexpr (!LEAN_AM) {
 #pragma unroll
     for (int r = 0; r < UC_ROWS; ++r) {
       const float4* A = reinterpret_cast<const float4*>(d.Acif + (size_t)(row0 + r < nv ? row0 + r : 0) * lda) + lane;
@@ -1402,6 +1439,8 @@ __device__ __forceinline__ void update_coarse_body(const Dev& d, int j, double s
       for (int i = 0; i < MAXIT; ++i)
         if (i < nit) am[r][i] = A[i * 64];
     }
+  }
+  if constexpr (!LEAN) {
 #pragma unroll
     for (int i = 0; i < MAXIT; ++i) {         // R w (raw): the corner restrictions of a vertex in the order of vtab (unused slots are zero)
       const int v = tid + i * 256;
@@ -1454,7 +1493,7 @@ __device__ __forceinline__ void update_coarse_body(const Dev& d, int j, double s
   double sr[UC_ROWS];
 #pragma unroll
   for (int r = 0; r < UC_ROWS; ++r) sr[r] = 0.0;
-  if constexpr (!LEAN) {
+  if constexpr (!LEAN_AM) {
 #pragma unroll
     for (int i = 0; i < MAXIT; ++i)
       if (i < nit) {
@@ -1744,6 +1783,71 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_divgs(Dev d, const double* __res
 }
 
 
+// k_proj_apply on the ELEMENT-ALIGNED thread map of the pressure kernels (thread -> (element, Gauss node), EPB elements per
+// workgroup, grid = nblk), for the two-launch GMRES iteration: g' = g - sum_i a_i E x_i goes RAW to Dev::Wr (A_0 normalises it
+// on the fly: the Schwarz workgroups read it across element boundaries), its |g'|^2 partials to row 0, and -- what the flat map
+// of k_proj_apply cannot do -- the element-corner restrictions of g' to Dev::ec / ecv, so that the solve can start INSIDE A_0
+// (Dev::uc_start) and k_gmres_update(j = -1) is not launched.  Same coefficients a_i as k_proj_apply (same partial sums).
+template <int N>
+__global__ __launch_bounds__(256) void k_proj_apply_e(Dev d) {
+  using C = Cfg<N>;
+  constexpr int NN = C::NN, MM = C::MM, EPB = C::EPB;
+  __shared__ double sh[MAXPROJ + 1];
+  __shared__ double sred[16];
+  __shared__ double sv[EPB * MM], shat[4 * MM];
+  const int tid = threadIdx.x, el = tid / NN, nd = tid % NN;
+  const long long e = (long long)blockIdx.x * EPB + el;
+  const bool act = (el < EPB) && (e < d.nel);
+  const bool pact = act && nd < MM;
+  GmresScal* G = d.gsc;
+  const int np = G->nproj;
+  const long long q = (act ? e : 0) * MM + (nd < MM ? nd : 0);
+  const int npre = d.nproj_max < MAXPROJ ? d.nproj_max : MAXPROJ;
+  const double g0 = d.V[q];
+  double pe[MAXPROJ];
+#pragma unroll
+  for (int k = 0; k < MAXPROJ; ++k) pe[k] = d.PEX[(size_t)(k < npre ? k : 0) * d.npr + q];      // (slots >= nproj: finite stale data, zero coefficient)
+  const double pnv = (tid < MAXPROJ) ? G->pn[tid] : 1.0;
+  const int ecs = d.ecslot[(act ? e : 0) * 4 + (nd & 3)];
+  double hatv[(4 * MM + 255) / 256];
+#pragma unroll
+  for (int r = 0; r < (4 * MM + 255) / 256; ++r) hatv[r] = d.hat[(tid + r * 256 < 4 * MM) ? tid + r * 256 : 0];
+  PartialRows<4> pr;                  // 16 rows per pass: a second pass for spaces of more than 16 vectors
+  pr.issue(d.ppart, d.nblk, d.nblk <= 512 ? d.nproj_max : 0, tid);
+  if (d.nblk <= 512) {
+    pr.reduce(d.ppart, d.nblk, np, sh, tid, 0, np <= 16);
+    if (np > 16) { pr.issue(d.ppart, d.nblk, np, tid, 16); pr.reduce(d.ppart, d.nblk, np, sh, tid, 16); }
+  } else sum_partials_multi(d.ppart, d.nblk, np, sh, tid, 256);
+  if (blockIdx.x == 0) {
+    double gg[1];
+    sum_partials<1>(d.ppart + (size_t)MAXPROJ * d.nblk, d.nblk, gg, sred, tid, 256);
+    if (tid == 0) G->gnorm0 = sqrt(gg[0]);
+  }
+  if (tid < np) sh[tid] = sh[tid] / pnv;
+#pragma unroll
+  for (int r = 0; r < (4 * MM + 255) / 256; ++r) if (tid + r * 256 < 4 * MM) shat[tid + r * 256] = hatv[r];
+  __syncthreads();
+  if (blockIdx.x == 0 && tid < np) G->pa[tid] = sh[tid];
+  double v[1] = {0.0};
+  if (pact) {
+    double g = g0;
+#pragma unroll
+    for (int k = 0; k < MAXPROJ; ++k) if (k < np) g -= sh[k] * pe[k];
+    d.Wr[q] = g;
+    sv[el * MM + nd] = g;
+    v[0] = g * g;
+  }
+  block_reduce<1>(v, sred, tid, 256);            // (two LDS barriers: sv is complete behind them)
+  if (tid == 0) d.gpart[blockIdx.x] = v[0];
+  if (act && nd < 4) {
+    double s = 0.0;
+#pragma unroll 6
+    for (int k = 0; k < MM; ++k) s += shat[nd * MM + k] * sv[el * MM + k];
+    d.ec[e * 4 + nd] = s;
+    d.ecv[ecs] = s;
+  }
+}
+
 // ---------------------------------------------------------------------------
 // Round 6: the merged GMRES iteration in TWO launches instead of three (core/matvec.f:216-233 spends its time here).
 //   A_j = k_schwarz_uc (grid = nsw Schwarz workgroups + cgrid coarse workgroups, 256 threads each):
@@ -1756,6 +1860,122 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_divgs(Dev d, const double* __res
 // The additive preconditioner is what allows it: Schwarz(v_j) and coarse(v_j) are independent given the column.  Same Krylov
 // method, same h and v_j bits as the three-launch form; w differs from it by rounding (the coarse part is summed separately).
 // ---------------------------------------------------------------------------
+// The coarse role of k_schwarz_uc: update_coarse_body<.., NOV> with its loads in the order that fits three workgroups per CU
+// (168 registers) WITHOUT chunking the matrix rows -- partial sums and the first chunk of corner values in the first trip; the
+// matrix rows (72 registers) go out when the partial-sum registers are free, behind them the other chunks of corner values, so
+// that the product finds its operands waiting (stamps of the chunked form: 4.5 us corner sums + 3.9 us product of 10.8).
+// The same operations in the same order as update_coarse_body: the same bits (the persistent tail runs that one).
+template <int MAXIT>
+__device__ __forceinline__ void uc_coarse_role(const Dev& d, int j, double scale, int min_iter, int ord, const unsigned bx_) {
+  extern __shared__ double srcv[];            // lda
+  __shared__ double sh[MAXMR + 2], scs[MAXMR], ssn[MAXMR], scol[MAXMR + 2], sbc[4];
+  const int tid = threadIdx.x;
+  GmresScal* G = d.gsc;
+  NSK_STAMP(1);
+  const int nv = d.nvert, lda = d.coarse_lda;
+  const int lane = tid & 63, w = tid >> 6;
+  const int row0 = (bx_ * 4 + w) * UC_ROWS;
+  constexpr int nit = MAXIT;                  // the host pads coarse_lda to 256 MAXIT (a multiple of 768): no run-time bounds, no branches between the loads
+  const int jj = j - 1;
+  constexpr int CH = 3;
+  const bool start = d.uc_start != 0;          // (j = 0 only) the solve starts here: row 0 of the partials = |g'|^2
+  const int nrow = (j > 0) ? jj + 2 : (start ? 1 : 0);
+  PartialRows<2> pr;
+  pr.issue(d.gpart, d.nblk, d.nblk <= 512 ? nrow : 0, tid);
+  double rh[UC_ROWS];
+#pragma unroll
+  for (int r = 0; r < UC_ROWS; ++r) rh[r] = (lane < j && row0 + r < nv) ? d.rch[(size_t)lane * lda + row0 + r] : 0.0;
+  double gj = 0.0;
+  if (j > 0) {
+    if (tid < jj) { scs[tid] = G->cs[tid]; ssn[tid] = G->sn[tid]; }
+    gj = G->gpre[jj];
+  }
+  double2 c0[CH][4];
+#pragma unroll
+  for (int i = 0; i < CH; ++i) {
+    const int v = tid + i * 256;
+    const double2* E = reinterpret_cast<const double2*>(d.ecv) + (size_t)(i < nit && v < nv ? v : 0) * 4;
+    if (i < nit) { c0[i][0] = E[0]; c0[i][1] = E[1]; c0[i][2] = E[2]; c0[i][3] = E[3]; }
+  }
+  if (nrow > 0) {
+    if (d.nblk <= 512) pr.reduce(d.gpart, d.nblk, nrow, sh, tid);               // ends with an LDS barrier
+    else sum_partials_multi(d.gpart, d.nblk, nrow, sh, tid, 256);
+  }
+  NSK_STAMP(2);
+  // (compiler fences between the phases: hoisting every load to the top costs 226 registers; the order below needs ~150)
+#define UC_FENCE() asm volatile("" ::: "memory")
+#pragma unroll
+  for (int i = 0; i < CH; ++i) {              // R w (raw): the corner restrictions of a vertex in the order of vtab (unused slots are zero)
+    const int v = tid + i * 256;
+    if (i < nit) srcv[v] = (v < nv) ? ((((((c0[i][0].x + c0[i][0].y) + c0[i][1].x) + c0[i][1].y) + c0[i][2].x) + c0[i][2].y) + c0[i][3].x) + c0[i][3].y : 0.0;
+  }
+  UC_FENCE();
+  float4 am[UC_ROWS][MAXIT];
+#pragma unroll
+  for (int r = 0; r < UC_ROWS; ++r) {
+    const float4* A = reinterpret_cast<const float4*>(d.Acif + (size_t)(row0 + r < nv ? row0 + r : 0) * lda) + lane;
+#pragma unroll
+    for (int i = 0; i < MAXIT; ++i)
+      if (i < nit) am[r][i] = A[i * 64];
+  }
+#pragma unroll
+  for (int ic = CH; ic < MAXIT; ic += CH) {
+    double2 c1[CH][4];
+#pragma unroll
+    for (int ii = 0; ii < CH; ++ii) {
+      const int i = ic + ii, v = tid + i * 256;
+      const double2* E = reinterpret_cast<const double2*>(d.ecv) + (size_t)(i < nit && v < nv ? v : 0) * 4;
+      if (i < MAXIT && i < nit) { c1[ii][0] = E[0]; c1[ii][1] = E[1]; c1[ii][2] = E[2]; c1[ii][3] = E[3]; }
+    }
+#pragma unroll
+    for (int ii = 0; ii < CH; ++ii) {
+      const int i = ic + ii, v = tid + i * 256;
+      if (i < MAXIT && i < nit) srcv[v] = (v < nv) ? ((((((c1[ii][0].x + c1[ii][0].y) + c1[ii][1].x) + c1[ii][1].y) + c1[ii][2].x) + c1[ii][2].y) + c1[ii][3].x) + c1[ii][3].y : 0.0;
+    }
+    UC_FENCE();
+  }
+  NSK_STAMP(3);
+  lds_barrier();
+  if (j > 0 && tid == 0) uc_rotate(d, G, jj, gj, scale, min_iter, ord, bx_ == 0, sh, scs, ssn, scol, sbc);
+  if (start && tid == 0) uc_start_solve(d, G, scale, min_iter, bx_ == 0, sh, sbc);
+  NSK_STAMP(4);
+  double sr[UC_ROWS];
+#pragma unroll
+  for (int r = 0; r < UC_ROWS; ++r) sr[r] = 0.0;
+#pragma unroll
+  for (int i = 0; i < MAXIT; ++i)
+    if (i < nit) {
+      const double* x = srcv + i * 256 + lane * 4;
+#pragma unroll
+      for (int r = 0; r < UC_ROWS; ++r)
+        sr[r] += (double)am[r][i].x * x[0] + (double)am[r][i].y * x[1] + (double)am[r][i].z * x[2] + (double)am[r][i].w * x[3];
+    }
+#pragma unroll
+  for (int r = 0; r < UC_ROWS; ++r) sr[r] = wave_sum63(sr[r]);
+  double hinv = 1.0;
+  NSK_STAMP(5);
+  if (nrow > 0) {
+    lds_barrier();                            // column rotated (start: |g'| known)
+    NSK_STAMP(6);
+    hinv = sbc[0];
+    if (sbc[1] != 0.0) return;                // converged: nothing of iteration j is needed
+  }
+#pragma unroll
+  for (int r = 0; r < UC_ROWS; ++r) {         // x_c(v_j)[row] = (s - sum_k h_k x_c(v_k)[row]) / h_{j,j-1}: lane k holds term k
+    double t = (lane < j) ? sh[lane] * rh[r] : 0.0;
+    t = wave_sum63(t);
+    sr[r] = (sr[r] - t) * hinv;
+  }
+  if (lane == 63) {
+#pragma unroll
+    for (int r = 0; r < UC_ROWS; ++r)
+      if (row0 + r < nv) { d.xc[row0 + r] = sr[r]; d.rch[(size_t)j * lda + row0 + r] = sr[r]; }
+  }
+  NSK_STAMP(7);
+}
+
+template <int N>
+struct UcPatch { static constexpr int M = N - 2, PS = (((M + 4) * (M + 4) + 3) / 4) * 4; };   // patch stride at two overlap layers
 template <int N>
 __device__ __forceinline__ void uc_schwarz_role(const Dev& d, int j, double scale, int min_iter, int ord, const unsigned bx_, const unsigned gx_) {
   using C = Cfg<N>;
@@ -1764,22 +1984,26 @@ __device__ __forceinline__ void uc_schwarz_role(const Dev& d, int j, double scal
   __shared__ double sJ12[NM], sD12[NM];
   __shared__ double sP[4 * EPB * MM], sB[4 * EPB * NM];
   __shared__ double sr[EPB * MAXP];
-  __shared__ double sh[MAXMR + 2], scs[MAXMR], ssn[MAXMR], scol[MAXMR + 2], sbc[2];
+  __shared__ double sh[MAXMR + 2], scs[MAXMR], ssn[MAXMR], scol[MAXMR + 2], sbc[4];
   const int tid = threadIdx.x, el = tid / NN, nd = tid % NN;
   const int bid = d.boff + (int)xcd_element(bx_, gx_);
   const long long e = (long long)bid * EPB + el;
   const bool act = (el < EPB) && (e < d.nel);
   GmresScal* G = d.gsc;
-  const int PS = d.p_stride;
+  constexpr int PS = UcPatch<N>::PS;            // = d.p_stride (checked on the host: two overlap layers)
   const int jj = j - 1;
   int i0 = -1, i1 = -1;
-  if (act) {
-    if (nd < PS) i0 = d.p_idx[e * PS + nd];
-    if (nd + NN < PS) i1 = d.p_idx[e * PS + nd + NN];
+  {                                            // (unconditional loads from clamped addresses, then a select: no branch per load)
+    const long long es = act ? e : 0;
+    const int a0 = d.p_idx[es * PS + (nd < PS ? nd : 0)], a1 = d.p_idx[es * PS + (nd + NN < PS ? nd + NN : 0)];
+    if (act && nd < PS) i0 = a0;
+    if (act && nd + NN < PS) i1 = a1;
   }
   NSK_STAMP(1);
+  const bool start = d.uc_start != 0;          // (j = 0 only) the solve starts here: g' raw in Wr, |g'|^2 in row 0 of the partials
+  const int nrow = (j > 0) ? jj + 2 : (start ? 1 : 0);
   PartialRows<2> pr;                          // rows w, w + 4 of the partials of B_{j-1} (d.nblk <= 512: the merged range)
-  pr.issue(d.gpart, d.nblk, (j > 0 && d.nblk <= 512) ? jj + 2 : 0, tid);
+  pr.issue(d.gpart, d.nblk, d.nblk <= 512 ? nrow : 0, tid);
   double gj = 0.0;
   if (j > 0) {
     if (tid < jj) { scs[tid] = G->cs[tid]; ssn[tid] = G->sn[tid]; }
@@ -1787,39 +2011,61 @@ __device__ __forceinline__ void uc_schwarz_role(const Dev& d, int j, double scal
   }
   const bool pact = act && nd < MM;
   const long long q = e * MM + nd;
-  double m0 = 0, m1 = 0, m2 = 0, m3 = 0;
-  if (pact) { m0 = d.w2rx[q]; m1 = d.w2sx[q]; m2 = d.w2ry[q]; m3 = d.w2sy[q]; }
   double j12a = 0, d12a = 0;
   if (tid < NM) { j12a = d.J12[tid]; d12a = d.D12[tid]; }
   // raw w (j = 0: V[0], normalised by k_gmres_update(-1)) and the basis at this thread's (up to) two patch nodes
-  const double* W = (j > 0) ? d.Wr : d.V;
-  double v0 = (i0 >= 0) ? W[i0] : 0.0, v1 = (i1 >= 0) ? W[i1] : 0.0;
-  double vk0[8], vk1[8];
+  const double* W = (j > 0 || start) ? d.Wr : d.V;
+  const int i0s = i0 >= 0 ? i0 : 0, i1s = i1 >= 0 ? i1 : 0;
+  double v0 = W[i0s], v1 = W[i1s];
+  if (i0 < 0) v0 = 0.0;
+  if (i1 < 0) v1 = 0.0;
+  constexpr int VK = 8;
+  double vk0[VK], vk1[VK];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    vk0[k] = (k < j && i0 >= 0) ? d.V[(size_t)k * d.ps + i0] : 0.0;
-    vk1[k] = (k < j && i1 >= 0) ? d.V[(size_t)k * d.ps + i1] : 0.0;
+  for (int k = 0; k < VK; ++k) { vk0[k] = 0.0; vk1[k] = 0.0; }
+  if (j > 0) {                                 // basis vectors in groups of four behind ONE uniform branch each (index clamped inside a group)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const int kk = k < j ? k : j - 1; vk0[k] = d.V[(size_t)kk * d.ps + i0s]; vk1[k] = d.V[(size_t)kk * d.ps + i1s]; }
+  }
+  if (j > 4) {
+#pragma unroll
+    for (int k = 4; k < 8; ++k) { const int kk = k < j ? k : j - 1; vk0[k] = d.V[(size_t)kk * d.ps + i0s]; vk1[k] = d.V[(size_t)kk * d.ps + i1s]; }
   }
   if (tid < NM) { sJ12[tid] = j12a; sD12[tid] = d12a; }
   NSK_STAMP(2);
-  if (j > 0) {
-    if (d.nblk <= 512) pr.reduce(d.gpart, d.nblk, jj + 2, sh, tid);            // ends with an LDS barrier
-    else sum_partials_multi(d.gpart, d.nblk, jj + 2, sh, tid, 256);
+  // The patch inverse (PS / 4 float4 per lane, the largest stream of the launch; from the Infinity Cache) in TWO prefetch stages:
+  // stamps showed the unroll-8 loop behind the column as four dependent trips, 8.9 of this role's 14.7 us.  Stage 1 goes out
+  // when the partial-sum registers are free, stage 2 when the basis registers are: both BEHIND the loads the column waits for
+  // (loads return in issue order).
+  constexpr int nq = PS / 4;                                    // PS is a multiple of 4
+  constexpr int PQ1 = nq < 26 ? (nq + 1) / 2 : 13, PQ2 = nq < 26 ? nq - PQ1 : 12;      // (lx1 = 8: 13 + 12 = all 25)
+  const float4* PA = reinterpret_cast<const float4*>(d.p_inv + (size_t)(act ? e : 0) * PS * MM) + (nd < MM ? nd : 0);
+  float4 pa1[PQ1], pa2[PQ2];
+#pragma unroll
+  for (int k4 = 0; k4 < PQ1; ++k4) if (k4 < nq) pa1[k4] = PA[(size_t)k4 * MM];      // (measured: here 14.43, behind the partial sums 14.33 matvecs/s)
+  if (nrow > 0) {
+    if (d.nblk <= 512) pr.reduce(d.gpart, d.nblk, nrow, sh, tid);               // ends with an LDS barrier
+    else sum_partials_multi(d.gpart, d.nblk, nrow, sh, tid, 256);
     NSK_STAMP(3);
-    if (tid == 0) uc_rotate(d, G, jj, gj, scale, min_iter, ord, false, sh, scs, ssn, scol, sbc);
+    if (tid == 0) { if (j > 0) uc_rotate(d, G, jj, gj, scale, min_iter, ord, false, sh, scs, ssn, scol, sbc); else uc_start_solve(d, G, scale, min_iter, false, sh, sbc); }
     lds_barrier();
     NSK_STAMP(4);
     const double hinv = sbc[0];
     if (sbc[1] != 0.0) return;                // column j-1 closed the solve
 #pragma unroll
-    for (int k = 0; k < 8; ++k) if (k < j) { v0 -= sh[k] * vk0[k]; v1 -= sh[k] * vk1[k]; }
-    for (int k = 8; k < j; ++k) {
+    for (int k = 0; k < VK; ++k) if (k < j) { v0 -= sh[k] * vk0[k]; v1 -= sh[k] * vk1[k]; }
+    for (int k = VK; k < j; ++k) {
       if (i0 >= 0) v0 -= sh[k] * d.V[(size_t)k * d.ps + i0];
       if (i1 >= 0) v1 -= sh[k] * d.V[(size_t)k * d.ps + i1];
     }
     v0 *= hinv; v1 *= hinv;
     if (pact) d.V[(size_t)j * d.ps + q] = v0;  // the first MM patch entries are the element's own nodes (p_idx[e][k] = e MM + k)
   }
+  asm volatile("" ::: "memory");              // (stage 2 not before the basis registers are free: 168 registers, three workgroups per CU)
+#pragma unroll
+  for (int k4 = 0; k4 < PQ2; ++k4) if (PQ1 + k4 < nq) pa2[k4] = PA[(size_t)(PQ1 + k4) * MM];
+  double m0 = 0, m1 = 0, m2 = 0, m3 = 0;      // (needed behind the patch solve only)
+  if (pact) { m0 = d.w2rx[q]; m1 = d.w2sx[q]; m2 = d.w2ry[q]; m3 = d.w2sy[q]; }
   if (act) {
     if (nd < PS) sr[el * MAXP + nd] = v0;
     if (nd + NN < PS) sr[el * MAXP + nd + NN] = v1;
@@ -1827,13 +2073,27 @@ __device__ __forceinline__ void uc_schwarz_role(const Dev& d, int j, double scal
   lds_barrier();
   NSK_STAMP(5);
   if (pact) {
-    const float4* A = reinterpret_cast<const float4*>(d.p_inv + (size_t)e * PS * MM) + nd;
     const double* r = sr + el * MAXP;
     double z0 = 0, z1 = 0, z2 = 0, z3 = 0;
-    const int nq = PS / 4;
+#pragma unroll
+    for (int k4 = 0; k4 < PQ1; ++k4) if (k4 < nq) {
+      const float4 a = pa1[k4];
+      z0 += (double)a.x * r[4 * k4 + 0];
+      z1 += (double)a.y * r[4 * k4 + 1];
+      z2 += (double)a.z * r[4 * k4 + 2];
+      z3 += (double)a.w * r[4 * k4 + 3];
+    }
+#pragma unroll
+    for (int k4 = 0; k4 < PQ2; ++k4) if (PQ1 + k4 < nq) {
+      const float4 a = pa2[k4];
+      z0 += (double)a.x * r[4 * (PQ1 + k4) + 0];
+      z1 += (double)a.y * r[4 * (PQ1 + k4) + 1];
+      z2 += (double)a.z * r[4 * (PQ1 + k4) + 2];
+      z3 += (double)a.w * r[4 * (PQ1 + k4) + 3];
+    }
 #pragma unroll 8
-    for (int k4 = 0; k4 < nq; ++k4) {
-      const float4 a = A[(size_t)k4 * MM];
+    for (int k4 = PQ1 + PQ2; k4 < nq; ++k4) {                     // (lx1 >= 10: patches of more than 100 dofs)
+      const float4 a = PA[(size_t)k4 * MM];
       z0 += (double)a.x * r[4 * k4 + 0];
       z1 += (double)a.y * r[4 * k4 + 1];
       z2 += (double)a.z * r[4 * k4 + 2];
@@ -1861,21 +2121,25 @@ __device__ __forceinline__ void uc_schwarz_role(const Dev& d, int j, double scal
 template <int N, int MAXIT>
 __global__ __launch_bounds__(256, 3) void k_schwarz_uc(Dev d, int j, double scale, int min_iter, int ord, unsigned nsw, unsigned cgrid) {
   NSK_STAMP(0);
-  if (d.gsc->done) return;
+  if (!d.uc_start && d.gsc->done) return;      // (uc_start: the flag still belongs to the previous solve; this launch resets it)
   if (blockIdx.x < nsw) uc_schwarz_role<N>(d, j, scale, min_iter, ord, blockIdx.x, nsw);
-  else update_coarse_body<MAXIT, true, true>(d, j, scale, min_iter, ord, blockIdx.x - nsw, cgrid);
+    else uc_coarse_role<MAXIT>(d, j, scale, min_iter, ord, blockIdx.x - nsw);
 }
 
-// B_j: see above.  TPRE columns of Tc and VPRE basis vectors live in registers (loads issued with the first trip).
-template <int N, int TPRE = 20, int VPRE = 8>
+// B_j: see above.  All NVL = 20 columns of Tc (fp32 copy: T32) and the first eight basis vectors live in registers.  Every load
+// of the first trip is UNCONDITIONAL (lanes without a node load a valid address and drop the value; basis vectors in groups of
+// four behind one uniform branch each): `cond ? load : 0` costs a branch per load, and a conversion inside such a branch a
+// full wait per load (seen in the instruction stream of the first cut: twenty dependent trips for the fp32 copy).
+constexpr int UC_NVL = 20;
+template <int N, bool T32, bool SLIM = false>
 __device__ __forceinline__ void divgs_t_body(const Dev& d, int j, const unsigned bx_, const unsigned gx_) {
   using C = Cfg<N>;
   constexpr int NN = C::NN, M = C::M, MM = C::MM, EPB = C::EPB, NM = N * M;
-  constexpr int NVLMAX = 32;
+  constexpr int NVL = UC_NVL;
   __shared__ double sJ12[NM], sD12[NM];
   __shared__ double su[2 * EPB * NN], sA[4 * EPB * NM];
   __shared__ double sdot[(MAXMR + 2) * 4];
-  __shared__ double swr[EPB * MM], shat[4 * MM], sxc[EPB * NVLMAX];
+  __shared__ double swr[EPB * MM], shat[4 * MM], sxc[EPB * NVL];
   const int tid = threadIdx.x, el = tid / NN, nd = tid % NN;
   const int bid = d.boff + (int)xcd_element(bx_, gx_);
   const long long e = (long long)bid * EPB + el;
@@ -1883,53 +2147,63 @@ __device__ __forceinline__ void divgs_t_body(const Dev& d, int j, const unsigned
   NSK_STAMP(0);
   if (d.gsc->done) return;
   NSK_STAMP(1);
-  const long long l = e * NN + nd;
   const bool pact = act && nd < MM;
-  const long long q = e * MM + nd;
-  const int nvl = d.nvl;
+  // safe addresses for the lanes without an element / a pressure node
+  const long long es = act ? e : 0;
+  const long long l = es * NN + nd;
+  const int nds = nd < MM ? nd : 0;
+  const long long q = es * MM + nds;
   // ---- first trip: everything addressable from the thread index
-  int4 tab = make_int4(0, -1, -1, -1);
-  double bi = 0;
-  if (act) { tab = d.gs_tab[l]; bi = d.binv[l]; }
-  int ecs = 0;
-  if (act && nd < 4) ecs = d.ecslot[e * 4 + nd];
-  int iv = 0;
-  if (act && nd < nvl) iv = d.evl[e * nvl + nd];
-  int4 ev = make_int4(0, 0, 0, 0);
-  double mw0 = 0, mw1 = 0, mw2 = 0, mw3 = 0, zq = 0, h0 = 0, h1 = 0, h2 = 0, h3 = 0;
-  double tt[TPRE], vk[VPRE];
-  if (pact) {
-    ev = reinterpret_cast<const int4*>(d.evert)[e];
-    mw0 = d.w2rx[q]; mw1 = d.w2sx[q]; mw2 = d.w2ry[q]; mw3 = d.w2sy[q];
-    zq = d.Z[(size_t)j * d.npr + q];
-    h0 = d.hat[0 * MM + nd]; h1 = d.hat[1 * MM + nd]; h2 = d.hat[2 * MM + nd]; h3 = d.hat[3 * MM + nd];
-  }
-  {
-    const double* T = d.Tc + ((size_t)(act ? e : 0) * nvl) * MM + (nd < MM ? nd : 0);
+  const int4 tab = d.gs_tab[l];
+  const double bi = d.binv[l];
+  const int ecs = d.ecslot[es * 4 + (nd & 3)];
+  const int iv = d.evl[es * NVL + (nd < NVL ? nd : 0)];
+  const int4 ev = reinterpret_cast<const int4*>(d.evert)[es];
+  const double mw0 = d.w2rx[q], mw1 = d.w2sx[q], mw2 = d.w2ry[q], mw3 = d.w2sy[q];
+  const double zq = d.Z[(size_t)j * d.npr + q];
+  float ttf[T32 ? NVL : 1];
+  double ttd[T32 ? 1 : NVL];
+  if constexpr (!SLIM) {
+    if constexpr (T32) {
+      const float* T = d.Tc32 + ((size_t)es * NVL) * MM + nds;
 #pragma unroll
-    for (int s = 0; s < TPRE; ++s) tt[s] = (pact && s < nvl) ? T[(size_t)s * MM] : 0.0;
-  }
+      for (int s = 0; s < NVL; ++s) ttf[s] = T[(size_t)s * MM];
+    } else {
+      const double* T = d.Tc + ((size_t)es * NVL) * MM + nds;
 #pragma unroll
-  for (int k = 0; k < VPRE; ++k) vk[k] = (pact && k <= j) ? d.V[(size_t)k * d.ps + q] : 0.0;
+      for (int s = 0; s < NVL; ++s) ttd[s] = T[(size_t)s * MM];
+    }
+  }
+  double vk[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) vk[k] = 0.0;
+  if constexpr (!SLIM) {
+    {                                           // basis vectors 0..3 (j >= 0 always: V_0 exists)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) vk[k] = d.V[(size_t)(k <= j ? k : j) * d.ps + q];
+    }
+    if (j >= 4) {
+#pragma unroll
+      for (int k = 4; k < 8; ++k) vk[k] = d.V[(size_t)(k <= j ? k : j) * d.ps + q];
+    }
+  }
   double j12a = 0, d12a = 0;
   if (tid < NM) { j12a = d.J12[tid]; d12a = d.D12[tid]; }
   double hatv[(4 * MM + 255) / 256];
 #pragma unroll
-  for (int r = 0; r < (4 * MM + 255) / 256; ++r) hatv[r] = (tid + r * 256 < 4 * MM) ? d.hat[tid + r * 256] : 0.0;
+  for (int r = 0; r < (4 * MM + 255) / 256; ++r) hatv[r] = d.hat[(tid + r * 256 < 4 * MM) ? tid + r * 256 : 0];
   NSK_STAMP(2);
   // ---- second trip: the neighbours' values of yl, the coarse solution at this element's vertices
-  GsVals g0, g1;
-  if (act) { g0 = gs_load(d.yl, tab, l); g1 = gs_load(d.yl + d.cs, tab, l); }
-  double xcv = 0.0, x0 = 0, x1 = 0, x2 = 0, x3 = 0;
-  if (act && nd < nvl) xcv = d.xc[iv];
-  if (pact) { x0 = d.xc[ev.x]; x1 = d.xc[ev.y]; x2 = d.xc[ev.z]; x3 = d.xc[ev.w]; }
+  const GsVals g0 = gs_load(d.yl, tab, l), g1 = gs_load(d.yl + d.cs, tab, l);
+  const double xcv = d.xc[iv];
+  const double x0 = d.xc[ev.x], x1 = d.xc[ev.y], x2 = d.xc[ev.z], x3 = d.xc[ev.w];
   if (tid < NM) { sJ12[tid] = j12a; sD12[tid] = d12a; }
 #pragma unroll
   for (int r = 0; r < (4 * MM + 255) / 256; ++r) if (tid + r * 256 < 4 * MM) shat[tid + r * 256] = hatv[r];
   if (act) {
     su[(0 * EPB + el) * NN + nd] = bi * gs_sum(g0, d.yl, d, tab, l);
     su[(1 * EPB + el) * NN + nd] = bi * gs_sum(g1, d.yl + d.cs, d, tab, l);
-    if (nd < nvl) sxc[el * NVLMAX + nd] = xcv;
+    if (nd < NVL) sxc[el * NVL + nd] = xcv;
   }
   NSK_STAMP(3);
   lds_barrier();
@@ -1966,13 +2240,18 @@ __device__ __forceinline__ void divgs_t_body(const Dev& d, int j, const unsigned
     }
     w = mw0 * ur + mw1 * us + mw2 * vr + mw3 * vs;
     // + E R^T x_c through its precomputed image
-    const double* xl = sxc + el * NVLMAX;
+    const double* xl = sxc + el * NVL;
     double wc = 0.0;
+    if constexpr (SLIM) {
+#pragma unroll 4
+      for (int s = 0; s < NVL; ++s) wc += (T32 ? (double)d.Tc32[((size_t)e * NVL + s) * MM + nd] : d.Tc[((size_t)e * NVL + s) * MM + nd]) * xl[s];
+    } else {
 #pragma unroll
-    for (int s = 0; s < TPRE; ++s) if (s < nvl) wc += tt[s] * xl[s];
-    for (int s = TPRE; s < nvl; ++s) wc += d.Tc[((size_t)e * nvl + s) * MM + nd] * xl[s];
+      for (int s = 0; s < NVL; ++s) wc += (T32 ? (double)ttf[s] : ttd[s]) * xl[s];
+    }
     w += wc;
     d.Wr[q] = w;
+    const double h0 = shat[0 * MM + nd], h1 = shat[1 * MM + nd], h2 = shat[2 * MM + nd], h3 = shat[3 * MM + nd];
     d.Z[(size_t)j * d.npr + q] = zq + (h0 * x0 + h1 * x1 + h2 * x2 + h3 * x3);
     swr[el * MM + nd] = w;
   }
@@ -1987,16 +2266,18 @@ __device__ __forceinline__ void divgs_t_body(const Dev& d, int j, const unsigned
   }
   {
     const int lane = tid & 63, wv = tid >> 6;
+    if constexpr (!SLIM) {
 #pragma unroll
-    for (int k = 0; k < VPRE; ++k) {
-      if (k <= j) {
-        double x = pact ? w * vk[k] : 0.0;
-        x = wave_sum63(x);
-        if (lane == 63) sdot[k * 4 + wv] = x;
+      for (int k = 0; k < 8; ++k) {
+        if (k <= j) {
+          double x = pact ? w * vk[k] : 0.0;
+          x = wave_sum63(x);
+          if (lane == 63) sdot[k * 4 + wv] = x;
+        }
       }
     }
 #pragma unroll 4
-    for (int k = VPRE; k <= j; ++k) {
+    for (int k = SLIM ? 0 : 8; k <= j; ++k) {
       double x = pact ? w * d.V[(size_t)k * d.ps + q] : 0.0;
       x = wave_sum63(x);
       if (lane == 63) sdot[k * 4 + wv] = x;
@@ -2016,9 +2297,9 @@ __device__ __forceinline__ void divgs_t_body(const Dev& d, int j, const unsigned
   }
   NSK_STAMP(6);
 }
-template <int N>
+template <int N, bool T32>
 __global__ __launch_bounds__(256, 2) void k_divgs_t(Dev d, int j) {
-  divgs_t_body<N>(d, j, blockIdx.x, gridDim.x);
+  divgs_t_body<N, T32>(d, j, blockIdx.x, gridDim.x);
 }
 
 // after GMRES: dp = h2 * sum_i y_i Z_i (+ projected part) ; p = p* + dp ; yl = D^T dp

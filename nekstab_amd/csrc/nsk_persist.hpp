@@ -481,7 +481,8 @@ __global__ __launch_bounds__(256, 2) void k_pres_tail2(Dev d, int j0, int j1, do
       ok = grid_barrier(sync, epoch++, (int)gridDim.x, &s_fail);
       if (!ok || __hip_atomic_load(&d.gsc->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;      // column j-1 closed the solve
     }
-    divgs_t_body<N, 4, 2>(d, j, blockIdx.x, gridDim.x);     // (register-lean: same sums in the same order)
+    if (d.tc32) divgs_t_body<N, true, true>(d, j, blockIdx.x, gridDim.x);     // (register-lean forms: same sums in the same order)
+    else divgs_t_body<N, false, true>(d, j, blockIdx.x, gridDim.x);
     ok = grid_barrier(sync, epoch++, (int)gridDim.x, &s_fail);
   }
   if (!ok && tid == 0) atomicAdd((unsigned long long*)&d.stats->sync_timeouts, 1ull);

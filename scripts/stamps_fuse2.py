@@ -38,8 +38,8 @@ def report(title, t, names):
 
 
 t = grab("schwarz_uc", nb + ncg)
-report("k_schwarz_uc j=%s, Schwarz role" % jd, t[:nb], ["done flag", "patch indices issued", "loads issued (metrics, w, V_k at the patch nodes)", "partial sums (waits for their loads) + barrier",
-                                                        "column rotation (one lane) + barrier", "v_j, store, patch -> LDS + barrier", "patch solve (inverse streamed)", "D^T (2 passes) + stores"])
-report("k_schwarz_uc j=%s, coarse role" % jd, t[nb:nb + ncg], ["done flag", "(second done check)", "loads + vertex sums -> LDS (lean: 3 chunks)", "partial sums + barrier", "column rotation (lane 0)", "matrix product (lean: 3 chunks) + wave sums", "barrier (column rotated)", "combine with the history, store"])
+report("k_schwarz_uc j=%s, Schwarz role" % jd, t[:nb], ["done flag, patch indices issued", "all loads issued (needs the patch indices), basis -> LDS", "partial sums + barrier",
+                                                        "column rotation (one lane) + barrier", "v_j, store, patch -> LDS + barrier", "patch solve", "D^T (2 passes) + stores"])
+report("k_schwarz_uc j=%s, coarse role" % jd, t[nb:nb + ncg], ["done flag", "loads + vertex sums -> LDS (3 chunks)", "partial sums + barrier", "column rotation (lane 0)", "matrix product + wave sums", "barrier (column rotated)", "combine with the history, store"])
 t = grab("divgs_t", nb)
 report("k_divgs_t j=%s" % jd, t[:nb], ["done flag", "first trip issued (table, metrics, Tc, V_k, Z)", "second trip issued (gathers, x_c) + sums -> LDS", "barrier", "divergence + Tc x_c + stores", "restriction + dots + partials"])

