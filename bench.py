@@ -62,6 +62,7 @@ def parse():
     ap.add_argument("--fused", type=int, default=-1, help="persistent velocity solve: 1 / 0 / -1 = library default")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = all host cores)")
     ap.add_argument("--cpu-baseline-child", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--no-preflight", action="store_true", help="N>1 over RCCL: skip the two-form RCCL check (tests/mp_rccl_worker.py in fresh processes) in front of the timed run")
     ap.add_argument("--ref-logfile", default=None, help="a logfile of a nekStab run of the same case (its 'Time per iteration' lines, core/krylov_decomposition.f:92-98, and Nek5000's step lines): the record gains `reference_logfile` with the reference's own matvecs/s")
     return ap.parse_args()
 
@@ -95,11 +96,26 @@ def supervise(a):
     modes = [1, 0] if a.shard_graph < 0 else [a.shard_graph]
     if a.replicas:
         modes = [0]
+    # ---- pre-flight: before the timed run, FRESH child processes run the two-GPU RCCL check of the test
+    # suite (tests/mp_rccl_worker.py: a sharded map with the all-reduce inside the halo messages' RCCL group, then with separate
+    # calls, and nsk_orth across the ranks, each against the single-rank result).  The grouped form had never executed between
+    # two GPUs when this was written: if it fails (wrong numbers, an error, a stall) and the separate calls pass, the timed run
+    # takes rccl_fuse = 0 and the record says so.
+    preflight = None
+    ngpu = 0
+    try:
+        import torch
+        ngpu = torch.cuda.device_count()                    # (counting devices does not initialise the GPU)
+    except Exception:                                       # noqa: BLE001
+        pass
+    if not a.replicas and not a.no_preflight and os.environ.get("NSK_DIST_BACKEND", "nccl") == "nccl" and ngpu >= world:
+        preflight = rccl_preflight(world, ranks, under_launcher, base_port)
+        print("bench.py supervisor: RCCL pre-flight: %s" % json.dumps(preflight), file=sys.stderr, flush=True)
     rc = 1
     for att, mode in enumerate(modes):
         procs = []
         for r in ranks:
-            env = dict(os.environ, NSK_BENCH_WORKER="1", NSK_BENCH_SHARD_GRAPH=str(mode), NSK_BENCH_ATTEMPT=str(att), RANK=str(r),
+            env = dict(os.environ, NSK_BENCH_WORKER="1", NSK_BENCH_PREFLIGHT=json.dumps(preflight) if preflight else "", NSK_BENCH_SHARD_GRAPH=str(mode), NSK_BENCH_ATTEMPT=str(att), RANK=str(r),
                        LOCAL_RANK=os.environ.get("LOCAL_RANK", str(r)) if under_launcher else str(r), WORLD_SIZE=str(world),
                        MASTER_ADDR="127.0.0.1", MASTER_PORT=str(base_port + (23 + att if under_launcher else att)),
                        HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
@@ -117,6 +133,41 @@ def supervise(a):
     if 0 in ranks:
         print(json.dumps({"metric": METRIC, "value": None, "unit": "matvecs/s", "n_gpus": world, "error": "the sharded run failed in every attempt (see stderr)"}), flush=True)
     return rc or 1
+
+
+def rccl_preflight(world, ranks, under_launcher, base_port):
+    """Run tests/mp_rccl_worker.py on `world` ranks (one GPU each) in fresh processes: grouped all-reduce + halos (rccl_fuse = 1),
+    then separate calls (0).  Returns {"fuse1": ok / error, "fuse0": ..., "rccl_fuse": the form the timed run should take}."""
+    worker = os.path.join(ROOT, "tests", "mp_rccl_worker.py")
+    res = {}
+    for k, fuse in enumerate(("1", "0")):
+        procs = []
+        for r in ranks:
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=os.environ.get("LOCAL_RANK", str(r)) if under_launcher else str(r), WORLD_SIZE=str(world),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(base_port + (47 + k if under_launcher else 11 + k)), NSK_PREFLIGHT_FUSE=fuse,
+                       HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+            env.pop("TORCHELASTIC_USE_AGENT_STORE", None)
+            procs.append(subprocess.Popen([sys.executable, worker], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+        ok, note = True, ""
+        for p in procs:
+            try:
+                so, se = p.communicate(timeout=420)
+            except subprocess.TimeoutExpired:
+                p.kill(); so, se = p.communicate()
+                ok, note = False, "stalled (420 s)"
+                continue
+            if p.returncode != 0:
+                ok, note = False, (note or ("exit code %d: %s" % (p.returncode, (se or so)[-200:].replace("\n", " "))))
+            for l in so.splitlines():
+                if l.startswith("MPRCCL errors"):
+                    note = l[len("MPRCCL errors"):].strip()
+        res["fuse" + fuse] = {"ok": ok, "note": note}
+        if ok and fuse == "1":
+            break                                            # the grouped form works: nothing else to try
+    res["rccl_fuse"] = 1 if res.get("fuse1", {}).get("ok") else 0
+    if not res.get("fuse1", {}).get("ok") and not res.get("fuse0", {}).get("ok", False):
+        res["warning"] = "the RCCL check failed with grouped AND separate all-reduces: the timed run is attempted anyway (its own retry and watchdog apply)"
+    return res
 
 
 def cpu_baseline(case, threads, tol, nproj, gpu_value, q_sample=None, lx1=None):
@@ -547,6 +598,9 @@ def main():
                 sh.set_option("halo_overlap", 1)
         else:
             sh.set_option("shard_graph", 0)                # eager until the first exchanges have run (RCCL sets its peer connections up lazily: not inside a capture)
+            pf = os.environ.get("NSK_BENCH_PREFLIGHT")
+            if pf and json.loads(pf).get("rccl_fuse") == 0:
+                sh.set_option("rccl_fuse", 0)              # the pre-flight check of this run found the grouped all-reduce wanting (supervise())
             if int(os.environ.get("NSK_BENCH_ATTEMPT", "0")) > 0:
                 sh.set_option("rccl_fuse", 0)              # the retry attempt: the all-reduces as calls of their own (the grouped form has not run on hardware before this node)
         return sh
@@ -899,7 +953,9 @@ def main():
                 full = make_context(case)
                 setup_local["whole_mesh_seconds_rank0"] = time.perf_counter() - t0
         out["setup"] = setup_local
-        out["shard_mode"] = dict(shard_mode, note="seconds for 24 sharded time steps with captured step graphs (RCCL calls inside) / with eager launches and host-read convergence flags / the same with the halo of the velocity solve overlapped with its interior work; the timed run uses the fastest") if shard_mode else \
+        if os.environ.get("NSK_BENCH_PREFLIGHT"):
+            out["rccl_preflight"] = dict(json.loads(os.environ["NSK_BENCH_PREFLIGHT"]), note="tests/mp_rccl_worker.py in fresh processes before the timed run: a sharded map with the all-reduce inside the halo messages' RCCL group (fuse1) and, only if that fails, with separate calls (fuse0); `rccl_fuse` is the form this run used")
+        out["shard_mode"] = dict(shard_mode, config=a.case, note="seconds for 24 sharded time steps with captured step graphs (RCCL calls inside) / with eager launches and host-read convergence flags / the same with the halo of the velocity solve overlapped with its interior work; the timed run uses the fastest") if shard_mode else \
             {"picked": "hostcheck" if backend != "nccl" or shard_graph == 0 else "graph", "note": "not compared in this attempt"}
         if rank == 0:
             try:

@@ -6,7 +6,7 @@ module nekstab_hip
   use iso_c_binding
   implicit none
   integer(c_int), parameter :: NSK_DIRECT = 0, NSK_ADJOINT = 1, NSK_DIRECT_ADJOINT = 2, NSK_NEWTON = 3, NSK_FORCE_SENSITIVITY = 4
-  integer(c_int), parameter :: NSK_EINVAL = -1, NSK_EHIP = -2, NSK_ENAN = -3, NSK_ENOCONV = -4, NSK_ENOMEM = -5
+  integer(c_int), parameter :: NSK_EINVAL = -1, NSK_EHIP = -2, NSK_ENAN = -3, NSK_ENOCONV = -4, NSK_ENOMEM = -5, NSK_ECOMM = -6
 
   type, bind(c) :: nsk_case
     integer(c_int) :: ndim, nel, lx1, lxd

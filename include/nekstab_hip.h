@@ -28,7 +28,9 @@ enum nsk_status {
   NSK_EHIP = -2,        /* HIP runtime error */
   NSK_ENAN = -3,        /* NaN in an inner product (core/krylov_subspace.f:53 aborts) */
   NSK_ENOCONV = -4,     /* an inner Helmholtz / pressure solve hit its iteration cap */
-  NSK_ENOMEM = -5
+  NSK_ENOMEM = -5,
+  NSK_ECOMM = -6        /* the ranks of a sharded run received DIFFERENT results from one all-reduce (checked bit for bit on the first
+                           all-reduces of a context): device-side convergence flags would diverge; the map is refused */
 };
 
 enum nsk_mode {          /* `evop`, core/matvec.f:124-151 */
@@ -115,10 +117,16 @@ int nsk_set_tolerances(nsk_ctx* ctx, double tol_helm, double tol_pres, int relat
  * "dbg_max_order" / "dbg_ab2" / "dbg_pext" (time-scheme sensitivity switches of scripts/wake_bisect.py; defaults = SURVEY App. A),
  * "dbg" (developer ablation mask),
  * "step_budgets" (1, default: launch budgets per TIME STEP from the per-step iteration record of the last maps instead of one
- *   per step class; graph-replayed single-rank contexts), "tail" (persistent tail kernels of the two inner solves behind a head
- *   of launches: -1 = where the grid is resident, 0 = never (default: measured the same speed), with "tail_off_h" / "tail_off_p"
+ *   per step class; graph-replayed single-rank contexts), "tail" (persistent tail kernels of the two inner solves behind the launches
+ *   of a solve: -1 (DEFAULT) = as a safety net behind the per-time-step budgets (mode 2) wherever every workgroup of the grid is
+ *   resident, else none; 0 = never; 1 = heads (median counts) + tail; 2 = budgets + safety net; with "tail_off_h" / "tail_off_p"
  *   = offsets of the heads from the median count), "rccl_fuse" (1, default: on RCCL ranks the all-reduce of an iteration rides
- *   in the group of that iteration's halo messages),
+ *   in the group of that iteration's halo messages), "allred_verify" (24, default: that many all-reduces of a sharded context
+ *   are verified bit for bit across the ranks; a mismatch makes the map return NSK_ECOMM),
+ * "fuse2" (1, default; round 6: the merged pressure GMRES iteration in TWO launches -- k_schwarz_uc: Schwarz workgroups and
+ *   coarse-solve workgroups side by side, k_divgs_t: the coarse part through its precomputed image under E; 0 = the three
+ *   launches of rounds 3-5), "fuse2_start" (1: the solve starts inside the first of them, no k_gmres_update(-1) launch),
+ *   "tc32" (0, default; 1: fp32 copy of the coarse image, moves a map by 2e-8),
  * "zero_metrics" (hexahedra; 1, default: arrays of the mapping and of the base-flow constants that are zero on every node -- the
  *   cross terms Nek5000 skips on its undeformed elements, hmholtz.f axhelm / ifdfrm -- are not loaded; 0: every array is loaded,
  *   same bits.  The set-up sets derivatives of the mapping that are rounding noise on every node to zero; NSK_ZERO_METRICS=0 in

@@ -165,6 +165,8 @@ struct nsk_ctx {
   // halo send / recv pairs (one group per CG iteration instead of two, three per GMRES iteration instead of four): option
   // "rccl_fuse" (NSK_RCCL_FUSE=0 restores the separate calls; bench.py's eager retry attempt does)
   int rccl_fuse = 1;
+  int arv_left = 24;                    // all-reduces of this context still to be verified bit for bit across the ranks (option "allred_verify"; k_ar_chunks / k_ar_check)
+  double* arv_buf = nullptr;            // 64 doubles
   // The same on a full-mesh context (option "hostcheck"): eager steps, no launch budgets, no redone maps.  -1 = yes for large
   // hexahedral meshes (>= 8192 elements: a launch that only finds its solve converged costs 25-140 us there and a map redone
   // with larger budgets tens of seconds) and for quadrilateral meshes of more than 4096 workgroups (config 3), 0 = never, 1 = always.
@@ -2332,6 +2334,7 @@ int nsk_set_option(nsk_ctx* c, const char* name, double value) {
   else if (n == "hostcheck") c->hostcheck = (int)value;
   else if (n == "halo_overlap") c->halo_overlap = value != 0.0;
   else if (n == "rccl_fuse") c->rccl_fuse = (int)value;
+  else if (n == "allred_verify") c->arv_left = (int)value;
   else if (n == "orth_overlap") c->orth_overlap = (int)value;
   else if (n == "nscal") {
     // krylov_vector%theta (core/krylov_subspace.f:13): carried by every vector operation and by the inner product; the time

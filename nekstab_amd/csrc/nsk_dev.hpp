@@ -65,6 +65,7 @@ struct Stats {
   double worst_cap_ratio;                         // largest residual / tolerance among them
   long long sync_timeouts;                        // grid barriers of the persistent kernels that gave up (never in a healthy run)
   long long pres_jsum;                            // sum over the GMRES columns of their basis index j (the Gram-Schmidt bytes are proportional to it)
+  long long allred_mismatch;                      // verified all-reduces whose result was NOT bit-identical on every rank (sharded runs: NSK_ECOMM)
   long long nonfinite;                            // pressure right-hand sides whose norm was NaN / Inf: the map's input or the solver state was not finite (map_finish: NSK_ENAN + state reset)
 };
 

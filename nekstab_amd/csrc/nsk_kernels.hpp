@@ -2772,6 +2772,24 @@ __global__ __launch_bounds__(256) void k_tot2(const double* __restrict__ part, i
 }
 // loop-back all-reduce for virtual ranks living in one process: every buffer <- sum of all (rank order)
 struct LoopPack { double* p[16]; };
+// Do all ranks hold the SAME bits after an all-reduce?  (Device-side convergence flags and launch budgets assume it; a
+// collective whose reduction order depends on the rank would break that silently.)  k_ar_chunks splits the first n <= 8
+// doubles of the result into four 16-bit chunks c (exact small integers as doubles) and appends c^2; the sums of both over
+// the ranks are exact in any order, so EVERY rank evaluates  W sum c^2 - (sum c)^2  identically: zero iff all ranks agree.
+__global__ void k_ar_chunks(const double* __restrict__ x, int n, double* __restrict__ out) {
+  const int t = threadIdx.x;
+  if (t >= 4 * n) return;
+  const unsigned long long b = (unsigned long long)__double_as_longlong(x[t >> 2]);
+  const double c = (double)((b >> (16 * (t & 3))) & 0xffffull);
+  out[t] = c;
+  out[4 * n + t] = c * c;
+}
+__global__ void k_ar_check(const double* __restrict__ sums, int n, int world, Stats* st) {
+  const int t = threadIdx.x;
+  bool bad = false;
+  if (t < 4 * n) { const double s = sums[t], s2 = sums[4 * n + t]; bad = ((double)world * s2 - s * s) != 0.0; }
+  if (__syncthreads_or(bad ? 1 : 0) && t == 0) st->allred_mismatch += 1;
+}
 __global__ void k_loop_allreduce_pack(LoopPack pk, int nr, int n) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;

@@ -403,6 +403,7 @@ __global__ __launch_bounds__(Cfg<N>::NT, 2) void k_helm_tail(Dev d, StepCoef sc,
   if (tid == 0) s_fail = 0;
   zero_sync(sync_other, tid, Cfg<N>::NT);
   __syncthreads();
+  if (d.stats->sync_timeouts != 0) return;       // an earlier tail of this map timed out: the map is redone with launch budgets (do not spin again)
   unsigned epoch = 1;
   bool ok = true, fin = false;
   int it = it0;
@@ -437,6 +438,7 @@ __global__ __launch_bounds__(Cfg<N>::NT, 2) void k_pres_tail(Dev d, int j0, int 
   if (tid == 0) s_fail = 0;
   zero_sync(sync_other, tid, Cfg<N>::NT);
   __syncthreads();
+  if (d.stats->sync_timeouts != 0) return;       // (as k_helm_tail)
   unsigned epoch = 1;
   bool ok = true;
   for (int j = j0; j < j1 && ok; ++j) {

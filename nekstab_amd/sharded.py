@@ -10,6 +10,8 @@ from __future__ import annotations
 
 import ctypes as C
 
+import os
+
 import numpy as np
 
 from .capi import NekStabHip, NskError, _dp
@@ -602,6 +604,11 @@ class HostTransport:
         import torch
         t = torch.from_numpy(buf)
         self.dist.all_reduce(t)
+        # test hook (tests/test_multiprocess_gpu.py): ONE rank receives the result of all-reduce number NSK_TEST_ALLRED_ULP one
+        # ulp off -- what a collective with a rank-dependent reduction order would deliver; the library must refuse the map (NSK_ECOMM)
+        hook = os.environ.get("NSK_TEST_ALLRED_ULP")
+        if hook is not None and self.n_allreduce == int(hook) and self.dist.get_rank() == self.dist.get_world_size() - 1:
+            buf[0] = np.nextafter(buf[0], np.inf)
         self.n_allreduce += 1
         return buf
 

@@ -41,7 +41,7 @@ def main():
     full.matvec(b, a, 0)
     ref = full.download(b)
     errs = []
-    for fuse in (1, 0):
+    for fuse in [int(x) for x in os.environ.get("NSK_PREFLIGHT_FUSE", "1,0").split(",")]:
         sh.set_option("rccl_fuse", fuse)
         sh.matvec(vf, vq, 0)
         loc = sh.download_local(vf)

@@ -155,7 +155,45 @@ def main_r3(kind):
     sys.exit(0 if flag.item() == 1.0 else 1)
 
 
+def main_allred_ulp():
+    """One rank receives ONE all-reduce result one ulp off (sharded.HostTransport test hook): what a collective with a rank-dependent
+    reduction order would deliver.  Every rank must get NSK_ECOMM (-6) from the map -- not silently diverging convergence flags --,
+    and a clean map afterwards must run (the verification found nothing: the hook fires once)."""
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    from nekstab_amd import mesh, seed
+    from nekstab_amd.capi import NekStabHip, NskError
+    from nekstab_amd.sharded import ShardRank, attach_host_transport, partition_rcb
+    case = mesh.load_case_npz(os.path.join(ROOT, "tests", "golden", "cylinder_case.npz"), 6)
+    full = NekStabHip(case, case.meta["vert"], case.meta["nvert"], tol_helm=1e-10, tol_pres=1e-4, tol_relative=1, max_helm_iter=120, max_pres_iter=48)
+    sh = ShardRank(full, case, rank, world, None, partition_rcb(case, world))
+    tr = attach_host_transport(sh, dist)
+    sh.set_nsteps(3)
+    qx, qy = seed.add_noise(case)
+    vq, vf = sh.alloc(2)
+    sh.upload(vq, qx, qy, np.zeros((case.nel, 4, 4)))
+    os.environ["NSK_TEST_ALLRED_ULP"] = str(tr.n_allreduce + 2)          # the third all-reduce from here: inside the first map
+    code = 0
+    try:
+        sh.matvec(vf, vq, 0)
+    except NskError as e:
+        code = e.code
+    os.environ.pop("NSK_TEST_ALLRED_ULP")
+    sh.set_option("allred_verify", 24)
+    sh.matvec(vf, vq, 0)                                                 # clean transport: verified again, accepted
+    flag = torch.tensor([1.0 if code == -6 else 0.0])
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        print("MPALLRED code on every rank == NSK_ECOMM:", flag.item() == 1.0, "(this rank: %d)" % code, flush=True)
+    sh.close(); full.close()
+    sys.exit(0 if flag.item() == 1.0 else 1)
+
+
 def main():
+    if len(sys.argv) > 2 and sys.argv[2] == "allred-ulp":
+        return main_allred_ulp()
     if len(sys.argv) > 2:
         return main_r3(sys.argv[2])
     import torch

@@ -46,6 +46,20 @@ def test_round3_shard_features_across_processes(kind, world, port):
     assert line
 
 
+def test_ranks_that_disagree_on_an_all_reduce_are_refused():
+    """the first all-reduces of a sharded context are verified bit for bit across the ranks (exact integer
+    chunk sums: k_ar_chunks / k_ar_check); one rank fed a result one ulp off => NSK_ECOMM on EVERY rank, no divergent
+    device-side convergence flags; the next map on the clean transport runs."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29671", os.path.join(ROOT, "tests", "mp_shard_worker.py"), "0", "allred-ulp"],
+                         capture_output=True, text=True, timeout=600, env=env)
+    line = [l for l in out.stdout.splitlines() if l.startswith("MPALLRED")]
+    print(line, out.stderr[-1500:] if out.returncode else "")
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert line and "True" in line[0]
+
+
 def test_bench_two_ranks_under_the_launcher_dry_run():
     """`bench.py --gpus 2` exactly as the driver starts it (torch.distributed.run, one supervisor per rank, each starting its
     worker), with the ranks sharing this GPU and the halos travelling over gloo (NSK_DIST_BACKEND=gloo: the protocol dry run):
