@@ -1157,7 +1157,7 @@ static void launch_proj_dots3(nsk_ctx* c, const Dev& d) {
   }
 }
 
-template <int N> static void launch_pres_tail(nsk_ctx* c, const Dev& d, int j0, int j1, double scale, int min_iter, int ord);
+template <int N> static void launch_pres_tail(nsk_ctx* c, const Dev& d, int j0, int j1, double scale, int min_iter, int ord, bool start = false);
 static int pres_solve_launch(nsk_ctx* c, double h2, int ord, int np, double tol_mul = 1.0, bool allow_cap = false, bool hc = false, bool tail = false) {
   Dev d = c->d;                                            // by value: the early steps of a map run with a tighter tolerance
   d.tol_pres = early_tol(d, tol_mul);
@@ -1176,8 +1176,10 @@ static int pres_solve_launch(nsk_ctx* c, double h2, int ord, int np, double tol_
     // round 6: with the two-launch iteration the solve starts INSIDE A_0 (element-aligned projection kernel -> raw g' in Wr
     // + its corner restrictions; no k_gmres_update(-1) launch) where the projection kernel is the last producer of g'
     const bool merged0 = c->merged_update && c->ndim == 2 && d.coarse_lda <= 3072 && !d.use_tot && d.nranks <= 1 && d.rch && d.ecv && !hc;
+    // (the choice must not depend on the launch budgets or on the tail mode: the two projection kernels sum their partials in
+    //  different groups, so a step that switched form with its budget would change bits between otherwise identical runs)
     const bool f2start = merged0 && fuse2_on(c) && c->fuse2_start && d.nproj_max > 0 && d.nproj_max <= MAXPROJ && !c->in_test && np > 0 &&
-                         std::min(np, std::min(c->merged_iters, c->gmres_cycle)) > 0 && !(tail && std::min(np, std::min(c->merged_iters, c->gmres_cycle) - 1) <= 0);
+                         std::min(c->merged_iters, c->gmres_cycle) > 0;
     if (f2start) launch_proj_apply_e<N>(c, d);
     else if (d.nproj_max > 0 && !c->in_test) { hipLaunchKernelGGL(k_proj_apply, dim3(c->nblk), dim3(256), 0, c->stream, d); tot_rows(c, d.gpart, 1, d.gtot); }
     if (!f2start) hipLaunchKernelGGL(k_gmres_update<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, -1, scale, c->min_pres, ord);
@@ -1212,15 +1214,22 @@ static int pres_solve_launch(nsk_ctx* c, double h2, int ord, int np, double tol_
       hipLaunchKernelGGL(k_schwarz<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, (const double*)(d.V + (size_t)j * d.ps), d.Z + (size_t)j * d.npr, 1, 1);
       hipLaunchKernelGGL(k_divgs<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, (const double*)d.yl, d.V + (size_t)(j + 1) * d.ps, j, 2);
     }
-    if (tl && nhead < nm) launch_pres_tail<N>(c, d, nhead, nm, scale, c->min_pres, ord);
+    if (tl && nhead < nm) launch_pres_tail<N>(c, d, nhead, nm, scale, c->min_pres, ord, f2start && nhead == 0);
     // a velocity tail ran in this step but no pressure tail will: the velocity tail's barrier words (set 0) are re-zeroed by
     // the pressure tail only, so zero them here (a dirty set lets the next velocity tail's first barriers fall through)
     if (tail && !(tl && nhead < nm) && c->sync) (void)hipMemsetAsync(c->sync, 0, SYNC_WORDS * sizeof(unsigned), c->stream);
     // closes the last merged column (normalises v_nm and writes its corner restriction: what the classic iteration nm reads)
     if (nm > 0) {
-      Dev dcl = d;
-      if (f2) dcl.wraw = d.Wr;                             // the raw w of B_{nm-1}
-      hipLaunchKernelGGL(k_gmres_update<N>, dim3(c->nblk), dim3(NT), 0, c->stream, dcl, nm - 1, scale, c->min_pres, ord);
+      if (f2 && nm < std::min(c->merged_iters, c->gmres_cycle)) {
+        // two-launch form, budget below the merged range: the last column is closed by A_nm -- the SAME code (uc_rotate) that closes
+        // every other column and that the persistent tail runs, so that a solve of exactly nm iterations ends with the same bits
+        // whatever budget or tail mode ended it (k_gmres_update's own copy of the rotation differs from it by rounding)
+        launch_schwarz_uc<N>(c, d, nm, scale, c->min_pres, ord);
+      } else {
+        Dev dcl = d;
+        if (f2) dcl.wraw = d.Wr;                           // the raw w of B_{nm-1}; classic iterations follow: they need v_nm normalised and its corner restrictions
+        hipLaunchKernelGGL(k_gmres_update<N>, dim3(c->nblk), dim3(NT), 0, c->stream, dcl, nm - 1, scale, c->min_pres, ord);
+      }
     }
     for (int jt = nm; jt < np; ++jt) {
       const int j = jt % c->gmres_cycle;                 // index inside the current GMRES cycle
@@ -1357,14 +1366,15 @@ static void launch_helm_tail(nsk_ctx* c, const Dev& d, const StepCoef& sc, int i
   hipLaunchKernelGGL(nsk::k2::k_helm_tail<N>, dim3(c->nblk), dim3(nsk::k2::Cfg<N>::NT), 0, c->stream, d, sc, it0, it_end, (const double*)d.rloc, c->sync, c->sync + SYNC_WORDS);
 }
 template <int N>
-static void launch_pres_tail(nsk_ctx* c, const Dev& d, int j0, int j1, double scale, int min_iter, int ord) {
+static void launch_pres_tail(nsk_ctx* c, const Dev& d, int j0, int j1, double scale, int min_iter, int ord, bool start) {
   if (c->ndim != 2) return;
   const unsigned cgrid = (d.nvert + 4 * UC_ROWS - 1) / (4 * UC_ROWS);
   const size_t sh = d.coarse_lda * sizeof(double);
   const int nit = d.coarse_lda / 256;
   unsigned* sy = c->sync + SYNC_WORDS;          // (set 1; zeroes set 0 for the next velocity tail)
   if (fuse2_on(c)) {
-    launch_schwarz_uc<N>(c, d, j0, scale, min_iter, ord);    // A_{j0} as a launch: closes column j0-1 (a solve of exactly j0 iterations ends here: skip_a)
+    Dev d0 = d; d0.uc_start = (start && j0 == 0) ? 1 : 0;      // (a head of zero launches: the solve starts in this one)
+    launch_schwarz_uc<N>(c, d0, j0, scale, min_iter, ord);   // A_{j0} as a launch: closes column j0-1 (a solve of exactly j0 iterations ends here: skip_a)
     const dim3 grid(c->nblk), blk(256);
     if (nit <= 3) hipLaunchKernelGGL((nsk::k2::k_pres_tail2<N, 3>), grid, blk, sh, c->stream, d, j0, j1, scale, min_iter, ord, cgrid, 1, sy, c->sync);
     else if (nit <= 6) hipLaunchKernelGGL((nsk::k2::k_pres_tail2<N, 6>), grid, blk, sh, c->stream, d, j0, j1, scale, min_iter, ord, cgrid, 1, sy, c->sync);

@@ -476,15 +476,14 @@ __global__ __launch_bounds__(256, 2) void k_pres_tail2(Dev d, int j0, int j1, do
     if (__hip_atomic_load(&d.gsc->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
     if (!(skip_a && j == j0)) {
       for (unsigned bx = blockIdx.x; bx < cgrid; bx += gridDim.x) {
-        update_coarse_body<MAXIT, true, true>(d, j, scale, min_iter, ord, bx, cgrid);
+        uc_coarse_role<MAXIT>(d, j, scale, min_iter, ord, bx);       // (the SAME role functions as the launched form: same bits)
         __syncthreads();                         // (its LDS is reused by the next pass / the Schwarz role)
       }
       uc_schwarz_role<N>(d, j, scale, min_iter, ord, blockIdx.x, gridDim.x);
       ok = grid_barrier(sync, epoch++, (int)gridDim.x, &s_fail);
       if (!ok || __hip_atomic_load(&d.gsc->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;      // column j-1 closed the solve
     }
-    if (d.tc32) divgs_t_body<N, true, true>(d, j, blockIdx.x, gridDim.x);     // (register-lean forms: same sums in the same order)
-    else divgs_t_body<N, false, true>(d, j, blockIdx.x, gridDim.x);
+    divgs_t_body<N, false>(d, j, blockIdx.x, gridDim.x);             // (the fp64 coarse image whatever option "tc32" says: one body, no spills)
     ok = grid_barrier(sync, epoch++, (int)gridDim.x, &s_fail);
   }
   if (!ok && tid == 0) atomicAdd((unsigned long long*)&d.stats->sync_timeouts, 1ull);
