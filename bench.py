@@ -41,7 +41,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="timed Arnoldi steps (default 128 at N=1 on cfg2, 2 on cfg4, 8 otherwise)")
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--case", choices=["cfg2", "cfg3", "cfg4"], default="cfg2", help="workload: BASELINE configs[1] (default, the metric's configuration), configs[2] at any N, or configs[3] (backward-facing step extruded to E = 50 100 hexahedra, adjoint) on one GPU")
+    ap.add_argument("--map-steps", type=int, default=8, help="--case cfg5: time steps per (truncated) map")
+    ap.add_argument("--case", choices=["cfg2", "cfg3", "cfg4", "cfg5"], default="cfg2", help="workload: BASELINE configs[1] (default, the metric's configuration), configs[2] at any N, or configs[3] (backward-facing step extruded to E = 50 100 hexahedra, adjoint) on one GPU")
     ap.add_argument("--lx1", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kdim", action="store_true", help="do not continue the factorisation to k_dim = 128 after the timed steps")
@@ -385,12 +386,11 @@ def run_extras(a, case, full, seed_state, stats, step_s, out, extras):
     try:
         hit, pit = out["helm_iters_per_step"], out["pres_iters_per_step"]
         st = full.stats()
-        kt = {kn: full.bench_kernel(kn, 100)["avg_us"] for kn in ("helm", "convect", "rhs", "pres_rhs", "proj_apply", "gmres_update", "schwarz", "divgs2", "pres_update", "vel_update_proj", "proj_update")}
-        kt["update_coarse"] = full.bench_kernel("update_coarse3", 100)["avg_us"]
+        kt = {kn: full.bench_kernel(kn, 100)["avg_us"] for kn in ("helm", "convect", "rhs", "pres_rhs", "proj_apply_e", "schwarz_uc3", "divgs_t", "pres_update", "vel_update_proj", "proj_update")}
         per = {"velocity solve (k_helm x (iterations + 1))": kt["helm"] * (hit + 1.0),
-               "pressure iterations (k_update_coarse + k_schwarz + k_divgs per iteration)": (kt["update_coarse"] + kt["schwarz"] + kt["divgs2"]) * pit,
-               "once per step (convect, rhs, pres_rhs, proj_apply, 2 x gmres_update, pres_update, vel_update_proj, proj_update)":
-                   kt["convect"] + kt["rhs"] + kt["pres_rhs"] + kt["proj_apply"] + 2.0 * kt["gmres_update"] + kt["pres_update"] + kt["vel_update_proj"] + kt["proj_update"]}
+               "pressure iterations (k_schwarz_uc + k_divgs_t per iteration: round 6, two launches)": (kt["schwarz_uc3"] + kt["divgs_t"]) * pit,
+               "once per step (convect, rhs, pres_rhs, proj_apply_e, pres_update, vel_update_proj, proj_update)":
+                   kt["convect"] + kt["rhs"] + kt["pres_rhs"] + kt["proj_apply_e"] + kt["pres_update"] + kt["vel_update_proj"] + kt["proj_update"]}
         wall_us = 1e3 * out["ms_per_time_step"]
         extras["step_time_budget"] = {"wall_us_per_time_step": wall_us, "kernel_us": kt, "kernel_us_back_to_back": per, "busy_fraction": sum(per.values()) / wall_us,
                                       "budgeted_launches_per_step": {"helm": st["budget_helm"], "pres": st["budget_pres"]},
@@ -425,6 +425,8 @@ def run_extras(a, case, full, seed_state, stats, step_s, out, extras):
             "round1_bench_settings": dict(rate(1e-9, 3e-1, 8, {"min_pres_iter": 2, "pres_cap": 4}), settings="1e-9 / 3e-1, 2-4 GMRES iterations, 8 projection vectors (BENCH_r01: 15.2 matvecs/s)"),
             "round2_initial_settings": dict(rate(1e-11, 1e-1, 16, {"min_pres_iter": 2}), settings="1e-11 / 1e-1, at least 2 GMRES iterations, 16 projection vectors (9.78 matvecs/s at the start of round 2)"),
             "production_without_projection_space": dict(rate(a.tol_helm, a.tol_pres, 0, {"min_pres_iter": a.min_pres}), settings="production tolerances, NO projection space"),
+            "production_three_launch_iteration": dict(rate(a.tol_helm, a.tol_pres, a.nproj, {"min_pres_iter": a.min_pres, "fuse2": 0}), settings="production settings with option fuse2 = 0: the pressure GMRES iteration as the three launches of rounds 3-5 (k_update_coarse, k_schwarz, k_divgs)"),
+            "production_two_launch_iteration": dict(rate(a.tol_helm, a.tol_pres, a.nproj, {"min_pres_iter": a.min_pres}), settings="production settings (as `value`: k_schwarz_uc + k_divgs_t), same window, for the A/B with the line above"),
         }
     except Exception as e:                                  # noqa: BLE001
         extras["same_build_other_settings"] = {"error": repr(e)[:300]}
@@ -468,10 +470,81 @@ def build_case(name, lx1_override=None):
     return case
 
 
+def run_cfg5(a):
+    """--case cfg5: BASELINE configs[4]'s SIZE -- a lid-driven cube of 46 x 46 x 47 = 99 452 hexahedra with cav.box's wall clustering, lx1 = 10:
+    99.5 M points per field, state vector 2.8 GB, ~175 GB of device memory on one GPU.  A whole linearised map is 696 time steps
+    (12 minutes): the line times `--steps` TRUNCATED maps of `--map-steps` time steps each after `--warmup` of them, reports
+    ms_per_time_step, projects `value` = 1 / (ms_per_time_step x 696) and carries the kernel roofline of k3::k_helm<10> (HIP events,
+    full-work launches) with this build's PMC traffic.  An auxiliary line (the metric's configuration is configs[1]: the default run)."""
+    import numpy as np
+    import torch
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    from nekstab_amd import mesh3d, roofline
+    from nekstab_amd.capi import NekStabHip
+    steps = a.steps if a.steps is not None else 2
+    warm = a.warmup if a.warmup != 2 else 1
+    stretch = lambda xi: 0.5 * (1.0 - np.cos(np.pi * xi))
+    t0 = time.perf_counter()
+    c = mesh3d.box_case_3d(46, 46, 47, 10, lengths=(1.0, 1.0, 1.0), re=1000.0, endtime=0.02, stretch=stretch)
+    sx, sy, sz = np.sin(np.pi * c.x), np.sin(np.pi * c.y), np.sin(np.pi * c.z)
+    c.ub[0] = sx ** 2 * np.sin(2 * np.pi * c.y) * sz ** 2 * c.mask
+    c.ub[1] = -np.sin(2 * np.pi * c.x) * sy ** 2 * sz ** 2 * c.mask
+    del sx, sy, sz
+    nproj = 8
+    h = NekStabHip(c, c.meta["vert"], c.meta["nvert"], tol_helm=1e-9, tol_pres=1e-2, tol_relative=1, max_helm_iter=400, max_pres_iter=192, nproj=nproj)
+    setup_s = time.perf_counter() - t0
+    nfull = h.nsteps
+    q, f = h.alloc(2)
+    w = 1e-2 * np.sin(2 * np.pi * c.x) * np.sin(3 * np.pi * c.y) * np.sin(2 * np.pi * c.z) * c.mask      # a smooth three-dimensional perturbation
+    h.upload3(q, c.ub[0] + w, c.ub[1] - w, w, np.zeros(h.npres))
+    del w
+    h.set_nsteps(a.map_steps)
+    for _ in range(warm):
+        h.matvec(f, q, 0)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(steps):
+        h.matvec(f, q, 0)
+    h.norm(f); torch.cuda.synchronize(); elapsed = time.perf_counter() - t0
+    st = h.stats()
+    ms_ts = 1e3 * elapsed / (steps * a.map_steps)
+    za = int(st.get("zero_arrays", 0))
+    rule, distinct = roofline.helm_launch_bytes(nel=c.nel, lx1=10, ndim=3, zero_arrays=za)
+    kr = h.bench_kernel("helm", 10)
+    traffic, tnote = pmc_traffic("k3::helm<10>")
+    out = {"metric": METRIC, "value": 1.0 / (1e-3 * ms_ts * nfull), "unit": "matvecs/s", "n_gpus": 1, "steps": steps, "warmup": warm,
+           "ms_per_step": 1e3 * elapsed / steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+           "data": "synthetic: a smooth three-dimensional perturbation of an analytic vortex on the box mesh (the reference's lid_driven case needs its 3-D base flow, which is not in the tree)",
+           "value_note": "PROJECTED: 1 / (ms_per_time_step x %d time steps of a whole map); the timed maps are truncated to %d time steps" % (nfull, a.map_steps),
+           "config": {"workload": "lid-driven cube at BASELINE configs[4]'s size: E=%d hexahedra (46 x 46 x 47, cav.box wall clustering), lx1=10, lxd=15, %d time steps per map (full map: %d); state vector %.2f GB"
+                                  % (c.nel, a.map_steps, nfull, 8e-9 * h.nstate),
+                      "tolerances": "Helmholtz 1e-9, pressure 1e-2 relative, projection space %d, host-read convergence flags" % nproj, "parallelism": "1 GPU"},
+           "setup_s": setup_s, "ms_per_time_step": ms_ts, "helm_iters_per_step": st["helm_iters"] / max(st["steps"], 1), "pres_iters_per_step": st["pres_iters"] / max(st["steps"], 1),
+           "zero_arrays": za,
+           "roofline": {"bound": "hbm", "kernel": "k3::k_helm<10> (one CG iteration of the three components)", "achieved": rule / kr["avg_us"] / 1e3, "peak": 8000.0, "unit": "GB/s",
+                        "frac": rule / kr["avg_us"] / 1e3 / 8000.0, "frac_shared_arrays_once": distinct / kr["avg_us"] / 1e3 / 8000.0, "achieved_shared_arrays_once": distinct / kr["avg_us"] / 1e3,
+                        "traffic": traffic, "traffic_source": tnote, "avg_launch_us": kr["avg_us"], "algorithmic_bytes_per_launch": rule, "algorithmic_bytes_shared_arrays_once": distinct,
+                        "note": "SURVEY 8(d) counts 172 B per point and COMPONENT (less the G factors that vanish on the whole mesh); the launch reads the arrays the components share once: frac_shared_arrays_once is the figure to quote"},
+           "cpu_baseline": None, "cpu_baseline_note": "the C / OpenMP port covers quadrilaterals: the default record (configs[1]) carries the CPU baseline"}
+    kt = {}
+    for kn in ("divgs", "schwarz"):
+        try:
+            kt[kn] = h.bench_kernel(kn, 10)["avg_us"]
+        except Exception as e:                              # noqa: BLE001
+            kt[kn] = repr(e)[:100]
+    out["kernel_us"] = dict(kt, helm=kr["avg_us"])
+    print(json.dumps(out), flush=True)
+    h.close()
+    return 0
+
+
 def main():
     a = parse()
     if a.cpu_baseline_child:
         return _cpu_baseline_child(a.cpu_baseline_child)
+    if a.case == "cfg5":
+        if a.gpus > 1:
+            raise SystemExit("bench.py --case cfg5: one GPU")
+        return run_cfg5(a)
     if a.gpus > 1 and os.environ.get("NSK_BENCH_WORKER") != "1":
         raise SystemExit(supervise(a))
     rank = int(os.environ.get("RANK", "0"))

@@ -1641,7 +1641,8 @@ static void step_budgets_update(nsk_ctx* c) {
   const bool net = tails_on(c);
   static const int env_h = std::getenv("NSK_SB_HEAD_H") ? std::atoi(std::getenv("NSK_SB_HEAD_H")) : -1;
   static const int env_p = std::getenv("NSK_SB_HEAD_P") ? std::atoi(std::getenv("NSK_SB_HEAD_P")) : -1;
-  const int head_h = env_h >= 0 ? env_h : (net ? 1 : 3), head_p = env_p >= 0 ? env_p : (net ? 0 : 2);
+  // (options "tail_off_h" / "tail_off_p" > 0 add to the head-room of the plain budgets too: tests use it for a reference run that cannot overflow)
+  const int head_h = (env_h >= 0 ? env_h : (net ? 1 : 3)) + std::max(0, c->tail_off_h), head_p = (env_p >= 0 ? env_p : (net ? 0 : 2)) + std::max(0, c->tail_off_p);
   if (tails_on(c) && c->tail == 1) {
     // HEADS for the persistent tails: the MEDIAN count of this step over the window (offline on 56 maps of config 2: the cheapest
     // predictor, 0.44 launches that find nothing to do and 0.56 tail iterations per pressure solve; profiles/r05_step_budgets.txt).
@@ -3165,7 +3166,7 @@ int nsk_bench_kernel(nsk_ctx* c, const char* name, int reps, double* avg_us) {
       HIPCHK(hipEventRecord(e1, c->stream));
     });
   } else if (n == "coarse" || n == "schwarz" || n == "divgs" || n == "gmres_update" || n == "pres_chain" || n == "pres_chain3" || n == "pres_chain_merged" || n == "pres_chain_fused" || n.rfind("schwarz_uc", 0) == 0 || n == "divgs_t" || n.rfind("update_coarse", 0) == 0 || n == "divgs2" ||
-             n == "proj_apply" || n == "proj_update" || n == "pres_update" || n == "vel_update_proj" || n == "pres_rhs" || n == "rhs") {
+             n == "proj_apply" || n == "proj_apply_e" || n == "proj_update" || n == "pres_update" || n == "vel_update_proj" || n == "pres_rhs" || n == "rhs") {
     // kernels of the pressure solve, back to back on the state the last map left (run one first).  Tolerance 0 and a cleared
     // `done` flag: every launch does full work.  `pres_chain`: whole GMRES iterations j = 0..7 (coarse, Schwarz, E, update).
     if (c->ndim != 2 || d.coarse_lda > 3072) return fail(NSK_EINVAL, "pressure-kernel timing: quadrilateral contexts with the dense in-LDS coarse solve");
@@ -3196,6 +3197,7 @@ int nsk_bench_kernel(nsk_ctx* c, const char* name, int reps, double* avg_us) {
         else if (n == "divgs") hipLaunchKernelGGL(k_divgs<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, (const double*)d.yl, d.V + (size_t)(jj + 1) * d.ps, jj, 1);
         else if (n == "gmres_update") hipLaunchKernelGGL(k_gmres_update<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, jj, scale, 2, 5);
         else if (n == "proj_apply") hipLaunchKernelGGL(k_proj_apply, dim3(c->nblk), dim3(256), 0, c->stream, d);
+        else if (n == "proj_apply_e") launch_proj_apply_e<N>(c, d);
         else if (n == "proj_update") hipLaunchKernelGGL(k_proj_update, dim3(c->nblk), dim3(256), 0, c->stream, d);
         else if (n == "pres_update") hipLaunchKernelGGL(k_pres_update<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, sc);
         else if (n == "vel_update_proj") hipLaunchKernelGGL(k_vel_update_proj<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, sc);

@@ -130,12 +130,22 @@ __device__ inline void sum_partials_multi(const double* part, int n, int nq, dou
 // the same sums with every load issued before the first wait: R rows per wavefront (rows w, w + 4, ...) of n <= 512 partials
 // live in registers; rows beyond 4 R fall back to the loop.  Same summation order as sum_partials_multi (bit-identical sums).
 // Rows q < nq_issue are LOADED (a bound known from the kernel arguments), rows q < nq are summed into sh.
-template <int R>
+template <int R, bool UNC = false>
 struct PartialRows {
   double p[R][8];
-  // (unconditional loads from clamped addresses + a select: `cond ? load : 0` costs a branch per load)
+  // UNC (the roles of k_schwarz_uc): unconditional loads from clamped addresses + a select -- `cond ? load : 0` costs a branch per
+  // load; the kernels of rounds 2-5 keep the conditional form they were tuned with (k_proj_update measured 13.4 -> 18.5 us in the
+  // trace when it was switched)
   __device__ inline void issue(const double* part, int n, int nq_issue, int tid, int row0 = 0) {
     const int lane = tid & 63, w = tid >> 6;
+    if constexpr (!UNC) {
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          p[r][k] = (row0 + w + 4 * r < nq_issue && lane + 64 * k < n) ? part[(size_t)(row0 + w + 4 * r) * n + lane + 64 * k] : 0.0;
+      return;
+    }
     if (nq_issue <= row0) {                     // (uniform) nothing to load
 #pragma unroll
       for (int r = 0; r < R; ++r)
@@ -1880,7 +1890,7 @@ __device__ __forceinline__ void uc_coarse_role(const Dev& d, int j, double scale
   constexpr int CH = 3;
   const bool start = d.uc_start != 0;          // (j = 0 only) the solve starts here: row 0 of the partials = |g'|^2
   const int nrow = (j > 0) ? jj + 2 : (start ? 1 : 0);
-  PartialRows<2> pr;
+  PartialRows<2, true> pr;
   pr.issue(d.gpart, d.nblk, d.nblk <= 512 ? nrow : 0, tid);
   double rh[UC_ROWS];
 #pragma unroll
@@ -2002,7 +2012,7 @@ __device__ __forceinline__ void uc_schwarz_role(const Dev& d, int j, double scal
   NSK_STAMP(1);
   const bool start = d.uc_start != 0;          // (j = 0 only) the solve starts here: g' raw in Wr, |g'|^2 in row 0 of the partials
   const int nrow = (j > 0) ? jj + 2 : (start ? 1 : 0);
-  PartialRows<2> pr;                          // rows w, w + 4 of the partials of B_{j-1} (d.nblk <= 512: the merged range)
+  PartialRows<2, true> pr;                    // rows w, w + 4 of the partials of B_{j-1} (d.nblk <= 512: the merged range)
   pr.issue(d.gpart, d.nblk, d.nblk <= 512 ? nrow : 0, tid);
   double gj = 0.0;
   if (j > 0) {

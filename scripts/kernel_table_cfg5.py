@@ -1,0 +1,48 @@
+"""Per-kernel table of config 5 (E = 99 452 hexahedra, lx1 = 10): HIP-event timings of the hot kernels (scripts/prof_cfg5.py, KERNELS=...),
+their algorithmic bytes (nekstab_amd/roofline.py) and the HBM-side bytes of the same launches from the PMC passes (2 x FETCH_SIZE +
+WRITE_SIZE).  Writes <dir>/r06_cfg5_pmc_traffic_part.json.  Usage: kernel_table_cfg5.py <prof_cfg5 output> <pmc_summary.json>"""
+import json, os, re, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from nekstab_amd import roofline
+txt, pmc_json = sys.argv[1:3]
+t, za, nel, steps = {}, 0, 99452, []
+for l in open(txt):
+    m = re.match(r"^(\w+)\s+([\d.]+) us", l)
+    if m:
+        t[m.group(1)] = float(m.group(2))
+    m = re.match(r"^E (\d+) set-up", l)
+    if m:
+        nel = int(m.group(1))
+    m = re.match(r"^zero_arrays = 0x([0-9a-f]+)", l)
+    if m:
+        za = int(m.group(1), 16)
+    m = re.match(r"^([\d.]+) ms per step \(([\d.]+) Helmholtz \+ ([\d.]+) pressure", l)
+    if m:
+        steps.append((float(m.group(1)), float(m.group(2)), float(m.group(3))))
+N = 10
+one = roofline.per_step_bytes(nel=nel, lx1=N, ndim=3, nvert=0, nproj=0, helm_iters=0.0, pres_iters=1.0, pres_jsum=0.0, coarse_bytes=0.0, zero_arrays=za)
+rule, distinct = roofline.helm_launch_bytes(nel=nel, lx1=N, ndim=3, zero_arrays=za)
+alg = {"helm": (distinct, "k_helm<10>", "all arrays of the three components once (SURVEY rule: %.2f GB)" % (rule / 1e9)),
+       "divgs": (one["K7 divgs (x n_pres)"], "k_divgs<10>", "E apply"), "schwarz": (one["K6 schwarz (x n_pres)"] - nel * 8 * 12.0, "k_schwarz<10>", "Schwarz + D^T, one workgroup per element")}
+pmc = json.load(open(pmc_json)) if os.path.exists(pmc_json) else {}
+def pmc_of(key):
+    for k, v in pmc.items():
+        if "k3::" + key in k:
+            return (2.0 * v["fetch_kb_p50"] + v["write_kb_p50"]) * 1024.0
+    return None
+for ms, hi, pi in steps[-1:]:
+    print("config 5 at full size: %.0f ms per time step (%.1f Helmholtz + %.1f pressure iterations per step); zero_arrays 0x%x\n" % (ms, hi, pi, za))
+print("| kernel (launch) | HIP-event us | algorithmic GB / launch | TB/s | frac of 8 TB/s | counter GB / launch (2 x FETCH + WRITE) | frac by counter bytes | note |")
+print("|---|---|---|---|---|---|---|---|")
+out = {}
+for kn in ("helm", "divgs", "schwarz"):
+    if kn not in t:
+        continue
+    a, key, note = alg[kn]
+    pm = pmc_of(key)
+    us = t[kn]
+    print("| k3::%s | %.1f | %.3f | %.2f | %.2f | %s | %s | %s |" % (key, us, a / 1e9, a / us / 1e6, a / us / 1e6 / 8.0, "%.3f" % (pm / 1e9) if pm else "-", "%.2f" % (pm / us / 1e6 / 8.0) if pm else "-", note))
+    if pm:
+        out["k3::%s<10>" % kn] = {"bytes_per_launch": pm}
+json.dump(out, open(os.path.join(os.path.dirname(pmc_json), "r06_cfg5_pmc_traffic_part.json"), "w"), indent=1)

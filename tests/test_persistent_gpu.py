@@ -109,8 +109,10 @@ def test_persistent_tails_are_bit_identical_to_launch_budgets(fuse2):
         hh, pp = h.step_iters()
         h.close()
         return H, last, st, hh.copy(), pp.copy()
-    H0, v0, s0, h0, p0 = run(0)
-    assert s0["tail_maps"] == 0
+    H0, v0, s0, h0, p0 = run(0, 8, 8)   # (head-room + 8 / + 8: the reference run must not overflow a budget -- a redone map starts from the
+    #                                      projection space its failed attempt left: different bits by design)
+    print("reference run (launch budgets, no tails): retries", s0["retries"], "budgets per step %.2f / %.2f" % (s0["step_budget_helm_mean"], s0["step_budget_pres_mean"]))
+    assert s0["tail_maps"] == 0 and s0["retries"] == 0
     for mode, off in (((1, (0, 0)), (1, (-6, -3)), (2, (0, 0)), (-1, (0, 0))) if fuse2 else ((1, (-6, -3)), (-1, (0, 0)))):       # median heads; heads far below the counts; safety net; the default
         H1, v1, s1, h1, p1 = run(mode, *off)
         print("tail maps", s1["tail_maps"], "heads per step %.2f / %.2f" % (s1["step_budget_helm_mean"], s1["step_budget_pres_mean"]), "retries", s1["retries"],
