@@ -249,7 +249,7 @@ def _cpu_baseline_impl(case, threads, tol, nproj, gpu_value, q_sample=None, visi
     # visible core of a 256-core host a time step takes 67 s instead of 35 ms (measured in round 2)
     cands = [threads] if threads else sorted({min(visible, 8), min(visible, 16), min(visible, 32), min(visible, 64)})
     best = None
-    calib = {}
+    calib, floor = {}, {}
     for nt in cands:                                        # calibration: one time step, then three more unless it is already hopeless
         cp.set_threads(nt)
         cp.proj_reset()
@@ -260,6 +260,13 @@ def _cpu_baseline_impl(case, threads, tol, nproj, gpu_value, q_sample=None, visi
         t0 = time.perf_counter(); cp.matvec(q0, nsteps=4); t = (time.perf_counter() - t0) / 4
         log("calibration: %d threads %.1f ms per time step" % (nt, 1e3 * t))
         calib[str(nt)] = 1e3 * t
+        try:                                                # the fork-join floor at this thread count: regions per time step x an empty region
+            cp.regions(reset=True); cp.proj_reset(); cp.matvec(q0, nsteps=2); nreg = cp.regions() / 2.0
+            er = cp.empty_region_us()
+            floor[str(nt)] = {"parallel_regions_per_time_step": nreg, "empty_region_us": er, "fork_join_floor_ms_per_time_step": 1e-3 * nreg * er}
+            log("             %d threads: %.0f parallel regions per time step x %.1f us per empty region = %.1f ms" % (nt, nreg, er, 1e-3 * nreg * er))
+        except Exception as e:                              # noqa: BLE001
+            floor[str(nt)] = {"error": repr(e)[:200]}
         if best is None or t < best[1]:
             best = (nt, t)
 
@@ -281,11 +288,11 @@ def _cpu_baseline_impl(case, threads, tol, nproj, gpu_value, q_sample=None, visi
     n4 = min(4, visible)
     c4 = sample(cp, n4, best[1] * best[0] / n4, 6.0)
     return {"value": a["matvecs_per_s"], "unit": "matvecs/s", "cores": a["threads"], "cores_used": a["threads"], "cores_visible": visible, "kind": "port",
-            "thread_calibration_ms_per_time_step": calib,
-            "thread_scaling_note": "fastest thread count of the calibration; beyond ~32 threads the port slows down again: a time step of this case is ~250 OpenMP "
-                                   "parallel regions of 127 744 points (two Helmholtz components solved one after the other, modified Gram-Schmidt with two regions "
-                                   "per basis vector), i.e. ~40 us of work per region at 16 threads against a fork-join cost that grows with the team and crosses "
-                                   "the socket's CCX / NUMA boundaries: profiles/r06_cpu_scaling_v0.txt (same table with and without binding)",
+            "thread_calibration_ms_per_time_step": calib, "fork_join_floor": floor,
+            "thread_scaling_note": "fastest thread count of the calibration; MEASURED reason why more threads do not pay (fork_join_floor): a time step of this case "
+                                   "opens several hundred OpenMP parallel regions over 127 744 points (two Helmholtz components solved one after the other, modified "
+                                   "Gram-Schmidt with two regions per basis vector); regions per time step x the measured cost of an EMPTY region at the same thread "
+                                   "count is the floor no amount of cores removes, and it grows with the team; profiles/r06_cpu_scaling_v0.txt has the same table with and without binding",
             "sample": ("%s of the same case (lx1=%d, E=%d), " + what_vec + "; oracle/cpu_step.c (C + OpenMP: Jacobi-PCG, GMRES + restricted Schwarz + vertex coarse "
                        "solve, tolerances %g / %g and a %d-vector pressure projection space as the GPU run); the Krylov projection (0.2 %% of a GPU step) is not in the sample; "
                        "%d cores visible; set-up %.0f s excluded") % (a["sample"], case.lx1, case.nel, tol[0], tol[1], nproj, visible, setup),

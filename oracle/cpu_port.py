@@ -71,6 +71,10 @@ def _load():
     lib.cpu_set_threads.argtypes = [C.c_int]
     lib.cpu_max_threads.restype = C.c_int
     lib.cpu_proj_reset.restype = None
+    lib.cpu_regions.restype = C.c_longlong
+    lib.cpu_regions_reset.restype = None
+    lib.cpu_empty_region_us.restype = C.c_double
+    lib.cpu_empty_region_us.argtypes = [C.c_int, C.c_int]
     return lib
 
 
@@ -190,6 +194,17 @@ class CpuPort:
     def proj_reset(self):
         """empty the pressure projection space (it is kept from matvec to matvec, as the device's)"""
         self.lib.cpu_proj_reset()
+
+    def regions(self, reset=False):
+        """OpenMP parallel regions opened since the last reset"""
+        n = int(self.lib.cpu_regions())
+        if reset:
+            self.lib.cpu_regions_reset()
+        return n
+
+    def empty_region_us(self, n=4096, reps=2000):
+        """microseconds per empty parallel-for region at the current thread count"""
+        return float(self.lib.cpu_empty_region_us(int(n), int(reps)))
 
     def set_threads(self, nthreads):
         self.lib.cpu_set_threads(int(nthreads))

@@ -51,10 +51,31 @@ static const double AB[3][3] = {{1.0, 0.0, 0.0}, {2.0, -1.0, 0.0}, {3.0, -3.0, 1
 static const double XG[4][3] = {{0, 0, 0}, {1, 0, 0}, {2, -1, 0}, {3, -3, 1}};
 
 void cpu_set_threads(int n) { if (n > 0) omp_set_num_threads(n); }
+/* how many OpenMP parallel regions a run opened (bench.py: regions per time step x the measured cost of an empty region = the
+   fork-join floor of this port at a given thread count: why more than ~32 threads do not pay on 127 744 points per field) */
+static long long g_regions = 0;
+long long cpu_regions(void) { return g_regions; }
+void cpu_regions_reset(void) { g_regions = 0; }
+/* microseconds per EMPTY parallel-for region (static schedule, n iterations of one double store) at the current thread count */
+double cpu_empty_region_us(int n, int reps) {
+  static double sink[4096];
+  if (n > 4096) n = 4096;
+  for (int r = 0; r < 10; ++r) {
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; ++i) sink[i] = (double)i;
+  }
+  const double t0 = omp_get_wtime();
+  for (int r = 0; r < reps; ++r) {
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; ++i) sink[i] = (double)(i + r);
+  }
+  return 1e6 * (omp_get_wtime() - t0) / reps;
+}
 int cpu_max_threads(void) { return omp_get_max_threads(); }
 
 /* out = dssum(f): sum over co-located local nodes, ascending (same order as the device gather) */
 static void dssum(const cpu_case* c, const double* f, double* out, long long nloc) {
+g_regions++;
 #pragma omp parallel for schedule(static)
   for (long long l = 0; l < nloc; ++l) {
     double s = 0.0;
@@ -205,6 +226,7 @@ static int helm_solve(const cpu_case* c, work_t* w, int k, double h2, cpu_stats*
   for (int cc = 0; cc < 2; ++cc) {
     double *r = w->hr + cc * nl, *x = w->hx + cc * nl, *p = w->hp + cc * nl, *z = w->hz + cc * nl, *q = w->hw + cc * nl, *bb = w->tmp + cc * nl;
     double rr = 0, ref = 0;
+g_regions++;
 #pragma omp parallel for schedule(static) reduction(+ : rr, ref)
     for (long long l = 0; l < nl; ++l) {
       r[l] *= c->mask[l]; x[l] = 0.0; p[l] = 0.0;
@@ -218,11 +240,13 @@ static int helm_solve(const cpu_case* c, work_t* w, int k, double h2, cpu_stats*
     for (; it < c->max_helm; ++it) {
       if (sqrt(rr / c->vol) <= tol) break;
       double rz = 0;
+g_regions++;
 #pragma omp parallel for schedule(static) reduction(+ : rz)
       for (long long l = 0; l < nl; ++l) { z[l] = di[l] * r[l]; rz += r[l] * z[l] * c->minv[l]; }
       if (!(rz > 0.0)) break;
       const double beta = (it == 0) ? 0.0 : rz / rz_old;
       rz_old = rz;
+g_regions++;
 #pragma omp parallel for schedule(static)
       for (long long e = 0; e < nel; ++e) {
         double* pe = p + e * NN;
@@ -233,10 +257,12 @@ static int helm_solve(const cpu_case* c, work_t* w, int k, double h2, cpu_stats*
       }
       dssum(c, w->yl, q, nl);
       double pq = 0;
+g_regions++;
 #pragma omp parallel for schedule(static) reduction(+ : pq)
       for (long long l = 0; l < nl; ++l) { q[l] *= c->mask[l]; pq += p[l] * q[l] * c->minv[l]; }
       const double alpha = rz / pq;
       rr = 0;
+g_regions++;
 #pragma omp parallel for schedule(static) reduction(+ : rr)
       for (long long l = 0; l < nl; ++l) { x[l] += alpha * p[l]; r[l] -= alpha * q[l]; rr += r[l] * r[l] * c->minv[l]; }
     }
@@ -251,6 +277,7 @@ static int helm_solve(const cpu_case* c, work_t* w, int k, double h2, cpu_stats*
 /* z = RAS(v) + R^T Aci R v   (preconditioner of the pressure GMRES) */
 static void precond(const cpu_case* c, work_t* w, const double* v, double* z) {
   const int M = c->M, MM = M * M, nel = c->nel, PS = c->PS, nv = c->nvert;
+g_regions++;
 #pragma omp parallel for schedule(static)
   for (long long e = 0; e < nel; ++e)
     for (int cn = 0; cn < 4; ++cn) {
@@ -258,12 +285,14 @@ static void precond(const cpu_case* c, work_t* w, const double* v, double* z) {
       for (int k = 0; k < MM; ++k) s += c->hat[cn * MM + k] * v[e * MM + k];
       w->ec[e * 4 + cn] = s;
     }
+g_regions++;
 #pragma omp parallel for schedule(static)
   for (int vtx = 0; vtx < nv; ++vtx) {
     double s = 0;
     for (int k = c->v_off[vtx]; k < c->v_off[vtx + 1]; ++k) s += w->ec[c->v_ent[k]];
     w->rc[vtx] = s;
   }
+g_regions++;
 #pragma omp parallel for schedule(static)
   for (int r = 0; r < nv; ++r) {
     const float* a = c->Aci + (size_t)r * nv;
@@ -271,6 +300,7 @@ static void precond(const cpu_case* c, work_t* w, const double* v, double* z) {
     for (int q = 0; q < nv; ++q) s += (double)a[q] * w->rc[q];
     w->xc[r] = s;
   }
+g_regions++;
 #pragma omp parallel for schedule(static)
   for (long long e = 0; e < nel; ++e) {
     double rloc[4 * MAXN * MAXN];
@@ -291,9 +321,11 @@ static void precond(const cpu_case* c, work_t* w, const double* v, double* z) {
 static void eapply(const cpu_case* c, work_t* w, const double* z, double* wout) {
   const int N = c->N, NN = N * N, MM = c->M * c->M, nel = c->nel;
   const long long nl = w->nloc;
+g_regions++;
 #pragma omp parallel for schedule(static)
   for (long long e = 0; e < nel; ++e) opgradt_e(c, e, z + e * MM, w->yl + e * NN, w->yl + nl + e * NN);
   dssum(c, w->yl, w->vv, nl); dssum(c, w->yl + nl, w->vv + nl, nl);
+g_regions++;
 #pragma omp parallel for schedule(static)
   for (long long e = 0; e < nel; ++e) {
     double a[MAXN * MAXN], b[MAXN * MAXN];
@@ -309,6 +341,7 @@ static int pres_solve(const cpu_case* c, work_t* w, double h2, double tol_mul, d
   const double scale = 1.0 / (h2 * sqrt(c->vol));
   double* V = w->V;
   double b2 = 0;
+g_regions++;
 #pragma omp parallel for schedule(static) reduction(+ : b2)
   for (long long q = 0; q < np; ++q) b2 += V[q] * V[q];
   const double beta0 = sqrt(b2);
@@ -318,6 +351,7 @@ static int pres_solve(const cpu_case* c, work_t* w, double h2, double tol_mul, d
   memset(w->wp, 0, np * sizeof(double));
   st->last_pres_iters = 0;
   if (!(beta0 > 0.0) || (c->min_pres <= 0 && beta0 * scale <= tol)) { st->last_pres_res = beta0 * scale; return 0; }
+g_regions++;
 #pragma omp parallel for schedule(static)
   for (long long q = 0; q < np; ++q) V[q] /= beta0;
   g[0] = beta0;
@@ -329,17 +363,21 @@ static int pres_solve(const cpu_case* c, work_t* w, double h2, double tol_mul, d
     for (int i = 0; i <= j; ++i) {                       /* modified Gram-Schmidt */
       const double* vi = V + (size_t)i * np;
       double h = 0;
+g_regions++;
 #pragma omp parallel for schedule(static) reduction(+ : h)
       for (long long q = 0; q < np; ++q) h += wn[q] * vi[q];
+g_regions++;
 #pragma omp parallel for schedule(static)
       for (long long q = 0; q < np; ++q) wn[q] -= h * vi[q];
       H[i * MAXMR + j] = h;
     }
     double hn = 0;
+g_regions++;
 #pragma omp parallel for schedule(static) reduction(+ : hn)
     for (long long q = 0; q < np; ++q) hn += wn[q] * wn[q];
     hn = sqrt(hn);
     if (hn > 0.0) {
+g_regions++;
 #pragma omp parallel for schedule(static)
       for (long long q = 0; q < np; ++q) wn[q] /= hn;
     }
@@ -365,6 +403,7 @@ static int pres_solve(const cpu_case* c, work_t* w, double h2, double tol_mul, d
     for (int k = q + 1; k < nit; ++k) s -= H[q * MAXMR + k] * y[k];
     y[q] = s / H[q * MAXMR + q];
   }
+g_regions++;
 #pragma omp parallel for schedule(static)
   for (long long q = 0; q < np; ++q) {
     double s = 0;
@@ -388,15 +427,18 @@ static void proj_ensure(int cap, long long np) {
 static double proj_apply(double* g, long long np) {
   proj_t* P = &g_proj;
   double gg = 0;
+g_regions++;
 #pragma omp parallel for schedule(static) reduction(+ : gg)
   for (long long q = 0; q < np; ++q) gg += g[q] * g[q];
   for (int i = 0; i < P->n; ++i) {
     const double* x = P->X + (size_t)i * np;
     double s = 0;
+g_regions++;
 #pragma omp parallel for schedule(static) reduction(+ : s)
     for (long long q = 0; q < np; ++q) s += x[q] * g[q];
     P->a[i] = s / P->nn[i];
   }
+g_regions++;
 #pragma omp parallel for schedule(static)
   for (long long q = 0; q < np; ++q) {
     double t = g[q];
@@ -413,10 +455,12 @@ static void proj_update(const double* delta, const double* edel, long long np) {
   for (int k = 0; k < n; ++k) {
     const double* ex = P->EX + (size_t)k * np;
     double t = 0;
+g_regions++;
 #pragma omp parallel for schedule(static) reduction(+ : t)
     for (long long q = 0; q < np; ++q) t += delta[q] * ex[q];
     c[k] = t;
   }
+g_regions++;
 #pragma omp parallel for schedule(static) reduction(+ : dd)
   for (long long q = 0; q < np; ++q) dd += delta[q] * edel[q];
   double nn = dd;
@@ -424,6 +468,7 @@ static void proj_update(const double* delta, const double* edel, long long np) {
   if (full) for (int k = 0; k < n; ++k) nn += P->a[k] * P->a[k] * P->nn[k];
   if (!(nn > 0.0)) { P->n = 0; P->pcnt = 0; return; }     /* degenerate direction: drop the space */
   double* xs = P->X + (size_t)s * np; double* exs = P->EX + (size_t)s * np;
+g_regions++;
 #pragma omp parallel for schedule(static)
   for (long long q = 0; q < np; ++q) {
     double x = delta[q], ex = edel[q];
@@ -442,6 +487,7 @@ static int step(const cpu_case* c, work_t* w, int istep, cpu_stats* st) {
   const double h2 = bd[0] / c->dt, invdt = 1.0 / c->dt;
   const double* xg = XG[c->helm_guess ? (istep < 4 ? istep : 4) - 1 : 0];
   /* makefp + makextp + makebdfp + lagfieldp + extrapprp + cresvipp  (oracle/linns.py step()) */
+g_regions++;
 #pragma omp parallel for schedule(static)
   for (long long e = 0; e < nel; ++e) {
     double bx[MAXN * MAXN], by[MAXN * MAXN], ug[2][MAXN * MAXN], au[MAXN * MAXN], gx[MAXN * MAXN], gy[MAXN * MAXN], pe[MAXN * MAXN];
@@ -476,6 +522,7 @@ static int step(const cpu_case* c, work_t* w, int istep, cpu_stats* st) {
   }
   helm_solve(c, w, k, h2, st);
   /* u* = u + du0 + dx ; g = -D u*   (incomprp) */
+g_regions++;
 #pragma omp parallel for schedule(static)
   for (long long e = 0; e < nel; ++e) {
     double us[2][MAXN * MAXN], dv[MAXN * MAXN];
@@ -497,6 +544,7 @@ static int step(const cpu_case* c, work_t* w, int istep, cpu_stats* st) {
   pres_solve(c, w, h2, istep <= 3 ? c->early_pres_mul : 1.0, gnorm0, st);
   if (useproj) {                      /* delta = GMRES correction (kept in w->pd); total solution = delta + sum a_i x_i */
     memcpy(w->pd, w->wp, w->npr * sizeof(double));
+g_regions++;
 #pragma omp parallel for schedule(static)
     for (long long q = 0; q < w->npr; ++q) {
       double t = w->wp[q];
@@ -505,6 +553,7 @@ static int step(const cpu_case* c, work_t* w, int istep, cpu_stats* st) {
     }
   }
   /* p = p* + h2 y ; u += (h2 B)^-1 mask dssum(D^T dp) */
+g_regions++;
 #pragma omp parallel for schedule(static)
   for (long long e = 0; e < nel; ++e) {
     double dp[MAXN * MAXN];
@@ -513,6 +562,7 @@ static int step(const cpu_case* c, work_t* w, int istep, cpu_stats* st) {
   }
   dssum(c, w->yl, w->vv, nl); dssum(c, w->yl + nl, w->vv + nl, nl);
   if (useproj) {                      /* E delta = D B^-1 dssum(D^T dp) / h2 - sum a_i E x_i, from the arrays of the velocity correction */
+g_regions++;
 #pragma omp parallel for schedule(static)
     for (long long e = 0; e < nel; ++e) {
       double a[MAXN * MAXN], b[MAXN * MAXN], dv[MAXN * MAXN];
@@ -525,6 +575,7 @@ static int step(const cpu_case* c, work_t* w, int istep, cpu_stats* st) {
       }
     }
   }
+g_regions++;
 #pragma omp parallel for schedule(static)
   for (long long l = 0; l < nl; ++l) {
     const double f = c->binv[l] / h2;
