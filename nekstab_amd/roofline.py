@@ -21,7 +21,7 @@ def _zero_counts(zero_arrays, ndim):
 
 
 def per_step_bytes(*, nel, lx1, ndim=2, nvert=0, coarse_lda=0, patch_stride=0, nproj=0, helm_iters=0.0, pres_iters=0.0,
-                   pres_jsum=None, coarse_bytes=None, gs_lag=1, zero_arrays=0):
+                   pres_jsum=None, coarse_bytes=None, gs_lag=1, zero_arrays=0, fuse2=0, tc_cols=20):
     """Algorithmic bytes of ONE time step, by kernel family.  ``helm_iters`` / ``pres_iters``: mean iterations per step
     (all velocity components advance together in one CG iteration).  Hexahedra (``ndim = 3``): ``pres_jsum`` = mean per step of
     the sum over the GMRES columns of their basis index j (nsk_stats.total_pres_jsum / total_steps; the Gram-Schmidt bytes
@@ -52,10 +52,23 @@ def per_step_bytes(*, nel, lx1, ndim=2, nvert=0, coarse_lda=0, patch_stride=0, n
         schwarz = 4.0 * nel * patch_stride * M ** d + 4.0 * nel * patch_stride + f * nel * patch_stride + f * P2 * (1 + nmet2) + f * P * d
         divgs = f * (P * (d + 1) + 2.0 * P) + f * P2 * (nmet2 + 1) + f * P2 * (jsum + pres_iters)   # yl gather (d), binv, 16-B table; metrics, w out; V_0..j for the dots
         gupd = f * P2 * (jsum + 3.0 * (pres_iters + 1.0))                                  # V_0..j, V_{j+1} read + write
-        out["K6 coarse (x n_pres)"] = coarse * pres_iters
-        out["K6 schwarz (x n_pres)"] = schwarz * pres_iters
-        out["K7 divgs (x n_pres)"] = divgs if pres_jsum is not None else f * (P * (d + 1) + 2.0 * P) * pres_iters + f * P2 * (nmet2 + 1 + (jbar + 1)) * pres_iters
-        out["K7 gmres_update (x n_pres)"] = gupd if pres_jsum is not None else f * P2 * (jbar + 3) * (pres_iters + 1.0)
+        if fuse2:
+            # round 6, two launches per iteration.  k_schwarz_uc = coarse workgroups (dense inverse, corner slots) + Schwarz workgroups that
+            # form v_j on the fly: raw w and V_0..j-1 at the PS patch nodes of every element, V_j and the Schwarz part of Z_j out;
+            # k_divgs_t = E apply + the coarse image Tc (tc_cols fp64 columns per pressure node) + Z_j read / write + V_0..j for the dots.
+            # No k_gmres_update per iteration (the column is closed inside k_schwarz_uc; the solve starts inside its first launch).
+            jb = jsum / pres_iters if pres_iters > 0 else 0.0
+            schwarz = schwarz + f * nel * patch_stride * jb + f * P2
+            divgs_it = f * (P * (d + 1) + 2.0 * P) + f * P2 * (nmet2 + 1) + f * P2 * (jb + 1) + f * nel * tc_cols * M ** d + 4.0 * nel * tc_cols + 2.0 * f * P2
+            out["K6 coarse (x n_pres)"] = coarse * pres_iters
+            out["K6 schwarz (x n_pres)"] = schwarz * pres_iters
+            out["K7 divgs (x n_pres)"] = divgs_it * pres_iters
+            out["K7 gmres_update (x n_pres)"] = 0.0
+        else:
+            out["K6 coarse (x n_pres)"] = coarse * pres_iters
+            out["K6 schwarz (x n_pres)"] = schwarz * pres_iters
+            out["K7 divgs (x n_pres)"] = divgs if pres_jsum is not None else f * (P * (d + 1) + 2.0 * P) * pres_iters + f * P2 * (nmet2 + 1 + (jbar + 1)) * pres_iters
+            out["K7 gmres_update (x n_pres)"] = gupd if pres_jsum is not None else f * P2 * (jbar + 3) * (pres_iters + 1.0)
     else:
         # hexahedra.  coarse solve: its operator storage (block-circulant inverses / dense inverse / degree x sparse rows:
         # nsk_stats.coarse_bytes_per_solve) + corner restrictions (8 per element, value + index) + two vertex vectors

@@ -36,6 +36,10 @@ alg = {
     "k_divgs<%d>" % NX: perj["K7 divgs (x n_pres)"] / npr_it, "k_gmres_update<%d>" % NX: perj["K7 gmres_update (x n_pres)"] / (npr_it + 1),
     # merged bookkeeping + coarse solve: the bytes of both (the restriction history is nvert doubles per basis vector: negligible)
     ("k_update_coarse<%d>" % (3 * ((geom["coarse_lda"] // 256 + 2) // 3))): perj["K6 coarse (x n_pres)"] / npr_it + perj["K7 gmres_update (x n_pres)"] / (npr_it + 1),
+    # round 6: the two launches of a merged iteration
+    ("k_schwarz_uc<%d, %d>" % (NX, 3 * ((geom["coarse_lda"] // 256 + 2) // 3))): (perj["K6 coarse (x n_pres)"] + perj["K6 schwarz (x n_pres)"]) / npr_it,
+    "k_divgs_t<%d, false>" % NX: perj["K7 divgs (x n_pres)"] / npr_it, "k_divgs_t<%d, true>" % NX: perj["K7 divgs (x n_pres)"] / npr_it,
+    "k_proj_apply_e<%d>" % NX: perj["projection apply/update"] * 0.4,
     "k_pres_update<%d>" % NX: perj["K10 pres_update"], "k_vel_update_proj<%d>" % NX: perj["K10 vel_update(+proj)"],
     "k_proj_apply": perj["projection apply/update"] * 0.4, "k_proj_update": perj["projection apply/update"] * 0.6,
 }

@@ -203,7 +203,8 @@ def test_bench_case_cfg4_record_shape():
     assert r["pres_basis_index_sum_per_step"] > 0
     assert r["bytes_per_matvec"]["time_stepper_shared_arrays_once"] < r["bytes_per_matvec"]["time_stepper"]
     rf = r["roofline"]
-    assert rf["bound"] == "hbm" and 0 < rf["frac"] < 1.5 and 0 < rf["frac_shared_arrays_once"] < rf["frac"] and rf["peak"] == 8000.0
+    # `frac` = every distinct array of the launch once; the SURVEY's per-component rule (shared arrays counted three times) is kept as `survey_rule`
+    assert rf["bound"] == "hbm" and 0 < rf["frac"] < 1.0 and rf["frac"] < rf["survey_rule"]["frac"] < 1.5 and rf["peak"] == 8000.0
     assert 0 < r["roofline_end_to_end"]["frac_shared_arrays_once"] < r["roofline_end_to_end"]["frac"] < 1.0
     assert set(r["kernels"]) >= {"helm", "divgs", "schwarz", "gs_dots8", "gs_lag8"} and all(v["avg_us"] > 0 for v in r["kernels"].values())
     print({k: (round(v["avg_us"], 1), round(v["frac"], 2)) for k, v in r["kernels"].items()}, r["ms_per_time_step"])
