@@ -406,8 +406,8 @@ def run_extras(a, case, full, seed_state, stats, step_s, out, extras):
         extras["step_time_budget"] = {"error": repr(e)[:300]}
 
     # The same build at the inner-solver settings earlier records were quoted on: 24 timed Arnoldi steps each, after 4 warm-up steps.
-    def rate(tol_helm, tol_pres, nproj, opts):
-        hc = NekStabHip(case, case.meta["vert"], case.meta["nvert"], tol_helm=tol_helm, tol_pres=tol_pres, tol_relative=1,
+    def rate(tol_helm, tol_pres, nproj, opts, tol_relative=1):
+        hc = NekStabHip(case, case.meta["vert"], case.meta["nvert"], tol_helm=tol_helm, tol_pres=tol_pres, tol_relative=tol_relative,
                         schwarz_layers=2, max_helm_iter=100, max_pres_iter=48, nproj=nproj)
         try:
             for k, v in opts.items():
@@ -432,6 +432,9 @@ def run_extras(a, case, full, seed_state, stats, step_s, out, extras):
             "round1_bench_settings": dict(rate(1e-9, 3e-1, 8, {"min_pres_iter": 2, "pres_cap": 4}), settings="1e-9 / 3e-1, 2-4 GMRES iterations, 8 projection vectors (BENCH_r01: 15.2 matvecs/s)"),
             "round2_initial_settings": dict(rate(1e-11, 1e-1, 16, {"min_pres_iter": 2}), settings="1e-11 / 1e-1, at least 2 GMRES iterations, 16 projection vectors (9.78 matvecs/s at the start of round 2)"),
             "production_without_projection_space": dict(rate(a.tol_helm, a.tol_pres, 0, {"min_pres_iter": a.min_pres}), settings="production tolerances, NO projection space"),
+            "nek5000_own_solver_semantics": dict(rate(1e-9, 1e-7, 20, {"helm_guess": 0, "min_pres_iter": 1}, tol_relative=0),
+                                                 settings="the reference's 1cyl.par:27-35 taken literally: ABSOLUTE residual tolerances 1e-9 (velocity) / 1e-7 (pressure) in Nek5000's norms, zero initial guess, "
+                                                          ">= 1 GMRES iteration, 20 projection vectors -- on unit-norm Krylov vectors these stop after ~1 pressure iteration per step; the wake rows of the spectrum move by up to 1.3e-3 at these settings (profiles/r06_wake_rows.json): not parity settings"),
             "production_three_launch_iteration": dict(rate(a.tol_helm, a.tol_pres, a.nproj, {"min_pres_iter": a.min_pres, "fuse2": 0}), settings="production settings with option fuse2 = 0: the pressure GMRES iteration as the three launches of rounds 3-5 (k_update_coarse, k_schwarz, k_divgs)"),
             "production_two_launch_iteration": dict(rate(a.tol_helm, a.tol_pres, a.nproj, {"min_pres_iter": a.min_pres}), settings="production settings (as `value`: k_schwarz_uc + k_divgs_t), same window, for the A/B with the line above"),
         }
@@ -479,10 +482,10 @@ def build_case(name, lx1_override=None):
 
 def run_cfg5(a):
     """--case cfg5: BASELINE configs[4]'s SIZE -- a lid-driven cube of 46 x 46 x 47 = 99 452 hexahedra with cav.box's wall clustering, lx1 = 10:
-    99.5 M points per field, state vector 2.8 GB, ~175 GB of device memory on one GPU.  A whole linearised map is 696 time steps
-    (12 minutes): the line times `--steps` TRUNCATED maps of `--map-steps` time steps each after `--warmup` of them, reports
-    ms_per_time_step, projects `value` = 1 / (ms_per_time_step x 696) and carries the kernel roofline of k3::k_helm<10> (HIP events,
-    full-work launches) with this build's PMC traffic.  An auxiliary line (the metric's configuration is configs[1]: the default run)."""
+    99.5 M points per field, state vector 2.8 GB, ~175 GB of device memory on one GPU.  The line times `--steps` TRUNCATED maps of
+    `--map-steps` time steps each after `--warmup` of them (a time step takes a second; the reference's case, T = 1 at its CFL, would be
+    ~700 of them per map), reports ms_per_time_step, projects `value` = 1 / (ms_per_time_step x the steps of a whole map of THIS
+    case's T) and carries the kernel roofline of k3::k_helm<10> (HIP events, full-work launches) with this build's PMC traffic.  An auxiliary line (the metric's configuration is configs[1]: the default run)."""
     import numpy as np
     import torch
     assert torch.cuda.is_available(), "bench.py needs a GPU"
