@@ -442,22 +442,45 @@ def run_extras(a, case, full, seed_state, stats, step_s, out, extras):
         extras["same_build_other_settings"] = {"error": repr(e)[:300]}
 
 
+KERNEL_FAMILIES = {"2d": ("nsk_kernels.hpp", "nsk_persist.hpp", "nsk_dev.hpp", "nsk_basis.hpp", "nsk_crtrig.hpp"),
+                   "3d": ("nsk3_kernels.hpp", "nsk3_mfma.hpp", "nsk3_mfma_ops.hpp", "nsk_dev.hpp")}
+
+
+def family_hashes():
+    """sha256 of the kernel SOURCES of the quadrilateral and of the hexahedral kernel set (the headers the kernels live in): what the
+    HBM-side bytes of a launch depend on.  A PMC table stays valid for a kernel family whose sources did not change, even when the
+    library was rebuilt for a host-side change or for the other family (its full source hash then differs)."""
+    import hashlib
+    out = {}
+    for fam, files in KERNEL_FAMILIES.items():
+        h = hashlib.sha256()
+        for f in files:
+            with open(os.path.join(ROOT, "nekstab_amd", "csrc", f), "rb") as fh:
+                h.update(fh.read())
+        out[fam] = h.hexdigest()
+    return out
+
+
 def pmc_traffic(kernel_key):
-    """HBM-side bytes per launch of the dominant kernel from the committed PMC passes (scripts/profile_r03.sh ->
-    profiles/rNN_pmc_traffic.json): used only when the file was produced by THIS build of the library (source hash)."""
+    """HBM-side bytes per launch of the dominant kernel from the committed PMC passes (scripts/profile_r06.sh ->
+    profiles/rNN_pmc_traffic.json): used only when the file was produced by THIS build of the library (full source hash) or, for
+    a table that records them, by a build with the same sources of the kernel's FAMILY (family_hashes)."""
     import glob
     stamp = os.path.join(ROOT, "nekstab_amd", "lib", "libnekstab_hip.so.srchash")
     if not os.path.exists(stamp):
         return None, "no PMC pass of this build"
     mine = open(stamp).read().strip()
+    fam = "3d" if kernel_key.startswith("k3::") else "2d"
+    famh = family_hashes()[fam]
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
         tab = json.load(open(path))
-        if tab.get("srchash") != mine:
+        if tab.get("srchash") != mine and (tab.get("family_hash") or {}).get(fam) != famh:
             continue
         rec = tab.get("kernels", {}).get(kernel_key)
         if not rec:
             return None, "kernel not in the PMC table of " + os.path.basename(path)
-        return rec["bytes_per_launch"], "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this build (2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction): profiles/" + os.path.basename(path)
+        same = "this build" if tab.get("srchash") == mine else "a build with the same %s kernel sources" % ("hexahedral" if fam == "3d" else "quadrilateral")
+        return rec["bytes_per_launch"], "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of %s (2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction): profiles/%s" % (same, os.path.basename(path))
     return None, "the committed PMC tables (profiles/r*_pmc_traffic.json) are from other builds of the library"
 
 

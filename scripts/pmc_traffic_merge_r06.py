@@ -19,7 +19,10 @@ for cfg3 in (tag + "_cfg3_pmc_fetch_write_per_kernel.json",):
             if "k_helm<12>" in k:
                 out["k_helm<12>"] = {"bytes_per_launch": (2.0 * v["fetch_kb_p90"] + v["write_kb_p90"]) * 1024.0, "fetch_kb_p90": v["fetch_kb_p90"], "write_kb_p90": v["write_kb_p90"]}
 stamp = os.path.join(ROOT, "nekstab_amd", "lib", "libnekstab_hip.so.srchash")
-json.dump({"srchash": open(stamp).read().strip() if os.path.exists(stamp) else None, "kernels": out,
+sys.path.insert(0, ROOT)
+import bench
+prev = json.load(open(p)) if os.path.exists(p) else {}
+json.dump({"srchash": open(stamp).read().strip() if os.path.exists(stamp) else None, "family_hash": bench.family_hashes(), "kernels": out,
            "source": "scripts/profile_r06.sh + profile_r06_b.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, kernel trace only); config 2: p90 over the launches of the bench command; "
                      "configs 4 and 5: p50 over full-work launches of scripts/kernels3d_bench.py / prof_cfg5.py; config 3: k_helm<12> (p90 over a bench run)"},
           open(p, "w"), indent=1)
