@@ -86,10 +86,10 @@ def test_bench_two_ranks_under_the_launcher_dry_run():
 
 def test_bench_eight_ranks_gloo_dry_run():
     """`python bench.py --gpus 8`: the script starts its own eight ranks; they share this GPU and every halo
-    travels over gloo (protocol dry run), on the cylinder at lx1 = 6 to keep it short.  The three-mode probe runs
+    travels over gloo (protocol dry run), on the cylinder at lx1 = 6 with maps of four time steps to keep it short.  The three-mode probe runs
     (NSK_BENCH_FORCE_MODE_PROBE), the record has the shape the driver reads and names the headline workload."""
     import json
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", NSK_DIST_BACKEND="gloo", NSK_BENCH_FORCE_MODE_PROBE="1", NSK_BENCH_PROBE_STEPS="2", NSK_BENCH_MAP_STEPS="8")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", NSK_DIST_BACKEND="gloo", NSK_BENCH_FORCE_MODE_PROBE="1", NSK_BENCH_PROBE_STEPS="2", NSK_BENCH_MAP_STEPS="4")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "1", "--lx1", "6", "--no-cfg3-probe"],
                          capture_output=True, text=True, timeout=1500, env=env)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
