@@ -53,6 +53,27 @@ def oracle6(case6):
     return make_oracle(case6)
 
 
+_ORACLE8 = {}
+
+
+def oracle8_direct():
+    """The lx1 = 8 direct-case oracle with its sparse factorisations (12 s to build): shared by the tests that step it
+    (tests/test_fuse2_gpu.py, test_persistent_gpu.py); returns (case, oracle)."""
+    if "o" not in _ORACLE8:
+        from nekstab_amd import mesh
+        case = mesh.load_case_npz(os.path.join(GOLDEN, "cylinder_case.npz"), 8)
+        _ORACLE8["o"] = (case, make_oracle(case))
+    return _ORACLE8["o"]
+
+
+def oracle8_five_steps(q):
+    """The oracle's map of five direct steps of `q` at lx1 = 8 (both tests use the same seeded state): computed once."""
+    key = ("ref5", float(np.sum(q[0])), float(np.sum(q[2])))
+    if key not in _ORACLE8:
+        _ORACLE8[key] = oracle8_direct()[1].matvec(q, nsteps=5)
+    return _ORACLE8[key]
+
+
 @pytest.fixture(scope="session")
 def oracle6_nosolve(case6):
     return make_oracle(case6, build_solvers=False)

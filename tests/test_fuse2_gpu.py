@@ -65,10 +65,8 @@ def test_two_launches_equal_three_launches(lx1, mode, tolp):
 def test_two_launch_form_against_the_oracle():
     """Five direct steps at lx1 = 8 with converged solves against the oracle's sparse direct solves (the parity bar of
     tests/test_matvec_gpu.py), on the two-launch form explicitly."""
-    from nekstab_amd import mesh
-    from tests.conftest import GOLDEN, make_oracle
-    case = mesh.load_case_npz(os.path.join(GOLDEN, "cylinder_case.npz"), 8)
-    o = make_oracle(case)
+    from tests.conftest import oracle8_direct, oracle8_five_steps
+    case, o = oracle8_direct()                 # (shared with the other test that steps the lx1 = 8 oracle)
     h = _ctx(case, tol_helm=1e-12, tol_pres=1e-9, max_helm_iter=150, max_pres_iter=160)
     h.set_option("fuse2", 1)
     rng = np.random.default_rng(3)
@@ -79,7 +77,7 @@ def test_two_launch_form_against_the_oracle():
     h.upload(vq, *q)
     h.matvec(vf, vq, 0)
     f = h.download(vf)
-    ref = o.matvec(q, nsteps=5)
+    ref = oracle8_five_steps(q)
     num = sum(np.sum(o.bm1 * (x - y) ** 2) for x, y in zip(f[:2], ref[:2]))
     den = sum(np.sum(o.bm1 * y ** 2) for y in ref[:2])
     print("two-launch form, rel L2 vs oracle %.2e" % np.sqrt(num / den), "pressure iterations", h.stats()["pres_iters"])

@@ -51,10 +51,8 @@ def test_fused_equals_launch_per_iteration(lx1, mode):
 def test_fused_full_map_vs_oracle_lx1_8():
     """Five direct steps at lx1 = 8 (config 2's order) through the persistent kernel against the oracle: the direct-mode
     full-step comparison at this order."""
-    from nekstab_amd import mesh
-    from tests.conftest import GOLDEN, make_oracle
-    case = mesh.load_case_npz(os.path.join(GOLDEN, "cylinder_case.npz"), 8)
-    o = make_oracle(case)
+    from tests.conftest import oracle8_direct, oracle8_five_steps
+    case, o = oracle8_direct()                 # (shared with the other test that steps the lx1 = 8 oracle)
     from nekstab_amd.capi import NekStabHip
     h = NekStabHip(case, case.meta["vert"], case.meta["nvert"], tol_helm=1e-12, tol_pres=1e-9, tol_relative=1,
                    schwarz_layers=2, max_helm_iter=150, max_pres_iter=160)       # pressure to 1e-9: restarted GMRES cycles
@@ -69,7 +67,7 @@ def test_fused_full_map_vs_oracle_lx1_8():
         h.set_option("fused", fused)
         h.matvec(vf, vq, 0)
         f = h.download(vf)
-        ref = o.matvec(q, nsteps=5) if fused else ref
+        ref = oracle8_five_steps(q)
         num = sum(np.sum(o.bm1 * (x - y) ** 2) for x, y in zip(f[:2], ref[:2]))
         den = sum(np.sum(o.bm1 * y ** 2) for y in ref[:2])
         print("fused", fused, "rel L2 vs oracle %.2e" % np.sqrt(num / den))
