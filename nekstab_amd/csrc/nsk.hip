@@ -147,6 +147,8 @@ struct nsk_ctx {
   int merged_iters = 24;                // ... for the first merged_iters iterations of a solve (see pres_solve_launch; 12 until round 4: 24 covers the tightened solves of time steps 1-3 too, +2 % on config 2 at identical iteration counts)
   int merged_update = 1;                // GMRES column bookkeeping inside the coarse-solve kernel (k_update_coarse)
   int tc32 = 0;                         // k_divgs_t: the fp32 copy of the coarse image (0 = never (default: it moves a map by 2e-8 for 0.6 us per iteration), 1 = always, -1 = where the solve's relative tolerance is >= 1e-5; option "tc32", NSK_TC32)
+  int skip_close = 1;                   // no closing launch behind a pressure tail that covers the merged range (option "skip_close", NSK_SKIP_CLOSE; measured +0.3 %)
+  int sb_pct = 90;                      // per-step budgets behind the safety-net tail: percentile of the window's counts (100 = the largest, rounds 5 to mid-6; option "sb_pct", NSK_SB_PCT; 90 measured +0.6 %, with skip_close +1.3 %: profiles/r06_ab_fuse2.txt)
   int fuse2_start = 1;                  // ... and the solve's start inside its first launch (k_proj_apply_e; no k_gmres_update(-1) launch); option "fuse2_start", NSK_FUSE2_START
   int fuse2 = 1;                        // round 6: the merged iteration in TWO launches (k_schwarz_uc, k_divgs_t; option "fuse2", NSK_FUSE2); 0 = the three launches of rounds 3-5
   double* kacc = nullptr;               // nsk_orth: coefficients accumulated over the two passes + the squared norm (device)
@@ -927,6 +929,8 @@ static int build(nsk_ctx* c, const nsk_case& cs) {
   if (const char* g = std::getenv("NSK_FUSE2")) c->fuse2 = std::atoi(g);
   if (const char* g = std::getenv("NSK_TC32")) c->tc32 = std::atoi(g);
   if (const char* g = std::getenv("NSK_FUSE2_START")) c->fuse2_start = std::atoi(g);
+  if (const char* g = std::getenv("NSK_SB_PCT")) c->sb_pct = std::atoi(g);
+  if (const char* g = std::getenv("NSK_SKIP_CLOSE")) c->skip_close = std::atoi(g);
   if (const char* g = std::getenv("NSK_HOSTCHECK")) c->hostcheck = std::atoi(g);
   if (const char* g = std::getenv("NSK_GRAPH_STEPS")) c->graph_steps = std::max(1, std::min(std::atoi(g), 64));
   if (const char* g = std::getenv("NSK_MERGED_ITERS")) c->merged_iters = std::max(0, std::min(std::atoi(g), MAXMR));
@@ -1219,7 +1223,9 @@ static int pres_solve_launch(nsk_ctx* c, double h2, int ord, int np, double tol_
     // the pressure tail only, so zero them here (a dirty set lets the next velocity tail's first barriers fall through)
     if (tail && !(tl && nhead < nm) && c->sync) (void)hipMemsetAsync(c->sync, 0, SYNC_WORDS * sizeof(unsigned), c->stream);
     // closes the last merged column (normalises v_nm and writes its corner restriction: what the classic iteration nm reads)
-    if (nm > 0) {
+    // (behind a persistent tail that covers the whole merged range, with no classic iteration budgeted, nothing is left to close: a solve
+    //  that is not finished after the tail's last iteration is unconverged whatever the closing launch records -- option "skip_close")
+    if (nm > 0 && !(c->skip_close && tl && f2 && np <= nm)) {
       if (f2 && nm < std::min(c->merged_iters, c->gmres_cycle)) {
         // two-launch form, budget below the merged range: the last column is closed by A_nm -- the SAME code (uc_rotate) that closes
         // every other column and that the persistent tail runs, so that a solve of exactly nm iterations ends with the same bits
@@ -1658,8 +1664,21 @@ static void step_budgets_update(nsk_ctx* c) {
     }
     return;
   }
+  // (option "sb_pct" < 100, with the safety-net tail only: the budget is that PERCENTILE of the counts at steps s-1..s+1 of the window
+  //  instead of the largest at s-2..s+2 -- fewer launches that find nothing to do, more solves that end in the tail; offline on the
+  //  recorded counts of 64 maps the 85th-90th percentile is the cheapest: DESIGN.md section 7)
+  const int pct = (net && nv >= 4) ? std::max(50, std::min(100, c->sb_pct)) : 100;
+  const int win = pct < 100 ? 1 : nsk_ctx::SBN;
   for (int s = 0; s < ns; ++s) {
     int mh = 0, mp = 0;
+    if (pct < 100) {
+      int vh[nsk_ctx::SBW * 3], vp[nsk_ctx::SBW * 3], n = 0;
+      for (int i = 0; i < nv; ++i)
+        for (int t = std::max(0, s - win); t <= std::min(ns - 1, s + win); ++t) { vh[n] = b.hist_h[i][t]; vp[n] = b.hist_p[i][t]; ++n; }
+      std::sort(vh, vh + n); std::sort(vp, vp + n);
+      const int k = std::min(n - 1, (int)std::ceil(0.01 * pct * (n - 1)));
+      mh = vh[k]; mp = vp[k];
+    } else
     for (int i = 0; i < nv; ++i)
       for (int t = std::max(0, s - nsk_ctx::SBN); t <= std::min(ns - 1, s + nsk_ctx::SBN); ++t) { mh = std::max(mh, b.hist_h[i][t]); mp = std::max(mp, b.hist_p[i][t]); }
     int xh = 0, xp = 0;
@@ -2361,6 +2380,8 @@ int nsk_set_option(nsk_ctx* c, const char* name, double value) {
   else if (n == "fuse2") { c->fuse2 = (int)value; c->tail_ok = -1; invalidate_graphs(c); }
   else if (n == "tc32") { c->tc32 = (int)value; invalidate_graphs(c); }
   else if (n == "fuse2_start") { c->fuse2_start = (int)value; invalidate_graphs(c); }
+  else if (n == "sb_pct") { c->sb_pct = (int)value; }
+  else if (n == "skip_close") { c->skip_close = (int)value; invalidate_graphs(c); }
   else if (n == "min_pres_iter") c->min_pres = (int)value;
   else if (n == "pres_cap") {
     if (value > 0 && c->ndim != 2) return fail(NSK_EINVAL, "pres_cap is validated on quadrilateral linearised maps only (DESIGN.md section 1)");
