@@ -78,7 +78,7 @@ struct nsk_ctx {
   int bh_helm[NCLS][8] = {}, bh_pres[NCLS][8] = {}, bh_n = 0;                         // iteration maxima of the last maps (budgets_update)
   int use_graph = 1;
   int gmres_cycle = MAXMR;              // pressure GMRES restarts after this many iterations (option "gmres_cycle": tests use short cycles)
-  int mfma_convect = 1;                 // hexahedra, lx1 = 8: convection kernel with the contractions on the fp64 matrix cores (nsk3_mfma.hpp)
+  int mfma_convect = 1;                 // hexahedra, lx1 = 8 and 10: convection kernel with the contractions on the fp64 matrix cores (nsk3_mfma.hpp: k_convect_mfma8, k_convect_mfma<10>)
   int fused = 0;                        // persistent velocity solve (k_helm_fused): one launch per time step instead of one per CG iteration
   unsigned* sync = nullptr;             // grid-barrier counters of the persistent kernels
   int in_test = 0;
@@ -88,7 +88,7 @@ struct nsk_ctx {
   int eapply_pipe = 4;                  // hexahedra, the Schwarz + D^T kernel: 0 = one workgroup per element, 1 = resident workgroups with the next element's loads in flight (k_schwarz_p), 2 = one wavefront per element (k_schwarz_w), 3 = 2 + k_divgs_w, 4 = one wavefront per element, sixteen per CU (k_schwarz_w16; default, lx1 <= 8)
   int zero_metrics = 1;                 // hexahedra: arrays of the mapping / base-flow constants that are zero on every node are cleaned at set-up and not loaded by the kernels (Dev::zmask, Dev::bfmask); NSK_ZERO_METRICS=0: set-up as rounds 1-4 (rounding noise kept); option zero_metrics = 0: cleaned arrays, every one loaded
   unsigned zmask_built = 0, bfmask_built = 0;
-  int divgs_c3 = 0;                     // hexahedra: k_divgs with the three components' pass chains side by side (k_divgs_c3: 5 barriers instead of 12; measured 6 % SLOWER at config 4's size, 718 against 678 us: the gather, not the passes, is what a workgroup waits for; kept as an option)
+  int divgs_c3 = -1;                    // hexahedra: k_divgs with the three components' pass chains side by side (k_divgs_c3: 5 barriers instead of 12).  -1 (default) = at lx1 = 10 only: there k_divgs<10> (80 registers x 1024 threads) is alone on its CU and k_divgs_c3<10> (56) is not -- 284 against 543 us at 13 824 elements, 1.96 against 3.98 ms at config 5's size; at lx1 = 8 it measured 6 % SLOWER (718 against 678 us at config 4's size: four workgroups per CU either way, and the gather, not the passes, is what a workgroup waits for)
   int eapply_grid[2] = {0, 0};          // their grid sizes (workgroups that fit the device at once; 0 = not yet asked)
   int flat_proj = -1;                   // hexahedra: once-per-step sums over the GMRES / projection bases as streaming kernels (k_pres_comb, k_proj_dots); -1 = yes on single-rank contexts
   int gs_lag = -1;                      // hexahedra: lagged second Gram-Schmidt correction (k_gs_lag: two basis reads per GMRES column instead of four); -1 = yes on single-rank contexts
@@ -1065,7 +1065,7 @@ static void launch_schwarz3(nsk_ctx* c, const Dev& d, int count, const double* v
     if (mode < 0) mode = c->eapply_pipe;
     if (mode == 3) mode = 2;                             // (3 = 2 + the divergence kernel in wavefront form: launch_divgs3)
     if (mode == 2 && N > 8 && !std::getenv("NSK_WAVE_LX10")) mode = 0;      // lx1 = 10: 16 nodes per lane, 234 registers: not measured faster
-    if (mode == 4 && N > 8) mode = 0;
+    if (mode == 4 && N > 8) mode = 1;                    // lx1 = 10 has no sixteen-per-CU wavefront form: resident workgroups with the next element's loads in flight (k_schwarz_p<10> 591 against k_schwarz<10> 692 us at 13 824 elements: one workgroup per CU either way, profiles/r06_cfg5_forms.txt)
     if (mode == 4) {          // one wavefront per element, sixteen per CU (in-place solve, metrics per component)
       if constexpr (N <= 8) hipLaunchKernelGGL(nsk::k3::k_schwarz_w16<N>, dim3(count), dim3(64), 0, c->stream, d, vin, zout, use_coarse, check_done);
     } else if (mode == 2)     // one wavefront per element
@@ -1091,7 +1091,7 @@ static void launch_divgs3(nsk_ctx* c, const Dev& d, int count, const double* yl,
         return;
       }
     }
-    if (c3 < 0) c3 = c->divgs_c3;
+    if (c3 < 0) c3 = c->divgs_c3 >= 0 ? c->divgs_c3 : (N > 8 ? 1 : 0);
     if (c3) hipLaunchKernelGGL(nsk::k3::k_divgs_c3<N>, dim3(count), dim3(nsk::k3::Cfg<N>::NT), 0, c->stream, d, yl, wout, j, check_done);
     else hipLaunchKernelGGL(nsk::k3::k_divgs<N>, dim3(count), dim3(nsk::k3::Cfg<N>::NT), 0, c->stream, d, yl, wout, j, check_done);
   }
@@ -1405,6 +1405,8 @@ static int step(nsk_ctx* c, int istep, int adjoint, int nh_over = -1, int np_ove
     constexpr int NT = Cfg<N>::NT;
     if (c->key == 108 && adjoint != 2 && c->mfma_convect)
       hipLaunchKernelGGL(nsk::k3::k_convect_mfma8, dim3(c->nel), dim3(512), 0, c->stream, d, (const double*)d.u, d.bf, adjoint);
+    else if (c->key == 110 && adjoint != 2 && c->mfma_convect)
+      hipLaunchKernelGGL(nsk::k3::k_convect_mfma<10>, dim3(c->nel), dim3(512), 0, c->stream, d, (const double*)d.u, d.bf, adjoint);
     else
       hipLaunchKernelGGL(k_convect<N>, dim3(c->nel), dim3(Cfg<N>::NTD), 0, c->stream, d, (const double*)d.u, d.bf, adjoint);
     if (c->fused) {
@@ -3119,12 +3121,13 @@ int nsk_bench_kernel(nsk_ctx* c, const char* name, int reps, double* avg_us) {
       HIPCHK(hipEventRecord(e1, c->stream));
     });
   } else if (n == "convect" || n == "convect_mfma") {
-    if (n == "convect_mfma" && c->key != 108) return fail(NSK_EINVAL, "k_convect_mfma8: hexahedra with lx1 = 8");
+    if (n == "convect_mfma" && c->key != 108 && c->key != 110) return fail(NSK_EINVAL, "k_convect_mfma8 / k_convect_mfma<10>: hexahedra with lx1 = 8 or 10");
     HIPCHK(hipStreamSynchronize(c->stream));
     DISPATCH_N(c->key, {
       for (int r = 0; r < reps + 3; ++r) {
         if (r == 3) HIPCHK(hipEventRecord(e0, c->stream));
-        if (n == "convect_mfma") hipLaunchKernelGGL(nsk::k3::k_convect_mfma8, dim3(c->nel), dim3(512), 0, c->stream, d, (const double*)d.u, d.bf, 0);
+        if (n == "convect_mfma" && c->key == 108) hipLaunchKernelGGL(nsk::k3::k_convect_mfma8, dim3(c->nel), dim3(512), 0, c->stream, d, (const double*)d.u, d.bf, 0);
+        else if (n == "convect_mfma") hipLaunchKernelGGL(nsk::k3::k_convect_mfma<10>, dim3(c->nel), dim3(512), 0, c->stream, d, (const double*)d.u, d.bf, 0);
         else hipLaunchKernelGGL(k_convect<N>, dim3(c->nel), dim3(Cfg<N>::NTD), 0, c->stream, d, (const double*)d.u, d.bf, 0);
       }
       HIPCHK(hipEventRecord(e1, c->stream));
@@ -3330,9 +3333,10 @@ int nsk_test_op3(nsk_ctx* c, int which, const double* in, double* out, int a, in
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipMemcpy(out, c->wv2, nv * sizeof(double), hipMemcpyDeviceToHost));
   } else if (which == 8) {                             // convection term on the matrix cores (lx1 = 8; a = 0 direct / 1 adjoint)
-    if (c->key != 108 || a == 2) return fail(NSK_EINVAL, "k_convect_mfma8: hexahedra with lx1 = 8, modes 0 and 1");
+    if ((c->key != 108 && c->key != 110) || a == 2) return fail(NSK_EINVAL, "k_convect_mfma8 / k_convect_mfma<10>: hexahedra with lx1 = 8 or 10, modes 0 and 1");
     HIPCHK(hipMemcpy(c->wv1, in, nv * sizeof(double), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(nsk::k3::k_convect_mfma8, dim3(c->nel), dim3(512), 0, c->stream, d, (const double*)c->wv1, c->wv2, a);
+    if (c->key == 108) hipLaunchKernelGGL(nsk::k3::k_convect_mfma8, dim3(c->nel), dim3(512), 0, c->stream, d, (const double*)c->wv1, c->wv2, a);
+    else hipLaunchKernelGGL(nsk::k3::k_convect_mfma<10>, dim3(c->nel), dim3(512), 0, c->stream, d, (const double*)c->wv1, c->wv2, a);
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipMemcpy(out, c->wv2, nv * sizeof(double), hipMemcpyDeviceToHost));
   } else if (which == 5) {

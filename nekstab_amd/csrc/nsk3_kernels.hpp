@@ -1629,8 +1629,11 @@ __global__ __launch_bounds__(64) void k_gmres_col(Dev d, int j, double scale, in
 // gather table derived at set-up from the velocity-mesh dssum lists, which resolves their orientation (p_idx).  Local solve by fast diagonalisation:
 // fdS = [nel][3][N*N] generalised eigenvectors S_d[pos][mode] of the 1-D pairs (A_d, M_d), fdL = [nel][3][N]:
 //   z = (S_t x S_s x S_r) diag(1/(lr+ls+lt)) (S_t x S_s x S_r)^T w,  restricted to the element's own nodes.
+#ifndef NSK_SCHW3_WAVES
+#define NSK_SCHW3_WAVES 1
+#endif
 template <int N>
-__global__ __launch_bounds__(Cfg<N>::NT) void k_schwarz(Dev d, const double* __restrict__ vin,
+__global__ __launch_bounds__(Cfg<N>::NT) __attribute__((amdgpu_waves_per_eu(NSK_SCHW3_WAVES))) void k_schwarz(Dev d, const double* __restrict__ vin,
                                                         double* __restrict__ zout, int use_coarse, int check_done) {
   using C = Cfg<N>;
   constexpr int NN = C::NN, M = C::M, MM = C::MM, NT = C::NT, NM = N * M, NNM = C::NNM, NMM = C::NMM;
@@ -2058,8 +2061,11 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_gradt(Dev d, const double* __res
 // from LDS in list order (the left-to-right sum of gs_csr; a missing member is -0.0, the identity of the addition).
 // (Until round 5 the basis was a round trip of its own ahead of the table, the metric terms went out after the gather and a
 //  corner thread walked its three components' lists one after the other: five round trips, 9 of a workgroup's 14 us.)
+#ifndef NSK_DIVGS3_WAVES
+#define NSK_DIVGS3_WAVES 1
+#endif
 template <int N>
-__global__ __launch_bounds__(Cfg<N>::NT) void k_divgs(Dev d, const double* __restrict__ yl,
+__global__ __launch_bounds__(Cfg<N>::NT) __attribute__((amdgpu_waves_per_eu(NSK_DIVGS3_WAVES))) void k_divgs(Dev d, const double* __restrict__ yl,
                                                       double* __restrict__ wout, int j, int check_done) {
   using C = Cfg<N>;
   constexpr int NN = C::NN, M = C::M, MM = C::MM, NT = C::NT, NM = N * M, NNM = C::NNM, NMM = C::NMM;

@@ -123,5 +123,147 @@ __global__ __launch_bounds__(512) void k_convect_mfma8(Dev d, const double* __re
   }
 }
 
+// ---- the same kernel for orders whose column counts are no multiples of 16 (lx1 = 10, lxd = 15: 100, 150 and 225 columns) ----
+// k_convect<10> (convect_lds) walks a lane's fine-mesh points one at a time with the base-flow constants loaded inside the loop, one
+// workgroup per CU: 116 ms per launch at config 5's size (99 452 elements), 11 % of a time step, seventeen times its streaming floor.
+// Here: every pass on the matrix cores through mo_pass (nsk3_mfma_ops.hpp: masked columns and contracted lengths), 512 threads with
+// seven fine-mesh points each, and THREE LDS regions of lxd^3 doubles (81 008 B: two workgroups per CU fill its 160 KB) --
+//   R1: the fine-mesh field sf / the accumulated output of a component; t1 (the [N][N][ND] intermediate) while sf is dead
+//   R2: one fine-mesh derivative at a time (d/dr, d/ds, d/dt in turn: the products with the convecting field are summed in a
+//       register per point); t2 ([N][ND][ND]) and the element's N^3 tile while the derivative is dead
+//   R3: the accumulator of the third output component (the other two live in registers: all three there spill 280 B per lane)
+// The constants of a phase are requested before the pass that precedes it (a barrier's memory clobber keeps them there).
+template <int N>
+__global__ __launch_bounds__(512, 4) void k_convect_mfma(Dev d, const double* __restrict__ uin, double* __restrict__ bf, int adjoint) {
+  const double* __restrict__ bfc = d.bfc + (d.bf_stride ? (size_t)(*d.bstep) * (size_t)d.bf_stride : (size_t)0);      // steady set or orbit slot
+  constexpr int ND = 3 * N / 2, NN = N * N * N, NDD = ND * ND * ND, NT = 512, NW = NT / 64;
+  constexpr int PPT = (NDD + NT - 1) / NT, PPN = (NN + NT - 1) / NT, KQU = (N + 3) / 4, KQD = (ND + 3) / 4;
+  static_assert(ND <= 16 && N * N * ND <= NDD && N * ND * ND + NN <= NDD, "one 16-row tile per operator; t1 inside R1, t2 and the element tile inside R2");
+  __shared__ double R1[NDD], R2[NDD], R3[NDD];
+  double* sf = R1; double* t1 = R1; double* sg = R2; double* t2 = R2; double* su = R2 + N * ND * ND;
+  double* so2 = R3;                                             // the third output component's accumulator (each lane its own points)
+  const int tid = threadIdx.x, lane0 = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const long long e = blockIdx.x;
+  const int m16 = lane0 & 15, kq = lane0 >> 4;
+  // A fragments, constant for the whole kernel:  up: J (ND x N);  gradient: Dd (ND x ND);  down: J^T (N x ND)
+  double aJ[KQU], aD[KQD];
+#pragma unroll
+  for (int q = 0; q < KQU; ++q) { const int k = 4 * q + kq; aJ[q] = (m16 < ND && k < N) ? d.Jd[m16 * N + k] : 0.0; }
+#pragma unroll
+  for (int q = 0; q < KQD; ++q) { const int k = 4 * q + kq; aD[q] = (m16 < ND && k < ND) ? d.Dd[m16 * ND + k] : 0.0; }
+  typedef ColRow<N> UR_in;                       typedef ColRow<ND> UR_out;                     // [(k,j)][i] -> [(k,j)][a]
+  typedef ColPlane<ND, N * ND, ND> US_in;        typedef ColPlane<ND, ND * ND, ND> US_out;      // [k][j][a]  -> [k][b][a]
+  typedef ColLinear<ND * ND> UT;                                                                // [k][(b,a)] -> [c'][(b,a)]
+  const size_t nf = (size_t)d.nfine;
+  const double* __restrict__ bfe = bfc + (size_t)e * NDD;       // uniform base + 32-bit lane offsets (global_load saddr form)
+  // byte offsets of this lane's points: tid * 8 + r * NT * 8, the last one clamped (its value is never used)
+  unsigned po0 = (unsigned)tid * 8u, pol = (unsigned)((tid + (PPT - 1) * NT < NDD) ? tid + (PPT - 1) * NT : NDD - 1) * 8u;
+  double o[PPT][2];
+#pragma unroll
+  for (int r = 0; r < PPT; ++r) { o[r][0] = o[r][1] = 0.0; const int p = tid + r * NT; if (p < NDD) so2[p] = 0.0; }
+  // constant `qi` at this lane's points (not loaded where the mask says it vanishes on the whole mesh: a wave-uniform branch)
+  auto ldc = [&](int qi, double (&b)[PPT]) {
+    if ((d.bfmask >> qi) & 1u) {
+#pragma unroll
+      for (int r = 0; r < PPT; ++r) b[r] = 0.0;
+    } else {
+      const double* __restrict__ bq = bfe + (size_t)qi * nf;
+#pragma unroll
+      for (int r = 0; r < PPT; ++r) b[r] = (r < PPT - 1) ? ld_boff(bq + r * NT, po0) : ld_boff(bq, pol);
+    }
+  };
+#pragma unroll 1
+  for (int c = 0; c < 3; ++c) {
+    // (the lane index is made opaque per iteration: otherwise every lane-dependent LDS offset of the nine passes below is hoisted out
+    //  of the loop and the kernel spills)
+    int lane = lane0;
+    asm volatile("" : "+v"(lane), "+v"(po0), "+v"(pol));          // (the offsets too: hoisted, the constants' loads become 21 64-bit addresses)
+#pragma unroll
+    for (int r = 0; r < PPN; ++r) { const int p = tid + r * NT; if (p < NN) su[p] = uin[c * d.cs + e * NN + p]; }
+    lds_barrier();
+    mo_pass<N, KQU, N * N, UR_in, StLin<UR_out, 1, ND>, false>(aJ, su, aJ, su, t1, wave, NW, lane);
+    lds_barrier();
+    mo_pass<N, KQU, N * ND, US_in, StLin<US_out, ND, ND>, false>(aJ, t1, aJ, t1, t2, wave, NW, lane);
+    lds_barrier();
+    mo_pass<N, KQU, ND * ND, UT, StLin<UT, ND * ND, ND>, false>(aJ, t2, aJ, t2, sf, wave, NW, lane);
+    double b[PPT], conv[PPT];
+    ldc(0, b);
+    lds_barrier();
+    // fine-mesh gradient, one direction at a time: d/dr, d/ds, d/dt
+    mo_pass<ND, KQD, ND * ND, ColRow<ND>, StLin<ColRow<ND>, 1, ND>, false>(aD, sf, aD, sf, sg, wave, NW, lane);
+    lds_barrier();
+#pragma unroll
+    for (int r = 0; r < PPT; ++r) { const int p = tid + r * NT; conv[r] = (p < NDD) ? b[r] * sg[p] : 0.0; }
+    ldc(1, b);
+    lds_barrier();
+    mo_pass<ND, KQD, ND * ND, US_out, StLin<US_out, ND, ND>, false>(aD, sf, aD, sf, sg, wave, NW, lane);
+    lds_barrier();
+#pragma unroll
+    for (int r = 0; r < PPT; ++r) { const int p = tid + r * NT; if (p < NDD) conv[r] += b[r] * sg[p]; }
+    ldc(2, b);
+    lds_barrier();
+    mo_pass<ND, KQD, ND * ND, UT, StLin<UT, ND * ND, ND>, false>(aD, sf, aD, sf, sg, wave, NW, lane);
+    lds_barrier();
+#pragma unroll
+    for (int r = 0; r < PPT; ++r) {
+      const int p = tid + r * NT;
+      if (p < NDD) conv[r] += b[r] * sg[p];                              // (U.grad) u'_c
+      const double sgn = adjoint ? -conv[r] : conv[r];
+      if (c == 0) o[r][0] += sgn; else if (c == 1) o[r][1] += sgn; else if (p < NDD) so2[p] += sgn;
+    }
+#pragma unroll
+    for (int x = 0; x < 3; ++x) {
+      // direct:  + u'_c dU_x/dx_c   (u'.grad) U ;   adjoint:  + u'_c dU_c/dx_x   (grad U)^T u'
+      ldc(adjoint ? 3 + 3 * c + x : 3 + 3 * x + c, b);
+#pragma unroll
+      for (int r = 0; r < PPT; ++r) {
+        const int p = tid + r * NT;
+        if (p < NDD) { if (x < 2) o[r][x] += sf[p] * b[r]; else so2[p] += sf[p] * b[r]; }
+      }
+      __builtin_amdgcn_sched_barrier(0);                                // (one constant's loads in flight at a time: three would spill)
+    }
+    lds_barrier();
+  }
+  double aJt[KQD];
+  {
+    int ln = lane0;
+    asm volatile("" : "+v"(ln));                                 // (m16 / kq recomputed: kept across the loop they are spilled)
+    const int m16b = ln & 15, kqb = ln >> 4;
+#pragma unroll
+    for (int q = 0; q < KQD; ++q) { const int k = 4 * q + kqb; aJt[q] = (m16b < N && k < ND) ? d.Jd[k * N + m16b] : 0.0; }
+  }
+  double sb[PPN], un[PPN];
+#pragma unroll
+  for (int r = 0; r < PPN; ++r) {
+    const int p = tid + r * NT;
+    const long long l = e * NN + (p < NN ? p : 0);
+    sb[r] = d.spng[l] * d.bm1[l];
+  }
+#pragma unroll 1
+  for (int c = 0; c < 3; ++c) {
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+#pragma unroll
+    for (int r = 0; r < PPT; ++r) { const int p = tid + r * NT; if (p < NDD && c < 2) sf[p] = (c == 0) ? o[r][0] : o[r][1]; }
+    const double* src = (c < 2) ? sf : so2;
+#pragma unroll
+    for (int r = 0; r < PPN; ++r) { const int p = tid + r * NT; un[r] = uin[c * d.cs + e * NN + (p < NN ? p : 0)]; }
+    lds_barrier();
+    // sf[c'][b][a] -> t2[k][b][a] -> t1[(k,j)][a] -> su[(k,j)][i]
+    mo_pass<ND, KQD, ND * ND, UT, StLin<UT, ND * ND, N>, false>(aJt, src, aJt, src, t2, wave, NW, lane);
+    lds_barrier();
+    mo_pass<ND, KQD, N * ND, US_out, StLin<US_in, ND, N>, false>(aJt, t2, aJt, t2, t1, wave, NW, lane);
+    lds_barrier();
+    mo_pass<ND, KQD, N * N, UR_out, StLin<UR_in, 1, N>, false>(aJt, t1, aJt, t1, su, wave, NW, lane);
+    lds_barrier();
+#pragma unroll
+    for (int r = 0; r < PPN; ++r) {
+      const int p = tid + r * NT;
+      if (p < NN) bf[c * d.cs + e * NN + p] = -(sb[r] * un[r] + su[p]);
+    }
+    lds_barrier();
+  }
+}
+
 }  // namespace k3
 }  // namespace nsk

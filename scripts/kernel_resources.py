@@ -5,7 +5,7 @@
 import os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 flt = sys.argv[1] if len(sys.argv) > 1 else ""
-cmd = ["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-Wno-unused-value", "-Rpass-analysis=kernel-resource-usage",
+cmd = ["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-Wno-unused-value", "-Rpass-analysis=kernel-resource-usage"] + os.environ.get("NSK_CXXFLAGS", "").split() + [
        "-o", "/tmp/_nsk_ru.so", os.path.join(ROOT, "nekstab_amd", "csrc", "nsk.hip")]
 err = subprocess.run(cmd, capture_output=True, text=True).stderr
 rows, cur = [], None

@@ -89,9 +89,9 @@ def test_convection_terms(setup3):
     assert _rel(h.t_op3(3, u, 1), adj) < 1e-12
     nl = np.stack([-o.convect(u, u[k]) for k in range(3)])
     assert _rel(h.t_op3(3, u, 2), nl) < 1e-12
-    if c.lx1 == 8:
-        # the same terms with the tensor contractions on v_mfma_f64_16x16x4_f64 (nsk3_mfma.hpp): against the oracle and
-        # against the thread-per-node kernel
+    if c.lx1 in (8, 10):
+        # the same terms with the tensor contractions on v_mfma_f64_16x16x4_f64 (nsk3_mfma.hpp: k_convect_mfma8, k_convect_mfma<10>):
+        # against the oracle and against the thread-per-node kernel
         assert _rel(h.t_op3(8, u, 0), direct) < 1e-12
         assert _rel(h.t_op3(8, u, 1), adj) < 1e-12
         assert _rel(h.t_op3(8, u, 0), h.t_op3(3, u, 0)) < 1e-13
