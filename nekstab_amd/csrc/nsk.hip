@@ -88,6 +88,7 @@ struct nsk_ctx {
   int eapply_pipe = 4;                  // hexahedra, the Schwarz + D^T kernel: 0 = one workgroup per element, 1 = resident workgroups with the next element's loads in flight (k_schwarz_p), 2 = one wavefront per element (k_schwarz_w), 3 = 2 + k_divgs_w, 4 = one wavefront per element, sixteen per CU (k_schwarz_w16; default, lx1 <= 8)
   int zero_metrics = 1;                 // hexahedra: arrays of the mapping / base-flow constants that are zero on every node are cleaned at set-up and not loaded by the kernels (Dev::zmask, Dev::bfmask); NSK_ZERO_METRICS=0: set-up as rounds 1-4 (rounding noise kept); option zero_metrics = 0: cleaned arrays, every one loaded
   unsigned zmask_built = 0, bfmask_built = 0;
+  int helm_pf = 1, helm_pf_grid = 0;    // hexahedra, lx1 = 10: the CG iteration as resident workgroups with LDS-DMA prefetch of the next element (k_helm_p; option "helm_pf", NSK_HELM_PF; 0 = k_helm<10>)
   int divgs_c3 = -1;                    // hexahedra: k_divgs with the three components' pass chains side by side (k_divgs_c3: 5 barriers instead of 12).  -1 (default) = at lx1 = 10 only: there k_divgs<10> (80 registers x 1024 threads) is alone on its CU and k_divgs_c3<10> (56) is not -- 284 against 543 us at 13 824 elements, 1.96 against 3.98 ms at config 5's size; at lx1 = 8 it measured 6 % SLOWER (718 against 678 us at config 4's size: four workgroups per CU either way, and the gather, not the passes, is what a workgroup waits for)
   int eapply_grid[2] = {0, 0};          // their grid sizes (workgroups that fit the device at once; 0 = not yet asked)
   int flat_proj = -1;                   // hexahedra: once-per-step sums over the GMRES / projection bases as streaming kernels (k_pres_comb, k_proj_dots); -1 = yes on single-rank contexts
@@ -1134,6 +1135,22 @@ static void launch_helm_iter(nsk_ctx* c, const Dev& d, const StepCoef& sc, int i
     }
   }
   if (c->ndim == 3) {
+    if constexpr (N == 10) {
+      // lx1 = 10: resident workgroups with the next element's r, p, s, x arriving in LDS under the current element's A z (k_helm_p;
+      // it = 0 stays k_helm's helm_first)
+      if (it >= 1 && c->helm_pf != 0 && d.boff == 0) {
+        if (!c->helm_pf_grid) {
+          int per_cu = 0, ncu = 0, dev = 0;
+          (void)hipGetDevice(&dev);
+          (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+          (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, nsk::k3::k_helm_p<N>, nsk::k3::Cfg<N>::NT, 0);
+          if (const char* g = std::getenv("NSK_HELM_PF_WGS")) per_cu = std::atoi(g);
+          c->helm_pf_grid = std::max(8, (std::max(1, per_cu) * std::max(1, ncu)) / 8 * 8);
+        }
+        hipLaunchKernelGGL(nsk::k3::k_helm_p<N>, dim3(std::min(c->nblk, c->helm_pf_grid)), dim3(nsk::k3::Cfg<N>::NT), 0, c->stream, d, sc, it, c->nblk);
+        return;
+      }
+    }
     if constexpr (N <= 10) hipLaunchKernelGGL(nsk::k3::k_helm<N>, dim3(c->nblk), dim3(nsk::k3::Cfg<N>::NT), 0, c->stream, d, sc, it, rhs);
   } else {
     hipLaunchKernelGGL(nsk::k2::k_helm<N>, dim3(c->nblk), dim3(nsk::k2::Cfg<N>::NT), 0, c->stream, d, sc, it, rhs);
@@ -2394,6 +2411,8 @@ int nsk_set_option(nsk_ctx* c, const char* name, double value) {
   else if (n == "gs_lag") c->gs_lag = (int)value;
   else if (n == "flat_proj") c->flat_proj = (int)value;
   else if (n == "divgs_c3") { c->divgs_c3 = (int)value; invalidate_graphs(c); }
+  else if (n == "helm_pf") { c->helm_pf = (int)value; invalidate_graphs(c); }
+  else if (n == "helm_pf_grid") { c->helm_pf_grid = std::max(8, (int)value / 8 * 8); invalidate_graphs(c); }      // resident workgroups of k_helm_p (tests: fewer than elements; default: what the device holds)
   else if (n == "zero_metrics") {       // 0: every array is loaded (the cleaned ones included: same bits); 1: back to the masks of the set-up
     c->d.zmask = value != 0.0 ? c->zmask_built : 0u; c->d.bfmask = (value != 0.0 && !c->d.bf_stride) ? c->bfmask_built : 0u;
     invalidate_graphs(c);
@@ -3103,23 +3122,26 @@ int nsk_bench_kernel(nsk_ctx* c, const char* name, int reps, double* avg_us) {
   HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
   Dev d = c->d;
   float ms = 0.f;
-  if (n == "helm") {
+  if (n == "helm" || n == "helm_wg") {
     d.tol_helm = 0.0; d.tol_relative = 0;                       // never converge: every launch does full work
     const StepCoef sc = make_coef(c, 3, 0);
     const int cyc = 8;
+    const int keep_pf = c->helm_pf;
+    if (n == "helm_wg") c->helm_pf = 0;                         // one workgroup per element whatever the context runs
     HIPCHK(hipStreamSynchronize(c->stream));
     DISPATCH_N(c->key, {
       for (int r = 0; r < cyc; ++r) {                             // warm
-        hipLaunchKernelGGL(k_helm<N>, dim3(c->nblk), dim3(Cfg<N>::NT), 0, c->stream, d, sc, r % cyc, (const double*)d.rloc);
+        launch_helm_iter<N>(c, d, sc, r % cyc, (const double*)d.rloc);
         tot_rows(c, d.hpart + (size_t)(r & 1) * c->hrows * c->nblk, c->hrows, d.htot + (r & 1) * c->hstride);
       }
       HIPCHK(hipEventRecord(e0, c->stream));
       for (int r = 0; r < reps; ++r) {
-        hipLaunchKernelGGL(k_helm<N>, dim3(c->nblk), dim3(Cfg<N>::NT), 0, c->stream, d, sc, r % cyc, (const double*)d.rloc);
+        launch_helm_iter<N>(c, d, sc, r % cyc, (const double*)d.rloc);
         tot_rows(c, d.hpart + (size_t)(r & 1) * c->hrows * c->nblk, c->hrows, d.htot + (r & 1) * c->hstride);   // use_tot contexts only (a few us, included)
       }
       HIPCHK(hipEventRecord(e1, c->stream));
     });
+    c->helm_pf = keep_pf;
   } else if (n == "convect" || n == "convect_mfma") {
     if (n == "convect_mfma" && c->key != 108 && c->key != 110) return fail(NSK_EINVAL, "k_convect_mfma8 / k_convect_mfma<10>: hexahedra with lx1 = 8 or 10");
     HIPCHK(hipStreamSynchronize(c->stream));

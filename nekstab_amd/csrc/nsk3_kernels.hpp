@@ -930,6 +930,227 @@ __global__ __launch_bounds__(Cfg<N>::NT, NSK_HELM3_WAVES) void k_helm(Dev d, Ste
 }
 
 
+// k_helm (it >= 1) as RESIDENT workgroups that walk their share of the elements, the next element's r, p, s, x (twelve arrays,
+// 96 KB at lx1 = 10) arriving in LDS by LDS-DMA (global_load_lds_dwordx4: no register is their destination) while the current
+// element's A z runs on the matrix cores.  Why: k_helm<10> is 1024 threads x 128 registers -- the whole register file of a CU, one
+// workgroup per CU -- so nothing hides a workgroup's trips to memory behind another's passes (config 5: 8.3 ms per launch, 0.47 of
+// 8 TB/s, 58-65 % of a time step; the 512-thread workgroups of lx1 = 8 reach 0.63 with the same code at two per CU), and a second
+// workgroup per CU would need 64 registers.  LDS holds what the registers cannot: 67 KB of tiles + 96 KB of
+// landing zone = 163 072 of the CU's 163 840 bytes.  Same arithmetic in the same order as k_helm: bit-identical.
+//   per element:  A  the arrays addressable from the thread index and the neighbours' A z (gather table in registers since the
+//                    previous element's phase C), wait, barrier
+//                 B  r, p, s, x from the landing zone; updates, stores; z tiles; barrier
+//                 -> LDS-DMA of the next element's r, p, s, x; its gather-table entry and corner-list entry
+//                 C  A z of the three components (axhelm3_mfma), partial sums
+// `count` elements from d.boff on, XCD-contiguous as in k_helm (a step of gridDim.x, a multiple of 8, stays in the XCD's run).
+template <int N>
+__global__ __launch_bounds__(Cfg<N>::NT, NSK_HELM3_WAVES) void k_helm_p(Dev d, StepCoef sc, int it, int count) {
+  using C = Cfg<N>;
+  constexpr int NN = C::NN, NT = C::NT;
+  static_assert(NT == 1024 && NN % 2 == 0 && NN / 2 <= 512, "LDS-DMA: two arrays per round, 16 bytes per lane");
+  using L = SlimLay<N>;
+  constexpr int EXT = L::EXT;
+  __shared__ double tiles[8 * EXT];
+  double* sz = tiles; double* sW = tiles + 3 * EXT; double* sO = tiles + 6 * EXT;
+  __shared__ double sred[9 * 16];
+  __shared__ double scv[192];
+  __shared__ double sDm[N * N];                                    // the derivative matrix: its fragments are rebuilt per element (36 registers that phases A and B need)
+  __shared__ __attribute__((aligned(16))) double pf[12 * NN];      // landing zone [component][r, p, s, x][NN]
+  const int tid = threadIdx.x;
+  const long long nl = d.cs;
+  const int par = it & 1, ppar = par ^ 1;
+  const unsigned G = gridDim.x;
+  unsigned b = blockIdx.x;
+  long long e = d.boff + xcd_element(b, count);
+  double alpha[3] = {0, 0, 0}, beta[3] = {0, 0, 0};
+  bool done[3] = {false, false, false};
+  int cm = -1;
+  int4 tab = make_int4(0, -1, -1, -1);
+  int dmask = 0;                                                   // finished components (wave-uniform, in a scalar register)
+  {
+    const bool act = tid < NN;
+    // lanes 0..11: htot[ppar][0..11]; 12..27: hscal[ppar][0..15]; 28..30: hscal[32..34]   (as k_helm)
+    const int ln = tid & 63;
+    double hv = 0.0;
+    if (ln < 12) hv = d.htot[ppar * 16 + ln];
+    else if (ln < 28) hv = d.hscal[ppar * 16 + ln - 12];
+    else if (ln < 31) hv = d.hscal[32 + ln - 28];
+    cm = (d.gs_corner && tid < 192) ? d.gs_corner[(size_t)e * 64 + (tid & 63)] : -1;      // tid = component * 64 + corner * 8 + member
+    if (act) tab = d.gs_tab[e * NN + tid];
+    if (tid < N * N) sDm[tid] = d.D[tid];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const double gg = lane_f64(hv, c * 3 + 0), del = lane_f64(hv, c * 3 + 1), rr = lane_f64(hv, c * 3 + 2);
+      const double o0 = lane_f64(hv, 12 + c * 4 + 0), o1 = lane_f64(hv, 12 + c * 4 + 1), o2 = lane_f64(hv, 12 + c * 4 + 2), o3 = lane_f64(hv, 12 + c * 4 + 3);
+      const double res = sqrt(rr / d.vol);
+      const double ref = (it == 1) ? sqrt(lane_f64(hv, 9 + c) / d.vol) : lane_f64(hv, 28 + c);
+      const double tol = d.tol_relative ? d.tol_helm * ref : d.tol_helm;
+      const bool was = (it > 1 && o2 != 0.0);
+      done[c] = was || (res <= tol) || !(gg > 0.0);
+      if (!done[c]) {
+        if (it == 1) { beta[c] = 0.0; alpha[c] = gg / del; }
+        else { beta[c] = gg / o0; alpha[c] = gg / (del - beta[c] * gg / o1); }
+      }
+      if (blockIdx.x == 0 && d.boff == 0 && tid == 0) {
+        double* cur = d.hscal + par * 16 + c * 4;
+        const double keep = was ? o3 : res;
+        cur[0] = gg; cur[1] = alpha[c]; cur[2] = done[c] ? 1.0 : 0.0; cur[3] = keep;
+        if (it == 1) d.hscal[32 + c] = ref;
+        if (done[c] && !was) {
+          if (c == 0) atomicAdd((unsigned long long*)&d.stats->helm_iters, (unsigned long long)(it - 1));
+          atomicMax((unsigned long long*)&d.stats->max_helm, (unsigned long long)(it - 1));
+          atomicMax((unsigned long long*)&d.stats->max_helm_k[sc.cls], (unsigned long long)(it - 1)); rec_step_iters(d, 0, it - 1);
+        }
+      }
+    }
+    if (done[0] && done[1] && done[2]) return;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { alpha[c] = uniform_f64(alpha[c]); beta[c] = uniform_f64(beta[c]); }
+    dmask = __builtin_amdgcn_readfirstlane((done[0] ? 1 : 0) | (done[1] ? 2 : 0) | (done[2] ? 4 : 0));
+  }
+  // LDS-DMA of element en's r, p, s, x: six rounds of two arrays (waves 0-7 / 8-15), lane t of a half moves doubles 2t, 2t + 1;
+  // the LDS address is the wave's base + lane * 16 (inactive lanes write nothing).  p, s, x of a finished component are not read.
+  const int half = __builtin_amdgcn_readfirstlane(tid >> 9), hw = __builtin_amdgcn_readfirstlane((tid & 511) >> 6), ht = tid & 511;
+  auto prefetch = [&](long long en) {
+#pragma unroll
+    for (int rd = 0; rd < 6; ++rd) {
+      const int a = 2 * rd + half, c = a >> 2, w = a & 3;
+      if (w != 0 && ((dmask >> c) & 1)) continue;
+      const double* src = ((w == 0) ? d.hr : ((w == 1) ? d.hp : ((w == 2) ? d.hs : d.hx))) + (size_t)c * nl + en * NN;
+      // (inline assembly: the builtin makes hipcc drain the DMA -- s_waitcnt vmcnt(0) -- in front of LDS writes of phase C that
+      //  it cannot tell from the landing zone; M0 = the wave's LDS base, written in the statement that reads it)
+      const unsigned ldst = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(pf + a * NN + hw * 128);
+      const double* gsrc = src + 2 * ht;
+      unsigned keep;
+      if (ht < NN / 2)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(gsrc), "s"(ldst) : "memory");
+    }
+  };
+  prefetch(e);
+  const double* wl0 = d.hwl + (size_t)ppar * 3 * nl;
+  for (;;) {
+    // (the thread index is made opaque per element: otherwise every lane-dependent address and LDS offset below is hoisted out of
+    //  the loop, and the loop spills)
+    int tl = tid;
+    asm volatile("" : "+v"(tl));
+    const bool act = tl < NN;
+    const int k = tl / (N * N), j = (tl / N) % N, i = tl % N;
+    const int tn = k * L::PS + j * L::RS + i;
+    const int cid = act ? corner_id<N>(k, j, i) : -1;
+    const long long l = e * NN + tl;
+    // ---- A: everything else addressable from the thread index, and the neighbours' values
+    // (unconditional loads from clamped addresses, selects behind them: `cond ? load : 0` is a branch and a wait per load;
+    //  uniform bases + 32-bit lane offsets: the global_load saddr form; the gather-table entry -- in flight since the previous
+    //  element's phase C -- is touched FIRST, so that its wait stands in front of the loads, not between them)
+    const bool wide = act && tab.x < 0;
+    const unsigned lown = (unsigned)(e * NN + (act ? tl : 0)) * 8u;
+    const unsigned ox = (tab.x >= 0 && act) ? (unsigned)tab.x * 8u : lown, oy = (tab.y >= 0) ? (unsigned)tab.y * 8u : lown,
+                   oz = (tab.z >= 0) ? (unsigned)tab.z * 8u : lown, ow = (tab.w >= 0) ? (unsigned)tab.w * 8u : lown;
+    const unsigned oc = (tl < 192 && cm >= 0) ? (unsigned)cm * 8u : 0u;
+    // a finished component's loads go to a live component's array (cache hits, no branch): their values are never used
+    const int live = (dmask & 1) ? ((dmask & 2) ? 2 : 1) : 0;
+    const double* __restrict__ w0 = wl0 + (size_t)((dmask & 1) ? live : 0) * nl;
+    const double* __restrict__ w1 = wl0 + (size_t)((dmask & 2) ? live : 1) * nl;
+    const double* __restrict__ w2 = wl0 + (size_t)((dmask & 4) ? live : 2) * nl;
+    GsVals gv[3];
+    gv[0].a = ld_boff(w0, ox); gv[0].b = ld_boff(w0, oy); gv[0].c = ld_boff(w0, oz); gv[0].d = ld_boff(w0, ow);
+    gv[1].a = ld_boff(w1, ox); gv[1].b = ld_boff(w1, oy); gv[1].c = ld_boff(w1, oz); gv[1].d = ld_boff(w1, ow);
+    gv[2].a = ld_boff(w2, ox); gv[2].b = ld_boff(w2, oy); gv[2].c = ld_boff(w2, oz); gv[2].d = ld_boff(w2, ow);
+    const int wv = __builtin_amdgcn_readfirstlane(tl >> 6);
+    double cv = ld_boff((wv == 0) ? w0 : ((wv == 1) ? w1 : w2), oc);         // waves 0..2: the corner lists of component wv
+    const unsigned lo = (unsigned)(act ? tl : 0) * 8u;              // this lane's node of the element (lanes past it: node 0)
+    double bm, g[6], mk, mi, di;
+    mk = ld_boff(d.mask + e * NN, lo); di = ld_boff(d.dinv + (size_t)(sc.k - 1) * d.nloc + e * NN, lo);
+    bm = ld_boff(d.bm1 + e * NN, lo); mi = ld_boff(d.minv + e * NN, lo);
+    g[0] = ld_boff(d.g1 + e * NN, lo); g[1] = ld_boff(d.g2 + e * NN, lo); g[2] = ld_boff(d.g3 + e * NN, lo);
+    g[3] = (d.zmask & (1u << 9)) ? 0.0 : ld_boff(d.g4 + e * NN, lo);        // (zmask: wave-uniform branches)
+    g[4] = (d.zmask & (1u << 10)) ? 0.0 : ld_boff(d.g5 + e * NN, lo);
+    g[5] = (d.zmask & (1u << 11)) ? 0.0 : ld_boff(d.g6 + e * NN, lo);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      if (tab.y < 0) gv[c].b = 0.0;
+      if (tab.z < 0) gv[c].c = 0.0;
+      if (tab.w < 0) gv[c].d = 0.0;
+    }
+    if (!(tl < 192 && cm >= 0) || ((dmask >> (wv < 3 ? wv : 0)) & 1)) cv = -0.0;
+    if (tl < 192) scv[tl] = (cm == -2) ? __builtin_nan("") : cv;
+    const bool from_list = wide && cid >= 0 && d.gs_corner;
+    // the landing zone is complete, and every load above (the builtin, not a statement hipcc cannot see: it goes on waiting for
+    // loads it believes in flight, and behind the stores of phase B such a wait waits for the stores)
+    __builtin_amdgcn_s_waitcnt(0x0F70);                          // vmcnt(0)
+    lds_barrier();
+    // ---- B
+    double rz[3] = {0, 0, 0}, rr[3] = {0, 0, 0};
+    if (act) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const long long lc = c * nl + l;
+        const double ro = pf[(c * 4 + 0) * NN + tl];
+        double r = ro;
+        if (!((dmask >> c) & 1)) {
+          const double po = pf[(c * 4 + 1) * NN + tl], so = pf[(c * 4 + 2) * NN + tl], xo = pf[(c * 4 + 3) * NN + tl];
+          const double* wl = wl0 + (size_t)c * nl;
+          const double sum = !wide ? (((gv[c].a + gv[c].b) + gv[c].c) + gv[c].d)
+                                   : (from_list ? corner_list_sum(scv + c * 64 + cid * 8, wl, d, l) : gs_csr_rolled(wl, d, l));
+          const double w = mk * sum;
+          const double pn = di * ro + beta[c] * po;
+          const double sn = w + beta[c] * so;
+          d.hp[lc] = pn; d.hs[lc] = sn;
+          d.hx[lc] = xo + alpha[c] * pn;
+          r = ro - alpha[c] * sn;
+          d.hr[lc] = r;
+        }
+        const double z = di * r;
+        sz[c * EXT + tn] = z;
+        rz[c] = r * z * mi; rr[c] = r * r * mi;
+      }
+    }
+    lds_barrier();                                               // (the landing zone and the corner values are read, the z tiles written)
+    // ---- the next element: its r, p, s, x by LDS-DMA, its gather-table and corner-list entries
+    const unsigned bn = b + G;
+    const bool more = bn < (unsigned)count;
+    const long long en = d.boff + xcd_element(more ? bn : b, count);
+    // (order: hipcc does not count the LDS-DMA statements, so every wait it places BEHIND them for an older load or store also
+    //  drains them -- the table loads and the fragment reads, whose waits guard registers, come first)
+    int cmn = -1;
+    int4 tabn = make_int4(0, -1, -1, -1);
+    if (more) {
+      cmn = (d.gs_corner && tl < 192) ? d.gs_corner[(size_t)en * 64 + (tl & 63)] : -1;
+      if (act) tabn = d.gs_tab[en * NN + tl];
+    }
+    const AxFrag<N> F = ax_frags<N>(sDm, tl & 63);
+    if (more) prefetch(en);
+    // ---- C
+#pragma unroll 1
+    for (int c = 0; c < 3; ++c) {
+      double z;
+      const double au = axhelm3_mfma<N>(F, sz + c * EXT, sW, sO, g, act, tn, tl >> 6, NT / 64, tl & 63, z);
+      double v[3] = {0, 0, 0};
+      if (act) {
+        const double wl = d.nu * au + sc.h2 * bm * z;
+        d.hwl[((size_t)par * 3 + c) * nl + l] = wl;
+        v[0] = (c == 0) ? rz[0] : ((c == 1) ? rz[1] : rz[2]); v[1] = z * wl; v[2] = (c == 0) ? rr[0] : ((c == 1) ? rr[1] : rr[2]);
+      }
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const double x = wave_sum63(v[q]);
+        if ((tl & 63) == 63) sred[(c * 3 + q) * 16 + (tl >> 6)] = x;
+      }
+      lds_barrier();
+    }
+    if (tl < 12) {
+      double s = 0.0;
+      if (tl < 9)
+        for (int w = 0; w < NT / 64; ++w) s += sred[tl * 16 + w];
+      d.hpart[((size_t)par * 12 + tl) * d.nblk + e] = s;      // (rows 9..11, (b, b), are it = 0's)
+    }
+    if (!more) break;
+    e = en; b = bn; tab = tabn; cm = cmn;
+  }
+}
+
+
 // ---------------------------------------------------------------------------
 // Velocity solve with an ELEMENT-BLOCK FAST-DIAGONALISATION preconditioner (option "helm_fdm"; config 5's wall cells have
 // aspect ratios of 29, where the Jacobi-preconditioned CG of k_helm needs 60-105 iterations per time step):

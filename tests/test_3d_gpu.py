@@ -689,6 +689,39 @@ def test_schwarz_kernel_forms_agree(lx1, outflow):
             assert np.abs(maps[form][k] - maps[0][k]).max() < 1e-9 * sc, (form, k)
 
 
+def test_resident_helmholtz_iteration_is_bit_identical_lx1_10():
+    """Option helm_pf (default at lx1 = 10): the CG iteration as resident workgroups that walk their elements with the next
+    element's r, p, s, x arriving in LDS by LDS-DMA (k_helm_p) against one workgroup per element (k_helm<10>).  Same arithmetic
+    in the same order: a five-step direct map and the iteration counts are equal BIT FOR BIT, with eight resident workgroups
+    (every workgroup walks several elements: prologue, steady state and last element of the loop) and with the default grid."""
+    c = mesh3d.box_case_3d(4, 3, 3, 10, lengths=(2.0, 1.0, 0.8), outflow_xmax=True, re=40.0, endtime=0.05, ub_func=_ubf, warp=0.06)      # 36 elements
+    x, y, z = c.x, c.y, c.z
+    q = [np.sin(1.3 * x + z) * np.cos(2.0 * y) * c.mask, np.cos(0.7 * x + 0.2) * np.sin(3.0 * y - z) * c.mask,
+         np.sin(x + y) * np.cos(2.0 * z) * c.mask, np.zeros((c.nel,) + (c.lx1 - 2,) * 3)]
+    out, its = {}, {}
+    for form in ("wg", "resident8", "resident"):
+        h = _hip(c)
+        try:
+            h.set_option("helm_pf", 0 if form == "wg" else 1)
+            if form == "resident8":
+                assert c.nel > 16
+                h.set_option("helm_pf_grid", 8)
+            a, b = h.alloc(2)
+            h.upload3(a, *q)
+            h.set_nsteps(5)
+            h.matvec(b, a, 0)
+            out[form] = h.download3(b)
+            st = h.stats()
+            its[form] = (st["helm_iters"], st["pres_iters"])
+            assert st["unconverged"] == 0
+        finally:
+            h.close()
+    for form in ("resident8", "resident"):
+        assert its[form] == its["wg"], its
+        for k in range(4):
+            assert np.array_equal(out[form][k], out["wg"][k]), (form, k, np.abs(out[form][k] - out["wg"][k]).max())
+
+
 @pytest.mark.parametrize("lx1,outflow", [(8, True), (6, False), (10, True)])
 def test_streaming_projection_kernels_equal_element_kernel_forms(lx1, outflow):
     """Option flat_proj (default on single-rank hexahedral contexts): the once-per-step sums over the GMRES basis and the
