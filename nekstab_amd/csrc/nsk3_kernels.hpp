@@ -943,6 +943,13 @@ __global__ __launch_bounds__(Cfg<N>::NT, NSK_HELM3_WAVES) void k_helm(Dev d, Ste
 //                 -> LDS-DMA of the next element's r, p, s, x; its gather-table entry and corner-list entry
 //                 C  A z of the three components (axhelm3_mfma), partial sums
 // `count` elements from d.boff on, XCD-contiguous as in k_helm (a step of gridDim.x, a multiple of 8, stays in the XCD's run).
+#ifdef NSK_HP_NT
+#define NSK_HP_NT_LD " nt"
+#define NSK_HP_ST(p, v) __builtin_nontemporal_store((v), (p))
+#else
+#define NSK_HP_NT_LD ""
+#define NSK_HP_ST(p, v) (*(p) = (v))
+#endif
 template <int N>
 __global__ __launch_bounds__(Cfg<N>::NT, NSK_HELM3_WAVES) void k_helm_p(Dev d, StepCoef sc, int it, int count) {
   using C = Cfg<N>;
@@ -1023,7 +1030,7 @@ __global__ __launch_bounds__(Cfg<N>::NT, NSK_HELM3_WAVES) void k_helm_p(Dev d, S
       const double* gsrc = src + 2 * ht;
       unsigned keep;
       if (ht < NN / 2)
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" NSK_HP_NT_LD "\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(gsrc), "s"(ldst) : "memory");
     }
   };
@@ -1096,10 +1103,10 @@ __global__ __launch_bounds__(Cfg<N>::NT, NSK_HELM3_WAVES) void k_helm_p(Dev d, S
           const double w = mk * sum;
           const double pn = di * ro + beta[c] * po;
           const double sn = w + beta[c] * so;
-          d.hp[lc] = pn; d.hs[lc] = sn;
-          d.hx[lc] = xo + alpha[c] * pn;
+          NSK_HP_ST(d.hp + lc, pn); NSK_HP_ST(d.hs + lc, sn);
+          NSK_HP_ST(d.hx + lc, xo + alpha[c] * pn);
           r = ro - alpha[c] * sn;
-          d.hr[lc] = r;
+          NSK_HP_ST(d.hr + lc, r);
         }
         const double z = di * r;
         sz[c * EXT + tn] = z;
@@ -1120,12 +1127,18 @@ __global__ __launch_bounds__(Cfg<N>::NT, NSK_HELM3_WAVES) void k_helm_p(Dev d, S
       if (act) tabn = d.gs_tab[en * NN + tl];
     }
     const AxFrag<N> F = ax_frags<N>(sDm, tl & 63);
+#ifndef NSK_HP_SKIP_DMA    // (timing experiment: no prefetch)
     if (more) prefetch(en);
+#endif
     // ---- C
 #pragma unroll 1
     for (int c = 0; c < 3; ++c) {
       double z;
+#ifdef NSK_HP_SKIP_C      // (timing experiment: phase C without its passes)
+      const double au = g[0] + F.d.a[0][0]; z = sz[c * EXT + tn];
+#else
       const double au = axhelm3_mfma<N>(F, sz + c * EXT, sW, sO, g, act, tn, tl >> 6, NT / 64, tl & 63, z);
+#endif
       double v[3] = {0, 0, 0};
       if (act) {
         const double wl = d.nu * au + sc.h2 * bm * z;
@@ -1850,11 +1863,8 @@ __global__ __launch_bounds__(64) void k_gmres_col(Dev d, int j, double scale, in
 // gather table derived at set-up from the velocity-mesh dssum lists, which resolves their orientation (p_idx).  Local solve by fast diagonalisation:
 // fdS = [nel][3][N*N] generalised eigenvectors S_d[pos][mode] of the 1-D pairs (A_d, M_d), fdL = [nel][3][N]:
 //   z = (S_t x S_s x S_r) diag(1/(lr+ls+lt)) (S_t x S_s x S_r)^T w,  restricted to the element's own nodes.
-#ifndef NSK_SCHW3_WAVES
-#define NSK_SCHW3_WAVES 1
-#endif
 template <int N>
-__global__ __launch_bounds__(Cfg<N>::NT) __attribute__((amdgpu_waves_per_eu(NSK_SCHW3_WAVES))) void k_schwarz(Dev d, const double* __restrict__ vin,
+__global__ __launch_bounds__(Cfg<N>::NT) void k_schwarz(Dev d, const double* __restrict__ vin,
                                                         double* __restrict__ zout, int use_coarse, int check_done) {
   using C = Cfg<N>;
   constexpr int NN = C::NN, M = C::M, MM = C::MM, NT = C::NT, NM = N * M, NNM = C::NNM, NMM = C::NMM;
@@ -2282,11 +2292,8 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_gradt(Dev d, const double* __res
 // from LDS in list order (the left-to-right sum of gs_csr; a missing member is -0.0, the identity of the addition).
 // (Until round 5 the basis was a round trip of its own ahead of the table, the metric terms went out after the gather and a
 //  corner thread walked its three components' lists one after the other: five round trips, 9 of a workgroup's 14 us.)
-#ifndef NSK_DIVGS3_WAVES
-#define NSK_DIVGS3_WAVES 1
-#endif
 template <int N>
-__global__ __launch_bounds__(Cfg<N>::NT) __attribute__((amdgpu_waves_per_eu(NSK_DIVGS3_WAVES))) void k_divgs(Dev d, const double* __restrict__ yl,
+__global__ __launch_bounds__(Cfg<N>::NT) void k_divgs(Dev d, const double* __restrict__ yl,
                                                       double* __restrict__ wout, int j, int check_done) {
   using C = Cfg<N>;
   constexpr int NN = C::NN, M = C::M, MM = C::MM, NT = C::NT, NM = N * M, NNM = C::NNM, NMM = C::NMM;

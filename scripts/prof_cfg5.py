@@ -26,7 +26,12 @@ else:                                          # node-wise noise: discontinuous 
 h.upload3(q, c.ub[0] + w, c.ub[1] - w, w, np.zeros(h.npres))
 h.set_nsteps(nst)
 for rep in range(int(os.environ.get('REPS', '2'))):
-    t0 = time.time(); h.matvec(f, q, 0); h.norm(f); dt = time.time() - t0
+    t0 = time.time()
+    try:
+        h.matvec(f, q, 0); h.norm(f)
+    except Exception as exc:                               # noqa: BLE001  (timing experiments with wrong values)
+        print("note:", exc)
+    dt = time.time() - t0
     st = h.stats()
     print("%.1f ms per step (%.1f Helmholtz + %.1f pressure iterations per step)" % (1e3 * dt / nst, st["helm_iters"] / nst, st["pres_iters"] / nst), flush=True)
 for kn in os.environ.get("KERNELS", "").split():          # HIP-event timings of single kernels on the state the last map left
