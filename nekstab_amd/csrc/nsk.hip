@@ -1060,13 +1060,23 @@ static unsigned eapply_grid(nsk_ctx* c, int which, int count) {
   }
   return (unsigned)std::min(count, c->eapply_grid[which]);
 }
+#ifndef NSK_SCHW10_MODE
+#define NSK_SCHW10_MODE 5             // what "the default form" means at lx1 = 10: four wavefronts per element (k_schwarz_q<10>: 263 us at 13 824 elements; k_schwarz_p<10> 596, k_schwarz<10> 679)
+#endif
 template <int N>
 static void launch_schwarz3(nsk_ctx* c, const Dev& d, int count, const double* vin, double* zout, int use_coarse, int check_done, int mode = -1) {
   if constexpr (N <= 10) {
     if (mode < 0) mode = c->eapply_pipe;
     if (mode == 3) mode = 2;                             // (3 = 2 + the divergence kernel in wavefront form: launch_divgs3)
     if (mode == 2 && N > 8 && !std::getenv("NSK_WAVE_LX10")) mode = 0;      // lx1 = 10: 16 nodes per lane, 234 registers: not measured faster
-    if (mode == 4 && N > 8) mode = 1;                    // lx1 = 10 has no sixteen-per-CU wavefront form: resident workgroups with the next element's loads in flight (k_schwarz_p<10> 591 against k_schwarz<10> 692 us at 13 824 elements: one workgroup per CU either way, profiles/r06_cfg5_forms.txt)
+    if (mode == 5 && N != 10) mode = 4;                  // (5 = four wavefronts per element: lx1 = 10 only)
+    if (mode == 4 && N > 8) mode = NSK_SCHW10_MODE;      // lx1 = 10 has no sixteen-per-CU wavefront form (sixteen nodes per lane: 224 registers)
+    if (mode == 5) {                                     // four wavefronts per element (lx1 = 10; elsewhere the default form)
+      if constexpr (N == 10) {
+        hipLaunchKernelGGL(nsk::k3::k_schwarz_q<N>, dim3(count), dim3(256), 0, c->stream, d, vin, zout, use_coarse, check_done);
+        return;
+      }
+    }
     if (mode == 4) {          // one wavefront per element, sixteen per CU (in-place solve, metrics per component)
       if constexpr (N <= 8) hipLaunchKernelGGL(nsk::k3::k_schwarz_w16<N>, dim3(count), dim3(64), 0, c->stream, d, vin, zout, use_coarse, check_done);
     } else if (mode == 2)     // one wavefront per element
@@ -3168,7 +3178,7 @@ int nsk_bench_kernel(nsk_ctx* c, const char* name, int reps, double* avg_us) {
       for (int r = 0; r < reps; ++r) { HIPCHK(hipMemsetAsync(c->sync, 0, SYNC_WORDS * sizeof(unsigned), c->stream)); launch_fused<N>(c, sc, its, &d); }
       HIPCHK(hipEventRecord(e1, c->stream));
     });
-  } else if (c->ndim == 3 && (n == "divgs" || n == "divgs_wg" || n == "divgs_w" || n == "divgs_c3" || n == "schwarz" || n == "schwarz_wg" || n == "schwarz_p" || n == "schwarz_w" || n == "schwarz_w16" || n == "gradt" || n.rfind("gs_lag", 0) == 0 || n.rfind("gs_dots", 0) == 0 || n == "pres_update" || n == "vel_update_proj" || n == "pres_rhs" || n == "rhs")) {
+  } else if (c->ndim == 3 && (n == "divgs" || n == "divgs_wg" || n == "divgs_w" || n == "divgs_c3" || n == "schwarz" || n == "schwarz_wg" || n == "schwarz_p" || n == "schwarz_w" || n == "schwarz_w16" || n == "schwarz_q" || n == "gradt" || n.rfind("gs_lag", 0) == 0 || n.rfind("gs_dots", 0) == 0 || n == "pres_update" || n == "vel_update_proj" || n == "pres_rhs" || n == "rhs")) {
     // hexahedral pressure kernels back to back on the state the last map left: the E apply without its dots ("divgs"), the
     // Schwarz preconditioner + D^T ("schwarz"), the streaming Gram-Schmidt passes at basis index j ("gs_lag<j>", "gs_dots<j>")
     d.tol_pres = 0.0; d.tol_relative = 0; d.pres_cap = 0;
@@ -3191,6 +3201,7 @@ int nsk_bench_kernel(nsk_ctx* c, const char* name, int reps, double* avg_us) {
         else if (n == "schwarz_p") launch_schwarz3<N>(c, d, c->nblk, (const double*)(d.V + (size_t)jj * d.ps), d.Z + (size_t)jj * d.npr, 1, 0, 1);
         else if (n == "schwarz_w") launch_schwarz3<N>(c, d, c->nblk, (const double*)(d.V + (size_t)jj * d.ps), d.Z + (size_t)jj * d.npr, 1, 0, 2);
         else if (n == "schwarz_w16") launch_schwarz3<N>(c, d, c->nblk, (const double*)(d.V + (size_t)jj * d.ps), d.Z + (size_t)jj * d.npr, 1, 0, 4);
+        else if (n == "schwarz_q") launch_schwarz3<N>(c, d, c->nblk, (const double*)(d.V + (size_t)jj * d.ps), d.Z + (size_t)jj * d.npr, 1, 0, 5);
         else if (n == "gradt") hipLaunchKernelGGL(k_gradt<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, (const double*)c->wp1, d.yl);
         else if (n == "pres_update") hipLaunchKernelGGL(k_pres_update<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, sc);
         else if (n == "vel_update_proj") hipLaunchKernelGGL(k_vel_update_proj<N>, dim3(c->nblk), dim3(NT), 0, c->stream, d, sc);

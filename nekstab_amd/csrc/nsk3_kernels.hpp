@@ -2262,6 +2262,86 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
   opgradt3_wave_ld<N, L, RM>(sJ12, sD12, z, d.w2m + e * MM, d.npr, d.zmask, buf, lane, d.yl + e * NN, d.cs);
 }
 
+// k_schwarz for lx1 = 10 as a SMALL workgroup per element: four wavefronts (256 threads, four patch nodes and two Gauss nodes per
+// thread), 24 KB of LDS -> five or six elements per CU in flight, where k_schwarz<10> / k_schwarz_p<10> are one 1024-thread
+// workgroup alone on its CU meeting at twenty-four barriers per element (4.2-4.9 ms per launch at config 5's size: 0.13-0.15 of
+// 8 TB/s).  The loads as in k_schwarz_w16 (three trips: everything addressable from the thread, then vertex and patch values,
+// the metrics per component under the passes), the six fast-diagonalisation passes and D^T on the matrix cores with the tiles
+// of a pass spread over the four waves (fd_forward_mfma / fd_back_mfma, opgradt3_wg_ld), barriers of four waves.
+template <int N>
+__global__ __launch_bounds__(256) void k_schwarz_q(Dev d, const double* __restrict__ vin, double* __restrict__ zout,
+                                                   int use_coarse, int check_done) {
+  using C = Cfg<N>;
+  using L = PadLay<N>;
+  constexpr int NW = 4, NT = 64 * NW;
+  constexpr int NN = C::NN, M = C::M, MM = C::MM, NM = N * M, NS = 3 * N * N, NSL = NS + 3 * N;
+  constexpr int RN = (NN + NT - 1) / NT, RM = (MM + NT - 1) / NT, RS = (NSL + NT - 1) / NT;
+  constexpr int GBUF = GtWave<N, L>::BUF, FBUF = 2 * L::FEXT, BUF = GBUF > FBUF ? GBUF : FBUF;
+  static_assert(NM <= NT && 2 * M <= NT, "basis and prolongation weights: one entry per thread");
+  __shared__ double sJ12[NM], sD12[NM], sSL[NSL], sH[2 * M];
+  __shared__ double buf[BUF];
+  double* sa = buf; double* sb = buf + L::FEXT;                    // fast-diagonalisation tiles; afterwards the D^T intermediates (GtWave)
+  const int tid = threadIdx.x;
+  if (check_done && d.gsc->done) return;
+  const long long e = d.boff + xcd_element(blockIdx.x, gridDim.x);
+  // (1) everything addressable from the thread, the heads of the two dependent chains first; unconditional loads from clamped addresses
+  const int ev = d.evert[e * 8 + (tid & 7)];
+  int id[RN];
+#pragma unroll
+  for (int r = 0; r < RN; ++r) { const int idx = r * NT + tid; id[r] = d.p_idx[e * NN + (idx < NN ? idx : 0)]; }
+  const int pend = d.gs_lag ? d.gsc->pending : 0;
+  const double phinv = d.gs_lag ? d.gsc->phinv : 1.0;
+  double sv[RS];
+#pragma unroll
+  for (int r = 0; r < RS; ++r) {
+    const int idx = r * NT + tid;
+    sv[r] = (idx < NS) ? d.fdS[(size_t)e * NS + idx] : ((idx < NSL) ? d.fdL[(size_t)e * 3 * N + (idx - NS)] : 0.0);
+  }
+  const double bJ = (tid < NM) ? d.J12[tid] : 0.0, bD = (tid < NM) ? d.D12[tid] : 0.0;
+  const double hh = (tid < 2 * M) ? d.hat[8 * MM + tid] : 0.0;
+  // (2) the vertex values and the patch values (index 0 where the patch has no node)
+  const double xl = d.xc[ev];
+  double pv[RN];
+#pragma unroll
+  for (int r = 0; r < RN; ++r) pv[r] = vin[id[r] >= 0 ? id[r] : 0];
+  const double vsc = pend ? phinv : 1.0;
+#pragma unroll
+  for (int r = 0; r < RS; ++r) { const int idx = r * NT + tid; if (idx < NSL) sSL[idx] = sv[r]; }
+  if (tid < NM) { sJ12[tid] = bJ; sD12[tid] = bD; }
+  if (tid < 2 * M) sH[tid] = hh;
+#pragma unroll
+  for (int r = 0; r < RN; ++r) {
+    const int idx = r * NT + tid;
+    if (idx < NN) sa[(idx / (N * N)) * L::F[0][0] + ((idx / N) % N) * L::F[0][1] + (idx % N) * L::F[0][2]] = (id[r] >= 0) ? vsc * pv[r] : 0.0;
+  }
+  lds_barrier();
+  fd_forward_mfma<N, L>(sSL, sSL + NS, sa, sb, d.fd_eps, tid, NT);
+  fd_back_mfma<N, L>(sSL, sa, sb, tid, NT);
+  // restriction to the element's own nodes + R^T x_c (the eight vertex values sit in lanes 0..7 of every wave)
+  double xv[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) xv[c] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(xl), c), __builtin_amdgcn_readlane(__double2loint(xl), c));
+  double z[RM];
+#pragma unroll
+  for (int r = 0; r < RM; ++r) {
+    const int idx = r * NT + tid;
+    z[r] = 0.0;
+    if (idx < MM) {
+      const int a = idx % M, bb = (idx / M) % M, cc = idx / (M * M);
+      double zc = 0.0;
+      if (use_coarse) {
+        const double hr[2] = {sH[a], sH[M + a]}, hs[2] = {sH[bb], sH[M + bb]}, ht[2] = {sH[cc], sH[M + cc]};
+#pragma unroll
+        for (int c = 0; c < 8; ++c) zc += ((hr[c & 1] * hs[(c >> 1) & 1]) * ht[c >> 2]) * xv[c];       // = hat[c][idx] * x_c
+      }
+      z[r] = sa[(cc + 1) * L::F[6][0] + (bb + 1) * L::F[6][1] + (a + 1) * L::F[6][2]] + zc;
+      zout[e * MM + idx] = z[r];
+    }
+  }
+  lds_barrier();                                         // (the tile is read: D^T reuses the buffer)
+  opgradt3_wg_ld<N, L, RM, NW>(sJ12, sD12, z, d.w2m + e * MM, d.npr, d.zmask, buf, tid, d.yl + e * NN, d.cs);
+}
+
 // yl = D^T p for an arbitrary pressure vector
 template <int N>
 __global__ __launch_bounds__(Cfg<N>::NT) void k_gradt(Dev d, const double* __restrict__ pin, double* __restrict__ yl) {

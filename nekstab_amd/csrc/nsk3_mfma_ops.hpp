@@ -610,6 +610,67 @@ __device__ inline void opgradt3_wave_ld(const double* sJ12, const double* sD12, 
   }
 }
 
+// opgradt3_wave_ld for a SMALL WORKGROUP of NW wavefronts that owns the element (k_schwarz_q: lx1 = 10, where sixteen nodes per lane
+// cost a single wavefront 224 registers): Gauss node r * 64 * NW + tid per thread, the tiles of a pass spread over the NW waves,
+// a workgroup barrier (of NW waves) where the wavefront form waits for its own LDS traffic.
+template <int N, class L, int RM, int NW>
+__device__ inline void opgradt3_wg_ld(const double* sJ12, const double* sD12, const double (&z)[RM], const double* __restrict__ wm,
+                                      long long npr, unsigned zmask, double* buf, int tid, double* __restrict__ y, long long cs) {
+  using G = GtWave<N, L>;
+  constexpr int M = N - 2, MM = M * M * M, KQ = (M + 3) / 4, NT = 64 * NW;
+  constexpr int RB = (N + 3) / 4;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const Frag4<KQ, RB> aJ = make_frag4<KQ, RB>(lane, [&](int mrow, int k) { return (mrow < N && k < M) ? sJ12[k * N + mrow] : 0.0; });
+  const Frag4<KQ, RB> aD = make_frag4<KQ, RB>(lane, [&](int mrow, int k) { return (mrow < N && k < M) ? sD12[k * N + mrow] : 0.0; });
+  typedef ColLinear<M * M> CT;
+  typedef Col2<M, L::C[1], L::C[2], L::C[0]> CT_out;
+  typedef Col2<M, L::C[0], L::C[2], L::C[1]> CS_in;
+  typedef Col2<M, L::E[0], L::E[2], L::E[1]> CS_out;
+  typedef Col2<N, L::E[0], L::E[1], L::E[2]> CR_in;
+  typedef ColRow<N> CR_out;
+  double wn[3][RM];                                      // metrics (axis a, this component) of the component in turn
+  auto load_w = [&](int c) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int r = 0; r < RM; ++r) {
+        const int idx = r * NT + tid;
+        wn[a][r] = ((zmask >> (a * 3 + c)) & 1u) ? 0.0 : *reinterpret_cast<const double*>(reinterpret_cast<const char*>(wm + (size_t)(a * 3 + c) * npr) + (unsigned)(idx < MM ? idx : 0) * 8u);
+      }
+  };
+  load_w(0);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    double p0[RM], p1[RM], p2[RM];
+#pragma unroll
+    for (int r = 0; r < RM; ++r) { p0[r] = z[r] * wn[0][r]; p1[r] = z[r] * wn[1][r]; p2[r] = z[r] * wn[2][r]; }
+    if (c < 2) load_w(c + 1);                              // in flight under this component's passes
+#pragma unroll
+    for (int r = 0; r < RM; ++r) {
+      const int idx = r * NT + tid;
+      if (idx < MM) { buf[G::oP12 + idx] = p1[r]; buf[G::oP12 + MM + idx] = p2[r]; }
+    }
+    lds_barrier();
+    mo_pass4<M, KQ, RB, M * M, CT, StLin<CT_out, CT_out::ks, N>, false>(aJ, buf + G::oP12, aJ, buf, buf + G::oC1, wave, NW, lane);
+    mo_pass4<M, KQ, RB, M * M, CT, StLin<CT_out, CT_out::ks, N>, false>(aD, buf + G::oP12 + MM, aD, buf, buf + G::oC2, wave, NW, lane);
+    lds_barrier();
+    mo_pass4<M, KQ, RB, N * M, CS_in, StLin<CS_out, CS_out::ks, N>, true>(aD, buf + G::oC1, aJ, buf + G::oC2, buf + G::oE1, wave, NW, lane);
+    lds_barrier();
+#pragma unroll
+    for (int r = 0; r < RM; ++r) {
+      const int idx = r * NT + tid;
+      if (idx < MM) buf[G::oP0 + idx] = p0[r];
+    }
+    lds_barrier();
+    mo_pass4<M, KQ, RB, M * M, CT, StLin<CT_out, CT_out::ks, N>, false>(aJ, buf + G::oP0, aJ, buf, buf + G::oC0, wave, NW, lane);
+    lds_barrier();
+    mo_pass4<M, KQ, RB, N * M, CS_in, StLin<CS_out, CS_out::ks, N>, false>(aJ, buf + G::oC0, aJ, buf, buf + G::oE0, wave, NW, lane);
+    lds_barrier();
+    mo_pass4<M, KQ, RB, N * N, CR_in, StLin<CR_out, 1, N>, true>(aD, buf + G::oE0, aJ, buf + G::oE1, y + c * cs, wave, NW, lane);
+    lds_barrier();
+  }
+}
+
 // Weak divergence with the THREE COMPONENTS' pass chains running side by side (k_divgs_c3): waves w, w + 3, ... of the workgroup own
 // component w % 3 and its buffer region (DvWave's regions: 3 x 10.5 KB at lx1 = 8), so the workgroup meets at 5 barriers instead
 // of 12 and every pass has three times the tiles to spread over the waves.  The last pass stays in the accumulators and is

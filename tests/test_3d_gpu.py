@@ -651,7 +651,8 @@ def test_schwarz_kernel_forms_agree(lx1, outflow):
     """Option eapply_pipe: the Schwarz + D^T kernel of the pressure iteration as one workgroup per element (0: k_schwarz),
     as resident workgroups with the next element's inputs in flight (1: k_schwarz_p) and as one wavefront per element with
     no workgroup barrier (2: k_schwarz_w; 4: k_schwarz_w16, the default at lx1 <= 8 -- the solve in place in one tile, sixteen
-    elements per CU in flight; 3: the divergence kernel in that form too, k_divgs_w: built, measured slower, not the default).
+    elements per CU in flight; 3: the divergence kernel in that form too, k_divgs_w: built, measured slower, not the default;
+    5: four wavefronts per element, k_schwarz_q -- lx1 = 10 only, the default form elsewhere).
     Same arithmetic except for the order of the sums inside the
     matrix-core passes (forms 1 and 2 run the six fast-diagonalisation passes there too): a pressure solve to 1e-8 and a
     five-step adjoint map agree to rounding amplified by the solves, with the same iteration counts."""
@@ -665,7 +666,7 @@ def test_schwarz_kernel_forms_agree(lx1, outflow):
     q = [np.sin(1.3 * x + z) * np.cos(2.0 * y) * c.mask, np.cos(0.7 * x + 0.2) * np.sin(3.0 * y - z) * c.mask,
          np.sin(x + y) * np.cos(2.0 * z) * c.mask, np.zeros((c.nel,) + (c.lx1 - 2,) * 3)]
     sol, its, maps = {}, {}, {}
-    for form in (0, 1, 2, 3, 4):
+    for form in (0, 1, 2, 3, 4, 5):
         h = _hip(c, max_pres_iter=96)
         try:
             h.set_option("eapply_pipe", form)
@@ -682,7 +683,7 @@ def test_schwarz_kernel_forms_agree(lx1, outflow):
             h.close()
     print("GMRES iterations by kernel form:", its)
     sc = max(np.abs(maps[0][k]).max() for k in range(3))
-    for form in (1, 2, 3, 4):
+    for form in (1, 2, 3, 4, 5):
         assert _rel(sol[form], sol[0]) < 1e-7, form
         assert abs(its[form] - its[0]) <= 1, its
         for k in range(3):
