@@ -109,8 +109,13 @@ int nsk_set_tolerances(nsk_ctx* ctx, double tol_helm, double tol_pres, int relat
  * -1 = default: on for single-rank contexts; 0 / 1 / 2), "flat_proj" (hexahedra: once-per-step sums over the bases as streaming
  * kernels; -1 = default: on for single-rank contexts), "eapply_pipe" (hexahedra, form of the Schwarz + D^T kernel: 0 = one
  * workgroup per element, 1 = resident workgroups, 2 = one wavefront per element, 3 = 2 + the divergence kernel in that form,
- * 4 = default at lx1 <= 8: one wavefront per element, sixteen per CU; same results to rounding: DESIGN.md section 4.3),
- * "divgs_c3" (hexahedra: divergence kernel with its components side by side, default 0: measured slower), "helm_fdm" (hexahedra:
+ * 4 = default: one wavefront per element, sixteen per CU, at lx1 <= 8 and form 5 at lx1 = 10; 5 = four wavefronts per element,
+ * lx1 = 10 only; same results to rounding: DESIGN.md section 4.3, 4.36),
+ * "divgs_c3" (hexahedra: divergence kernel with its components side by side; -1 = default: at lx1 = 10, where it runs two
+ * workgroups per CU and the plain form one; 0 / 1), "helm_pf" (hexahedra, lx1 = 10: the CG iteration as resident workgroups with
+ * the next element's vectors arriving in LDS by LDS-DMA, default 1; bit-identical to 0), "helm_pf_grid" (its resident workgroups;
+ * default: what the device holds), "mfma_convect" (hexahedra, lx1 = 8 and 10: convection kernel on the matrix cores, default 1),
+ * "helm_fdm" (hexahedra:
  * element-block fast-diagonalisation preconditioner of the velocity solves, default 0: measured slower), "graph_steps" (time steps
  * per captured graph of the last step class, default 1),
  * "budget_freeze" / "budget_add_helm" / "budget_add_pres" (measurement switches of scripts/noop_cost.py),

@@ -85,7 +85,7 @@ struct nsk_ctx {
   int helm_guess = 1;
   int budget_freeze = 0;
   int helm_fdm = -1;                    // hexahedra: element-block fast-diagonalisation preconditioner of the velocity solves (NSK_HELM_FDM=1 builds it; measured slower than Jacobi-CG, off)
-  int eapply_pipe = 4;                  // hexahedra, the Schwarz + D^T kernel: 0 = one workgroup per element, 1 = resident workgroups with the next element's loads in flight (k_schwarz_p), 2 = one wavefront per element (k_schwarz_w), 3 = 2 + k_divgs_w, 4 = one wavefront per element, sixteen per CU (k_schwarz_w16; default, lx1 <= 8)
+  int eapply_pipe = 4;                  // hexahedra, the Schwarz + D^T kernel: 0 = one workgroup per element, 1 = resident workgroups with the next element's loads in flight (k_schwarz_p), 2 = one wavefront per element (k_schwarz_w), 3 = 2 + k_divgs_w, 4 = the default form: one wavefront per element, sixteen per CU (k_schwarz_w16) at lx1 <= 8, four wavefronts per element (k_schwarz_q, = 5) at lx1 = 10
   int zero_metrics = 1;                 // hexahedra: arrays of the mapping / base-flow constants that are zero on every node are cleaned at set-up and not loaded by the kernels (Dev::zmask, Dev::bfmask); NSK_ZERO_METRICS=0: set-up as rounds 1-4 (rounding noise kept); option zero_metrics = 0: cleaned arrays, every one loaded
   unsigned zmask_built = 0, bfmask_built = 0;
   int helm_pf = 1, helm_pf_grid = 0;    // hexahedra, lx1 = 10: the CG iteration as resident workgroups with LDS-DMA prefetch of the next element (k_helm_p; option "helm_pf", NSK_HELM_PF; 0 = k_helm<10>)

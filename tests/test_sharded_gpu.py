@@ -125,8 +125,8 @@ def test_rccl_transport_single_rank_plumbing(hip6, case6, oracle6_nosolve, modes
     hip6.free([vq, vf]); hip6.set_nsteps(100)
 
 
-@pytest.mark.parametrize("nranks", [2, 3])
-def test_sharded_hexahedral_matvec_equals_single_rank(nranks):
+@pytest.mark.parametrize("nranks,lx1", [(2, 6), (3, 6), (2, 10)])
+def test_sharded_hexahedral_matvec_equals_single_rank(nranks, lx1):
     """Element sharding of a hexahedral context (BASELINE configs 4 and 5 are 3-D on 8 GPUs): dssum halo of three
     velocity components, halo of the Schwarz patch layers (face, edge and corner neighbours on other ranks),
     all-reduced totals of both Gram-Schmidt passes and of the coarse restriction; virtual ranks on one GPU."""
@@ -134,13 +134,15 @@ def test_sharded_hexahedral_matvec_equals_single_rank(nranks):
     from nekstab_amd.capi import NekStabHip
     from nekstab_amd.sharded import ShardGroup, partition_rcb
     ubf = lambda x, y, z: np.stack([1.0 - 0.3 * y * y + 0.1 * np.sin(x + z), 0.2 * np.cos(x) * y + 0.1 * z, 0.15 * np.sin(y + 0.5 * z)])
-    c = mesh3d.box_case_3d(4, 3, 2, 6, lengths=(2.0, 1.0, 0.8), outflow_xmax=True, re=40.0, endtime=0.05, ub_func=ubf, warp=0.05)
+    # (lx1 = 10: the sharded step launches k_convect_mfma<10>, k_schwarz_q<10> and k_divgs_c3<10> as the single-rank context does)
+    c = mesh3d.box_case_3d(4, 3, 2, lx1, lengths=(2.0, 1.0, 0.8), outflow_xmax=True, re=40.0, endtime=0.05, ub_func=ubf, warp=0.05)
+    m = lx1 - 2
     h = NekStabHip(c, c.meta["vert"], c.meta["nvert"], tol_helm=1e-12, tol_pres=1e-7, tol_relative=1, max_helm_iter=200,
                    max_pres_iter=48)
     try:
         x, y, z = c.x, c.y, c.z
         q = [np.sin(1.3 * x + z) * np.cos(2.0 * y) * c.mask, np.cos(0.7 * x + 0.2) * np.sin(3.0 * y - z) * c.mask,
-             np.sin(x + y) * np.cos(2.0 * z) * c.mask, np.zeros((c.nel, 4, 4, 4))]
+             np.sin(x + y) * np.cos(2.0 * z) * c.mask, np.zeros((c.nel, m, m, m))]
         h.set_nsteps(4)
         vq, vf = h.alloc(2)
         h.upload3(vq, *q)
@@ -152,7 +154,7 @@ def test_sharded_hexahedral_matvec_equals_single_rank(nranks):
         rng = np.random.default_rng(0)
         u = rng.standard_normal(c.x.shape)
         assert np.abs(g.group_test(0, u) - h.t_dssum(u)).max() < 1e-12 * 8
-        p = rng.standard_normal((c.nel, 4, 4, 4))
+        p = rng.standard_normal((c.nel, m, m, m))
         er = h.t_eapply(p)
         assert np.abs(g.group_test(1, p) - er).max() < 1e-12 * np.abs(er).max()
         g.set_nsteps(4)
