@@ -508,7 +508,7 @@ def run_cfg5(a):
     99.5 M points per field, state vector 2.8 GB, ~175 GB of device memory on one GPU.  The line times `--steps` TRUNCATED maps of
     `--map-steps` time steps each after `--warmup` of them (a time step takes a second; the reference's case, T = 1 at its CFL, would be
     ~700 of them per map), reports ms_per_time_step, projects `value` = 1 / (ms_per_time_step x the steps of a whole map of THIS
-    case's T) and carries the kernel roofline of k3::k_helm<10> (HIP events, full-work launches) with this build's PMC traffic.  An auxiliary line (the metric's configuration is configs[1]: the default run)."""
+    case's T) and carries the kernel roofline of k3::k_helm_p<10> (HIP events, full-work launches) with this build's PMC traffic.  An auxiliary line (the metric's configuration is configs[1]: the default run)."""
     import numpy as np
     import torch
     assert torch.cuda.is_available(), "bench.py needs a GPU"
@@ -553,13 +553,13 @@ def run_cfg5(a):
                       "tolerances": "Helmholtz 1e-9, pressure 1e-2 relative, projection space %d, host-read convergence flags" % nproj, "parallelism": "1 GPU"},
            "setup_s": setup_s, "ms_per_time_step": ms_ts, "helm_iters_per_step": st["helm_iters"] / max(st["steps"], 1), "pres_iters_per_step": st["pres_iters"] / max(st["steps"], 1),
            "zero_arrays": za,
-           "roofline": {"bound": "hbm", "kernel": "k3::k_helm<10> (one CG iteration of the three components)", "achieved": distinct / kr["avg_us"] / 1e3, "peak": 8000.0, "unit": "GB/s",
+           "roofline": {"bound": "hbm", "kernel": "k3::k_helm_p<10> (one CG iteration of the three components: resident workgroups, the next element's vectors by LDS-DMA; 64-69 % of the kernel time of a time step: profiles/r06_cfg5_trace_summary.txt)", "achieved": distinct / kr["avg_us"] / 1e3, "peak": 8000.0, "unit": "GB/s",
                         "frac": distinct / kr["avg_us"] / 1e3 / 8000.0, "traffic": traffic, "traffic_source": tnote, "avg_launch_us": kr["avg_us"], "algorithmic_bytes_per_launch": distinct,
                         "survey_rule": {"algorithmic_bytes_per_launch": rule, "frac": rule / kr["avg_us"] / 1e3 / 8000.0},
                         "note": "every distinct array of the launch ONCE (the figure to quote); SURVEY 8(d)'s per-component rule counts the arrays the three components share three times: `survey_rule`, not a bandwidth"},
            "cpu_baseline": None, "cpu_baseline_note": "the C / OpenMP port covers quadrilaterals: the default record (configs[1]) carries the CPU baseline"}
     kt = {}
-    for kn in ("divgs", "schwarz"):
+    for kn in ("divgs", "schwarz", "convect_mfma", "helm_wg"):
         try:
             kt[kn] = h.bench_kernel(kn, 10)["avg_us"]
         except Exception as e:                              # noqa: BLE001

@@ -23,8 +23,17 @@ for l in open(txt):
 N = 10
 one = roofline.per_step_bytes(nel=nel, lx1=N, ndim=3, nvert=0, nproj=0, helm_iters=0.0, pres_iters=1.0, pres_jsum=0.0, coarse_bytes=0.0, zero_arrays=za)
 rule, distinct = roofline.helm_launch_bytes(nel=nel, lx1=N, ndim=3, zero_arrays=za)
-alg = {"helm": (distinct, "k_helm<10>", "all arrays of the three components once (SURVEY rule: %.2f GB)" % (rule / 1e9)),
-       "divgs": (one["K7 divgs (x n_pres)"], "k_divgs<10>", "E apply"), "schwarz": (one["K6 schwarz (x n_pres)"] - nel * 8 * 12.0, "k_schwarz<10>", "Schwarz + D^T, one workgroup per element")}
+conv = one["K1 convect"]                                   # (the base-flow constants that vanish on the whole mesh are not counted: zero_arrays)
+# (bench name, kernel-name key of the PMC table, algorithmic bytes, note); the first of a group is the form the context runs
+rows = [("helm", "k_helm_p<10>", distinct, "one CG iteration of the three components, resident workgroups + LDS-DMA prefetch (round 6); all arrays once (SURVEY rule: %.2f GB)" % (rule / 1e9)),
+        ("helm_wg", "k_helm<10>", distinct, "... one workgroup per element (rounds 3-5)"),
+        ("divgs", "k_divgs_c3<10>", one["K7 divgs (x n_pres)"], "E apply, components side by side: two workgroups per CU (default at lx1 = 10 since round 6)"),
+        ("divgs_wg", "k_divgs<10>", one["K7 divgs (x n_pres)"], "... one workgroup per CU (rounds 3-5)"),
+        ("schwarz", "k_schwarz_q<10>", one["K6 schwarz (x n_pres)"] - nel * 8 * 12.0, "Schwarz + D^T, four wavefronts per element, six elements per CU (round 6)"),
+        ("schwarz_p", "k_schwarz_p<10>", one["K6 schwarz (x n_pres)"] - nel * 8 * 12.0, "... resident 1024-thread workgroups"),
+        ("schwarz_wg", "k_schwarz<10>", one["K6 schwarz (x n_pres)"] - nel * 8 * 12.0, "... one 1024-thread workgroup per element (rounds 3-5)"),
+        ("convect_mfma", "k_convect_mfma<10>", conv, "dealiased convection on the matrix cores (round 6)"),
+        ("convect", "k_convect<10>", conv, "... thread per node, constants loaded inside the point loop (rounds 2-5)")]
 pmc = json.load(open(pmc_json)) if os.path.exists(pmc_json) else {}
 def pmc_of(key):
     for k, v in pmc.items():
@@ -36,13 +45,12 @@ for ms, hi, pi in steps[-1:]:
 print("| kernel (launch) | HIP-event us | algorithmic GB / launch | TB/s | frac of 8 TB/s | counter GB / launch (2 x FETCH + WRITE) | frac by counter bytes | note |")
 print("|---|---|---|---|---|---|---|---|")
 out = {}
-for kn in ("helm", "divgs", "schwarz"):
+for kn, key, a, note in rows:
     if kn not in t:
         continue
-    a, key, note = alg[kn]
     pm = pmc_of(key)
     us = t[kn]
     print("| k3::%s | %.1f | %.3f | %.2f | %.2f | %s | %s | %s |" % (key, us, a / 1e9, a / us / 1e6, a / us / 1e6 / 8.0, "%.3f" % (pm / 1e9) if pm else "-", "%.2f" % (pm / us / 1e6 / 8.0) if pm else "-", note))
-    if pm:
-        out["k3::%s<10>" % kn] = {"bytes_per_launch": pm}
+    if pm and kn in ("helm", "divgs", "schwarz", "convect_mfma"):
+        out["k3::%s<10>" % kn] = {"bytes_per_launch": pm, "kernel": key}
 json.dump(out, open(os.path.join(os.path.dirname(pmc_json), "r06_cfg5_pmc_traffic_part.json"), "w"), indent=1)
