@@ -1,5 +1,6 @@
 #!/bin/bash
 # GPU job 28: borrowed captured steps while a budget pair is young (gc_slack) -- the driver's timed window (Arnoldi steps 5-24) and a
+# (the gc_slack option of this job ran on an experimental build: NOT in the tree -- DESIGN.md section 7)
 # 60-step window, alternating on one box; iteration counts and Ritz values must not move
 R=${GRAFT_REPO_ROOT:-$PWD}; cd $R
 O=gpurun_out/r06; mkdir -p $O

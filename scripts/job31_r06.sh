@@ -1,6 +1,7 @@
 #!/bin/bash
 # GPU job 31: lx1 = 8 convection on the matrix cores -- k_convect_mfma8 (seven LDS tiles, 75 KB, two workgroups per CU) against the generic
 # k_convect_mfma<8> (three regions, 41 KB, 80 registers: three per CU); parity of the generic form through the test hook
+# (ran on an experimental build: option mfma_convect = 2 / bench name convect_mfma_g are NOT in the tree -- DESIGN.md section 7)
 R=${GRAFT_REPO_ROOT:-$PWD}; cd $R
 python3 - <<'PY'
 import numpy as np, sys
