@@ -1134,6 +1134,18 @@ static void launch_gs_lag3(nsk_ctx* c, const Dev& d, int j, double scale, int or
   }
 }
 
+// resident workgroups of k_helm_p<10>: what the device holds at once, a multiple of 8 (a workgroup's stride stays inside its XCD's run)
+static int helm_pf_grid(nsk_ctx* c) {
+  if (!c->helm_pf_grid) {
+    int per_cu = 0, ncu = 0, dev = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, nsk::k3::k_helm_p<10>, nsk::k3::Cfg<10>::NT, 0);
+    if (const char* g = std::getenv("NSK_HELM_PF_WGS")) per_cu = std::atoi(g);
+    c->helm_pf_grid = std::max(8, (std::max(1, per_cu) * std::max(1, ncu)) / 8 * 8);
+  }
+  return c->helm_pf_grid;
+}
 // one CG iteration of the velocity solve: k_helm, or (hexahedra with Dev::helm_fdm) the two launches of the block-preconditioned form
 template <int N>
 static void launch_helm_iter(nsk_ctx* c, const Dev& d, const StepCoef& sc, int it, const double* rhs) {
@@ -1149,15 +1161,7 @@ static void launch_helm_iter(nsk_ctx* c, const Dev& d, const StepCoef& sc, int i
       // lx1 = 10: resident workgroups with the next element's r, p, s, x arriving in LDS under the current element's A z (k_helm_p;
       // it = 0 stays k_helm's helm_first)
       if (it >= 1 && c->helm_pf != 0 && d.boff == 0) {
-        if (!c->helm_pf_grid) {
-          int per_cu = 0, ncu = 0, dev = 0;
-          (void)hipGetDevice(&dev);
-          (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-          (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, nsk::k3::k_helm_p<N>, nsk::k3::Cfg<N>::NT, 0);
-          if (const char* g = std::getenv("NSK_HELM_PF_WGS")) per_cu = std::atoi(g);
-          c->helm_pf_grid = std::max(8, (std::max(1, per_cu) * std::max(1, ncu)) / 8 * 8);
-        }
-        hipLaunchKernelGGL(nsk::k3::k_helm_p<N>, dim3(std::min(c->nblk, c->helm_pf_grid)), dim3(nsk::k3::Cfg<N>::NT), 0, c->stream, d, sc, it, c->nblk);
+        hipLaunchKernelGGL(nsk::k3::k_helm_p<N>, dim3(std::min(c->nblk, helm_pf_grid(c))), dim3(nsk::k3::Cfg<N>::NT), 0, c->stream, d, sc, it, c->nblk);
         return;
       }
     }
