@@ -78,7 +78,7 @@ struct nsk_ctx {
   int bh_helm[NCLS][8] = {}, bh_pres[NCLS][8] = {}, bh_n = 0;                         // iteration maxima of the last maps (budgets_update)
   int use_graph = 1;
   int gmres_cycle = MAXMR;              // pressure GMRES restarts after this many iterations (option "gmres_cycle": tests use short cycles)
-  int mfma_convect = 1;                 // hexahedra, lx1 = 8 and 10: convection kernel with the contractions on the fp64 matrix cores (nsk3_mfma.hpp: k_convect_mfma8, k_convect_mfma<10>)
+  int mfma_convect = 1;                 // hexahedra, lx1 = 8 and 10: convection kernel with the contractions on the fp64 matrix cores (nsk3_mfma.hpp: k_convect_mfma8, k_convect_mfma<10>, and the full equations' k_convect_mfma_nl<10>)
   int fused = 0;                        // persistent velocity solve (k_helm_fused): one launch per time step instead of one per CG iteration
   unsigned* sync = nullptr;             // grid-barrier counters of the persistent kernels
   int in_test = 0;
@@ -1438,6 +1438,8 @@ static int step(nsk_ctx* c, int istep, int adjoint, int nh_over = -1, int np_ove
       hipLaunchKernelGGL(nsk::k3::k_convect_mfma8, dim3(c->nel), dim3(512), 0, c->stream, d, (const double*)d.u, d.bf, adjoint);
     else if (c->key == 110 && adjoint != 2 && c->mfma_convect)
       hipLaunchKernelGGL(nsk::k3::k_convect_mfma<10>, dim3(c->nel), dim3(512), 0, c->stream, d, (const double*)d.u, d.bf, adjoint);
+    else if (c->key == 110 && adjoint == 2 && c->mfma_convect)      // the full equations (Newton-Krylov)
+      hipLaunchKernelGGL(nsk::k3::k_convect_mfma_nl<10>, dim3(c->nel), dim3(1024), 0, c->stream, d, (const double*)d.u, d.bf);
     else
       hipLaunchKernelGGL(k_convect<N>, dim3(c->nel), dim3(Cfg<N>::NTD), 0, c->stream, d, (const double*)d.u, d.bf, adjoint);
     if (c->fused) {
@@ -3156,6 +3158,18 @@ int nsk_bench_kernel(nsk_ctx* c, const char* name, int reps, double* avg_us) {
       HIPCHK(hipEventRecord(e1, c->stream));
     });
     c->helm_pf = keep_pf;
+  } else if (n == "convect_nl" || n == "convect_mfma_nl") {
+    // the full equations' convection term (mode 2): thread-per-node kernel / matrix-core kernel (hexahedra, lx1 = 10)
+    if (n == "convect_mfma_nl" && c->key != 110) return fail(NSK_EINVAL, "k_convect_mfma_nl<10>: hexahedra with lx1 = 10");
+    HIPCHK(hipStreamSynchronize(c->stream));
+    DISPATCH_N(c->key, {
+      for (int r = 0; r < reps + 3; ++r) {
+        if (r == 3) HIPCHK(hipEventRecord(e0, c->stream));
+        if (n == "convect_mfma_nl") hipLaunchKernelGGL(nsk::k3::k_convect_mfma_nl<10>, dim3(c->nel), dim3(1024), 0, c->stream, d, (const double*)d.u, d.bf);
+        else hipLaunchKernelGGL(k_convect<N>, dim3(c->nel), dim3(Cfg<N>::NTD), 0, c->stream, d, (const double*)d.u, d.bf, 2);
+      }
+      HIPCHK(hipEventRecord(e1, c->stream));
+    });
   } else if (n == "convect" || n == "convect_mfma") {
     if (n == "convect_mfma" && c->key != 108 && c->key != 110) return fail(NSK_EINVAL, "k_convect_mfma8 / k_convect_mfma<10>: hexahedra with lx1 = 8 or 10");
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -3370,9 +3384,10 @@ int nsk_test_op3(nsk_ctx* c, int which, const double* in, double* out, int a, in
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipMemcpy(out, c->wv2, nv * sizeof(double), hipMemcpyDeviceToHost));
   } else if (which == 8) {                             // convection term on the matrix cores (lx1 = 8; a = 0 direct / 1 adjoint)
-    if ((c->key != 108 && c->key != 110) || a == 2) return fail(NSK_EINVAL, "k_convect_mfma8 / k_convect_mfma<10>: hexahedra with lx1 = 8 or 10, modes 0 and 1");
+    if ((c->key != 108 && c->key != 110) || (a == 2 && c->key != 110)) return fail(NSK_EINVAL, "k_convect_mfma8 / k_convect_mfma<10>: hexahedra with lx1 = 8 or 10, modes 0 and 1; k_convect_mfma_nl<10>: mode 2 at lx1 = 10");
     HIPCHK(hipMemcpy(c->wv1, in, nv * sizeof(double), hipMemcpyHostToDevice));
     if (c->key == 108) hipLaunchKernelGGL(nsk::k3::k_convect_mfma8, dim3(c->nel), dim3(512), 0, c->stream, d, (const double*)c->wv1, c->wv2, a);
+    else if (a == 2) hipLaunchKernelGGL(nsk::k3::k_convect_mfma_nl<10>, dim3(c->nel), dim3(1024), 0, c->stream, d, (const double*)c->wv1, c->wv2);
     else hipLaunchKernelGGL(nsk::k3::k_convect_mfma<10>, dim3(c->nel), dim3(512), 0, c->stream, d, (const double*)c->wv1, c->wv2, a);
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipMemcpy(out, c->wv2, nv * sizeof(double), hipMemcpyDeviceToHost));

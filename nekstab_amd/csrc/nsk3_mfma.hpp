@@ -265,5 +265,113 @@ __global__ __launch_bounds__(512, 4) void k_convect_mfma(Dev d, const double* __
   }
 }
 
+// ---- the FULL equations' convection term (u . grad) u (mode 2: Newton-Krylov, core/matvec.f:64-108) on the matrix cores, lx1 = 10 ----
+// [UPSTREAM advab]  v_c = sum_a c_a d(u_c)/d(xi_a),  c_a = sum_x w_d J d(xi_a)/d(x_x) u_x  on the dealiasing mesh.  The convecting field needs
+// all three fine-mesh components at every point, so they all live in LDS (U: 81 KB) next to one derivative tile G (27 KB) and t2
+// (18 KB): 126 KB, one 1024-thread workgroup per CU (as k_convect<10>, whose lanes walk their points one at a time with the nine
+// metric terms loaded inside the loop: 116 ms per launch at config 5's size).  c_a of a lane's four points is formed ONCE (nine metric
+// loads per point, less the terms that vanish on the whole mesh) and kept in registers across the three components.
+//   G also holds t1 on the way up (dead before the first derivative) and v_c, then t1, on the way down; the element tile rides in t2's place.
+template <int N>
+__global__ __launch_bounds__(1024, 4) void k_convect_mfma_nl(Dev d, const double* __restrict__ uin, double* __restrict__ bf) {
+  constexpr int ND = 3 * N / 2, NN = N * N * N, NDD = ND * ND * ND, NT = 1024, NW = NT / 64;
+  constexpr int PPT = (NDD + NT - 1) / NT, KQU = (N + 3) / 4, KQD = (ND + 3) / 4;
+  static_assert(ND <= 16 && N * N * ND <= NDD && NN <= N * ND * ND && NN <= NT, "one 16-row tile per operator; t1 inside G, the element tile inside t2, one GLL node per thread");
+  __shared__ double U[3 * NDD], G[NDD], T2[N * ND * ND];
+  double* t1 = G; double* su = T2;
+  const int tid = threadIdx.x, lane0 = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const long long e = blockIdx.x;
+  double aJ[KQU], aD[KQD];
+  {
+    const int m16 = lane0 & 15, kq = lane0 >> 4;
+#pragma unroll
+    for (int q = 0; q < KQU; ++q) { const int k = 4 * q + kq; aJ[q] = (m16 < ND && k < N) ? d.Jd[m16 * N + k] : 0.0; }
+#pragma unroll
+    for (int q = 0; q < KQD; ++q) { const int k = 4 * q + kq; aD[q] = (m16 < ND && k < ND) ? d.Dd[m16 * ND + k] : 0.0; }
+  }
+  typedef ColRow<N> UR_in;                       typedef ColRow<ND> UR_out;                     // [(k,j)][i] -> [(k,j)][a]
+  typedef ColPlane<ND, N * ND, ND> US_in;        typedef ColPlane<ND, ND * ND, ND> US_out;      // [k][j][a]  -> [k][b][a]
+  typedef ColLinear<ND * ND> UT;                                                                // [k][(b,a)] -> [c'][(b,a)]
+  const size_t nf = (size_t)d.nfine;
+  // ---- the three components on the dealiasing mesh
+#pragma unroll 1
+  for (int c = 0; c < 3; ++c) {
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    if (tid < NN) su[tid] = uin[c * d.cs + e * NN + tid];
+    lds_barrier();
+    mo_pass<N, KQU, N * N, UR_in, StLin<UR_out, 1, ND>, false>(aJ, su, aJ, su, t1, wave, NW, lane);
+    lds_barrier();
+    mo_pass<N, KQU, N * ND, US_in, StLin<US_out, ND, ND>, false>(aJ, t1, aJ, t1, T2, wave, NW, lane);
+    lds_barrier();
+    mo_pass<N, KQU, ND * ND, UT, StLin<UT, ND * ND, ND>, false>(aJ, T2, aJ, T2, U + c * NDD, wave, NW, lane);
+    lds_barrier();
+  }
+  // ---- the convecting field at this lane's points: c_a = sum_x mtd[a][x] u_x
+  double ca[PPT][3];
+  {
+    const double* __restrict__ me = d.mtd + (size_t)e * NDD;
+#pragma unroll
+    for (int r = 0; r < PPT; ++r) {
+      const int p = tid + r * NT;
+      const unsigned po = (unsigned)(p < NDD ? p : NDD - 1) * 8u;
+      const double u0 = U[p < NDD ? p : 0], u1 = U[NDD + (p < NDD ? p : 0)], u2 = U[2 * NDD + (p < NDD ? p : 0)];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const double m0 = ((d.zmask >> (a * 3 + 0)) & 1u) ? 0.0 : ld_boff(me + (size_t)(a * 3 + 0) * nf, po);      // (zmask: wave-uniform branches)
+        const double m1 = ((d.zmask >> (a * 3 + 1)) & 1u) ? 0.0 : ld_boff(me + (size_t)(a * 3 + 1) * nf, po);
+        const double m2 = ((d.zmask >> (a * 3 + 2)) & 1u) ? 0.0 : ld_boff(me + (size_t)(a * 3 + 2) * nf, po);
+        ca[r][a] = (m0 * u0 + m1 * u1) + m2 * u2;
+      }
+    }
+  }
+  double aJt[KQD];
+  {
+    const int m16 = lane0 & 15, kq = lane0 >> 4;
+#pragma unroll
+    for (int q = 0; q < KQD; ++q) { const int k = 4 * q + kq; aJt[q] = (m16 < N && k < ND) ? d.Jd[k * N + m16] : 0.0; }
+  }
+  const long long l = e * NN + (tid < NN ? tid : 0);
+  const double kk = d.spng[l] * d.bm1[l] * d.nl_spng_str;
+#pragma unroll 1
+  for (int c = 0; c < 3; ++c) {
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const double* uc = U + c * NDD;
+    double v[PPT];
+    // d/dr, d/ds, d/dt of component c, one at a time through G
+    mo_pass<ND, KQD, ND * ND, ColRow<ND>, StLin<ColRow<ND>, 1, ND>, false>(aD, uc, aD, uc, G, wave, NW, lane);
+    lds_barrier();
+#pragma unroll
+    for (int r = 0; r < PPT; ++r) { const int p = tid + r * NT; v[r] = (p < NDD) ? ca[r][0] * G[p] : 0.0; }
+    lds_barrier();
+    mo_pass<ND, KQD, ND * ND, US_out, StLin<US_out, ND, ND>, false>(aD, uc, aD, uc, G, wave, NW, lane);
+    lds_barrier();
+#pragma unroll
+    for (int r = 0; r < PPT; ++r) { const int p = tid + r * NT; if (p < NDD) v[r] += ca[r][1] * G[p]; }
+    lds_barrier();
+    mo_pass<ND, KQD, ND * ND, UT, StLin<UT, ND * ND, ND>, false>(aD, uc, aD, uc, G, wave, NW, lane);
+    lds_barrier();
+#pragma unroll
+    for (int r = 0; r < PPT; ++r) { const int p = tid + r * NT; if (p < NDD) v[r] += ca[r][2] * G[p]; }
+    lds_barrier();                                               // (every lane has read the derivative: G takes v_c)
+#pragma unroll
+    for (int r = 0; r < PPT; ++r) { const int p = tid + r * NT; if (p < NDD) G[p] = v[r]; }
+    lds_barrier();
+    // v[c'][b][a] -> t2[k][b][a] -> t1[(k,j)][a] (in G: v is dead) -> su[(k,j)][i] (in t2's place)
+    mo_pass<ND, KQD, ND * ND, UT, StLin<UT, ND * ND, N>, false>(aJt, G, aJt, G, T2, wave, NW, lane);
+    lds_barrier();
+    mo_pass<ND, KQD, N * ND, US_out, StLin<US_in, ND, N>, false>(aJt, T2, aJt, T2, t1, wave, NW, lane);
+    lds_barrier();
+    mo_pass<ND, KQD, N * N, UR_out, StLin<UR_in, 1, N>, false>(aJt, t1, aJt, t1, su, wave, NW, lane);
+    lds_barrier();
+    if (tid < NN) {
+      const double s = su[tid];
+      bf[c * d.cs + l] = ((kk != 0.0) ? kk * (d.spng_vr[c * d.cs + l] - uin[c * d.cs + l]) : 0.0) - s;
+    }
+    lds_barrier();
+  }
+}
+
 }  // namespace k3
 }  // namespace nsk

@@ -17,12 +17,12 @@ python3 $R/scripts/kernel_table_cfg4.py $O/${T}_cfg4_kernels.txt $O/${T}_cfg4_pm
 rm -rf $O/p_c4f $O/p_c4w
 head -16 $O/${T}_cfg4_kernel_table.md
 # ---- config 5 (E = 99 452 hexahedra, lx1 = 10): the new forms and the old ones, timings + PMC passes of the same launches
-K5="helm helm_wg divgs divgs_wg schwarz schwarz_p schwarz_wg convect_mfma"
+K5="helm helm_wg divgs divgs_wg schwarz schwarz_p schwarz_wg convect_mfma convect_mfma_nl"
 SMOOTH=1 NPROJ=8 REPS=1 KERNELS="$K5" timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/p_c5f --output-format csv -- python3 $R/scripts/prof_cfg5.py 46 46 47 3 > $O/${T}_cfg5_kernels_under_pmc.txt 2> $O/${T}_cfg5_fetch.err
 SMOOTH=1 NPROJ=8 REPS=1 KERNELS="$K5" timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/p_c5w --output-format csv -- python3 $R/scripts/prof_cfg5.py 46 46 47 3 > /dev/null 2> $O/${T}_cfg5_write.err
 python3 $R/scripts/pmc_summary.py $O/p_c5f $O/p_c5w $O/${T}_cfg5_pmc_fetch_write_per_kernel.json > $O/${T}_cfg5_pmc_summary.txt 2>&1
 rm -rf $O/p_c5f $O/p_c5w
-SMOOTH=1 NPROJ=8 REPS=2 KERNELS="$K5 convect" timeout 900 python3 $R/scripts/prof_cfg5.py 46 46 47 8 > $O/${T}_cfg5_steps.txt 2>&1
+SMOOTH=1 NPROJ=8 REPS=2 KERNELS="$K5 convect convect_nl" timeout 900 python3 $R/scripts/prof_cfg5.py 46 46 47 8 > $O/${T}_cfg5_steps.txt 2>&1
 python3 $R/scripts/kernel_table_cfg5.py $O/${T}_cfg5_steps.txt $O/${T}_cfg5_pmc_fetch_write_per_kernel.json > $O/${T}_cfg5_kernel_table.md 2> $O/${T}_cfg5_kernel_table.err
 python3 $R/scripts/pmc_traffic_merge_r06.py $O ${T} 2>&1 | tail -3
 cat $O/${T}_cfg5_kernel_table.md

@@ -24,6 +24,8 @@ N = 10
 one = roofline.per_step_bytes(nel=nel, lx1=N, ndim=3, nvert=0, nproj=0, helm_iters=0.0, pres_iters=1.0, pres_jsum=0.0, coarse_bytes=0.0, zero_arrays=za)
 rule, distinct = roofline.helm_launch_bytes(nel=nel, lx1=N, ndim=3, zero_arrays=za)
 conv = one["K1 convect"]                                   # (the base-flow constants that vanish on the whole mesh are not counted: zero_arrays)
+zm = bin(za & 0x1ff).count("1")                             # metric terms that vanish on the whole mesh
+conv_nl = 8.0 * (nel * N ** 3 * 8 + nel * (3 * N // 2) ** 3 * (9 - zm))      # u (3) in, bf (3) out, sponge, mass on the GLL mesh; the nine metric terms on the dealiasing mesh
 # (bench name, kernel-name key of the PMC table, algorithmic bytes, note); the first of a group is the form the context runs
 rows = [("helm", "k_helm_p<10>", distinct, "one CG iteration of the three components, resident workgroups + LDS-DMA prefetch (round 6); all arrays once (SURVEY rule: %.2f GB)" % (rule / 1e9)),
         ("helm_wg", "k_helm<10>", distinct, "... one workgroup per element (rounds 3-5)"),
@@ -33,7 +35,9 @@ rows = [("helm", "k_helm_p<10>", distinct, "one CG iteration of the three compon
         ("schwarz_p", "k_schwarz_p<10>", one["K6 schwarz (x n_pres)"] - nel * 8 * 12.0, "... resident 1024-thread workgroups"),
         ("schwarz_wg", "k_schwarz<10>", one["K6 schwarz (x n_pres)"] - nel * 8 * 12.0, "... one 1024-thread workgroup per element (rounds 3-5)"),
         ("convect_mfma", "k_convect_mfma<10>", conv, "dealiased convection on the matrix cores (round 6)"),
-        ("convect", "k_convect<10>", conv, "... thread per node, constants loaded inside the point loop (rounds 2-5)")]
+        ("convect", "k_convect<10>", conv, "... thread per node, constants loaded inside the point loop (rounds 2-5)"),
+        ("convect_mfma_nl", "k_convect_mfma_nl<10>", conv_nl, "the FULL equations' convection term (mode 2: Newton-Krylov) on the matrix cores (round 6)"),
+        ("convect_nl", "k_convect<10>", conv_nl, "... thread per node (mode 2 of k_convect<10>)")]
 pmc = json.load(open(pmc_json)) if os.path.exists(pmc_json) else {}
 def pmc_of(key):
     for k, v in pmc.items():
@@ -48,7 +52,7 @@ out = {}
 for kn, key, a, note in rows:
     if kn not in t:
         continue
-    pm = pmc_of(key)
+    pm = None if kn in ("convect_nl", "convect") else pmc_of(key)      # (k_convect<10> runs in two modes under the counters: no per-mode figure)
     us = t[kn]
     print("| k3::%s | %.1f | %.3f | %.2f | %.2f | %s | %s | %s |" % (key, us, a / 1e9, a / us / 1e6, a / us / 1e6 / 8.0, "%.3f" % (pm / 1e9) if pm else "-", "%.2f" % (pm / us / 1e6 / 8.0) if pm else "-", note))
     if pm and kn in ("helm", "divgs", "schwarz", "convect_mfma"):

@@ -95,6 +95,10 @@ def test_convection_terms(setup3):
         assert _rel(h.t_op3(8, u, 0), direct) < 1e-12
         assert _rel(h.t_op3(8, u, 1), adj) < 1e-12
         assert _rel(h.t_op3(8, u, 0), h.t_op3(3, u, 0)) < 1e-13
+    if c.lx1 == 10:
+        # the full equations' term on the matrix cores (k_convect_mfma_nl<10>: Newton-Krylov at config 5's order)
+        assert _rel(h.t_op3(8, u, 2), nl) < 1e-12
+        assert _rel(h.t_op3(8, u, 2), h.t_op3(3, u, 2)) < 1e-13
 
 
 def test_helmholtz_solve(setup3):
