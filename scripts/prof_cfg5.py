@@ -17,6 +17,8 @@ del sx, sy, sz
 t0 = time.time()
 h = NekStabHip(c, c.meta["vert"], c.meta["nvert"], tol_helm=1e-9, tol_pres=1e-2, tol_relative=1, max_helm_iter=400, max_pres_iter=192, nproj=int(os.environ.get('NPROJ', '0')))
 print("E %d set-up %.0f s, nsteps %d dt %.3e" % (c.nel, time.time() - t0, h.nsteps, h.dt), flush=True)
+if os.environ.get("MFMA_CONVECT") is not None:           # 0: the thread-per-node convection kernels (A/B of the matrix-core ones)
+    h.set_option("mfma_convect", int(os.environ["MFMA_CONVECT"]))
 q, f = h.alloc(2)
 rng = np.random.default_rng(2)
 if os.environ.get("SMOOTH", "0") == "1":      # a smooth, continuous, three-dimensional perturbation (what a Krylov vector of a physical run looks like after a few maps)
@@ -28,7 +30,10 @@ h.set_nsteps(nst)
 for rep in range(int(os.environ.get('REPS', '2'))):
     t0 = time.time()
     try:
-        h.matvec(f, q, 0); h.norm(f)
+        if os.environ.get("MODE") == "nl":                 # the FULL equations' map (Newton-Krylov's nonlinear step) instead of the linearised one
+            h.nonlinear_map(f, q); h.norm(f)
+        else:
+            h.matvec(f, q, 0); h.norm(f)
     except Exception as exc:                               # noqa: BLE001  (timing experiments with wrong values)
         print("note:", exc)
     dt = time.time() - t0
